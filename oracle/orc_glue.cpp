@@ -1,0 +1,193 @@
+/*
+ * orc_glue.cpp -- ORACLE (test infrastructure only; see orc.h).
+ *
+ * Restates the SeqLib glue of /root/reference/src/BWAAligner.cpp:89-250: region filtering
+ * (:117-129), std::sort by (mapq desc, rid, pos) (:7-11,:133), the secondary filters (:136-146),
+ * record construction (:151-236) and the NA/NM/AS tags (:238-241, src/BamRecord.cpp:960-970).
+ * C++ only because the reference sorts with std::sort and ties must fall the same way.
+ */
+#include "orc.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" orc_counters *orc_counters_ptr(void);
+
+namespace {
+/* src/BWAAligner.cpp:7-11 */
+bool aln_sort(const orc_aln &a, const orc_aln &b)
+{
+    if (a.mapq != b.mapq) return a.mapq > b.mapq;
+    if (a.rid != b.rid) return a.rid < b.rid;
+    return a.pos < b.pos;
+}
+
+void append_int_tag(std::vector<uint8_t> &d, const char *tag, int32_t v)
+{ /* bam_aux_append(b, tag, 'i', 4, &v) */
+    d.push_back((uint8_t)tag[0]); d.push_back((uint8_t)tag[1]); d.push_back('i');
+    uint8_t raw[4]; std::memcpy(raw, &v, 4);
+    d.insert(d.end(), raw, raw + 4);
+}
+} // namespace
+
+extern "C" int orc_align_sequence(const orc_opt *opt, const orc_index *idx, const char *seq, int len,
+                                  const char *name, int hardclip, double keepSecFrac, int maxSecondary,
+                                  uint64_t rng_base, uint64_t ordinal, orc_hit **out)
+{
+    *out = nullptr;
+    if (!idx) return 0;                                     /* :101 */
+    /* mem_align1 passes lrand48() as the hash salt: draw number `ordinal` (0-based) of the stream */
+    uint64_t salt = orc_lrand48_nth(rng_base, ordinal + 1);
+    orc_reg *regs = nullptr;
+    int n_regs = orc_align1(opt, idx, len, seq, salt, &regs); /* :104-109 */
+
+    double primaryScore = 0;
+    std::vector<orc_aln> hits;
+    hits.reserve((size_t)n_regs);
+    for (int i = 0; i < n_regs; ++i) {                      /* :117-129 */
+        orc_reg &r = regs[i];
+        /* `r.secondary` is an int used as a truth value: -1 (primary) is true, 0 (secondary to region 0) is false */
+        if (r.secondary && (keepSecFrac < 0.0 || keepSecFrac > 1.0)) continue;
+        hits.push_back(orc_reg2aln(opt, idx, len, seq, &r));
+    }
+    std::free(regs);
+    std::sort(hits.begin(), hits.end(), aln_sort);          /* :133 */
+
+    std::vector<orc_hit> recs;
+    for (size_t i = 0; i < hits.size(); ++i) {              /* :136-248 */
+        orc_aln &h = hits[i];
+        bool isSec = (h.flag & 0x100);
+        bool tooLow = isSec && (primaryScore * keepSecFrac > h.score);
+        bool tooMany = isSec && (int(i) > maxSecondary);
+        if (tooLow || tooMany) { std::free(h.cigar); continue; }
+        if (!isSec) primaryScore = h.score;
+
+        orc_hit rec;
+        std::memset(&rec, 0, sizeof rec);
+        rec.rid = h.rid; rec.pos = h.pos; rec.mapq = (uint8_t)h.mapq;
+        rec.flag = (uint16_t)(h.flag | (h.is_rev ? 0x10 : 0));
+        rec.n_cigar = h.n_cigar;
+        rec.score = h.score; rec.nm = (int32_t)h.NM; rec.na = n_regs;
+
+        /* optional hard clip (:164-177): leading op-3 length and query-consuming total */
+        size_t tstart = 0, clen = (size_t)len;
+        if (hardclip) {
+            clen = 0;
+            for (int c = 0; c < h.n_cigar; ++c) {
+                uint32_t op = h.cigar[c] & 0xf, ol = h.cigar[c] >> 4;
+                if (c == 0 && op == 3) tstart = ol;
+                else if ((0x3C1A7 >> (op << 1)) & 1) clen += ol; /* bam_cigar_type(op)&1 */
+            }
+        }
+        const char *cl = seq + tstart;
+        int sl = (int)clen;
+
+        size_t l_qname = std::strlen(name) + 1;
+        std::vector<uint8_t> d;
+        d.insert(d.end(), (const uint8_t *)name, (const uint8_t *)name + l_qname);
+        /* cigar with op 3 rewritten to S(4) or H(5) (:191-202) */
+        rec.cigar = (uint32_t *)std::malloc(4 * (size_t)(h.n_cigar ? h.n_cigar : 1));
+        for (int k = 0; k < h.n_cigar; ++k) {
+            uint32_t w = h.cigar[k];
+            if ((w & 0xf) == 3) w = (w & ~0xfu) | (hardclip ? 5u : 4u);
+            rec.cigar[k] = w;
+            uint8_t raw[4]; std::memcpy(raw, &w, 4);
+            d.insert(d.end(), raw, raw + 4);
+        }
+        std::free(h.cigar);
+        /* 4-bit packed sequence (:206-233); reverse strand swaps A<->T only, C/G untouched */
+        size_t seq_off = d.size();
+        d.resize(seq_off + (size_t)((sl + 1) >> 1), 0);
+        if (h.is_rev) {
+            int j = 0;
+            for (int p = sl - 1; p >= 0; --p, ++j) {
+                uint8_t v = 15;
+                switch (cl[p]) { case 'A': v = 8; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = 1; break; }
+                d[seq_off + (size_t)(j >> 1)] |= (uint8_t)(v << ((~j & 1) << 2));
+            }
+        } else {
+            for (int p = 0; p < sl; ++p) {
+                uint8_t v = 15;
+                switch (cl[p]) { case 'A': v = 1; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = 8; break; }
+                d[seq_off + (size_t)(p >> 1)] |= (uint8_t)(v << ((~p & 1) << 2));
+            }
+        }
+        /* qualities (:235-236): byte 0 = 0xff, rest uninitialised in the reference -> zero here */
+        size_t q_off = d.size();
+        d.resize(q_off + (size_t)sl, 0);
+        if (sl > 0) d[q_off] = 0xff;
+        append_int_tag(d, "NA", n_regs);                    /* :238 */
+        append_int_tag(d, "NM", (int32_t)h.NM);             /* :239 */
+        append_int_tag(d, "AS", h.score);                   /* :241 (XA never fires) */
+        rec.l_qname = (int32_t)l_qname; rec.l_qseq = sl;
+        rec.l_data = (int32_t)d.size();
+        rec.data = (uint8_t *)std::malloc(d.size());
+        std::memcpy(rec.data, d.data(), d.size());
+        recs.push_back(rec);
+    }
+    orc_counters *cnt = orc_counters_ptr();
+    cnt->n_reads += 1; cnt->read_bases += (uint64_t)len; cnt->n_hits += recs.size();
+    for (auto &r : recs) cnt->n_cigar_ops += (uint64_t)r.n_cigar;
+    if (!recs.empty()) {
+        *out = (orc_hit *)std::malloc(recs.size() * sizeof(orc_hit));
+        std::memcpy(*out, recs.data(), recs.size() * sizeof(orc_hit));
+    }
+    return (int)recs.size();
+}
+
+extern "C" void orc_hits_free(orc_hit *h, int n)
+{
+    if (!h) return;
+    for (int i = 0; i < n; ++i) { std::free(h[i].cigar); std::free(h[i].data); }
+    std::free(h);
+}
+
+extern "C" int orc_align_batch(const orc_opt *opt, const orc_index *idx, const char *bases, const uint64_t *offs,
+                               int64_t n_reads, int hardclip, double keepSecFrac, int maxSecondary,
+                               uint64_t rng_base, uint64_t first_ordinal, orc_batch_out *o)
+{
+    std::vector<int32_t> read_idx, rid, score, nm, na, n_cigar;
+    std::vector<int64_t> pos, cig_off, hit_off;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint32_t> cigar;
+    hit_off.push_back(0); cig_off.push_back(0);
+    for (int64_t r = 0; r < n_reads; ++r) {
+        orc_hit *h = nullptr;
+        int n = orc_align_sequence(opt, idx, bases + offs[r], (int)(offs[r + 1] - offs[r]), "r", hardclip, keepSecFrac,
+                                   maxSecondary, rng_base, first_ordinal + (uint64_t)r, &h);
+        for (int i = 0; i < n; ++i) {
+            read_idx.push_back((int32_t)r); rid.push_back(h[i].rid); pos.push_back(h[i].pos); flag.push_back(h[i].flag);
+            mapq.push_back(h[i].mapq); score.push_back(h[i].score); nm.push_back(h[i].nm); na.push_back(h[i].na);
+            n_cigar.push_back(h[i].n_cigar);
+            cigar.insert(cigar.end(), h[i].cigar, h[i].cigar + h[i].n_cigar);
+            cig_off.push_back((int64_t)cigar.size());
+        }
+        hit_off.push_back((int64_t)rid.size());
+        orc_hits_free(h, n);
+    }
+    auto dup = [](const void *p, size_t bytes) { void *q = std::malloc(bytes ? bytes : 1); std::memcpy(q, p, bytes); return q; };
+    o->n_hits = (int64_t)rid.size();
+    o->read_idx = (int32_t *)dup(read_idx.data(), read_idx.size() * 4);
+    o->rid = (int32_t *)dup(rid.data(), rid.size() * 4);
+    o->score = (int32_t *)dup(score.data(), score.size() * 4);
+    o->nm = (int32_t *)dup(nm.data(), nm.size() * 4);
+    o->na = (int32_t *)dup(na.data(), na.size() * 4);
+    o->n_cigar = (int32_t *)dup(n_cigar.data(), n_cigar.size() * 4);
+    o->pos = (int64_t *)dup(pos.data(), pos.size() * 8);
+    o->flag = (uint16_t *)dup(flag.data(), flag.size() * 2);
+    o->mapq = (uint8_t *)dup(mapq.data(), mapq.size());
+    o->cig_off = (int64_t *)dup(cig_off.data(), cig_off.size() * 8);
+    o->cigar = (uint32_t *)dup(cigar.data(), cigar.size() * 4);
+    o->hit_off = (int64_t *)dup(hit_off.data(), hit_off.size() * 8);
+    return (int)o->n_hits;
+}
+
+extern "C" void orc_batch_free(orc_batch_out *o)
+{
+    std::free(o->read_idx); std::free(o->rid); std::free(o->score); std::free(o->nm); std::free(o->na);
+    std::free(o->n_cigar); std::free(o->pos); std::free(o->flag); std::free(o->mapq); std::free(o->cig_off);
+    std::free(o->cigar); std::free(o->hit_off);
+    std::memset(o, 0, sizeof *o);
+}

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as _orc
+    _orc.lib()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def tiny_index(orc):
+    return orc.Index.load(os.path.join(GOLDEN, "tiny.fa"))
+
+
+@pytest.fixture(scope="session")
+def sim_reads(orc):
+    n1, s1 = orc.read_fastq(os.path.join(GOLDEN, "sim1_bcr.head3000.fq"))
+    n2, s2 = orc.read_fastq(os.path.join(GOLDEN, "sim2_bcr.head3000.fq"))
+    return (n1, s1), (n2, s2)
