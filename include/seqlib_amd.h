@@ -1,0 +1,148 @@
+/*
+ * seqlib_amd.h -- C-ABI of the MI355X-native BWAAligner hot path (libseqlib_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types, never throws.
+ * Every function returns 0 on success or a negative SLX_E* code; slx_last_error() gives the text
+ * (thread-local).  The C++ mirror of the reference's classes (include/SeqLib/BWAAligner.h,
+ * BWAIndex.h, BamRecord.h, UnalignedSequence.h) is a thin header-only wrapper over these entry
+ * points that turns error codes back into the exceptions the reference throws.
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference):
+ *   slx_opt_init        mem_opt_init() + MEM_F_SOFTCLIP          SeqLib/BWAAligner.h:14-18
+ *   slx_fill_scmat      bwa_fill_scmat()                          src/BWAAligner.cpp:32-33
+ *   slx_index_build     BWAIndex::ConstructIndex                  src/BWAIndex.cpp:83-180
+ *   slx_index_load      BWAIndex::LoadIndex -> bwa_idx_load       src/BWAIndex.cpp:28-33
+ *   slx_index_write     BWAIndex::WriteIndex                      src/BWAIndex.cpp:382-406
+ *   slx_index_free      BWAIndex::~BWAIndex -> bwa_idx_destroy    src/BWAIndex.cpp:16-21
+ *   slx_index_nseq/name/len/l_pac/n_holes                         src/BWAIndex.cpp:44-78,408-417
+ *   slx_aligner_create  BWAAligner::BWAAligner(BWAIndexPtr)       SeqLib/BWAAligner.h:14-18
+ *   slx_aligner_free    BWAAligner::~BWAAligner                   SeqLib/BWAAligner.h:20-22
+ *   slx_align_batch     n successive BWAAligner::alignSequence calls: mem_align1 + mem_reg2aln +
+ *                       the hit sort/filter glue                  src/BWAAligner.cpp:89-146
+ *                       (record materialisation :151-248 stays in the C++ mirror)
+ *   slx_lrand48_*       the libc lrand48() stream mem_align1 consumes
+ */
+#ifndef SEQLIB_AMD_H
+#define SEQLIB_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLX_OK            0
+#define SLX_EINVAL      (-1)   /* bad argument (empty name/sequence, negative penalty, ...) */
+#define SLX_EIO         (-2)   /* index file missing/corrupt, cannot write */
+#define SLX_ENOMEM      (-3)
+#define SLX_ENODEVICE   (-4)   /* no usable MI355X / HIP runtime error: the hot path has NO CPU fallback */
+#define SLX_EUNSUPPORTED (-5)  /* read longer than the GPU path supports (SLX_MAX_READ_LEN) */
+#define SLX_EINTERNAL   (-6)
+
+/* Reads at or above this length enter bwa's mem_flt_chained_seeds/ksw_align2 branch (live when
+ * 5.5*ln(L) <= 0.05*L, i.e. L >= ~727), which this round's GPU path does not implement. */
+#define SLX_MAX_READ_LEN 700
+
+/* mirrors bwa's mem_opt_t (fields the single-end path reads) */
+typedef struct {
+    int a, b;
+    int o_del, e_del, o_ins, e_ins;
+    int pen_unpaired;
+    int pen_clip5, pen_clip3;
+    int w, zdrop;
+    int T;
+    int flag;
+    int min_seed_len;
+    int min_chain_weight;
+    int max_chain_extend;
+    float split_factor;
+    int split_width;
+    int max_occ;
+    int max_chain_gap;
+    int max_mem_intv;
+    float mask_level;
+    float drop_ratio;
+    float mask_level_redun;
+    float mapQ_coef_len;
+    int mapQ_coef_fac;
+    int8_t mat[25];
+} slx_opt;
+
+typedef struct slx_index slx_index;
+typedef struct slx_aligner slx_aligner;
+
+void slx_opt_init(slx_opt *opt);
+void slx_fill_scmat(int a, int b, int8_t mat[25]);
+
+/* ---- index (host object in bwa's on-disk layout; uploaded to HBM by slx_aligner_create) ---- */
+/* Needs a GPU (suffix sorting runs on the device).  N bases are replaced by lrand48()&3 from the
+ * process's real libc stream, once for the forward pac and once for the BWT text, as the reference does. */
+int  slx_index_build(const char *const *names, const char *const *seqs, const int64_t *lens, int n, slx_index **out);
+int  slx_index_load(const char *prefix, slx_index **out);
+int  slx_index_write(const slx_index *idx, const char *prefix);
+void slx_index_free(slx_index *idx);
+int  slx_index_nseq(const slx_index *idx);
+const char *slx_index_name(const slx_index *idx, int i);
+int64_t slx_index_len(const slx_index *idx, int i);
+int64_t slx_index_l_pac(const slx_index *idx);
+int  slx_index_n_holes(const slx_index *idx);
+
+/* ---- aligner (device-resident FM-index + workspaces on one GPU) ---- */
+/* devices/n_dev: HIP device ordinals; this round one aligner drives devices[0] (one process per GPU).
+ * NULL/0 = current device. */
+int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
+void slx_aligner_free(slx_aligner *al);
+/* tuning / test knobs: "chunk_reads", "cap_intv", "dense_sa" (1 = SA decompressed to sa_intv 1 in HBM,
+ * 0 = bwa's sa_intv walk), "threads" */
+int  slx_aligner_set(slx_aligner *al, const char *key, int64_t value);
+
+/* SoA result of a batch.  Hits of read i are [hit_off[i], hit_off[i+1]) in output order (after the
+ * reference's sort by mapq desc, rid, pos and its secondary filters).  cigar holds BAM op codes
+ * (bwa's op 3 already rewritten to S=4, or H=5 when hardclip).  flag includes 0x10 / 0x100. */
+typedef struct {
+    int64_t   n_reads;
+    int64_t   n_hits;
+    int64_t   n_cigar;      /* total cigar words */
+    int64_t  *hit_off;      /* n_reads + 1 */
+    int32_t  *rid;
+    int64_t  *pos;
+    uint16_t *flag;
+    uint8_t  *mapq;
+    int32_t  *score;        /* AS */
+    int32_t  *nm;           /* NM */
+    int32_t  *na;           /* NA = number of regions of the read */
+    int32_t  *n_cigar_ops;
+    int64_t  *cig_off;      /* n_hits + 1 */
+    uint32_t *cigar;
+    int       on_device;    /* 1: pointers are device pointers owned by the aligner (valid until its next call) */
+} slx_hits;
+
+/* bases/offs on the HOST: read i is bases[offs[i] .. offs[i+1]) in ASCII.  Read i behaves as the
+ * i-th successive alignSequence call: it consumes lrand48 draw number first_ordinal+i of the stream
+ * whose state before draw 0 is rng_state (0 = unseeded glibc).  Results copied to malloc'd host arrays. */
+int  slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
+                     uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary,
+                     slx_hits *out);
+/* Same, with bases/offs already resident in HBM and results left in HBM (out->on_device = 1). */
+int  slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_bases, const void *d_offs,
+                            int64_t n_reads, uint64_t rng_state, uint64_t first_ordinal, int hardclip,
+                            double keepSecFrac, int maxSecondary, slx_hits *out);
+void slx_hits_free(slx_hits *h);          /* host results only */
+
+/* per-stage kernel time of the last batch, measured with HIP events on the aligner's stream (ms) */
+#define SLX_N_STAGES 8
+int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
+const char *slx_stage_name(int i);
+
+/* libc lrand48 stream helpers */
+uint64_t slx_lrand48_advance(uint64_t state, uint64_t n);   /* state after n draws */
+uint64_t slx_lrand48_peek_libc(void);                       /* this process's current libc state */
+void     slx_lrand48_skip_libc(uint64_t n);                 /* advance the libc state by n draws */
+
+const char *slx_last_error(void);
+const char *slx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,169 @@
+// dev_chain.h -- seed lookup + chaining + chain filtering: bwa's mem_chain (SA lookup of every seed
+// occurrence, test_and_merge into an ordered set of chains), mem_chain_weight and mem_chain_flt, as
+// reached from /root/reference/src/BWAAligner.cpp:104 (mem_align1 -> mem_align1_core).
+// SURVEY.md Appendix A.3, A.6.  One lane per read; every list lives in the read's seed-slot region.
+#pragma once
+#include "dev_fm.h"
+#include "dev_sort.h"
+#include "dev_types.h"
+
+struct ReadWS {               // views into the per-seed-slot arrays for one read
+    int64_t *s_rbeg; uint32_t *s_ql; int32_t *s_next;
+    int64_t *c_pos; int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first; int8_t *c_kept;
+    int32_t *ia, *ib, *ic; uint64_t *srt;
+    DReg *regs; DHit *hits;
+    int cap;
+    __device__ __forceinline__ int s_qbeg(int s) const { return (int)(s_ql[s] >> 16); }
+    __device__ __forceinline__ int s_len(int s) const { return (int)(s_ql[s] & 0xffff); }
+};
+
+__device__ __forceinline__ ReadWS make_ws(const Chunk &ck, int r)
+{
+    const uint64_t o = ck.seed_off[r];
+    ReadWS w;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o;
+    w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
+    w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
+    w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
+    w.regs = ck.regs + o; w.hits = ck.hits + o;
+    w.cap = (int)(ck.seed_off[r + 1] - o);
+    return w;
+}
+
+// mem_chain_weight
+__device__ inline int dev_chain_weight(const ReadWS &w, int c)
+{
+    int64_t end = 0;
+    int wt = 0, tmp;
+    for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) {
+        const int qb = w.s_qbeg(s), l = w.s_len(s);
+        if (qb >= end) wt += l;
+        else if (qb + l > end) wt += (int)(qb + l - end);
+        end = end > qb + l ? end : qb + l;
+    }
+    tmp = wt; wt = 0; end = 0;
+    for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) {
+        const int64_t rb = w.s_rbeg[s]; const int l = w.s_len(s);
+        if (rb >= end) wt += l;
+        else if (rb + l > end) wt += (int)(rb + l - end);
+        end = end > rb + l ? end : rb + l;
+    }
+    wt = wt < tmp ? wt : tmp;
+    return wt < 1 << 30 ? wt : (1 << 30) - 1;
+}
+
+template <typename I>
+__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt)
+{
+    const slx_opt &opt = dopt.o;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int r = tid; r < ck.n_reads; r += ck.n_threads) {
+        ReadWS w = make_ws(ck, r);
+        const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
+        const int n_intv = (int)ck.intv_n[r];
+        const uint32_t *iinfo = ck.intv_info + (size_t)r * ck.cap_intv;
+        const I *ix0 = (const I *)ck.intv_x0 + (size_t)r * ck.cap_intv;
+        const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
+        int ns = 0, nc = 0;                      // seeds stored, chains
+        int *ord = w.ia;                         // chain handles ordered by pos (stands in for bwa's kbtree)
+        for (int i = 0; i < n_intv; ++i) {
+            const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
+            const I x2 = ix2[i];
+            const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
+            I k = 0;
+            for (int count = 0; k < x2 && count < opt.max_occ; k += step, ++count) {
+                const int64_t rbeg = fm_sa<I>(fm, ix0[i] + k);
+                const int rid = dev_intv2rid(R, rbeg, rbeg + slen);
+                if (rid < 0) continue;           // bridges two contigs or the forward/reverse boundary
+                // lower = first chain with pos == rbeg, else the chain with the largest pos < rbeg
+                int lo = -1;
+                bool to_add = true;
+                if (nc) {
+                    int b = 0, e = nc;
+                    while (b < e) { int m = (b + e) >> 1; if (w.c_pos[ord[m]] < rbeg) b = m + 1; else e = m; }
+                    if (b == nc) lo = nc - 1;
+                    else lo = rbeg < w.c_pos[ord[b]] ? b - 1 : b;
+                    if (lo >= 0) {               // test_and_merge
+                        const int c = ord[lo];
+                        const int first = w.c_head[c], last = w.c_tail[c];
+                        const int l_qbeg = w.s_qbeg(last), l_len = w.s_len(last);
+                        const int64_t l_rbeg = w.s_rbeg[last];
+                        const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
+                        int res;
+                        if (rid != w.c_rid[c]) res = 0;
+                        else if (qbeg >= w.s_qbeg(first) && qbeg + slen <= qend && rbeg >= w.s_rbeg[first] && rbeg + slen <= rend) res = 1; // contained
+                        else if ((l_rbeg < R.l_pac || w.s_rbeg[first] < R.l_pac) && rbeg >= R.l_pac) res = 0;
+                        else {
+                            const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
+                            if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
+                                const int s = ns++;
+                                w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                                w.s_next[last] = s; w.c_tail[c] = s; ++w.c_n[c];
+                                res = 1;
+                            } else res = 0;
+                        }
+                        to_add = !res;
+                    }
+                }
+                if (to_add) {
+                    const int s = ns++, c = nc;
+                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                    w.c_pos[c] = rbeg; w.c_head[c] = w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
+                    for (int m = nc; m > lo + 1; --m) ord[m] = ord[m - 1];
+                    ord[lo + 1] = c;
+                    ++nc;
+                }
+            }
+        }
+        ck.frac_rep[r] = (float)ck.l_rep[r] / len;
+        // ---------------- mem_chain_flt
+        int n_chn = 0;
+        int *a = w.ia;                           // chains in pos order, then sorted by weight
+        for (int i = 0; i < nc; ++i) {
+            const int c = a[i];
+            w.c_first[c] = -1; w.c_kept[c] = 0;
+            w.c_w[c] = dev_chain_weight(w, c);
+            if (w.c_w[c] >= opt.min_chain_weight) a[n_chn++] = c;
+        }
+        int n_out = 0;
+        if (n_chn > 0) {
+            ks_introsort_idx(n_chn, a, [&](int x, int y) { return w.c_w[x] > w.c_w[y]; });
+            int *kept = w.ib, n_kept = 0;        // positions in a[] of non-overlapping chains
+            auto cbeg = [&](int c) { return w.s_qbeg(w.c_head[c]); };
+            auto cend = [&](int c) { return w.s_qbeg(w.c_tail[c]) + w.s_len(w.c_tail[c]); };
+            w.c_kept[a[0]] = 3;
+            kept[n_kept++] = 0;
+            for (int i = 1; i < n_chn; ++i) {
+                int large_ovlp = 0, k;
+                const int ci = a[i];
+                for (k = 0; k < n_kept; ++k) {
+                    const int j = kept[k], cj = a[j];
+                    const int b_max = cbeg(cj) > cbeg(ci) ? cbeg(cj) : cbeg(ci);
+                    const int e_min = cend(cj) < cend(ci) ? cend(cj) : cend(ci);
+                    if (e_min > b_max) {         // overlap on the query (no ALT contigs on this path)
+                        const int li = cend(ci) - cbeg(ci), lj = cend(cj) - cbeg(cj);
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+                            large_ovlp = 1;
+                            if (w.c_first[cj] < 0) w.c_first[cj] = i;
+                            if ((float)w.c_w[ci] < (float)w.c_w[cj] * opt.drop_ratio && w.c_w[cj] - w.c_w[ci] >= opt.min_seed_len << 1) break;
+                        }
+                    }
+                }
+                if (k == n_kept) { kept[n_kept++] = i; w.c_kept[ci] = large_ovlp ? 2 : 3; }
+            }
+            for (int i = 0; i < n_kept; ++i) {
+                const int c = a[kept[i]];
+                if (w.c_first[c] >= 0) w.c_kept[a[w.c_first[c]]] = 1;
+            }
+            int i, k;
+            for (i = k = 0; i < n_chn; ++i) {    // at most max_chain_extend chains of kind 1/2
+                if (w.c_kept[a[i]] == 0 || w.c_kept[a[i]] == 3) continue;
+                if (++k >= opt.max_chain_extend) break;
+            }
+            for (; i < n_chn; ++i) if (w.c_kept[a[i]] < 3) w.c_kept[a[i]] = 0;
+            for (i = 0; i < n_chn; ++i) if (w.c_kept[a[i]] != 0) a[n_out++] = a[i];
+        }
+        ck.n_chain[r] = n_out;                   // kept chains, in extension order, are a[0..n_out)
+    }
+}

@@ -1,0 +1,453 @@
+// dev_fin.h -- everything after extension, one lane per read:
+//   mem_sort_dedup_patch + mem_patch_reg, mem_mark_primary_se  (still inside mem_align1,
+//       /root/reference/src/BWAAligner.cpp:104-109)
+//   mem_reg2aln: mem_approx_mapq_se, infer_bw, bwa_gen_cigar2 -> ksw_global2 + traceback, NM
+//       (/root/reference/src/BWAAligner.cpp:117-129)
+//   the SeqLib glue's hit sort and secondary filters (/root/reference/src/BWAAligner.cpp:133-146)
+// SURVEY.md Appendix A.9-A.11, C.3.  Floating-point decisions keep C's promotion rules; log() comes
+// from a table the host fills with its own libm so that MAPQ cannot differ by an ulp.
+#pragma once
+#include "dev_ext.h"
+
+#define DEV_MINUS_INF (-0x40000000)
+
+// ksw_global2 (score; direction bytes into z when z != nullptr)
+template <typename QF, typename TF>
+__device__ int dev_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, uint8_t *z, int n_col, int *eh_h, int *eh_e)
+{
+    const int8_t *mat = o.mat;
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int i, j;
+    eh_h[0] = 0; eh_e[0] = DEV_MINUS_INF;
+    for (j = 1; j <= qlen && j <= w; ++j) { eh_h[j] = -(o_ins + e_ins * j); eh_e[j] = DEV_MINUS_INF; }
+    for (; j <= qlen; ++j) eh_h[j] = eh_e[j] = DEV_MINUS_INF;
+    for (i = 0; i < tlen; ++i) {
+        int f = DEV_MINUS_INF, h1, beg, end, t;
+        const int8_t *qrow = mat + tf(i) * 5;
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_MINUS_INF;
+        uint8_t *zi = z ? z + (size_t)i * n_col : nullptr;
+        for (j = beg; j < end; ++j) {
+            int h, m = eh_h[j], e = eh_e[j];
+            uint8_t d;
+            eh_h[j] = h1;
+            m += qrow[qf(j)];
+            d = m >= e ? 0 : 1;
+            h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = m - oe_del;
+            e -= e_del;
+            d |= e > t ? 1 << 2 : 0;
+            e = e > t ? e : t;
+            eh_e[j] = e;
+            t = m - oe_ins;
+            f -= e_ins;
+            d |= f > t ? 2 << 4 : 0;
+            f = f > t ? f : t;
+            if (zi) zi[j - beg] = d;
+        }
+        eh_h[end] = h1; eh_e[end] = DEV_MINUS_INF;
+    }
+    return eh_h[qlen];
+}
+
+// traceback; F(op, len) is called for merged ops from the END of the alignment to its start
+template <typename F>
+__device__ void dev_traceback(const uint8_t *z, int n_col, int qlen, int tlen, int w, F emit)
+{
+    int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+    int cur_op = -1, cur_len = 0;
+    auto unit = [&](int op, int len) {
+        if (op == cur_op) cur_len += len;
+        else { if (cur_op >= 0) emit(cur_op, cur_len); cur_op = op; cur_len = len; }
+    };
+    while (i >= 0 && k >= 0) {
+        which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+        if (which == 0) { unit(0, 1); --i; --k; }
+        else if (which == 1) { unit(2, 1); --i; }
+        else { unit(1, 1); --k; }
+    }
+    if (i >= 0) unit(2, i + 1);
+    if (k >= 0) unit(1, k + 1);
+    if (cur_op >= 0) emit(cur_op, cur_len);
+}
+
+struct GenCig {               // state of one bwa_gen_cigar2 call, kept so that the traceback can run later
+    int score;
+    bool valid;               // false: rejected (bridging / empty)
+    bool fast;                // no-DP path: single M op
+    bool rev;                 // both sequences reversed (rb >= l_pac)
+    int w, n_col, qlen, tlen;
+    uint8_t *z;
+};
+
+// bwa_gen_cigar2 up to and including the DP (no traceback)
+template <int MAXQ>
+__device__ GenCig dev_gen_cigar2(const DevRef &R, const slx_opt &o, const Chunk &ck, int w_, int l_query, const uint8_t *qseg,
+                                 int64_t rb, int64_t re, bool want_z, int *eh_h, int *eh_e)
+{
+    GenCig g;
+    g.score = 0; g.valid = false; g.fast = false; g.rev = false; g.w = 0; g.n_col = 0; g.qlen = l_query; g.tlen = 0; g.z = nullptr;
+    if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return g;
+    g.valid = true;
+    const int rlen = (int)(re - rb);
+    g.tlen = rlen;
+    g.rev = rb >= R.l_pac;
+    const bool rev = g.rev;
+    auto qf = [&](int j) { return (int)(rev ? qseg[l_query - 1 - j] : qseg[j]); };
+    auto tf = [&](int i) { return rev ? ref_base(R, re - 1 - i) : ref_base(R, rb + i); };
+    if (l_query == rlen && w_ == 0) {
+        g.fast = true;
+        int sc = 0;
+        for (int i = 0; i < l_query; ++i) sc += o.mat[tf(i) * 5 + qf(i)];
+        g.score = sc;
+    } else {
+        int w, max_gap, max_ins, max_del, min_w;
+        max_ins = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_ins) / o.e_ins + 1.);
+        max_del = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_del) / o.e_del + 1.);
+        max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
+        w = (max_gap + dl + 1) >> 1;
+        w = w < w_ ? w : w_;
+        min_w = dl + 3;
+        w = w > min_w ? w : min_w;
+        g.w = w;
+        g.n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
+        if (want_z) {
+            const unsigned long long need = (unsigned long long)g.n_col * (unsigned long long)rlen;
+            const unsigned long long off = atomicAdd(ck.zused, need);
+            if (off + need > ck.zcap) { atomicOr(ck.flags, OVF_ZARENA); g.valid = false; return g; }
+            g.z = ck.zarena + off;
+        }
+        g.score = dev_ksw_global2(l_query, qf, rlen, tf, o, w, g.z, g.n_col, eh_h, eh_e);
+    }
+    return g;
+}
+
+// mem_patch_reg
+template <int MAXQ>
+__device__ int dev_patch_reg(const DevRef &R, const slx_opt &o, const Chunk &ck, const uint8_t *query, const DReg &a, const DReg &b,
+                             int *_w, int *eh_h, int *eh_e)
+{
+    int w, score, q_s, r_s;
+    double r;
+    if (a.rb < R.l_pac && b.rb >= R.l_pac) return 0;
+    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+    w = (int)((a.re - b.rb) - (a.qe - b.qb));
+    w = w > 0 ? w : -w;
+    r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
+    r = r > 0. ? r : -r;
+    if (a.re < b.rb || a.qe < b.qb) {
+        if (w > o.w << 1 || r >= (double)0.05f) return 0;
+    } else if (w > o.w << 2 || r >= (double)(0.05f * 2)) return 0;
+    w += a.w + b.w;
+    w = w < o.w << 2 ? w : o.w << 2;
+    GenCig g = dev_gen_cigar2<MAXQ>(R, o, ck, w, b.qe - a.qb, query + a.qb, a.rb, b.re, false, eh_h, eh_e);
+    score = g.score;
+    q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
+    r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (double)(b.score + a.score) + .499);
+    if ((double)score / (double)(q_s > r_s ? q_s : r_s) < (double)0.90f) return 0;
+    *_w = w;
+    return score;
+}
+
+__device__ __forceinline__ uint64_t dev_hash_64(uint64_t key)
+{
+    key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+    key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+    return key;
+}
+
+__device__ __forceinline__ uint64_t dev_lrand48_nth(uint64_t state, uint64_t n)
+{   // value of the n-th draw (n >= 1) of glibc's 48-bit LCG starting at `state`
+    const uint64_t M = (1ULL << 48) - 1;
+    uint64_t a = 0x5DEECE66DULL, c = 0xBULL, ra = 1, rc = 0;
+    while (n) {
+        if (n & 1) { ra = (ra * a) & M; rc = (rc * a + c) & M; }
+        c = ((a + 1) * c) & M;
+        a = (a * a) & M;
+        n >>= 1;
+    }
+    return ((ra * (state & M) + rc) & M) >> 17;
+}
+
+__device__ __forceinline__ int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
+{
+    int w;
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    const int d = l1 - l2 < 0 ? l2 - l1 : l1 - l2;
+    if (w < d) w = d;
+    return w;
+}
+
+__device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const Chunk &ck)
+{
+    int mapq, l, sub = a.sub ? a.sub : o.min_seed_len * o.a;
+    double identity;
+    sub = a.csub > sub ? a.csub : sub;
+    if (sub >= a.score) return 0;
+    l = a.qe - a.qb > a.re - a.rb ? a.qe - a.qb : (int)(a.re - a.rb);
+    identity = 1. - (double)(l * o.a - a.score) / (double)(o.a + o.b) / (double)l;
+    if (a.score == 0) mapq = 0;
+    else if (o.mapQ_coef_len > 0) {
+        double tmp;
+        if ((float)l < o.mapQ_coef_len) tmp = 1.;
+        else {
+            if (l >= ck.log_lut_n) { atomicOr(ck.flags, ERR_LOGLUT); return 0; }
+            tmp = (double)o.mapQ_coef_fac / ck.log_lut[l];
+        }
+        tmp *= identity * identity;
+        mapq = (int)(6.02 * (double)(a.score - sub) / (double)o.a * tmp * tmp + .499);
+    } else {
+        if (a.seedcov >= ck.log_lut_n || a.seedcov < 1) { atomicOr(ck.flags, ERR_LOGLUT); return 0; }
+        mapq = (int)(30.0 * (1. - (double)sub / (double)a.score) * ck.log_lut[a.seedcov] + .499);
+        mapq = identity < 0.95 ? (int)((double)mapq * identity * identity + .499) : mapq;
+    }
+    if (a.sub_n > 0) {
+        if (a.sub_n + 1 >= ck.log_lut_n) { atomicOr(ck.flags, ERR_LOGLUT); return 0; }
+        mapq -= (int)(4.343 * ck.log_lut[a.sub_n + 1] + .499);
+    }
+    if (mapq > 60) mapq = 60;
+    if (mapq < 0) mapq = 0;
+    mapq = (int)((double)mapq * (1. - (double)a.frac_rep) + .499);
+    return mapq;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt)
+{
+    const slx_opt &opt = dopt.o;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    for (int r = tid; r < ck.n_reads; r += ck.n_threads) {
+        ReadWS w = make_ws(ck, r);
+        const uint8_t *query = ck.codes + ck.offs[r];
+        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+        int n = ck.n_reg[r];
+        int *a = w.ia;                            // region handles
+        DReg *G = w.regs;
+        for (int i = 0; i < n; ++i) a[i] = i;
+        // ---------------- mem_sort_dedup_patch
+        if (n > 1) {
+            ks_introsort_idx(n, a, [&](int x, int y) { return G[x].re < G[y].re; });
+            for (int i = 0; i < n; ++i) G[a[i]].n_comp = 1;
+            for (int i = 1; i < n; ++i) {
+                DReg &p = G[a[i]];
+                if (p.rid != G[a[i - 1]].rid || p.rb >= G[a[i - 1]].re + opt.max_chain_gap) continue;
+                for (int j = i - 1; j >= 0 && p.rid == G[a[j]].rid && p.rb < G[a[j]].re + opt.max_chain_gap; --j) {
+                    DReg &q = G[a[j]];
+                    int64_t orr, oq, mr, mq;
+                    int score, ww;
+                    if (q.qe == q.qb) continue;
+                    orr = q.re - p.rb;
+                    oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+                    mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+                    mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+                    if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+                        if (p.score < q.score) { p.qe = p.qb; break; }
+                        else q.qe = q.qb;
+                    } else if (q.rb < p.rb && (score = dev_patch_reg<MAXQ>(R, opt, ck, query, q, p, &ww, eh_h, eh_e)) > 0) {
+                        p.n_comp += q.n_comp + 1;
+                        p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
+                        p.sub = p.sub > q.sub ? p.sub : q.sub;
+                        p.csub = p.csub > q.csub ? p.csub : q.csub;
+                        p.qb = q.qb; p.rb = q.rb;
+                        p.truesc = p.score = score;
+                        p.w = ww;
+                        q.qb = q.qe;
+                    }
+                }
+            }
+            int m = 0;
+            for (int i = 0; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
+            n = m;
+            ks_introsort_idx(n, a, [&](int x, int y) {
+                const DReg &X = G[x], &Y = G[y];
+                return X.score > Y.score || (X.score == Y.score && (X.rb < Y.rb || (X.rb == Y.rb && X.qb < Y.qb)));
+            });
+            for (int i = 1; i < n; ++i)
+                if (G[a[i]].score == G[a[i - 1]].score && G[a[i]].rb == G[a[i - 1]].rb && G[a[i]].qb == G[a[i - 1]].qb)
+                    G[a[i]].qe = G[a[i]].qb;
+            m = n > 0 ? 1 : 0;
+            for (int i = 1; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
+            n = m;
+        }
+        ck.na[r] = n;
+        // ---------------- mem_mark_primary_se (salt = this read's lrand48() draw)
+        if (n > 0) {
+            const uint64_t id = dev_lrand48_nth(ck.rng_state, ck.first_ordinal + (uint64_t)r + 1);
+            for (int i = 0; i < n; ++i) {
+                DReg &p = G[a[i]];
+                p.sub = 0; p.secondary = -1;
+                p.hash = dev_hash_64(id + (uint64_t)i);
+            }
+            ks_introsort_idx(n, a, [&](int x, int y) {
+                const DReg &X = G[x], &Y = G[y];
+                return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // is_alt is 0 for every region
+            });
+            int tmp = opt.a + opt.b;
+            tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
+            tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
+            int *z = w.ib, nz = 0;
+            z[nz++] = 0;
+            for (int i = 1; i < n; ++i) {
+                int k;
+                DReg &ai = G[a[i]];
+                for (k = 0; k < nz; ++k) {
+                    DReg &aj = G[a[z[k]]];
+                    const int b_max = aj.qb > ai.qb ? aj.qb : ai.qb;
+                    const int e_min = aj.qe < ai.qe ? aj.qe : ai.qe;
+                    if (e_min > b_max) {
+                        const int min_l = ai.qe - ai.qb < aj.qe - aj.qb ? ai.qe - ai.qb : aj.qe - aj.qb;
+                        if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) {
+                            if (aj.sub == 0) aj.sub = ai.score;
+                            if (aj.score - ai.score <= tmp) ++aj.sub_n;
+                            break;
+                        }
+                    }
+                }
+                if (k == nz) z[nz++] = i;
+                else ai.secondary = z[k];
+            }
+        }
+        // ---------------- glue: reg2aln for every region the caller keeps (src/BWAAligner.cpp:117-129)
+        int nh = 0;
+        int *hh = w.ic;                           // hit handles
+        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+        for (int i = 0; i < n; ++i) {
+            const DReg &ar = G[a[i]];
+            if (ar.secondary != 0 && drop_sec) continue;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
+            DHit h;
+            h.flag = 0; h.n_cigar = 0; h.cig_start = 0; h.nm = -1;
+            const int qb = ar.qb, qe = ar.qe;
+            const int64_t rb = ar.rb, re = ar.re;
+            h.mapq = ar.secondary < 0 ? dev_approx_mapq_se(opt, ar, ck) : 0;
+            if (ar.secondary >= 0) h.flag |= 0x100;
+            int tmp = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+            int w2 = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+            w2 = w2 > tmp ? w2 : tmp;
+            if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+            int it = 0, score, last_sc = -(1 << 30);
+            GenCig g;
+            do {
+                w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+                g = dev_gen_cigar2<MAXQ>(R, opt, ck, w2, qe - qb, query + qb, rb, re, true, eh_h, eh_e);
+                score = g.score;
+                if (score == last_sc || w2 == opt.w << 2) break;
+                last_sc = score;
+                w2 <<= 1;
+            } while (++it < 3 && score < ar.truesc - opt.a);
+            int is_rev;
+            int64_t pos = dev_depos(R, rb < R.l_pac ? rb : re - 1, &is_rev);
+            // cigar: [slot for 5' clip][ops][slot for 3' clip] in the pool
+            int n_ops = 0;
+            if (g.valid) {
+                if (g.fast) n_ops = 1;
+                else dev_traceback(g.z, g.n_col, g.qlen, g.tlen, g.w, [&](int, int) { ++n_ops; });
+            }
+            const unsigned long long need = (unsigned long long)n_ops + 2;
+            const unsigned long long base = atomicAdd(ck.cigused, need);
+            if (base + need > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
+            uint32_t *cg = ck.cigpool + base + 1;
+            if (g.valid) {
+                if (g.fast) cg[0] = (uint32_t)g.qlen << 4;
+                else { int wp = n_ops; dev_traceback(g.z, g.n_col, g.qlen, g.tlen, g.w, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; }); }
+                // NM = mismatches in M + inserted + deleted bases (a D that is the first or last op is not counted)
+                const bool rev = g.rev;
+                const uint8_t *qseg = query + qb;
+                const int lq = qe - qb;
+                int x = 0, y = 0, n_mm = 0, n_gap = 0;
+                for (int k = 0; k < n_ops; ++k) {
+                    const int op = (int)(cg[k] & 0xf), len = (int)(cg[k] >> 4);
+                    if (op == 0) {
+                        for (int u = 0; u < len; ++u) {
+                            const int qc = rev ? qseg[lq - 1 - (x + u)] : qseg[x + u];
+                            const int tc = rev ? ref_base(R, re - 1 - (y + u)) : ref_base(R, rb + y + u);
+                            if (qc != tc) ++n_mm;
+                        }
+                        x += len; y += len;
+                    } else if (op == 2) { if (k > 0 && k < n_ops - 1) n_gap += len; y += len; }
+                    else if (op == 1) { x += len; n_gap += len; }
+                }
+                h.nm = n_mm + n_gap;
+            }
+            int64_t cs = (int64_t)base + 1;
+            int nc = n_ops;
+            if (nc > 0) {                         // squeeze out a leading or else a trailing deletion
+                if ((ck.cigpool[cs] & 0xf) == 2) { pos += ck.cigpool[cs] >> 4; ++cs; --nc; }
+                else if ((ck.cigpool[cs + nc - 1] & 0xf) == 2) --nc;
+            }
+            if (qb != 0 || qe != l_query) {       // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
+                const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+                const uint32_t cop = ck.hardclip ? 5u : 4u;
+                if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
+                if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
+            }
+            h.rid = dev_pos2rid(R, pos);
+            h.pos = pos - R.ann_off[h.rid];
+            h.score = ar.score;
+            if (is_rev) h.flag |= 0x10;
+            h.n_cigar = nc; h.cig_start = cs;
+            w.hits[nh] = h; hh[nh] = nh; ++nh;
+        }
+        // ---------------- std::sort(hits, aln_sort) then the secondary filters (src/BWAAligner.cpp:133-146)
+        std_sort_idx(nh, hh, [&](int x, int y) {
+            const DHit &A = w.hits[x], &B = w.hits[y];
+            if (A.mapq != B.mapq) return A.mapq > B.mapq;
+            if (A.rid != B.rid) return A.rid < B.rid;
+            return A.pos < B.pos;
+        });
+        double primaryScore = 0;
+        int n_out = 0;
+        for (int i = 0; i < nh; ++i) {
+            const DHit &h = w.hits[hh[i]];
+            const bool isSec = (h.flag & 0x100) != 0;
+            const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)h.score);
+            const bool tooMany = isSec && (i > ck.maxSecondary);
+            if (tooLow || tooMany) continue;
+            if (!isSec) primaryScore = (double)h.score;
+            hh[n_out++] = hh[i];
+        }
+        ck.n_hit[r] = n_out;
+    }
+}
+
+// ---------------------------------------------------------------- compaction into the SoA result
+struct HitsSoA {
+    int64_t *hit_off; int32_t *rid; int64_t *pos; uint16_t *flag; uint8_t *mapq; int32_t *score, *nm, *na, *n_cigar_ops;
+    int64_t *cig_off; uint32_t *cigar;
+};
+
+__global__ void k_hit_counts(Chunk ck, unsigned long long *n_cig_words)
+{   // per read: number of cigar words of its surviving hits
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ck.n_reads) return;
+    const uint64_t o = ck.seed_off[r];
+    unsigned long long c = 0;
+    for (int i = 0; i < ck.n_hit[r]; ++i) c += (unsigned long long)ck.hits[o + ck.ic[o + i]].n_cigar;
+    n_cig_words[r] = c;
+}
+
+__global__ void k_compact(Chunk ck, const unsigned long long *hit_off, const unsigned long long *cig_off_read, HitsSoA out,
+                          int64_t read_base, int64_t hit_base, int64_t cig_base)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ck.n_reads) return;
+    const uint64_t o = ck.seed_off[r];
+    int64_t ho = hit_base + (int64_t)hit_off[r];
+    int64_t co = cig_base + (int64_t)cig_off_read[r];
+    out.hit_off[read_base + r] = ho;
+    for (int i = 0; i < ck.n_hit[r]; ++i, ++ho) {
+        const DHit &h = ck.hits[o + ck.ic[o + i]];
+        out.rid[ho] = h.rid; out.pos[ho] = h.pos; out.flag[ho] = (uint16_t)h.flag; out.mapq[ho] = (uint8_t)h.mapq;
+        out.score[ho] = h.score; out.nm[ho] = h.nm; out.na[ho] = ck.na[r]; out.n_cigar_ops[ho] = h.n_cigar;
+        out.cig_off[ho] = co;
+        for (int k = 0; k < h.n_cigar; ++k) out.cigar[co++] = ck.cigpool[h.cig_start + k];
+    }
+}

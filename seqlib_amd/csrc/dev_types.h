@@ -1,0 +1,140 @@
+// dev_types.h -- device-side views of one chunk of reads and its per-read work areas.
+// Vocabulary follows bwa / SeqLib: intervals (SMEMs), seeds, chains, regions (mem_alnreg_t), hits
+// (mem_aln_t after the glue's sort + filters).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "seqlib_amd.h"
+
+// overflow / error bits raised by kernels for a chunk (the host re-runs the chunk with larger caps)
+enum : uint32_t {
+    OVF_INTV = 1u << 0,      // more kept intervals than cap_intv
+    OVF_LIST = 1u << 1,      // SMEM work list longer than cap_list
+    OVF_ZARENA = 1u << 2,    // traceback arena exhausted
+    OVF_CIGAR = 1u << 3,     // cigar pool exhausted
+    ERR_LOGLUT = 1u << 4,    // log() argument outside the host-built table
+    ERR_INTERNAL = 1u << 5,
+};
+
+struct DevRef {               // packed reference + contig table (bntseq_t)
+    const uint8_t *pac;       // forward strand, 2 bit/base
+    int64_t l_pac;
+    int n_seqs;
+    const int64_t *ann_off;   // n_seqs
+    const int32_t *ann_len;
+};
+
+struct DevOpt {               // mem_opt_t as the kernels see it (plain copy of slx_opt)
+    slx_opt o;
+};
+
+struct alignas(8) DReg {      // mem_alnreg_t
+    int64_t rb, re;
+    int qb, qe;
+    int rid;
+    int score, truesc, sub, csub, sub_n;
+    int w, seedcov, secondary, seedlen0;
+    int n_comp;
+    float frac_rep;
+    uint64_t hash;
+};
+
+struct alignas(8) DHit {      // mem_aln_t after reg2aln
+    int64_t pos;
+    int rid;
+    int flag;                 // 0x100 secondary, 0x10 reverse already folded in
+    int mapq;
+    int score;
+    int nm;
+    int n_cigar;
+    int64_t cig_start;        // word offset in the cigar pool
+};
+
+// one chunk of reads, all device pointers
+struct Chunk {
+    int n_reads;
+    const uint8_t *codes;     // nt4 codes, reads concatenated
+    const uint64_t *offs;     // n_reads + 1 (relative to codes)
+    uint64_t first_ordinal;   // lrand48 draw index of read 0
+    uint64_t rng_state;
+    // stage 1 -> 2
+    int cap_intv;
+    uint32_t *intv_n;         // [n_reads]
+    uint32_t *intv_info;      // [n_reads * cap_intv]  qbeg << 16 | qend
+    void *intv_x0;            // idx_t
+    void *intv_x2;            // idx_t
+    int32_t *l_rep;           // [n_reads]
+    unsigned long long *seed_cnt; // [n_reads + 1] upper bound of seeds this read will generate
+    uint64_t *seed_off;       // [n_reads + 1] exclusive scan of seed_cnt
+    // per-seed-slot work areas (indexed seed_off[r] + i)
+    int64_t *s_rbeg;
+    uint32_t *s_ql;           // qbeg << 16 | len
+    int32_t *s_next;
+    int64_t *c_pos;
+    int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first;
+    int8_t *c_kept;
+    int32_t *ia, *ib, *ic;    // int scratch lists (orders, kept lists, sort handles)
+    uint64_t *srt;            // seed sort keys
+    DReg *regs;
+    DHit *hits;
+    // per-read results
+    int32_t *n_chain;         // kept chains
+    int32_t *n_reg;
+    int32_t *n_hit;
+    int32_t *na;              // regs.n after dedup (NA tag)
+    float *frac_rep;
+    // arenas
+    uint8_t *zarena; unsigned long long zcap; unsigned long long *zused;
+    uint32_t *cigpool; unsigned long long cigcap; unsigned long long *cigused;
+    // misc
+    const double *log_lut; int log_lut_n;
+    uint32_t *flags;          // OVF_* bits
+    // SMEM work lists: [2 lists][cap_list][n_threads] interleaved by thread
+    void *lists; int cap_list; int n_threads;
+    // glue parameters (src/BWAAligner.cpp:89-95)
+    int hardclip; double keepSecFrac; int maxSecondary;
+};
+
+__device__ __forceinline__ int ref_base(const DevRef &R, int64_t p)
+{   // base at coordinate p of forward ++ reverse-complement (bns_get_seq)
+    if (p >= R.l_pac) { int64_t f = (R.l_pac << 1) - 1 - p; return 3 - ((R.pac[f >> 2] >> ((~f & 3) << 1)) & 3); }
+    return (R.pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+}
+
+__device__ __forceinline__ int64_t dev_depos(const DevRef &R, int64_t pos, int *is_rev)
+{
+    return (*is_rev = (pos >= R.l_pac)) ? (R.l_pac << 1) - 1 - pos : pos;
+}
+
+__device__ inline int dev_pos2rid(const DevRef &R, int64_t pos_f)
+{   // bns_pos2rid
+    if (pos_f >= R.l_pac) return -1;
+    int left = 0, mid = 0, right = R.n_seqs;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= R.ann_off[mid]) {
+            if (mid == R.n_seqs - 1) break;
+            if (pos_f < R.ann_off[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+
+__device__ inline int dev_intv2rid(const DevRef &R, int64_t rb, int64_t re)
+{   // bns_intv2rid
+    int is_rev;
+    if (rb < R.l_pac && re > R.l_pac) return -2;
+    int rid_b = dev_pos2rid(R, dev_depos(R, rb, &is_rev));
+    int rid_e = rb < re ? dev_pos2rid(R, dev_depos(R, re - 1, &is_rev)) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+
+__device__ __forceinline__ int dev_cal_max_gap(const slx_opt &o, int qlen)
+{
+    int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+    int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < o.w << 1 ? l : o.w << 1;
+}

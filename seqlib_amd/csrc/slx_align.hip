@@ -1,0 +1,518 @@
+// slx_align.hip -- the aligner handle (FM-index resident in HBM + chunk workspaces) and the batch
+// entry points of the C-ABI.  Replaces n successive calls of SeqLib::BWAAligner::alignSequence
+// (/root/reference/src/BWAAligner.cpp:89-146) with a staged pipeline of HIP kernels:
+//   encode -> seed (SMEM x3) -> scan -> chain (SA lookup, chaining, filter) -> extend -> finalize
+//   (dedup/patch, primary marking, MAPQ, CIGAR, hit sort + filters) -> compact (SoA result).
+// There is no CPU fallback: without a HIP device every entry point fails with SLX_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "slx_internal.h"
+#include "dev_seed.h"
+#include "dev_fin.h"
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            slx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); \
+            return SLX_ENODEVICE;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SLX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return SLX_OK;
+    }
+    // grow keeping contents
+    int grow(size_t bytes, size_t keep, hipStream_t st)
+    {
+        if (bytes <= cap) return SLX_OK;
+        void *q = nullptr;
+        size_t want = bytes + bytes / 2 + 256;
+        HIPCHK(hipMalloc(&q, want));
+        if (p && keep) HIPCHK(hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (p) (void)hipFree(p);
+        p = q; cap = want;
+        return SLX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+static const char *STAGE_NAMES[SLX_N_STAGES] = {"encode", "seed", "scan", "chain", "extend", "finalize", "compact", "total"};
+extern "C" const char *slx_stage_name(int i) { return i >= 0 && i < SLX_N_STAGES ? STAGE_NAMES[i] : ""; }
+
+struct slx_aligner {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // index in HBM
+    DevBuf d_bwt, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
+    DevFM<uint32_t> fm32;
+    DevRef ref;
+    bool dense_sa = true;
+    bool have_dense = false;
+    const slx_index *host_idx = nullptr;
+    // knobs
+    int64_t chunk_reads = 1 << 20;
+    int cap_intv = 40;
+    int max_threads = 0;
+    int n_cu = 256;
+    unsigned long long zcap = 1ull << 30;
+    // workspaces
+    DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
+    DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
+    DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
+    // outputs
+    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
+    hipEvent_t ev[SLX_N_STAGES + 1];
+    float stage_ms[SLX_N_STAGES];
+};
+
+// ---------------------------------------------------------------- small kernels
+__global__ void k_encode(const uint8_t *ascii, uint8_t *codes, size_t n)
+{   // nst_nt4_table as mem_align1_core applies it: bytes < 4 are kept, A/C/G/T (either case) -> 0..3, else 4
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint8_t b = ascii[i];
+        uint8_t c = 4;
+        if (b < 4) c = b;
+        else {
+            const uint8_t u = b & 0xDF;
+            c = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+            if (b < 'A') c = 4;
+        }
+        codes[i] = c;
+    }
+}
+
+__global__ void k_rel_offsets(const uint64_t *offs, uint64_t *rel, int n_reads, uint64_t base)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_reads) rel[i] = offs[i] - base;
+}
+
+// dense SA from bwa's samples: every sample walks invPsi until the next sampled rank
+__global__ void k_sa_seed(DevFM<uint32_t> fm, uint32_t *dense, uint64_t n_sa)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sa) return;
+    dense[j * (uint64_t)fm.sa_intv] = j == 0 ? fm.seq_len : (uint32_t)fm.sa_samp[j];
+}
+
+__global__ void k_sa_walk(DevFM<uint32_t> fm, uint32_t *dense, uint64_t n_sa)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sa) return;
+    uint32_t k = (uint32_t)(j * (uint64_t)fm.sa_intv);
+    uint32_t v = j == 0 ? fm.seq_len : (uint32_t)fm.sa_samp[j];
+    const uint32_t mask = (uint32_t)fm.sa_intv - 1;
+    while (true) {
+        if (k == fm.primary) break;              // suffix 0: its predecessor is the sentinel at rank 0, a sampled rank
+        uint32_t x = k - (k > fm.primary ? 1 : 0);
+        const uint32_t *blk = fm.bwt + ((size_t)(x >> 7) << 4) + 8;
+        int jj = (int)(x & 127);
+        int c = (blk[jj >> 4] >> ((~jj & 15) << 1)) & 3;
+        uint32_t tk[4], tl[4];
+        occ4_pair<uint32_t>(fm, k, k, tk, tl);
+        k = fm.L2[c] + tk[c];
+        --v;
+        if ((k & mask) == 0) break;
+        dense[k] = v;
+    }
+}
+
+// ---------------------------------------------------------------- create / free
+extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out)
+{
+    if (!out) return SLX_EINVAL;
+    *out = nullptr;
+    if (!idx) { slx_set_error("slx_aligner_create: index is null"); return SLX_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        slx_set_error("no HIP device: the BWAAligner hot path runs on MI355X only (no CPU fallback)");
+        return SLX_ENODEVICE;
+    }
+    if (idx->seq_len + 1 >= (1ULL << 32)) {
+        slx_set_error("index with %llu BWT symbols needs the 64-bit rank path, not built in this round", (unsigned long long)idx->seq_len);
+        return SLX_EUNSUPPORTED;
+    }
+    slx_aligner *al = new slx_aligner();
+    al->device = (devices && n_dev > 0) ? devices[0] : 0;
+    if (!(devices && n_dev > 0)) (void)hipGetDevice(&al->device);
+    HIPCHK(hipSetDevice(al->device));
+    HIPCHK(hipStreamCreate(&al->stream));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, al->device));
+    al->n_cu = prop.multiProcessorCount;
+    al->max_threads = al->n_cu * 1024;
+    for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&al->ev[i]));
+    al->host_idx = idx;
+    // FM-index
+    int rc;
+    if ((rc = al->d_bwt.ensure(idx->bwt.size() * 4 + 64)) != SLX_OK) return rc;
+    HIPCHK(hipMemcpy(al->d_bwt.p, idx->bwt.data(), idx->bwt.size() * 4, hipMemcpyHostToDevice));
+    if ((rc = al->d_sa_samp.ensure(idx->sa.size() * 8)) != SLX_OK) return rc;
+    HIPCHK(hipMemcpy(al->d_sa_samp.p, idx->sa.data(), idx->sa.size() * 8, hipMemcpyHostToDevice));
+    DevFM<uint32_t> &fm = al->fm32;
+    fm.bwt = al->d_bwt.as<uint32_t>();
+    fm.primary = (uint32_t)idx->primary;
+    for (int i = 0; i < 5; ++i) fm.L2[i] = (uint32_t)idx->L2[i];
+    fm.seq_len = (uint32_t)idx->seq_len;
+    fm.sa_dense = nullptr;
+    fm.sa_samp = al->d_sa_samp.as<uint64_t>();
+    fm.sa_intv = idx->sa_intv;
+    // dense SA: straight from a device-built index, otherwise decompressed from the samples
+    const uint64_t n1 = idx->seq_len + 1;
+    if ((rc = al->d_sa_dense.ensure(n1 * 4)) != SLX_OK) return rc;
+    if (idx->dense_sa32.size() == n1) {
+        HIPCHK(hipMemcpy(al->d_sa_dense.p, idx->dense_sa32.data(), n1 * 4, hipMemcpyHostToDevice));
+    } else {
+        const uint64_t n_sa = idx->sa.size();
+        const int bs = 256;
+        hipLaunchKernelGGL(k_sa_seed, dim3((unsigned)((n_sa + bs - 1) / bs)), dim3(bs), 0, al->stream, fm, al->d_sa_dense.as<uint32_t>(), n_sa);
+        hipLaunchKernelGGL(k_sa_walk, dim3((unsigned)((n_sa + bs - 1) / bs)), dim3(bs), 0, al->stream, fm, al->d_sa_dense.as<uint32_t>(), n_sa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(al->stream));
+    }
+    al->have_dense = true;
+    // reference + contig table
+    if ((rc = al->d_pac.ensure(idx->pac.size() + 16)) != SLX_OK) return rc;
+    HIPCHK(hipMemcpy(al->d_pac.p, idx->pac.data(), idx->pac.size(), hipMemcpyHostToDevice));
+    std::vector<int64_t> aoff; std::vector<int32_t> alen;
+    for (const slx_ann &a : idx->anns) { aoff.push_back(a.offset); alen.push_back(a.len); }
+    if ((rc = al->d_ann_off.ensure(aoff.size() * 8 + 8)) != SLX_OK) return rc;
+    if ((rc = al->d_ann_len.ensure(alen.size() * 4 + 8)) != SLX_OK) return rc;
+    HIPCHK(hipMemcpy(al->d_ann_off.p, aoff.data(), aoff.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(al->d_ann_len.p, alen.data(), alen.size() * 4, hipMemcpyHostToDevice));
+    al->ref.pac = al->d_pac.as<uint8_t>();
+    al->ref.l_pac = idx->l_pac;
+    al->ref.n_seqs = (int)idx->anns.size();
+    al->ref.ann_off = al->d_ann_off.as<int64_t>();
+    al->ref.ann_len = al->d_ann_len.as<int32_t>();
+    // log() table from the host's libm
+    const int LUT_N = 1 << 16;
+    std::vector<double> lut((size_t)LUT_N);
+    lut[0] = -INFINITY;
+    for (int i = 1; i < LUT_N; ++i) lut[(size_t)i] = log((double)i);
+    if ((rc = al->d_loglut.ensure((size_t)LUT_N * 8)) != SLX_OK) return rc;
+    HIPCHK(hipMemcpy(al->d_loglut.p, lut.data(), (size_t)LUT_N * 8, hipMemcpyHostToDevice));
+    if ((rc = al->counters.ensure(64)) != SLX_OK) return rc;
+    *out = al;
+    return SLX_OK;
+}
+
+extern "C" void slx_aligner_free(slx_aligner *al)
+{
+    if (!al) return;
+    (void)hipSetDevice(al->device);
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut,
+                      &al->codes, &al->offs_rel, &al->intv_n, &al->intv_info, &al->intv_x0, &al->intv_x2, &al->l_rep, &al->seed_cnt,
+                      &al->seed_off, &al->scan_tmp, &al->s_rbeg, &al->s_ql, &al->s_next, &al->c_pos, &al->c_head, &al->c_tail,
+                      &al->c_n, &al->c_rid, &al->c_w, &al->c_first, &al->c_kept, &al->ia, &al->ib, &al->ic, &al->srt, &al->regs,
+                      &al->hits, &al->n_chain, &al->n_reg, &al->n_hit, &al->na, &al->frac_rep, &al->zarena, &al->cigpool,
+                      &al->counters, &al->lists, &al->hit_cnt, &al->cig_cnt, &al->hit_off_c, &al->cig_off_c, &al->o_hit_off,
+                      &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig,
+                      &al->o_cig_off, &al->o_cigar};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i <= SLX_N_STAGES; ++i) (void)hipEventDestroy(al->ev[i]);
+    if (al->stream) (void)hipStreamDestroy(al->stream);
+    delete al;
+}
+
+extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
+{
+    if (!al || !key) return SLX_EINVAL;
+    if (!strcmp(key, "chunk_reads")) { if (value < 1) return SLX_EINVAL; al->chunk_reads = value; }
+    else if (!strcmp(key, "cap_intv")) { if (value < 1) return SLX_EINVAL; al->cap_intv = (int)value; }
+    else if (!strcmp(key, "dense_sa")) al->dense_sa = value != 0;
+    else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
+    else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
+    else { slx_set_error("slx_aligner_set: unknown key %s", key); return SLX_EINVAL; }
+    return SLX_OK;
+}
+
+extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES])
+{
+    if (!al) return SLX_EINVAL;
+    for (int i = 0; i < SLX_N_STAGES; ++i) ms[i] = al->stage_ms[i];
+    return SLX_OK;
+}
+
+// ---------------------------------------------------------------- one chunk
+template <int MAXQ>
+static void launch_ext_fin(slx_aligner *al, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
+{
+    hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+    (void)hipEventRecord(al->ev[5], al->stream);
+    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+}
+
+struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
+
+struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
+
+// runs the pipeline on reads [r0, r0+n) whose ASCII bases are d_ascii + d_offs[r0]...; appends to the outputs.
+static int run_chunk(slx_aligner *al, const slx_opt *opt, const uint8_t *d_ascii, const uint64_t *d_offs, const uint64_t *h_offs_pair,
+                     int64_t r0, int n, int max_len, uint64_t rng_state, uint64_t first_ordinal, int hardclip, double ksf, int maxsec,
+                     const ChunkCaps &caps, int64_t *hit_base, int64_t *cig_base, uint32_t *flags_out)
+{
+    hipStream_t st = al->stream;
+    int rc;
+    const uint64_t base0 = h_offs_pair[0], n_bases = h_offs_pair[1] - h_offs_pair[0];
+    const int bs = 128;
+    int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)al->max_threads);
+    const int grid = n_threads / bs;
+    const int cap_list = max_len + 1;
+#define ENS(buf, bytes) if ((rc = al->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
+    ENS(codes, n_bases + 16); ENS(offs_rel, ((size_t)n + 1) * 8);
+    ENS(intv_n, (size_t)n * 4); ENS(intv_info, (size_t)n * caps.cap_intv * 4); ENS(intv_x0, (size_t)n * caps.cap_intv * 4);
+    ENS(intv_x2, (size_t)n * caps.cap_intv * 4); ENS(l_rep, (size_t)n * 4); ENS(seed_cnt, ((size_t)n + 1) * 8); ENS(seed_off, ((size_t)n + 1) * 8);
+    ENS(n_chain, (size_t)n * 4); ENS(n_reg, (size_t)n * 4); ENS(n_hit, ((size_t)n + 1) * 4); ENS(na, (size_t)n * 4); ENS(frac_rep, (size_t)n * 4);
+    ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<uint32_t>));
+    ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
+    ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
+    // counters: [0] zused, [1] cigused, [2] flags(u32)
+    HIPCHK(hipMemsetAsync(al->counters.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(al->seed_cnt.p, 0, ((size_t)n + 1) * 8, st));
+
+    Chunk ck;
+    memset(&ck, 0, sizeof ck);
+    ck.n_reads = n;
+    ck.codes = al->codes.as<uint8_t>();
+    ck.offs = al->offs_rel.as<uint64_t>();
+    ck.first_ordinal = first_ordinal + (uint64_t)r0;
+    ck.rng_state = rng_state;
+    ck.cap_intv = caps.cap_intv;
+    ck.intv_n = al->intv_n.as<uint32_t>(); ck.intv_info = al->intv_info.as<uint32_t>();
+    ck.intv_x0 = al->intv_x0.p; ck.intv_x2 = al->intv_x2.p;
+    ck.l_rep = al->l_rep.as<int32_t>();
+    ck.seed_off = al->seed_off.as<uint64_t>();
+    ck.n_chain = al->n_chain.as<int32_t>(); ck.n_reg = al->n_reg.as<int32_t>(); ck.n_hit = al->n_hit.as<int32_t>();
+    ck.na = al->na.as<int32_t>(); ck.frac_rep = al->frac_rep.as<float>();
+    ck.zarena = al->zarena.as<uint8_t>(); ck.zcap = caps.zcap; ck.zused = al->counters.as<unsigned long long>();
+    ck.cigpool = al->cigpool.as<uint32_t>(); ck.cigcap = caps.cigcap; ck.cigused = al->counters.as<unsigned long long>() + 1;
+    ck.flags = (uint32_t *)(al->counters.as<unsigned long long>() + 2);
+    ck.log_lut = al->d_loglut.as<double>(); ck.log_lut_n = 1 << 16;
+    ck.lists = al->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
+    ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
+    ck.seed_cnt = al->seed_cnt.as<unsigned long long>();
+    DevOpt dopt; dopt.o = *opt;
+    DevFM<uint32_t> fm = al->fm32;
+    fm.sa_dense = (al->dense_sa && al->have_dense) ? al->d_sa_dense.as<uint32_t>() : nullptr;
+
+    (void)hipEventRecord(al->ev[0], st);
+    {   // encode + relative offsets
+        const unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256 + 1, 65535u * 4);
+        hipLaunchKernelGGL(k_encode, dim3(g), dim3(256), 0, st, d_ascii + base0, al->codes.as<uint8_t>(), (size_t)n_bases);
+        hipLaunchKernelGGL(k_rel_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_offs + r0, al->offs_rel.as<uint64_t>(), n, base0);
+    }
+    (void)hipEventRecord(al->ev[1], st);
+    hipLaunchKernelGGL(k_seed<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt);
+    (void)hipEventRecord(al->ev[2], st);
+    {   // exclusive scan of the per-read seed counts -> seed-slot regions
+        size_t tmp_bytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (unsigned long long *)al->seed_cnt.p, (unsigned long long *)al->seed_off.p, n + 1, st);
+        ENS(scan_tmp, tmp_bytes + 256);
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tmp_bytes, (unsigned long long *)al->seed_cnt.p, (unsigned long long *)al->seed_off.p, n + 1, st));
+    }
+    unsigned long long S = 0;
+    HIPCHK(hipMemcpyAsync(&S, al->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    {
+        uint32_t fl = 0;
+        HIPCHK(hipMemcpy(&fl, ck.flags, 4, hipMemcpyDeviceToHost));
+        if (fl) { *flags_out = fl; return SLX_OK; }
+    }
+    const size_t S1 = (size_t)S + 1;
+    ENS(s_rbeg, S1 * 8); ENS(s_ql, S1 * 4); ENS(s_next, S1 * 4); ENS(c_pos, S1 * 8); ENS(c_head, S1 * 4); ENS(c_tail, S1 * 4);
+    ENS(c_n, S1 * 4); ENS(c_rid, S1 * 4); ENS(c_w, S1 * 4); ENS(c_first, S1 * 4); ENS(c_kept, S1); ENS(ia, S1 * 4); ENS(ib, S1 * 4);
+    ENS(ic, S1 * 4); ENS(srt, S1 * 8); ENS(regs, S1 * sizeof(DReg)); ENS(hits, S1 * sizeof(DHit));
+    ck.s_rbeg = al->s_rbeg.as<int64_t>(); ck.s_ql = al->s_ql.as<uint32_t>(); ck.s_next = al->s_next.as<int32_t>();
+    ck.c_pos = al->c_pos.as<int64_t>(); ck.c_head = al->c_head.as<int32_t>(); ck.c_tail = al->c_tail.as<int32_t>();
+    ck.c_n = al->c_n.as<int32_t>(); ck.c_rid = al->c_rid.as<int32_t>(); ck.c_w = al->c_w.as<int32_t>();
+    ck.c_first = al->c_first.as<int32_t>(); ck.c_kept = al->c_kept.as<int8_t>();
+    ck.ia = al->ia.as<int32_t>(); ck.ib = al->ib.as<int32_t>(); ck.ic = al->ic.as<int32_t>(); ck.srt = al->srt.as<uint64_t>();
+    ck.regs = al->regs.as<DReg>(); ck.hits = al->hits.as<DHit>();
+    (void)hipEventRecord(al->ev[3], st);
+    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt);
+    (void)hipEventRecord(al->ev[4], st);
+    if (max_len <= 160) launch_ext_fin<160>(al, ck, dopt, grid, bs);
+    else if (max_len <= 320) launch_ext_fin<320>(al, ck, dopt, grid, bs);
+    else launch_ext_fin<SLX_MAX_READ_LEN + 4>(al, ck, dopt, grid, bs);
+    (void)hipEventRecord(al->ev[6], st);
+    // hit / cigar counts -> offsets
+    hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, al->cig_cnt.as<unsigned long long>());
+    {
+        hipcub::TransformInputIterator<unsigned long long, CvtI32U64, const int *> it(al->n_hit.as<int>(), CvtI32U64());
+        size_t tb = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, al->hit_off_c.as<unsigned long long>(), n + 1, st);
+        ENS(scan_tmp, tb + 256);
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tb, it, al->hit_off_c.as<unsigned long long>(), n + 1, st));
+        size_t tb2 = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, al->cig_cnt.as<unsigned long long>(), al->cig_off_c.as<unsigned long long>(), n + 1, st);
+        ENS(scan_tmp, tb2 + 256);
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tb2, al->cig_cnt.as<unsigned long long>(), al->cig_off_c.as<unsigned long long>(), n + 1, st));
+    }
+    unsigned long long Hc = 0, Cc = 0;
+    uint32_t fl = 0;
+    HIPCHK(hipMemcpyAsync(&Hc, al->hit_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&Cc, al->cig_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&fl, ck.flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (fl) { *flags_out = fl; return SLX_OK; }
+    // grow the outputs and compact
+    const size_t H = (size_t)*hit_base + Hc, C = (size_t)*cig_base + Cc;
+#define GROW(buf, bytes, keep) if ((rc = al->buf.grow((size_t)(bytes), (size_t)(keep), st)) != SLX_OK) return rc
+    GROW(o_rid, (H + 1) * 4, *hit_base * 4); GROW(o_pos, (H + 1) * 8, *hit_base * 8); GROW(o_flag, (H + 1) * 2, *hit_base * 2);
+    GROW(o_mapq, (H + 1), *hit_base); GROW(o_score, (H + 1) * 4, *hit_base * 4); GROW(o_nm, (H + 1) * 4, *hit_base * 4);
+    GROW(o_na, (H + 1) * 4, *hit_base * 4); GROW(o_ncig, (H + 1) * 4, *hit_base * 4); GROW(o_cig_off, (H + 2) * 8, *hit_base * 8);
+    GROW(o_cigar, (C + 1) * 4, *cig_base * 4);
+    HitsSoA so;
+    so.hit_off = al->o_hit_off.as<int64_t>(); so.rid = al->o_rid.as<int32_t>(); so.pos = al->o_pos.as<int64_t>();
+    so.flag = al->o_flag.as<uint16_t>(); so.mapq = al->o_mapq.as<uint8_t>(); so.score = al->o_score.as<int32_t>();
+    so.nm = al->o_nm.as<int32_t>(); so.na = al->o_na.as<int32_t>(); so.n_cigar_ops = al->o_ncig.as<int32_t>();
+    so.cig_off = al->o_cig_off.as<int64_t>(); so.cigar = al->o_cigar.as<uint32_t>();
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, al->hit_off_c.as<unsigned long long>(),
+                       al->cig_off_c.as<unsigned long long>(), so, r0, *hit_base, *cig_base);
+    (void)hipEventRecord(al->ev[7], st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 7; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, al->ev[i], al->ev[i + 1]) == hipSuccess) al->stage_ms[i] += ms;
+    }
+    *hit_base += (int64_t)Hc;
+    *cig_base += (int64_t)Cc;
+    *flags_out = 0;
+    return SLX_OK;
+#undef ENS
+#undef GROW
+}
+
+extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_bases, const void *d_offs_, int64_t n_reads,
+                                      uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary,
+                                      slx_hits *out)
+{
+    if (!al || !opt || !out || n_reads < 0) { slx_set_error("slx_align_batch_device: bad argument"); return SLX_EINVAL; }
+    memset(out, 0, sizeof *out);
+    HIPCHK(hipSetDevice(al->device));
+    if (opt->e_del <= 0 || opt->e_ins <= 0) { slx_set_error("gap extension penalty must be > 0 on the GPU path (bwa divides by it)"); return SLX_EINVAL; }
+    for (int i = 0; i < SLX_N_STAGES; ++i) al->stage_ms[i] = 0;
+    const uint64_t *d_offs = (const uint64_t *)d_offs_;
+    int rc;
+    if ((rc = al->o_hit_off.ensure(((size_t)n_reads + 1) * 8)) != SLX_OK) return rc;
+    int64_t hit_base = 0, cig_base = 0;
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, al->stream));
+    std::vector<uint64_t> h_offs;       // chunk boundaries need host copies of a few offsets
+    for (int64_t r0 = 0; r0 < n_reads; r0 += al->chunk_reads) {
+        const int n = (int)std::min<int64_t>(al->chunk_reads, n_reads - r0);
+        // offsets of this chunk to the host: total bases and the longest read
+        h_offs.resize((size_t)n + 1);
+        HIPCHK(hipMemcpy(h_offs.data(), d_offs + r0, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+        int max_len = 0;
+        for (int i = 0; i < n; ++i) {
+            if (h_offs[(size_t)i + 1] < h_offs[(size_t)i]) { slx_set_error("offsets are not monotonic at read %lld", (long long)(r0 + i)); return SLX_EINVAL; }
+            max_len = std::max<int>(max_len, (int)std::min<uint64_t>(h_offs[(size_t)i + 1] - h_offs[(size_t)i], 1u << 30));
+        }
+        if (max_len > SLX_MAX_READ_LEN) {
+            slx_set_error("read of %d bp: the GPU path supports reads up to %d bp (longer reads enter bwa's mem_flt_chained_seeds branch)", max_len, SLX_MAX_READ_LEN);
+            return SLX_EUNSUPPORTED;
+        }
+        uint64_t pair[2] = {h_offs[0], h_offs[(size_t)n]};
+        ChunkCaps caps;
+        caps.cap_intv = al->cap_intv;
+        caps.zcap = al->zcap;
+        caps.cigcap = (unsigned long long)n * 8 + 4096;
+        for (int attempt = 0;; ++attempt) {
+            uint32_t fl = 0;
+            int64_t hb = hit_base, cb = cig_base;
+            rc = run_chunk(al, opt, (const uint8_t *)d_bases, d_offs, pair, r0, n, max_len, rng_state, first_ordinal, hardclip, keepSecFrac,
+                           maxSecondary, caps, &hb, &cb, &fl);
+            if (rc != SLX_OK) return rc;
+            if (!fl) { hit_base = hb; cig_base = cb; break; }
+            if (fl & (ERR_LOGLUT | ERR_INTERNAL)) { slx_set_error("device pipeline error flags 0x%x", fl); return SLX_EINTERNAL; }
+            if (attempt >= 8) { slx_set_error("chunk still overflows its work areas after %d retries (flags 0x%x)", attempt, fl); return SLX_ENOMEM; }
+            if (fl & OVF_INTV) caps.cap_intv *= 2;
+            if (fl & OVF_ZARENA) caps.zcap *= 2;
+            if (fl & OVF_CIGAR) caps.cigcap *= 2;
+        }
+    }
+    // terminal offsets
+    {
+        int64_t last[1] = {hit_base};
+        HIPCHK(hipMemcpyAsync(al->o_hit_off.as<int64_t>() + n_reads, last, 8, hipMemcpyHostToDevice, al->stream));
+        if ((rc = al->o_cig_off.grow(((size_t)hit_base + 2) * 8, (size_t)hit_base * 8, al->stream)) != SLX_OK) return rc;
+        int64_t lastc[1] = {cig_base};
+        HIPCHK(hipMemcpyAsync(al->o_cig_off.as<int64_t>() + hit_base, lastc, 8, hipMemcpyHostToDevice, al->stream));
+    }
+    HIPCHK(hipEventRecord(t1, al->stream));
+    HIPCHK(hipStreamSynchronize(al->stream));
+    float tot = 0;
+    (void)hipEventElapsedTime(&tot, t0, t1);
+    al->stage_ms[7] = tot;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    out->n_reads = n_reads; out->n_hits = hit_base; out->n_cigar = cig_base;
+    out->hit_off = al->o_hit_off.as<int64_t>(); out->rid = al->o_rid.as<int32_t>(); out->pos = al->o_pos.as<int64_t>();
+    out->flag = al->o_flag.as<uint16_t>(); out->mapq = al->o_mapq.as<uint8_t>(); out->score = al->o_score.as<int32_t>();
+    out->nm = al->o_nm.as<int32_t>(); out->na = al->o_na.as<int32_t>(); out->n_cigar_ops = al->o_ncig.as<int32_t>();
+    out->cig_off = al->o_cig_off.as<int64_t>(); out->cigar = al->o_cigar.as<uint32_t>();
+    out->on_device = 1;
+    return SLX_OK;
+}
+
+extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
+                               uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
+{
+    if (!al || !opt || !out || n_reads < 0 || (n_reads > 0 && (!bases || !offs))) { slx_set_error("slx_align_batch: bad argument"); return SLX_EINVAL; }
+    memset(out, 0, sizeof *out);
+    HIPCHK(hipSetDevice(al->device));
+    const uint64_t total = n_reads ? offs[n_reads] : 0;
+    void *d_b = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_b, total + 16));
+    HIPCHK(hipMalloc(&d_o, ((size_t)n_reads + 1) * 8));
+    uint64_t zero = 0;
+    if (total) HIPCHK(hipMemcpy(d_b, bases, total, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_o, n_reads ? offs : &zero, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+    slx_hits dv;
+    int rc = slx_align_batch_device(al, opt, d_b, d_o, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, &dv);
+    (void)hipFree(d_b); (void)hipFree(d_o);
+    if (rc != SLX_OK) return rc;
+    const size_t H = (size_t)dv.n_hits, C = (size_t)dv.n_cigar, N = (size_t)n_reads;
+    out->n_reads = n_reads; out->n_hits = dv.n_hits; out->n_cigar = dv.n_cigar; out->on_device = 0;
+#define D2H(field, type, count)                                                                     \
+    out->field = (type *)malloc(((count) + 1) * sizeof(type));                                      \
+    if (!out->field) { slx_set_error("out of host memory"); return SLX_ENOMEM; }                    \
+    if ((count) > 0) HIPCHK(hipMemcpy(out->field, dv.field, (count) * sizeof(type), hipMemcpyDeviceToHost));
+    D2H(hit_off, int64_t, N + 1) D2H(rid, int32_t, H) D2H(pos, int64_t, H) D2H(flag, uint16_t, H) D2H(mapq, uint8_t, H)
+    D2H(score, int32_t, H) D2H(nm, int32_t, H) D2H(na, int32_t, H) D2H(n_cigar_ops, int32_t, H) D2H(cig_off, int64_t, H + 1)
+    D2H(cigar, uint32_t, C)
+#undef D2H
+    return SLX_OK;
+}
+
+extern "C" void slx_hits_free(slx_hits *h)
+{
+    if (!h || h->on_device) return;
+    free(h->hit_off); free(h->rid); free(h->pos); free(h->flag); free(h->mapq); free(h->score); free(h->nm); free(h->na);
+    free(h->n_cigar_ops); free(h->cig_off); free(h->cigar);
+    memset(h, 0, sizeof *h);
+}
