@@ -20,6 +20,7 @@
  *   slx_align_batch     n successive BWAAligner::alignSequence calls: mem_align1 + mem_reg2aln +
  *                       the hit sort/filter glue                  src/BWAAligner.cpp:89-146
  *                       (record materialisation :151-248 stays in the C++ mirror)
+ *   slx_hits_pack       (new) packed image of the hits for the multi-GPU gather; no reference counterpart
  *   slx_lrand48_*       the libc lrand48() stream mem_align1 consumes
  */
 #ifndef SEQLIB_AMD_H
@@ -128,6 +129,14 @@ int  slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_b
                             int64_t n_reads, uint64_t rng_state, uint64_t first_ordinal, int hardclip,
                             double keepSecFrac, int maxSecondary, slx_hits *out);
 void slx_hits_free(slx_hits *h);          /* host results only */
+
+/* One contiguous image of a result, for the single RCCL gather of hits to rank 0.
+ * Layout (little endian): int64 hdr[4] = {n_reads, n_hits, n_cigar, 0}; int64 hit_off[n_reads+1];
+ * int64 pos[n_hits]; int64 cig_off[n_hits+1]; int32 rid, score, nm, na, n_cigar_ops [n_hits] each;
+ * uint32 cigar[n_cigar]; uint16 flag[n_hits]; uint8 mapq[n_hits].  Works for device-resident results
+ * (d_dst is a device buffer) and host results (dst is host memory). */
+uint64_t slx_hits_packed_size(const slx_hits *h);
+int  slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_bytes);
 
 /* per-stage kernel time of the last batch, measured with HIP events on the aligner's stream (ms) */
 #define SLX_N_STAGES 8

@@ -18,7 +18,7 @@ SLX_MAX_READ_LEN = 700
 EXPORTS = [
     "slx_opt_init", "slx_fill_scmat", "slx_index_build", "slx_index_load", "slx_index_write", "slx_index_free",
     "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_aligner_create",
-    "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free",
+    "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free", "slx_hits_packed_size", "slx_hits_pack",
     "slx_aligner_stage_ms", "slx_stage_name", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
     "slx_last_error", "slx_version",
 ]
@@ -75,6 +75,9 @@ def lib():
     L.slx_align_batch_device.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_double, C.c_int, C.POINTER(Hits)]
     L.slx_hits_free.argtypes = [C.POINTER(Hits)]
+    L.slx_hits_packed_size.argtypes = [C.POINTER(Hits)]
+    L.slx_hits_packed_size.restype = C.c_uint64
+    L.slx_hits_pack.argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_uint64]
     L.slx_aligner_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.slx_stage_name.argtypes = [C.c_int]
     L.slx_stage_name.restype = C.c_char_p

@@ -184,6 +184,27 @@ class BWAAligner:
         _ffi.lib().slx_hits_free(C.byref(h))
         return res
 
+    def align_device(self, d_bases_ptr, d_offs_ptr, n_reads, first_ordinal=None, hardclip=False, keepSecFrac=0.9,
+                     maxSecondary=10):
+        """Device-resident batch: bases (ASCII) and uint64 offsets already in HBM; results stay in HBM.
+        Returns the ctypes Hits struct (device pointers owned by the aligner until its next call)."""
+        h = _ffi.Hits()
+        fo = self.ordinal if first_ordinal is None else first_ordinal
+        rc = _ffi.lib().slx_align_batch_device(self._handle(), C.byref(self.opt), d_bases_ptr, d_offs_ptr, n_reads,
+                                               self.rng_state, fo, int(hardclip), float(keepSecFrac), int(maxSecondary),
+                                               C.byref(h))
+        _ffi.check(rc)
+        if first_ordinal is None:
+            self.ordinal += n_reads
+        return h
+
+    def pack_into(self, hits, dst_ptr, dst_bytes):
+        _ffi.check(_ffi.lib().slx_hits_pack(self._handle(), C.byref(hits), dst_ptr, dst_bytes))
+
+    @staticmethod
+    def packed_size(hits):
+        return int(_ffi.lib().slx_hits_packed_size(C.byref(hits)))
+
     def alignSequence(self, seq, name="", hardclip=False, keepSecFrac=0.9, maxSecondary=10):
         """One read -> list of dict records (flag, rid, pos, mapq, cigar words, AS, NM, NA)."""
         r = self.alignSequences([seq], hardclip, keepSecFrac, maxSecondary)

@@ -516,3 +516,38 @@ extern "C" void slx_hits_free(slx_hits *h)
     free(h->n_cigar_ops); free(h->cig_off); free(h->cigar);
     memset(h, 0, sizeof *h);
 }
+
+// ---------------------------------------------------------------- packed image for the RCCL gather
+extern "C" uint64_t slx_hits_packed_size(const slx_hits *h)
+{
+    if (!h) return 0;
+    const uint64_t N = (uint64_t)h->n_reads, H = (uint64_t)h->n_hits, Cg = (uint64_t)h->n_cigar;
+    return 32 + 8 * (N + 1) + 8 * H + 8 * (H + 1) + 5 * 4 * H + 4 * Cg + 2 * H + H;
+}
+
+extern "C" int slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_bytes)
+{
+    if (!h || !dst) return SLX_EINVAL;
+    if (dst_bytes < slx_hits_packed_size(h)) { slx_set_error("slx_hits_pack: destination too small"); return SLX_EINVAL; }
+    const size_t N = (size_t)h->n_reads, H = (size_t)h->n_hits, Cg = (size_t)h->n_cigar;
+    int64_t hdr[4] = {h->n_reads, h->n_hits, h->n_cigar, 0};
+    uint8_t *d = (uint8_t *)dst;
+    struct Part { const void *src; size_t bytes; };
+    const Part parts[] = {{h->hit_off, 8 * (N + 1)}, {h->pos, 8 * H}, {h->cig_off, 8 * (H + 1)}, {h->rid, 4 * H}, {h->score, 4 * H},
+                          {h->nm, 4 * H}, {h->na, 4 * H}, {h->n_cigar_ops, 4 * H}, {h->cigar, 4 * Cg}, {h->flag, 2 * H}, {h->mapq, H}};
+    if (h->on_device) {
+        if (!al) return SLX_EINVAL;
+        HIPCHK(hipSetDevice(al->device));
+        HIPCHK(hipMemcpyAsync(d, hdr, 32, hipMemcpyHostToDevice, al->stream));
+        d += 32;
+        for (const Part &p : parts) {
+            if (p.bytes) HIPCHK(hipMemcpyAsync(d, p.src, p.bytes, hipMemcpyDeviceToDevice, al->stream));
+            d += p.bytes;
+        }
+        HIPCHK(hipStreamSynchronize(al->stream));
+    } else {
+        memcpy(d, hdr, 32); d += 32;
+        for (const Part &p : parts) { if (p.bytes) memcpy(d, p.src, p.bytes); d += p.bytes; }
+    }
+    return SLX_OK;
+}
