@@ -1,0 +1,300 @@
+// dev_ext_wave.h -- seed extension, wavefront-cooperative: one 64-lane wave owns one read; the
+// per-read control flow of mem_chain2aln runs wave-uniform and every ksw_extend2 row is computed by
+// the whole wave, one query column per lane (64-column tiles for longer extensions).
+//
+// bwa's ksw_extend2 is row-sequential with a data-dependent band, so a literal anti-diagonal sweep
+// cannot reproduce it; a ROW-parallel one can, because E and F are fed by M (the diagonal move), not
+// by H:
+//     M_j  = Hprev_{j-1} ? Hprev_{j-1} + s(i,j) : 0
+//     E'_j = max(E_j - e_del, max(M_j - oe_del, 0))                       (elementwise)
+//     F_j  = max_{beg<=k<j}( max(M_k - oe_ins, 0) + k*e_ins ) - (j-1)*e_ins   (prefix max; F_beg = 0)
+//     H_j  = max(M_j, E_j, F_j)
+// The H/E row lives in LDS (eh[] of the reference), written only inside [beg, end] so that stale
+// cells re-enter the band exactly as in the scalar code; the band is updated from ballots of the
+// zero mask; ties resolve as the scalar loop does (last arg-max in a row, first row for the maximum).
+#pragma once
+#include "dev_ext.h"
+
+#define WAVE 64
+#define NEG_BIG (-0x3fffffff)
+
+__device__ __forceinline__ int wave_incl_max_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v = v > o ? v : o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(v, d, WAVE);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+struct MatRows {              // score matrix repacked for a per-lane lookup: row t -> 4 packed int8 for q = 0..3, plus the q = 4 column
+    uint32_t packed[5];
+    int q4[5];
+};
+
+__device__ __forceinline__ MatRows make_matrows(const int8_t *mat)
+{
+    MatRows m;
+    for (int t = 0; t < 5; ++t) {
+        m.packed[t] = (uint32_t)(uint8_t)mat[t * 5] | (uint32_t)(uint8_t)mat[t * 5 + 1] << 8 | (uint32_t)(uint8_t)mat[t * 5 + 2] << 16 |
+                      (uint32_t)(uint8_t)mat[t * 5 + 3] << 24;
+        m.q4[t] = mat[t * 5 + 4];
+    }
+    return m;
+}
+
+// wave-cooperative ksw_extend2; every lane returns the same result.  eh_h / eh_e are LDS rows of qlen+2 ints.
+template <int NCH, typename QF, typename TF>
+__device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0,
+                                      int *eh_h, int *eh_e, int lane)
+{
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    // query codes of this lane's columns, one register per 64-column tile
+    int qc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { const int j = c * WAVE + lane; qc[c] = j < qlen ? qf(j) : 4; }
+    // row -1: eh[0].h = h0, then the insertion ramp while it stays positive
+    for (int j = lane; j <= qlen; j += WAVE) {
+        int v = h0 - oe_ins - (j - 1) * e_ins;
+        eh_h[j] = j == 0 ? h0 : (v > 0 ? v : 0);
+        eh_e[j] = 0;
+    }
+    int max = 0;
+    for (int i = 0; i < 25; ++i) max = max > o.mat[i] ? max : o.mat[i];
+    int max_ins = (int)((double)(qlen * max + end_bonus - o_ins) / e_ins + 1.);
+    max_ins = max_ins > 1 ? max_ins : 1;
+    w = w < max_ins ? w : max_ins;
+    int max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
+    max_del = max_del > 1 ? max_del : 1;
+    w = w < max_del ? w : max_del;
+    max = h0;
+    int max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+    for (int i = 0; i < tlen; ++i) {
+        const int t = tf(i);
+        const uint32_t rowp = mr.packed[t];
+        const int row4 = mr.q4[t];
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1_init;
+        if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+        else h1_init = 0;
+        int m = 0, mj = -1;
+        int carry_u = NEG_BIG;                       // running prefix max of t_k + k*e_ins over the tiles to the left
+        int carry_diag = 0;                          // eh_h at the first column of the next tile, read before it is overwritten
+        const int c_lo = beg / WAVE;                 // tiles are aligned to absolute columns so that qc[] can be reused
+        for (int c = c_lo; c * WAVE < end; ++c) {
+            const int j = c * WAVE + lane;
+            const bool act = j >= beg && j < end;
+            int hd = 0, e = 0;
+            if (act) { hd = eh_h[j]; e = eh_e[j]; }
+            if (c > c_lo && lane == 0) hd = carry_diag;
+            const int nj = (c + 1) * WAVE;           // first column of the next tile
+            carry_diag = nj <= qlen ? eh_h[nj] : 0;  // same address in every lane: LDS broadcast
+            const int q = qc[c < NCH ? c : NCH - 1];
+            const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            int M = hd ? hd + s : 0;
+            int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
+            int u = act ? tins + j * e_ins : NEG_BIG;
+            const int pm = wave_incl_max_scan(u, lane);
+            int pmx = __shfl_up(pm, 1, WAVE);
+            if (lane == 0) pmx = NEG_BIG;
+            pmx = pmx > carry_u ? pmx : carry_u;
+            const int top = __shfl(pm, WAVE - 1, WAVE);
+            carry_u = carry_u > top ? carry_u : top;
+            int f = j == beg ? 0 : pmx - (j - 1) * e_ins;
+            int h = M > e ? M : e;
+            h = h > f ? h : f;
+            int tdel = M - oe_del; tdel = tdel > 0 ? tdel : 0;
+            int en = e - e_del; en = en > tdel ? en : tdel;
+            if (act) { eh_e[j] = en; eh_h[j + 1] = h; }
+            if (j == beg) eh_h[beg] = h1_init;
+            // row maximum; ties -> the larger column, as `mj = m > h ? mj : j` does
+            const int hv = act ? h : -1;
+            const int mx = wave_max(hv);
+            if (mx >= m) {
+                const unsigned long long bal = __ballot(hv == mx);
+                if (bal) { m = mx; mj = c * WAVE + (63 - __clzll((long long)bal)); }
+            }
+        }
+        if (end > beg) eh_e[end] = 0;                // eh[end].h was written by the lane of column end-1
+        else { eh_h[end] = h1_init; eh_e[end] = 0; } // empty band: the scalar loop still stores h1 into eh[end]
+        const int jfin = end > beg ? end : beg;      // value of the scalar loop variable after the row
+        if (jfin == qlen) {                           // the row reached the end of the query
+            const int h1 = end > beg ? eh_h[end] : h1_init;
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            const int off = mj - i < 0 ? i - mj : mj - i;
+            max_off = max_off > off ? max_off : off;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        // band for the next row: skip leading and trailing cells whose h and e are both zero
+        int first_nz = -1, last_nz = -1;
+        for (int c = beg / WAVE; c * WAVE <= end; ++c) {
+            const int j = c * WAVE + lane;
+            const bool in = j >= beg && j <= end;
+            const bool nz = in && (eh_h[j] != 0 || eh_e[j] != 0);
+            const unsigned long long bal = __ballot(nz);
+            if (bal) {
+                if (first_nz < 0) first_nz = c * WAVE + (__ffsll((long long)bal) - 1);
+                last_nz = c * WAVE + (63 - __clzll((long long)bal));
+            }
+        }
+        // first loop scans [beg, end): a non-zero eh[end] alone does not stop it
+        int nbeg = (first_nz >= 0 && first_nz < end) ? first_nz : end;
+        int jl = last_nz >= nbeg ? last_nz : nbeg - 1;
+        beg = nbeg;
+        end = jl + 2 < qlen ? jl + 2 : qlen;
+    }
+    ExtResult r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(64) k_extend_wave(DevRef R, Chunk ck, DevOpt dopt)
+{
+    constexpr int NCH = (MAXQ + WAVE - 1) / WAVE;
+    __shared__ int eh_h[MAXQ + 2 + WAVE], eh_e[MAXQ + 2 + WAVE];
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(opt.mat);
+    for (int r = blockIdx.x; r < ck.n_reads; r += gridDim.x) {
+        ReadWS w = make_ws(ck, r);
+        const uint8_t *query = ck.codes + ck.offs[r];
+        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+        const int n_chn = ck.n_chain[r];
+        const float frac_rep = ck.frac_rep[r];
+        const int64_t l_pac = R.l_pac;
+        int n_av = 0;
+        int *cs = w.ib, *srt_h = w.ic;
+        for (int ci = 0; ci < n_chn; ++ci) {
+            const int c = w.ia[ci];
+            int n = 0;
+            for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) cs[n++] = s;
+            if (n == 0) continue;
+            int64_t rmax0 = l_pac << 1, rmax1 = 0;
+            for (int i = 0; i < n; ++i) {
+                const int s = cs[i];
+                const int qb = w.s_qbeg(s), sl = w.s_len(s);
+                const int64_t b = w.s_rbeg[s] - (qb + dev_cal_max_gap(opt, qb));
+                const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + dev_cal_max_gap(opt, l_query - qb - sl));
+                rmax0 = rmax0 < b ? rmax0 : b;
+                rmax1 = rmax1 > e ? rmax1 : e;
+            }
+            rmax0 = rmax0 > 0 ? rmax0 : 0;
+            rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+            if (rmax0 < l_pac && l_pac < rmax1) {
+                if (w.s_rbeg[cs[0]] < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+            }
+            {
+                int is_rev;
+                const int rid = dev_pos2rid(R, dev_depos(R, w.s_rbeg[cs[0]], &is_rev));
+                int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
+                if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+                rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+                rmax1 = rmax1 < far_end ? rmax1 : far_end;
+            }
+            for (int i = 0; i < n; ++i) { w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i; srt_h[i] = i; }
+            ks_introsort_idx(n, srt_h, [&](int x, int y) { return w.srt[x] < w.srt[y]; });
+            for (int k = n - 1; k >= 0; --k) {
+                const int si = (int)(uint32_t)w.srt[srt_h[k]];
+                const int s = cs[si];
+                const int s_qbeg = w.s_qbeg(s), s_len = w.s_len(s);
+                const int64_t s_rbeg = w.s_rbeg[s];
+                int i;
+                for (i = 0; i < n_av; ++i) {
+                    const DReg &p = w.regs[i];
+                    if (s_rbeg < p.rb || s_rbeg + s_len > p.re || s_qbeg < p.qb || s_qbeg + s_len > p.qe) continue;
+                    if ((double)(s_len - p.seedlen0) > .1 * l_query) continue;
+                    int qd = s_qbeg - p.qb; int64_t rd = s_rbeg - p.rb;
+                    int max_gap = dev_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                    int ww = max_gap < p.w ? max_gap : p.w;
+                    if (qd - rd < ww && rd - qd < ww) break;
+                    qd = p.qe - (s_qbeg + s_len); rd = p.re - (s_rbeg + s_len);
+                    max_gap = dev_cal_max_gap(opt, qd < rd ? qd : (int)rd);
+                    ww = max_gap < p.w ? max_gap : p.w;
+                    if (qd - rd < ww && rd - qd < ww) break;
+                }
+                if (i < n_av) {
+                    for (i = k + 1; i < n; ++i) {
+                        if (srt_h[i] < 0) continue;
+                        const uint64_t key = w.srt[srt_h[i]];
+                        const int t = cs[(int)(uint32_t)key];
+                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+                        const int64_t t_rbeg = w.s_rbeg[t];
+                        if ((double)t_len < s_len * .95) continue;
+                        if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
+                        if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) break;
+                    }
+                    if (i == n) { srt_h[k] = -1; continue; }
+                }
+                DReg a;
+                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
+                a.n_comp = 0; a.hash = 0;
+                int aw0 = opt.w, aw1 = opt.w;
+                a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
+                if (s_qbeg) {
+                    const int64_t tmp = s_rbeg - rmax0;
+                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+                    for (i = 0; i < 2; ++i) {
+                        const int prev = a.score;
+                        aw0 = opt.w << i;
+                        er = wave_ksw_extend2<NCH>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
+                                                   [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5,
+                                                   s_len * opt.a, eh_h, eh_e, lane);
+                        a.score = er.score;
+                        if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+                    }
+                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
+                    else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
+                } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
+                if (s_qbeg + s_len != l_query) {
+                    const int sc0 = a.score, qe = s_qbeg + s_len;
+                    const int64_t re0 = s_rbeg + s_len;
+                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+                    for (i = 0; i < 2; ++i) {
+                        const int prev = a.score;
+                        aw1 = opt.w << i;
+                        er = wave_ksw_extend2<NCH>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
+                                                   [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, eh_h, eh_e, lane);
+                        a.score = er.score;
+                        if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+                    }
+                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
+                    else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
+                } else { a.qe = l_query; a.re = s_rbeg + s_len; }
+                a.seedcov = 0;
+                for (i = 0; i < n; ++i) {
+                    const int t = cs[i];
+                    const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+                    const int64_t t_rbeg = w.s_rbeg[t];
+                    if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
+                }
+                a.w = aw0 > aw1 ? aw0 : aw1;
+                a.seedlen0 = s_len;
+                a.frac_rep = frac_rep;
+                w.regs[n_av++] = a;                  // every lane stores the same bytes
+            }
+        }
+        ck.n_reg[r] = n_av;
+    }
+}

@@ -15,6 +15,7 @@
 #include "slx_internal.h"
 #include "dev_seed.h"
 #include "dev_fin.h"
+#include "dev_ext_wave.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -71,6 +72,7 @@ struct slx_aligner {
     // knobs
     int64_t chunk_reads = 1 << 20;
     int cap_intv = 40;
+    int ext_mode = 1;             // 1 = wave-cooperative extension, 0 = one lane per read
     int max_threads = 0;
     int n_cu = 256;
     unsigned long long zcap = 1ull << 30;
@@ -242,6 +244,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     if (!strcmp(key, "chunk_reads")) { if (value < 1) return SLX_EINVAL; al->chunk_reads = value; }
     else if (!strcmp(key, "cap_intv")) { if (value < 1) return SLX_EINVAL; al->cap_intv = (int)value; }
     else if (!strcmp(key, "dense_sa")) al->dense_sa = value != 0;
+    else if (!strcmp(key, "ext_mode")) al->ext_mode = (int)value;
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
     else { slx_set_error("slx_aligner_set: unknown key %s", key); return SLX_EINVAL; }
@@ -259,7 +262,11 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 template <int MAXQ>
 static void launch_ext_fin(slx_aligner *al, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
 {
-    hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+    else {
+        const int g = std::min(ck.n_reads, al->n_cu * 32);
+        hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt);
+    }
     (void)hipEventRecord(al->ev[5], al->stream);
     hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
 }

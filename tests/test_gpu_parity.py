@@ -1,0 +1,257 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(libseqlib_amd.so), against the CPU oracle on the same inputs -- bit-exact on every field of every
+record (count, flag, rid, pos, CIGAR, mapq, AS, NM, NA) -- and against the committed golden vectors.
+"""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("hit_off", "rid", "pos", "flag", "mapq", "score", "nm", "na", "n_cigar", "cig_off", "cigar")
+
+
+def assert_same(got, exp, what=""):
+    for k in FIELDS:
+        if not np.array_equal(got[k], exp[k]):
+            # locate the first differing read for the message
+            import seqlib_amd
+            n = len(exp["hit_off"]) - 1
+            for i in range(n):
+                a, b = seqlib_amd.records_of(got, i), seqlib_amd.records_of(exp, i)
+                if a != b:
+                    raise AssertionError("%s: field %s differs; first bad read %d\n gpu=%s\n cpu=%s" % (what, k, i, a, b))
+            raise AssertionError("%s: field %s differs" % (what, k))
+
+
+@pytest.fixture(scope="module")
+def sl():
+    import seqlib_amd
+    from seqlib_amd import _ffi
+    _ffi.lib()   # raises if the HIP extension is missing: there is no fallback
+    return seqlib_amd
+
+
+@pytest.fixture(scope="module")
+def tiny_gpu(sl, golden_dir):
+    idx = sl.BWAIndex()
+    idx.LoadIndex(os.path.join(golden_dir, "tiny.fa"))
+    return idx
+
+
+def test_fixture_reads_match_oracle_and_golden(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
+    (_, s1), (_, s2) = sim_reads
+    for seqs, fn in ((s1, "sim1_head3000.records.tsv"), (s2, "sim2_head3000.records.tsv")):
+        al = sl.BWAAligner(tiny_gpu)
+        got = al.alignSequences(seqs)
+        exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+        assert_same(got, exp, fn)
+        # and the committed golden text (Appendix-F format)
+        lines = []
+        for i in range(len(seqs)):
+            for j, r in enumerate(sl.records_of(got, i)):
+                lines.append("\t".join(map(str, [i, j, r["flag"], r["rid"], r["pos"], r["mapq"], sl.cigar_str(r["cigar"]), r["AS"], r["NM"], r["NA"]])))
+        assert "\n".join(lines) + "\n" == open(os.path.join(golden_dir, fn)).read()
+
+
+@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2)])
+def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
+    """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
+    a tiny interval capacity that forces the overflow-retry path: identical records."""
+    (_, s1), _ = sim_reads
+    seqs = s1[:1500]
+    al = sl.BWAAligner(tiny_gpu)
+    al.set(knob, val)
+    got = al.alignSequences(seqs)
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    assert_same(got, exp, "%s=%d" % (knob, val))
+
+
+def test_ordinal_stream_matches_successive_calls(sl, orc, tiny_gpu, tiny_index, sim_reads):
+    """batch read i == i-th successive alignSequence call (lrand48 salt by ordinal); two batches continue the stream"""
+    (_, s1), _ = sim_reads
+    al = sl.BWAAligner(tiny_gpu)
+    a = al.alignSequences(s1[:300])
+    b = al.alignSequences(s1[300:600])
+    e1 = orc.align_batch(orc.default_opt(), tiny_index, s1[:300], first_ordinal=0)
+    e2 = orc.align_batch(orc.default_opt(), tiny_index, s1[300:600], first_ordinal=300)
+    assert_same(a, e1, "batch 1")
+    assert_same(b, e2, "batch 2")
+    one = sl.BWAAligner(tiny_gpu)
+    for i in range(5):
+        assert one.alignSequence(s1[i]) == [
+            {k: r[k] for k in ("rid", "pos", "flag", "mapq", "AS", "NM", "NA", "cigar")}
+            for r in orc.align_sequence(orc.default_opt(), tiny_index, s1[i], ordinal=i)]
+
+
+def test_edge_cases(sl, orc, tiny_gpu, tiny_index, golden_dir):
+    """empty / too-short / all-N / N-containing / low-complexity / ragged lengths / lower case"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    rng = np.random.default_rng(3)
+    seqs = ["", "ACGT", "N" * 150, "ACGTACGTACGTACGTAC", "A" * 150, "AC" * 75, refs[0][5000:5150].lower()]
+    for L in (19, 20, 33, 75, 100, 149, 151, 250, 400, 699):
+        p = int(rng.integers(0, len(refs[1]) - L))
+        s = list(refs[1][p:p + L])
+        for _ in range(L // 40):
+            s[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+        seqs.append("".join(s))
+    # chimeric + indel reads
+    seqs.append(refs[0][1000:1080] + refs[2][500:570])
+    seqs.append(refs[0][2000:2070] + "ACG" + refs[0][2070:2140])
+    seqs.append(refs[0][3000:3070] + refs[0][3078:3150])
+    seqs.append(orc_revcomp(refs[3][100:250]))
+    al = sl.BWAAligner(tiny_gpu)
+    got = al.alignSequences(seqs)
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    assert_same(got, exp, "edge cases")
+    assert got["hit_off"][1] == 0 and got["hit_off"][3] == 0     # empty, ACGT, N*150 produce no record
+    # hardclip / secondary-filter arguments of the glue
+    for hc, ksf, ms in ((True, 0.9, 10), (False, 0.0, 1), (False, 1.5, 10), (False, -1.0, 0), (True, 0.5, 2)):
+        al = sl.BWAAligner(tiny_gpu)
+        got = al.alignSequences(seqs, hardclip=hc, keepSecFrac=ksf, maxSecondary=ms)
+        exp = orc.align_batch(orc.default_opt(), tiny_index, seqs, hardclip=hc, keep_sec_frac=ksf, max_secondary=ms)
+        assert_same(got, exp, "glue args %s %s %s" % (hc, ksf, ms))
+
+
+def orc_revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def test_read_too_long_fails_loudly(sl, tiny_gpu):
+    from seqlib_amd import _ffi
+    al = sl.BWAAligner(tiny_gpu)
+    with pytest.raises(_ffi.SlxError) as e:
+        al.alignSequences(["ACGT" * 200])
+    assert e.value.code == _ffi.SLX_EUNSUPPORTED
+
+
+def test_setters_reference_kat_options(sl, orc, tiny_gpu, tiny_index, sim_reads):
+    """the option set of the reference's own KAT (seq_test/seq_test.cpp:798-806), incl. SetAScore's stale matrix"""
+    (_, s1), _ = sim_reads
+    al = sl.BWAAligner(tiny_gpu)
+    opt = orc.default_opt()
+    al.SetGapOpen(32); opt.o_ins = opt.o_del = 32
+    al.SetGapExtension(1); opt.e_ins = opt.e_del = 1
+    al.SetMismatchPenalty(18); opt.b = 18; orc.lib().orc_fill_scmat(opt.a, opt.b, opt.mat)
+    al.SetAScore(2)
+    opt.a = 2
+    for f in ("b", "T", "o_ins", "o_del", "e_ins", "e_del", "zdrop", "pen_clip5", "pen_clip3", "pen_unpaired"):
+        setattr(opt, f, getattr(opt, f) * 2)
+    al.SetZDropoff(100); opt.zdrop = 100
+    al.Set3primeClippingPenalty(5); opt.pen_clip3 = 5
+    al.Set5primeClippingPenalty(5); opt.pen_clip5 = 5
+    al.SetBandwidth(1000); opt.w = 1000
+    al.SetReseedTrigger(1.5); opt.split_factor = 1.5
+    for name in ("SetGapOpen", "SetGapExtension", "SetMismatchPenalty", "SetAScore", "SetZDropoff", "Set3primeClippingPenalty",
+                 "Set5primeClippingPenalty", "SetBandwidth", "SetReseedTrigger"):
+        with pytest.raises(ValueError):
+            getattr(al, name)(-1)
+    seqs = s1[:800]
+    assert_same(al.alignSequences(seqs), orc.align_batch(opt, tiny_index, seqs), "KAT options")
+
+
+def test_construct_index_on_gpu_matches_reference_fixture(sl, orc, golden_dir, tmp_path):
+    """ConstructIndex (suffix sort, BWT, Occ blocks, SA samples on the GPU) + WriteIndex == the reference's
+    checked-in `bwa index` output, byte for byte; LoadIndex of it round-trips."""
+    names, seqs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    idx = sl.BWAIndex()
+    idx.ConstructIndex(list(zip(names, seqs)))
+    assert idx.NumSequences() == 4 and idx.ChrIDToName(2) == "tp53"
+    idx.WriteIndex(str(tmp_path / "t"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(str(tmp_path / ("t." + ext)), os.path.join(golden_dir, "tiny.fa." + ext), shallow=False), ext
+    with pytest.raises(ValueError):
+        sl.BWAIndex().ConstructIndex([("a", "ACGT"), ("", "ACGT")])
+    with pytest.raises(ValueError):
+        sl.BWAIndex().ConstructIndex([("a", "ACGT"), ("b", "")])
+
+
+def test_reference_kat_index_with_N(sl, orc, tmp_path):
+    """/root/reference/seq_test/seq_test.cpp:846-911: 4 refs incl. 100 N; write + reload; 38M hit; 2 records for the 33-mer.
+    N bases draw lrand48() from the real libc stream -- the oracle's emulated stream is set to the same state."""
+    import ctypes as C
+    from seqlib_amd import _ffi
+    refs = [("ref3", "ACATGGCGAGCACTTCTAGCATCAGCTAGCTACGATCGATCGATCGATCGTAGC"),
+            ("ref4", "CTACTTTATCATCTACACACTGCCTGACTGCGGCGACGAGCGAGCAGCTACTATCGACT"),
+            ("ref5", "CGATCGTAGCTAGCTGATGCTAGAAGTGCTCGCCATGT"),
+            ("ref6", "TATCTACTGCGCGCGATCATCTAGCGCAGGACGAGCATC" + "N" * 100 + "CGATCGTTATTATCGAGCGACGATCTACTACGT")]
+    state = _ffi.lib().slx_lrand48_peek_libc()
+    orc.lib().orc_rng_set_state(state)
+    idx = sl.BWAIndex()
+    idx.ConstructIndex(refs)
+    oidx = orc.Index.build([r[0] for r in refs], [r[1] for r in refs])
+    assert _ffi.lib().slx_lrand48_peek_libc() == orc.lib().orc_rng_get_state()   # 200 draws consumed on both sides
+    idx.WriteIndex(str(tmp_path / "k"))
+    oidx.write(str(tmp_path / "o"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(str(tmp_path / ("k." + ext)), str(tmp_path / ("o." + ext)), shallow=False), ext
+    idx2 = sl.BWAIndex()
+    idx2.LoadIndex(str(tmp_path / "k"))
+    assert [idx2.ChrIDToName(i) for i in range(4)] == ["ref3", "ref4", "ref5", "ref6"]
+    with pytest.raises(IndexError):
+        idx2.ChrIDToName(4)
+    al = sl.BWAAligner(idx2)
+    r1 = al.alignSequence("ACATGGCGAGCACTTCTAGCATCAGCTAGCTACGATCG", "name", False, 0.9, 1)
+    r2 = al.alignSequence("CGATCGTAGCTAGCTGATGCTAGAAGTGCTCGC", "name", False, 0.9, 2)
+    e1 = orc.align_sequence(orc.default_opt(), oidx, "ACATGGCGAGCACTTCTAGCATCAGCTAGCTACGATCG", max_secondary=1, ordinal=0)
+    e2 = orc.align_sequence(orc.default_opt(), oidx, "CGATCGTAGCTAGCTGATGCTAGAAGTGCTCGC", max_secondary=2, ordinal=1)
+    strip = lambda rs: [{k: r[k] for k in ("rid", "pos", "flag", "mapq", "AS", "NM", "NA", "cigar")} for r in rs]
+    assert r1 == strip(e1) and r2 == strip(e2)
+    assert sl.cigar_str(r1[0]["cigar"]) == "38M" and len(r2) == 2
+
+
+def test_synthetic_ecoli_block_matches_oracle(sl, orc, tmp_path):
+    """C2-shaped data: GPU-built index of the 4.6 Mb synthetic reference, 30 000 synthetic 150 bp reads
+    (repeats, low-complexity tracts, indels) -- bit-exact vs the oracle loading the index the GPU wrote."""
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    g = synth.make_genome(cfg["length"])
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(cfg["name"], synth.genome_ascii(g))])
+    idx.WriteIndex(str(tmp_path / "e"))
+    oidx = orc.Index.load(str(tmp_path / "e"))
+    reads = synth.make_reads_block(g, 7, synth.BLOCK, cfg["read_len"], cfg["read_seed"])[0][:30000]
+    offs = synth.offsets_for(len(reads), cfg["read_len"])
+    al = sl.BWAAligner(idx)
+    got = al.align_flat(reads.tobytes(), offs)
+    exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
+    assert_same(got, exp, "ecoli_syn")
+
+
+def test_full_size_properties(sl):
+    """BASELINE-size batch (2 M reads of C2 here; bench.py runs the 10 M) checked through size-independent
+    properties: query-consuming CIGAR length == read length, positions inside the contig, idempotence of a
+    second pass, and error-free forward reads land exactly where they were drawn."""
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    g = synth.make_genome(cfg["length"])
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(cfg["name"], synth.genome_ascii(g))])
+    n = 2_000_000 // synth.BLOCK * synth.BLOCK
+    reads = synth.make_reads(g, n, cfg["read_len"], cfg["read_seed"])
+    offs = synth.offsets_for(n, cfg["read_len"])
+    al = sl.BWAAligner(idx)
+    a = al.align_flat(reads.tobytes(), offs)
+    al2 = sl.BWAAligner(idx)
+    b = al2.align_flat(reads.tobytes(), offs)
+    for k in FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    ops, lens = a["cigar"] & 0xf, a["cigar"] >> 4
+    qcons = np.where((ops == 0) | (ops == 1) | (ops == 4), lens, 0).astype(np.int64)
+    per_hit = np.add.reduceat(qcons, a["cig_off"][:-1]) if len(qcons) else qcons
+    assert np.all(per_hit == cfg["read_len"])
+    rcons = np.where((ops == 0) | (ops == 2), lens, 0).astype(np.int64)
+    rspan = np.add.reduceat(rcons, a["cig_off"][:-1])
+    assert np.all(a["pos"] >= 0) and np.all(a["pos"] + rspan <= cfg["length"])
+    nh = np.diff(a["hit_off"])
+    assert (nh >= 1).mean() > 0.999
+    # truth check on block 0
+    blk, start, strand = synth.make_reads_block(g, 0, synth.BLOCK, cfg["read_len"], cfg["read_seed"])
+    first = a["hit_off"][:synth.BLOCK]
+    ok = (nh[:synth.BLOCK] >= 1)
+    fwd_exact = ok & (strand == 0) & (a["mapq"][np.minimum(first, len(a["mapq"]) - 1)] >= 30)
+    lead = np.where((a["cigar"][a["cig_off"][first]] & 0xf) == 4, a["cigar"][a["cig_off"][first]] >> 4, 0)
+    near = np.abs((a["pos"][first] - lead) - start) <= 40
+    assert near[fwd_exact].mean() > 0.995
