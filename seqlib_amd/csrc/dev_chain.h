@@ -7,6 +7,17 @@
 #include "dev_sort.h"
 #include "dev_types.h"
 
+// Reads are handed out 64 at a time (one per lane) from a device-wide queue, in heaviest-first order, so
+// that the lanes of a wave work on reads of similar weight and the heavy tail starts early.
+__device__ __forceinline__ int next_slot(unsigned int *queue)
+{
+    unsigned int base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) base = atomicAdd(queue, 64u);
+    base = __shfl(base, 0, 64);
+    return (int)(base + lane);
+}
+
 struct ReadWS {               // views into the per-seed-slot arrays for one read
     int64_t *s_rbeg; uint32_t *s_ql; int32_t *s_next;
     int64_t *c_pos; int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first; int8_t *c_kept;
@@ -53,11 +64,14 @@ __device__ inline int dev_chain_weight(const ReadWS &w, int c)
 }
 
 template <typename I>
-__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int r = tid; r < ck.n_reads; r += ck.n_threads) {
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_intv = (int)ck.intv_n[r];

@@ -170,14 +170,19 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
 }
 
 template <int MAXQ>
-__global__ void __launch_bounds__(64) k_extend_wave(DevRef R, Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(64) k_extend_wave(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
 {
     constexpr int NCH = (MAXQ + WAVE - 1) / WAVE;
     __shared__ int eh_h[MAXQ + 2 + WAVE], eh_e[MAXQ + 2 + WAVE];
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
-    for (int r = blockIdx.x; r < ck.n_reads; r += gridDim.x) {
+    while (true) {
+        int slot = 0;
+        if (lane == 0) slot = (int)atomicAdd(queue, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= ck.n_reads) break;
+        const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);

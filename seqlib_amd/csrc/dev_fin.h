@@ -220,12 +220,15 @@ __device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const 
 }
 
 template <int MAXQ>
-__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    for (int r = tid; r < ck.n_reads; r += ck.n_threads) {
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);

@@ -16,6 +16,7 @@
 #include "dev_seed.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
+#include "dev_ext_reg.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -70,17 +71,22 @@ struct slx_aligner {
     bool have_dense = false;
     const slx_index *host_idx = nullptr;
     // knobs
-    int64_t chunk_reads = 1 << 20;
+    int64_t chunk_reads = 1 << 24;  // one chunk for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
-    int ext_mode = 1;             // 1 = wave-cooperative extension, 0 = one lane per read
+    int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
+    int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
     int max_threads = 0;
     int n_cu = 256;
-    unsigned long long zcap = 1ull << 30;
+    unsigned long long zcap = 1ull << 26;   // floor of the traceback arena (bytes)
+    unsigned long long z_per_read = 512;    // arena bytes budgeted per read (grows when a chunk overflows)
+    unsigned long long cig_per_read = 8;    // cigar-pool words per read
+    int n_retries = 0;
     // workspaces
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     // outputs
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp;
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
     hipEvent_t ev[SLX_N_STAGES + 1];
     float stage_ms[SLX_N_STAGES];
@@ -102,6 +108,15 @@ __global__ void k_encode(const uint8_t *ascii, uint8_t *codes, size_t n)
         }
         codes[i] = c;
     }
+}
+
+__global__ void k_order_keys(const unsigned long long *seed_cnt, int n, unsigned int *key, int *val)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c = seed_cnt[i];
+    key[i] = c > 0xfffffu ? 0xfffffu : (unsigned int)c;   // 20-bit keys are plenty to separate heavy from light
+    val[i] = i;
 }
 
 __global__ void k_rel_offsets(const uint64_t *offs, uint64_t *rel, int n_reads, uint64_t base)
@@ -229,7 +244,7 @@ extern "C" void slx_aligner_free(slx_aligner *al)
                       &al->seed_off, &al->scan_tmp, &al->s_rbeg, &al->s_ql, &al->s_next, &al->c_pos, &al->c_head, &al->c_tail,
                       &al->c_n, &al->c_rid, &al->c_w, &al->c_first, &al->c_kept, &al->ia, &al->ib, &al->ic, &al->srt, &al->regs,
                       &al->hits, &al->n_chain, &al->n_reg, &al->n_hit, &al->na, &al->frac_rep, &al->zarena, &al->cigpool,
-                      &al->counters, &al->lists, &al->hit_cnt, &al->cig_cnt, &al->hit_off_c, &al->cig_off_c, &al->o_hit_off,
+                      &al->counters, &al->lists, &al->order_key_in, &al->order_key_out, &al->order_in, &al->order_out, &al->queues, &al->sort_tmp, &al->hit_cnt, &al->cig_cnt, &al->hit_off_c, &al->cig_off_c, &al->o_hit_off,
                       &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig,
                       &al->o_cig_off, &al->o_cigar};
     for (DevBuf *b : bufs) b->release();
@@ -245,6 +260,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cap_intv")) { if (value < 1) return SLX_EINVAL; al->cap_intv = (int)value; }
     else if (!strcmp(key, "dense_sa")) al->dense_sa = value != 0;
     else if (!strcmp(key, "ext_mode")) al->ext_mode = (int)value;
+    else if (!strcmp(key, "sched")) al->sched = (int)value;
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
     else { slx_set_error("slx_aligner_set: unknown key %s", key); return SLX_EINVAL; }
@@ -262,13 +278,16 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 template <int MAXQ>
 static void launch_ext_fin(slx_aligner *al, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
 {
-    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+    const int *order = al->sched ? al->order_out.as<int>() : nullptr;
+    unsigned int *q = al->queues.as<unsigned int>();
+    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt, order, q + 1);
     else {
         const int g = std::min(ck.n_reads, al->n_cu * 32);
-        hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt);
+        if (al->ext_mode == 1) hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt, order, q + 1);
+        else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt, order, q + 1);
     }
     (void)hipEventRecord(al->ev[5], al->stream);
-    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt);
+    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt, order, q + 2);
 }
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
@@ -357,8 +376,22 @@ static int run_chunk(slx_aligner *al, const slx_opt *opt, const uint8_t *d_ascii
     ck.c_first = al->c_first.as<int32_t>(); ck.c_kept = al->c_kept.as<int8_t>();
     ck.ia = al->ia.as<int32_t>(); ck.ib = al->ib.as<int32_t>(); ck.ic = al->ic.as<int32_t>(); ck.srt = al->srt.as<uint64_t>();
     ck.regs = al->regs.as<DReg>(); ck.hits = al->hits.as<DHit>();
+    ENS(queues, 64);
+    HIPCHK(hipMemsetAsync(al->queues.p, 0, 64, st));
+    if (al->sched) {   // heaviest reads first: sort read ids by their seed count, descending
+        ENS(order_key_in, (size_t)n * 4); ENS(order_key_out, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
+        hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, al->seed_cnt.as<unsigned long long>(), n,
+                           al->order_key_in.as<unsigned int>(), al->order_in.as<int>());
+        size_t tb = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, al->order_key_in.as<unsigned int>(), al->order_key_out.as<unsigned int>(),
+                                                            al->order_in.as<int>(), al->order_out.as<int>(), n, 0, 20, st));
+        ENS(sort_tmp, tb + 256);
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(al->sort_tmp.p, tb, al->order_key_in.as<unsigned int>(), al->order_key_out.as<unsigned int>(),
+                                                            al->order_in.as<int>(), al->order_out.as<int>(), n, 0, 20, st));
+    }
     (void)hipEventRecord(al->ev[3], st);
-    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt);
+    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, al->sched ? al->order_out.as<int>() : nullptr,
+                       al->queues.as<unsigned int>());
     (void)hipEventRecord(al->ev[4], st);
     if (max_len <= 160) launch_ext_fin<160>(al, ck, dopt, grid, bs);
     else if (max_len <= 320) launch_ext_fin<320>(al, ck, dopt, grid, bs);
@@ -447,15 +480,23 @@ extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const
         uint64_t pair[2] = {h_offs[0], h_offs[(size_t)n]};
         ChunkCaps caps;
         caps.cap_intv = al->cap_intv;
-        caps.zcap = al->zcap;
-        caps.cigcap = (unsigned long long)n * 8 + 4096;
+        caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
+        caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096;
         for (int attempt = 0;; ++attempt) {
             uint32_t fl = 0;
             int64_t hb = hit_base, cb = cig_base;
             rc = run_chunk(al, opt, (const uint8_t *)d_bases, d_offs, pair, r0, n, max_len, rng_state, first_ordinal, hardclip, keepSecFrac,
                            maxSecondary, caps, &hb, &cb, &fl);
             if (rc != SLX_OK) return rc;
-            if (!fl) { hit_base = hb; cig_base = cb; break; }
+            if (!fl) {
+                hit_base = hb; cig_base = cb;
+                // remember what this workload needed so that the next batch does not pay for the retry again
+                al->cap_intv = caps.cap_intv;
+                al->z_per_read = std::max<unsigned long long>(al->z_per_read, (caps.zcap + n - 1) / (unsigned long long)n);
+                al->cig_per_read = std::max<unsigned long long>(al->cig_per_read, (caps.cigcap + n - 1) / (unsigned long long)n);
+                al->n_retries += attempt;
+                break;
+            }
             if (fl & (ERR_LOGLUT | ERR_INTERNAL)) { slx_set_error("device pipeline error flags 0x%x", fl); return SLX_EINTERNAL; }
             if (attempt >= 8) { slx_set_error("chunk still overflows its work areas after %d retries (flags 0x%x)", attempt, fl); return SLX_ENOMEM; }
             if (fl & OVF_INTV) caps.cap_intv *= 2;
