@@ -1,0 +1,186 @@
+// BamRecord.h -- the subset of SeqLib::BamRecord / Cigar / CigarField that the BWAAligner path writes
+// and that a caller needs to read its output.  Same names, signatures and
+// semantics as /root/reference/SeqLib/BamRecord.h:49-192,202-675 and src/BamRecord.cpp:33-106,
+// 255-274,646-664,861-917,960-970,1039-1054; the rest of that 70-method class (mate/pair fields,
+// interval algebra, pile-up helpers) is BAM utility API outside this path.
+#pragma once
+#include <cassert>
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <regex>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+#include "SeqLib/hts_compat.h"
+
+namespace SeqLib {
+
+struct Bam1Deleter {            // /root/reference/SeqLib/BamWalker.h:19-24
+    void operator()(bam1_t *b) const { if (b) bam_destroy1(b); }
+};
+
+constexpr char BASES[16] = {' ', 'A', 'C', ' ', 'G', ' ', ' ', ' ', 'T', ' ', ' ', ' ', ' ', ' ', ' ', 'N'};
+
+class CigarField {
+    friend class Cigar;
+public:
+    CigarField(char opChr, uint32_t len)
+    {
+        static const char ops[] = BAM_CIGAR_STR;
+        int op = -1;
+        for (int i = 0; i < 9; ++i) if (ops[i] == opChr) op = i;
+        if (op < 0) throw std::invalid_argument("Cigar type must be one of MIDSHPN=X");
+        data = (len << BAM_CIGAR_SHIFT) | static_cast<uint32_t>(op);
+    }
+    explicit CigarField(uint32_t f) : data(f) {}
+    constexpr uint32_t raw() const noexcept { return data; }
+    constexpr char Type() const noexcept { return bam_cigar_opchr(data); }
+    constexpr uint8_t RawType() const noexcept { return bam_cigar_op(data); }
+    constexpr uint32_t Length() const noexcept { return bam_cigar_oplen(data); }
+    constexpr bool ConsumesReference() const noexcept { return (bam_cigar_type(bam_cigar_op(data)) & 2) != 0; }
+    constexpr bool ConsumesQuery() const noexcept { return (bam_cigar_type(bam_cigar_op(data)) & 1) != 0; }
+    constexpr bool operator==(const CigarField &o) const noexcept { return data == o.data; }
+    constexpr bool operator!=(const CigarField &o) const noexcept { return !(*this == o); }
+    friend std::ostream &operator<<(std::ostream &out, const CigarField &c) noexcept { return out << c.Length() << c.Type(); }
+private:
+    uint32_t data;
+};
+
+class Cigar {
+public:
+    Cigar() = default;
+    explicit Cigar(const std::string &cig)
+    {
+        static const std::regex token{R"((\d+)([MIDNSHP=X]))"};
+        std::smatch m;
+        auto s = cig;
+        while (std::regex_search(s, m, token)) {
+            add(CigarField(m[2].str()[0], static_cast<uint32_t>(std::stoi(m[1].str()))));
+            s = m.suffix().str();
+        }
+    }
+    using iterator = std::vector<CigarField>::iterator;
+    using const_iterator = std::vector<CigarField>::const_iterator;
+    iterator begin() noexcept { return m_data.begin(); }
+    iterator end() noexcept { return m_data.end(); }
+    const_iterator begin() const noexcept { return m_data.begin(); }
+    const_iterator end() const noexcept { return m_data.end(); }
+    const CigarField &back() const noexcept { return m_data.back(); }
+    const CigarField &front() const noexcept { return m_data.front(); }
+    size_t size() const noexcept { return m_data.size(); }
+    void reserve(size_t n) { m_data.reserve(n); }
+    CigarField &operator[](size_t i) noexcept { return m_data[i]; }
+    const CigarField &operator[](size_t i) const noexcept { return m_data[i]; }
+    int NumQueryConsumed() const noexcept { int t = 0; for (auto &c : m_data) if (c.ConsumesQuery()) t += (int)c.Length(); return t; }
+    int NumReferenceConsumed() const noexcept { int t = 0; for (auto &c : m_data) if (c.ConsumesReference()) t += (int)c.Length(); return t; }
+    void add(const CigarField &c) { m_data.push_back(c); }
+    bool operator==(const Cigar &c) const noexcept { return m_data == c.m_data; }
+    bool operator!=(const Cigar &c) const { return !(c == *this); }
+    friend std::ostream &operator<<(std::ostream &out, const Cigar &c) noexcept { for (auto &f : c) out << f; return out; }
+private:
+    std::vector<CigarField> m_data;
+};
+
+class BamRecord;
+typedef std::shared_ptr<BamRecord> BamRecordPtr;
+typedef std::vector<BamRecordPtr> BamRecordPtrVector;
+
+class BamRecord {
+    friend class BWAAligner;
+public:
+    BamRecord() : b(bam_init1(), Bam1Deleter()) {}
+    explicit BamRecord(bam1_t *raw) : b(raw, Bam1Deleter()) {}
+    BamRecord(const BamRecord &) = delete;
+    BamRecord &operator=(const BamRecord &) = delete;
+    BamRecord(BamRecord &&) = default;
+    BamRecord &operator=(BamRecord &&) = default;
+
+    bool isEmpty() const { return !b; }
+    bool ReverseFlag() const { return b ? ((b->core.flag & BAM_FREVERSE) != 0) : false; }
+    bool SecondaryFlag() const { return b ? ((b->core.flag & BAM_FSECONDARY) != 0) : false; }
+    bool SupplementaryFlag() const { return b ? ((b->core.flag & BAM_FSUPPLEMENTARY) != 0) : false; }
+    bool MappedFlag() const { return b ? ((b->core.flag & BAM_FUNMAP) == 0) : false; }
+    int32_t Position() const { return b ? (int32_t)b->core.pos : -1; }
+    int32_t PositionEnd() const { return b ? (int32_t)bam_endpos(b.get()) : -1; }
+    int32_t ChrID() const { return b ? b->core.tid : -1; }
+    int32_t MateChrID() const { return b ? b->core.mtid : -1; }
+    int32_t MapQuality() const { return b ? b->core.qual : -1; }
+    std::string Qname() const { return std::string(bam_get_qname(b)); }
+    uint32_t AlignmentFlag() const { return b->core.flag; }
+    int32_t Length() const { return b->core.l_qseq; }
+    int32_t CigarSize() const { return b ? (int32_t)b->core.n_cigar : -1; }
+    void SetID(int32_t id) { if (b) b->core.tid = id; }
+
+    std::string Sequence() const
+    {
+        if (!b) return {};
+        const uint8_t *s = bam_get_seq(b.get());
+        std::string out;
+        out.reserve((size_t)b->core.l_qseq);
+        for (int i = 0; i < b->core.l_qseq; ++i) out.push_back(BASES[bam_seqi(s, i)]);
+        return out;
+    }
+    Cigar GetCigar() const
+    {
+        Cigar cig;
+        cig.reserve(b->core.n_cigar);
+        const uint8_t *raw = reinterpret_cast<const uint8_t *>(bam_get_cigar(b.get()));
+        for (size_t i = 0; i < b->core.n_cigar; ++i) { uint32_t w; std::memcpy(&w, raw + i * 4, 4); cig.add(CigarField{w}); }
+        return cig;
+    }
+    std::string CigarString() const
+    {
+        if (!b) return {};
+        std::string out;
+        const uint8_t *raw = reinterpret_cast<const uint8_t *>(bam_get_cigar(b.get()));
+        for (uint32_t i = 0; i < b->core.n_cigar; ++i) {
+            uint32_t w; std::memcpy(&w, raw + i * 4, 4);
+            out += std::to_string(bam_cigar_oplen(w));
+            out.push_back(BAM_CIGAR_STR[w & BAM_CIGAR_MASK]);
+        }
+        return out;
+    }
+    bool GetIntTag(std::string_view tag, int32_t &out) const
+    {
+        if (!b) return false;
+        uint8_t *aux = bam_aux_get(b.get(), tag.data());
+        if (!aux) return false;
+        char type = (char)*aux;
+        if (type != 'i' && type != 'I' && type != 'c' && type != 'C' && type != 's' && type != 'S') return false;
+        out = (int32_t)bam_aux2i(aux);
+        return true;
+    }
+    bool GetZTag(std::string_view tag, std::string &out) const
+    {
+        if (!b) return false;
+        uint8_t *aux = bam_aux_get(b.get(), tag.data());
+        if (!aux) return false;
+        char *z = bam_aux2Z(aux);
+        if (!z) return false;
+        out = z;
+        return true;
+    }
+    void AddIntTag(std::string_view tag, int32_t val)
+    {
+        if (!b) return;
+        bam_aux_append(b.get(), tag.data(), 'i', sizeof(val), reinterpret_cast<const uint8_t *>(&val));
+    }
+    void AddZTag(std::string_view tag, std::string_view val)
+    {
+        if (tag.empty() || val.empty()) return;
+        uint8_t *existing = bam_aux_get(b.get(), tag.data());
+        if (existing) bam_aux_del(b.get(), existing);
+        std::string z(val);
+        bam_aux_append(b.get(), tag.data(), 'Z', static_cast<int>(z.size() + 1), reinterpret_cast<const uint8_t *>(z.c_str()));
+    }
+    bam1_t *raw() const { return b.get(); }
+
+private:
+    std::shared_ptr<bam1_t> b;
+};
+
+typedef std::vector<BamRecord> BamRecordVector;
+
+}  // namespace SeqLib

@@ -1,0 +1,144 @@
+// Drives the C++ drop-in headers (include/SeqLib/*.h) the way a SeqLib user would.
+//   seqlib_api_test cpu <index_prefix> <tmp_prefix>
+//       host-only checks: Cigar/CigarField (mirrors /root/reference/tests/test_BamRecord.cpp:9-66),
+//       setter exceptions and index accessors (mirrors /root/reference/seq_test/seq_test.cpp:798-828,
+//       863-883), LoadIndex -> WriteIndex round trip.  No GPU call.
+//   seqlib_api_test gpu <index_prefix> <fastq> <n_single> <n_batch>
+//       aligns the first n_single reads one alignSequence call at a time and the next n_batch reads through
+//       alignSequences, printing "read# rec# flag rid pos mapq CIGAR AS NM NA seq" per record.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include "SeqLib/BWAAligner.h"
+
+using namespace SeqLib;
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+#define CHECK_THROWS(expr, ex) do { bool ok_ = false; try { expr; } catch (const ex &) { ok_ = true; } catch (...) {} \
+    if (!ok_) { std::fprintf(stderr, "expected " #ex " from %s (line %d)\n", #expr, __LINE__); return 1; } } while (0)
+
+static int cpu_checks(const std::string &prefix, const std::string &tmp)
+{
+    // --- Cigar / CigarField
+    CigarField cf('M', 35);
+    std::ostringstream ss; ss << cf;
+    CHECK(ss.str() == "35M");
+    CHECK(cf.Type() == 'M' && cf.Length() == 35 && cf.ConsumesQuery() && cf.ConsumesReference());
+    CHECK_THROWS(CigarField('Z', 3), std::invalid_argument);
+    Cigar cig("5M2I3D4S");
+    CHECK(cig.size() == 4);
+    CHECK(cig[0].Type() == 'M' && cig[0].Length() == 5 && cig[1].Type() == 'I' && cig[2].Type() == 'D' && cig[3].Type() == 'S');
+    CHECK(cig.NumQueryConsumed() == 11 && cig.NumReferenceConsumed() == 8);
+    Cigar c2("5M2I3D4S"), c3("5M2I3D5S");
+    CHECK(cig == c2 && cig != c3);
+    std::ostringstream s2; s2 << cig;
+    CHECK(s2.str() == "5M2I3D4S");
+    // --- BamRecord tags / accessors on a hand-built record
+    {
+        BamRecord r;
+        bam1_t *b = r.raw();
+        const char *nm = "q1";
+        b->core.l_qname = 3; b->core.n_cigar = 1; b->core.l_qseq = 4;
+        b->l_data = 3 + 4 + 2 + 4;
+        b->data = (uint8_t *)std::calloc((size_t)b->l_data, 1);
+        std::memcpy(b->data, nm, 3);
+        uint32_t w = bam_cigar_gen(4, BAM_CMATCH); std::memcpy(b->data + 3, &w, 4);
+        b->data[7] = 0x12; b->data[8] = 0x48;     // ACGT
+        r.AddIntTag("NM", 7); r.AddZTag("XA", "hello"); r.AddIntTag("AS", -3); r.AddZTag("XA", "again");
+        int32_t v = 0; std::string z;
+        CHECK(r.GetIntTag("NM", v) && v == 7);
+        CHECK(r.GetIntTag("AS", v) && v == -3);
+        CHECK(r.GetZTag("XA", z) && z == "again");
+        CHECK(!r.GetIntTag("ZZ", v));
+        CHECK(r.Qname() == "q1" && r.Sequence() == "ACGT" && r.CigarString() == "4M" && r.Length() == 4);
+        CHECK(r.GetCigar() == Cigar("4M"));
+    }
+    // --- index accessors and errors
+    auto idx = std::make_shared<BWAIndex>();
+    CHECK(idx->IsEmpty() && idx->NumSequences() == 0 && idx->printSamHeader().empty());
+    CHECK_THROWS(idx->ChrIDToName(1), std::runtime_error);
+    CHECK_THROWS(idx->WriteIndex(tmp), std::runtime_error);
+    CHECK_THROWS(idx->LoadIndex("/nonexistent/prefix"), std::runtime_error);
+    idx->LoadIndex(prefix);
+    CHECK(!idx->IsEmpty() && idx->NumSequences() == 4);
+    CHECK(idx->ChrIDToName(0) == "bcr" && idx->ChrIDToName(3) == "myc");
+    CHECK_THROWS(idx->ChrIDToName(4), std::out_of_range);
+    CHECK_THROWS(idx->ChrIDToName(-1), std::out_of_range);
+    BamHeader hh = idx->HeaderFromIndex();
+    CHECK(hh.NumSequences() == 4 && hh.IDtoName(1) == "abl" && hh.GetSequenceLength(1) == 178633);
+    std::ostringstream s3; s3 << *idx;
+    CHECK(s3.str() == "[BWAIndex] #seqs=4 pac_len=354751 holes=0");
+    idx->WriteIndex(tmp);
+    for (const char *ext : {".bwt", ".sa", ".pac", ".ann", ".amb"}) {
+        std::ifstream a(prefix + ext, std::ios::binary), b(tmp + ext, std::ios::binary);
+        std::stringstream sa, sb; sa << a.rdbuf(); sb << b.rdbuf();
+        CHECK(sa.str() == sb.str() && !sa.str().empty());
+    }
+    UnalignedSequenceVector bad1 = {{"ref1", "ACGT"}, {"ref4", ""}}, bad2 = {{"", "ACGT"}};
+    CHECK_THROWS(idx->ConstructIndex(bad1), std::invalid_argument);
+    CHECK_THROWS(idx->ConstructIndex(bad2), std::invalid_argument);
+    // --- aligner setters
+    BWAAligner bwa(idx);
+    bwa.SetGapOpen(32); bwa.SetGapExtension(1); bwa.SetMismatchPenalty(18); bwa.SetAScore(2); bwa.SetZDropoff(100);
+    bwa.Set3primeClippingPenalty(5); bwa.Set5primeClippingPenalty(5); bwa.SetBandwidth(1000); bwa.SetReseedTrigger(1.5);
+    CHECK_THROWS(bwa.SetGapOpen(-1), std::invalid_argument);
+    CHECK_THROWS(bwa.SetGapExtension(-1), std::invalid_argument);
+    CHECK_THROWS(bwa.SetMismatchPenalty(-18), std::invalid_argument);
+    CHECK_THROWS(bwa.SetAScore(-2), std::invalid_argument);
+    CHECK_THROWS(bwa.SetZDropoff(-100), std::invalid_argument);
+    CHECK_THROWS(bwa.Set3primeClippingPenalty(-5), std::invalid_argument);
+    CHECK_THROWS(bwa.Set5primeClippingPenalty(-5), std::invalid_argument);
+    CHECK_THROWS(bwa.SetBandwidth(-1000), std::invalid_argument);
+    CHECK_THROWS(bwa.SetReseedTrigger(-1.5), std::invalid_argument);
+    // empty index => silent no-op
+    BWAAligner none(std::make_shared<BWAIndex>());
+    BamRecordPtrVector out;
+    none.alignSequence("ACGTACGTACGTACGTACGTACGT", "x", out, false, 0.9, 10);
+    CHECK(out.empty());
+    std::puts("cpu checks OK");
+    return 0;
+}
+
+static void print_rec(long read_no, size_t j, const BamRecord &r)
+{
+    int32_t as = 0, nm = 0, na = 0;
+    r.GetIntTag("AS", as); r.GetIntTag("NM", nm); r.GetIntTag("NA", na);
+    std::printf("%ld\t%zu\t%u\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%s\n", read_no, j, r.AlignmentFlag(), r.ChrID(), r.Position(), r.MapQuality(),
+                r.CigarString().c_str(), as, nm, na, r.Sequence().c_str());
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);
+    if (argc >= 6 && std::string(argv[1]) == "gpu") {
+        auto idx = std::make_shared<BWAIndex>();
+        idx->LoadIndex(argv[2]);
+        BWAAligner bwa(idx);
+        const long n1 = std::atol(argv[4]), n2 = std::atol(argv[5]);
+        std::ifstream fq(argv[3]);
+        std::string h, s, p, q;
+        UnalignedSequenceVector reads;
+        while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q) && (long)reads.size() < n1 + n2)
+            reads.emplace_back(h.substr(1), s, q);
+        long i = 0;
+        for (; i < n1 && i < (long)reads.size(); ++i) {
+            BamRecordPtrVector out;
+            bwa.alignSequence(reads[(size_t)i], out, false, 0.9, 10);
+            for (size_t j = 0; j < out.size(); ++j) print_rec(i, j, *out[j]);
+        }
+        UnalignedSequenceVector rest(reads.begin() + i, reads.end());
+        std::vector<BamRecordPtrVector> outs;
+        bwa.alignSequences(rest, outs, false, 0.9, 10);
+        for (size_t k = 0; k < outs.size(); ++k)
+            for (size_t j = 0; j < outs[k].size(); ++j) print_rec(i + (long)k, j, *outs[k][j]);
+        // north-star spelling with a BamRecordVector
+        BamRecordVector brv;
+        bwa.AlignSequence(reads[0].Seq, "name", brv, false, 0.9, 1);
+        std::fprintf(stderr, "AlignSequence/BamRecordVector: %zu record(s), qname %s\n", brv.size(), brv.empty() ? "-" : brv[0].Qname().c_str());
+        return 0;
+    }
+    std::fprintf(stderr, "usage: %s cpu <prefix> <tmp> | gpu <prefix> <fastq> <n_single> <n_batch>\n", argv[0]);
+    return 2;
+}

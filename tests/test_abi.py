@@ -1,0 +1,130 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/seqlib_amd.h
+declares, its host-side pieces (options, index files, lrand48 helpers) agree with the oracle / the reference's
+fixtures, and it FAILS LOUDLY when no GPU is present (no CPU fallback).  No compute call needs a GPU here."""
+import ctypes as C
+import filecmp
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "seqlib_amd", "libseqlib_amd.so")):
+        g.build()
+    from seqlib_amd import _ffi
+    _ffi.lib()
+    return _ffi
+
+
+def test_exports_match_header(ffi):
+    hdr = open(os.path.join(ROOT, "include", "seqlib_amd.h")).read()
+    body = hdr[hdr.index("extern \"C\""):]
+    declared = set(re.findall(r"\b(slx_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
+    L = ffi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    # every entry point cites the reference interface it replaces
+    for name in ("slx_opt_init", "slx_index_build", "slx_index_load", "slx_index_write", "slx_aligner_create", "slx_align_batch"):
+        assert name in hdr[:hdr.index("#ifndef")]
+    assert "src/BWAAligner.cpp:89-146" in hdr and "src/BWAIndex.cpp:83-180" in hdr
+
+
+def test_opt_init_matches_oracle(ffi, orc):
+    o = ffi.Opt()
+    ffi.lib().slx_opt_init(C.byref(o))
+    e = orc.default_opt()
+    for name, _ in ffi.Opt._fields_:
+        a, b = getattr(o, name), getattr(e, name)
+        assert (list(a) == list(b)) if name == "mat" else (a == b), name
+    m1, m2 = (C.c_int8 * 25)(), (C.c_int8 * 25)()
+    ffi.lib().slx_fill_scmat(2, 18, m1)
+    orc.lib().orc_fill_scmat(2, 18, m2)
+    assert list(m1) == list(m2)
+
+
+def test_index_files_roundtrip_through_c_abi(ffi, golden_dir, tmp_path):
+    """slx_index_load reads the reference's own `bwa index` fixture; slx_index_write reproduces it byte for byte"""
+    import seqlib_amd
+    idx = seqlib_amd.BWAIndex()
+    assert idx.IsEmpty() and idx.NumSequences() == 0 and idx.printSamHeader() == ""
+    with pytest.raises(RuntimeError):
+        idx.ChrIDToName(0)
+    with pytest.raises(RuntimeError):
+        idx.WriteIndex(str(tmp_path / "x"))
+    with pytest.raises(RuntimeError):
+        idx.LoadIndex(str(tmp_path / "does_not_exist"))
+    idx.LoadIndex(os.path.join(golden_dir, "tiny.fa"))
+    assert idx.NumSequences() == 4 and [idx.ChrIDToName(i) for i in range(4)] == ["bcr", "abl", "tp53", "myc"]
+    with pytest.raises(IndexError):
+        idx.ChrIDToName(4)
+    assert idx.printSamHeader() == "@SQ\tSN:bcr\tLN:141530\n@SQ\tSN:abl\tLN:178633\n@SQ\tSN:tp53\tLN:23070\n@SQ\tSN:myc\tLN:11518\n"
+    assert str(idx) == "[BWAIndex] #seqs=4 pac_len=354751 holes=0"
+    idx.WriteIndex(str(tmp_path / "w"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(str(tmp_path / ("w." + ext)), os.path.join(golden_dir, "tiny.fa." + ext), shallow=False), ext
+    with pytest.raises(RuntimeError):
+        idx.WriteIndex(str(tmp_path))          # prefix is a directory (src/BWAIndex.cpp:393-395)
+    # truncated file is rejected
+    bad = tmp_path / "bad"
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        data = open(os.path.join(golden_dir, "tiny.fa." + ext), "rb").read()
+        open(str(bad) + "." + ext, "wb").write(data[:len(data) // 2] if ext == "sa" else data)
+    with pytest.raises(RuntimeError):
+        seqlib_amd.BWAIndex().LoadIndex(str(bad))
+
+
+def test_lrand48_helpers(ffi, orc):
+    L = ffi.lib()
+    libc = C.CDLL(None)
+    libc.lrand48.restype = C.c_long
+    libc.srand48(777)
+    st = L.slx_lrand48_peek_libc()
+    assert st == ((777 << 16) | 0x330E)
+    assert L.slx_lrand48_peek_libc() == st                        # peeking does not disturb the stream
+    want = [libc.lrand48() for _ in range(5)]
+    assert [orc.lib().orc_lrand48_nth(st, k + 1) for k in range(5)] == want
+    assert L.slx_lrand48_advance(st, 5) == L.slx_lrand48_peek_libc()
+    libc.srand48(777)
+    L.slx_lrand48_skip_libc(3)
+    assert libc.lrand48() == want[3]
+
+
+def test_no_gpu_fails_loudly(ffi, golden_dir):
+    """Without a HIP device the alignment path must refuse to run (no silent CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import seqlib_amd
+    idx = seqlib_amd.BWAIndex()
+    idx.LoadIndex(os.path.join(golden_dir, "tiny.fa"))
+    al = seqlib_amd.BWAAligner(idx)
+    with pytest.raises(ffi.SlxError) as e:
+        al.alignSequences(["ACGT" * 30])
+    assert e.value.code == ffi.SLX_ENODEVICE
+    with pytest.raises(ffi.SlxError) as e:
+        seqlib_amd.BWAIndex().ConstructIndex([("a", "ACGTACGTAC")])
+    assert e.value.code == ffi.SLX_ENODEVICE
+    with pytest.raises(ValueError):
+        seqlib_amd.BWAIndex().ConstructIndex([("a", "ACGT"), ("", "ACGT")])
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under seqlib_amd/ or include/ may include, import, link or load anything from oracle/."""
+    bad = []
+    for base in ("seqlib_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep) or "__pycache__" in dp:
+                continue
+            for fn in fns:
+                if not fn.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"oracle[/.]|liborc|orc_[a-z]|from oracle|import oracle", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

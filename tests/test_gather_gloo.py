@@ -1,0 +1,63 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, reads sharded by contiguous ordinal range, one gather
+of the packed hits to rank 0, merged result identical to the single-process result.  The hits come
+from the oracle here (no GPU in this container); the pack / gather / unpack / merge code is the one bench.py uses
+with RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("hit_off", "rid", "pos", "flag", "mapq", "score", "nm", "na", "n_cigar", "cig_off", "cigar")
+
+
+def _worker(rank, world, port, n, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orc
+    from seqlib_amd import gather
+    G = os.path.join(ROOT, "tests", "golden")
+    _, seqs = orc.read_fastq(os.path.join(G, "sim1_bcr.head3000.fq"), n)
+    idx = orc.Index.load(os.path.join(G, "tiny.fa"))
+    lo, hi = rank * n // world, (rank + 1) * n // world            # contiguous read-ordinal shard
+    res = orc.align_batch(orc.default_opt(), idx, seqs[lo:hi], first_ordinal=lo)
+    buf = torch.from_numpy(gather.pack_numpy(res).copy())
+    parts = gather.gather_packed(buf, dst=0)
+    if rank == 0:
+        merged = gather.merge([gather.unpack(p.numpy()) for p in parts])
+        np.savez(out_path, **{k: merged[k] for k in FIELDS})
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_equals_single_process(orc, tiny_index, sim_reads, tmp_path):
+    n = 700
+    out = str(tmp_path / "merged.npz")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
+    merged = np.load(out)
+    (_, s1), _ = sim_reads
+    exp = orc.align_batch(orc.default_opt(), tiny_index, s1[:n])
+    for k in FIELDS:
+        assert np.array_equal(merged[k], exp[k]), k
+
+
+def test_pack_unpack_roundtrip(orc, tiny_index, sim_reads):
+    from seqlib_amd import gather
+    (_, s1), _ = sim_reads
+    res = orc.align_batch(orc.default_opt(), tiny_index, s1[:200])
+    back = gather.unpack(gather.pack_numpy(res))
+    for k in FIELDS:
+        assert np.array_equal(back[k], res[k]), k
+    # empty shard
+    empty = orc.align_batch(orc.default_opt(), tiny_index, [])
+    assert gather.unpack(gather.pack_numpy(empty))["n_hits"] == 0
