@@ -184,6 +184,17 @@ __device__ ExtResult reg_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx
     return r;
 }
 
+// pick the narrowest register tile that holds the extension: most extensions of 150 bp reads are < 64 columns wide,
+// so one column per lane (a third of the per-row work of the widest variant) is the common case
+template <int CPLMAX, typename QF, typename TF>
+__device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus,
+                                                          int h0, int lane)
+{
+    if (CPLMAX > 1 && qlen + 1 <= WAVE) return reg_ksw_extend2<1>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    if (CPLMAX > 2 && qlen + 1 <= 2 * WAVE) return reg_ksw_extend2<2>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    return reg_ksw_extend2<CPLMAX>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+}
+
 template <int MAXQ>
 __global__ void __launch_bounds__(64) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
 {
@@ -304,7 +315,7 @@ __global__ void __launch_bounds__(64) k_extend_reg(DevRef R, Chunk ck, DevOpt do
                     for (i = 0; i < 2; ++i) {
                         const int prev = a.score;
                         aw0 = opt.w << i;
-                        er = reg_ksw_extend2<CPL>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
+                        er = reg_ksw_extend2_auto<CPL>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
                                                   [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5, s_len * opt.a, lane);
                         a.score = er.score;
                         if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -319,7 +330,7 @@ __global__ void __launch_bounds__(64) k_extend_reg(DevRef R, Chunk ck, DevOpt do
                     for (i = 0; i < 2; ++i) {
                         const int prev = a.score;
                         aw1 = opt.w << i;
-                        er = reg_ksw_extend2<CPL>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
+                        er = reg_ksw_extend2_auto<CPL>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
                                                   [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, lane);
                         a.score = er.score;
                         if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
