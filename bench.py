@@ -124,6 +124,9 @@ def main():
     idx.ConstructIndex([(cfg["name"], synth.genome_ascii(genome))])     # suffix sort + BWT/Occ/SA on the GPU
     t_index = time.time() - t_setup
     al = seqlib_amd.BWAAligner(idx, device=local_rank)
+    for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=workers=4,sched=1
+        k, v = kv.split("=")
+        al.set(k, int(v))
     n = args.reads
     blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
     reads = gen_reads(genome, n, read_len, cfg["read_seed"], first_block=rank * blocks_per_rank)

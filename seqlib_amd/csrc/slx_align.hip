@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include "slx_internal.h"
 #include "dev_seed.h"
@@ -60,6 +63,38 @@ struct DevBuf {
 static const char *STAGE_NAMES[SLX_N_STAGES] = {"encode", "seed", "scan", "chain", "extend", "finalize", "compact", "total"};
 extern "C" const char *slx_stage_name(int i) { return i >= 0 && i < SLX_N_STAGES ? STAGE_NAMES[i] : ""; }
 
+struct slx_aligner;
+
+// One worker = one HIP stream with its own work areas and result buffers.  A large batch is split into
+// contiguous halves that two workers push through the pipeline concurrently, so that the single-read critical
+// paths at the end of the chain / extend / finalize kernels of one half overlap with the bulk of the other.
+struct Worker {
+    hipStream_t stream = nullptr;
+    DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
+    DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
+    DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp;
+    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
+    hipEvent_t ev[SLX_N_STAGES + 1];
+    float stage_ms[SLX_N_STAGES];
+    int64_t n_hits = 0, n_cig = 0;
+    int rc = SLX_OK;
+    std::string err;
+    std::vector<uint64_t> h_offs;
+    DevBuf *all[64];
+    int n_all = 0;
+    void collect()
+    {
+        DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
+                       &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
+                       &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &o_na, &o_ncig, &o_cig_off, &o_cigar};
+        n_all = (int)(sizeof(b) / sizeof(b[0]));
+        for (int i = 0; i < n_all; ++i) all[i] = b[i];
+    }
+};
+
 struct slx_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -71,24 +106,22 @@ struct slx_aligner {
     bool have_dense = false;
     const slx_index *host_idx = nullptr;
     // knobs
-    int64_t chunk_reads = 1 << 24;  // one chunk for a 10 M-read batch: the heavy-tail reads are then paid for once
+    int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
+    int n_workers = 2;            // concurrent halves of a large batch
+    int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
     int max_threads = 0;
     int n_cu = 256;
     unsigned long long zcap = 1ull << 26;   // floor of the traceback arena (bytes)
     unsigned long long z_per_read = 512;    // arena bytes budgeted per read (grows when a chunk overflows)
     unsigned long long cig_per_read = 8;    // cigar-pool words per read
     int n_retries = 0;
-    // workspaces
-    DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
-    DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
-    DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    // outputs
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp;
+    std::mutex mu;                // guards the capacity hints above when workers update them
+    std::vector<Worker *> workers;
+    // concatenated outputs of a multi-worker batch
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
-    hipEvent_t ev[SLX_N_STAGES + 1];
     float stage_ms[SLX_N_STAGES];
 };
 
@@ -174,12 +207,18 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     al->device = (devices && n_dev > 0) ? devices[0] : 0;
     if (!(devices && n_dev > 0)) (void)hipGetDevice(&al->device);
     HIPCHK(hipSetDevice(al->device));
-    HIPCHK(hipStreamCreate(&al->stream));
+    HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, al->device));
     al->n_cu = prop.multiProcessorCount;
     al->max_threads = al->n_cu * 1024;
-    for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&al->ev[i]));
+    for (int k = 0; k < 4; ++k) {
+        Worker *wk = new Worker();
+        wk->collect();
+        HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
+        for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
+        al->workers.push_back(wk);
+    }
     al->host_idx = idx;
     // FM-index
     int rc;
@@ -230,7 +269,6 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     for (int i = 1; i < LUT_N; ++i) lut[(size_t)i] = log((double)i);
     if ((rc = al->d_loglut.ensure((size_t)LUT_N * 8)) != SLX_OK) return rc;
     HIPCHK(hipMemcpy(al->d_loglut.p, lut.data(), (size_t)LUT_N * 8, hipMemcpyHostToDevice));
-    if ((rc = al->counters.ensure(64)) != SLX_OK) return rc;
     *out = al;
     return SLX_OK;
 }
@@ -239,16 +277,15 @@ extern "C" void slx_aligner_free(slx_aligner *al)
 {
     if (!al) return;
     (void)hipSetDevice(al->device);
-    DevBuf *bufs[] = {&al->d_bwt, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut,
-                      &al->codes, &al->offs_rel, &al->intv_n, &al->intv_info, &al->intv_x0, &al->intv_x2, &al->l_rep, &al->seed_cnt,
-                      &al->seed_off, &al->scan_tmp, &al->s_rbeg, &al->s_ql, &al->s_next, &al->c_pos, &al->c_head, &al->c_tail,
-                      &al->c_n, &al->c_rid, &al->c_w, &al->c_first, &al->c_kept, &al->ia, &al->ib, &al->ic, &al->srt, &al->regs,
-                      &al->hits, &al->n_chain, &al->n_reg, &al->n_hit, &al->na, &al->frac_rep, &al->zarena, &al->cigpool,
-                      &al->counters, &al->lists, &al->order_key_in, &al->order_key_out, &al->order_in, &al->order_out, &al->queues, &al->sort_tmp, &al->hit_cnt, &al->cig_cnt, &al->hit_off_c, &al->cig_off_c, &al->o_hit_off,
-                      &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig,
-                      &al->o_cig_off, &al->o_cigar};
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
+                      &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar};
     for (DevBuf *b : bufs) b->release();
-    for (int i = 0; i <= SLX_N_STAGES; ++i) (void)hipEventDestroy(al->ev[i]);
+    for (Worker *wk : al->workers) {
+        for (int i = 0; i < wk->n_all; ++i) wk->all[i]->release();
+        for (int i = 0; i <= SLX_N_STAGES; ++i) (void)hipEventDestroy(wk->ev[i]);
+        if (wk->stream) (void)hipStreamDestroy(wk->stream);
+        delete wk;
+    }
     if (al->stream) (void)hipStreamDestroy(al->stream);
     delete al;
 }
@@ -261,6 +298,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "dense_sa")) al->dense_sa = value != 0;
     else if (!strcmp(key, "ext_mode")) al->ext_mode = (int)value;
     else if (!strcmp(key, "sched")) al->sched = (int)value;
+    else if (!strcmp(key, "workers")) { if (value < 1 || value > 4) return SLX_EINVAL; al->n_workers = (int)value; }
+    else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
     else { slx_set_error("slx_aligner_set: unknown key %s", key); return SLX_EINVAL; }
@@ -276,18 +315,18 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 
 // ---------------------------------------------------------------- one chunk
 template <int MAXQ>
-static void launch_ext_fin(slx_aligner *al, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
+static void launch_ext_fin(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
 {
-    const int *order = al->sched ? al->order_out.as<int>() : nullptr;
-    unsigned int *q = al->queues.as<unsigned int>();
-    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt, order, q + 1);
+    const int *order = al->sched ? wk->order_out.as<int>() : nullptr;
+    unsigned int *q = wk->queues.as<unsigned int>();
+    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
     else {
         const int g = std::min(ck.n_reads, al->n_cu * 32);
-        if (al->ext_mode == 1) hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt, order, q + 1);
-        else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, al->stream, al->ref, ck, dopt, order, q + 1);
+        if (al->ext_mode == 1) hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
+        else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
     }
-    (void)hipEventRecord(al->ev[5], al->stream);
-    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, al->stream, al->ref, ck, dopt, order, q + 2);
+    (void)hipEventRecord(wk->ev[5], wk->stream);
+    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 2);
 }
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
@@ -295,18 +334,18 @@ struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) cons
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
 
 // runs the pipeline on reads [r0, r0+n) whose ASCII bases are d_ascii + d_offs[r0]...; appends to the outputs.
-static int run_chunk(slx_aligner *al, const slx_opt *opt, const uint8_t *d_ascii, const uint64_t *d_offs, const uint64_t *h_offs_pair,
-                     int64_t r0, int n, int max_len, uint64_t rng_state, uint64_t first_ordinal, int hardclip, double ksf, int maxsec,
+static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint8_t *d_ascii, const uint64_t *d_offs, const uint64_t *h_offs_pair,
+                     int64_t r0, int64_t part_lo, int n, int max_len, uint64_t rng_state, uint64_t first_ordinal, int hardclip, double ksf, int maxsec,
                      const ChunkCaps &caps, int64_t *hit_base, int64_t *cig_base, uint32_t *flags_out)
 {
-    hipStream_t st = al->stream;
+    hipStream_t st = wk->stream;
     int rc;
     const uint64_t base0 = h_offs_pair[0], n_bases = h_offs_pair[1] - h_offs_pair[0];
     const int bs = 128;
     int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)al->max_threads);
     const int grid = n_threads / bs;
     const int cap_list = max_len + 1;
-#define ENS(buf, bytes) if ((rc = al->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
+#define ENS(buf, bytes) if ((rc = wk->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
     ENS(codes, n_bases + 16); ENS(offs_rel, ((size_t)n + 1) * 8);
     ENS(intv_n, (size_t)n * 4); ENS(intv_info, (size_t)n * caps.cap_intv * 4); ENS(intv_x0, (size_t)n * caps.cap_intv * 4);
     ENS(intv_x2, (size_t)n * caps.cap_intv * 4); ENS(l_rep, (size_t)n * 4); ENS(seed_cnt, ((size_t)n + 1) * 8); ENS(seed_off, ((size_t)n + 1) * 8);
@@ -314,129 +353,131 @@ static int run_chunk(slx_aligner *al, const slx_opt *opt, const uint8_t *d_ascii
     ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<uint32_t>));
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
+    ENS(counters, 64);
     // counters: [0] zused, [1] cigused, [2] flags(u32)
-    HIPCHK(hipMemsetAsync(al->counters.p, 0, 64, st));
-    HIPCHK(hipMemsetAsync(al->seed_cnt.p, 0, ((size_t)n + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(wk->seed_cnt.p, 0, ((size_t)n + 1) * 8, st));
 
     Chunk ck;
     memset(&ck, 0, sizeof ck);
     ck.n_reads = n;
-    ck.codes = al->codes.as<uint8_t>();
-    ck.offs = al->offs_rel.as<uint64_t>();
+    ck.codes = wk->codes.as<uint8_t>();
+    ck.offs = wk->offs_rel.as<uint64_t>();
     ck.first_ordinal = first_ordinal + (uint64_t)r0;
     ck.rng_state = rng_state;
     ck.cap_intv = caps.cap_intv;
-    ck.intv_n = al->intv_n.as<uint32_t>(); ck.intv_info = al->intv_info.as<uint32_t>();
-    ck.intv_x0 = al->intv_x0.p; ck.intv_x2 = al->intv_x2.p;
-    ck.l_rep = al->l_rep.as<int32_t>();
-    ck.seed_off = al->seed_off.as<uint64_t>();
-    ck.n_chain = al->n_chain.as<int32_t>(); ck.n_reg = al->n_reg.as<int32_t>(); ck.n_hit = al->n_hit.as<int32_t>();
-    ck.na = al->na.as<int32_t>(); ck.frac_rep = al->frac_rep.as<float>();
-    ck.zarena = al->zarena.as<uint8_t>(); ck.zcap = caps.zcap; ck.zused = al->counters.as<unsigned long long>();
-    ck.cigpool = al->cigpool.as<uint32_t>(); ck.cigcap = caps.cigcap; ck.cigused = al->counters.as<unsigned long long>() + 1;
-    ck.flags = (uint32_t *)(al->counters.as<unsigned long long>() + 2);
+    ck.intv_n = wk->intv_n.as<uint32_t>(); ck.intv_info = wk->intv_info.as<uint32_t>();
+    ck.intv_x0 = wk->intv_x0.p; ck.intv_x2 = wk->intv_x2.p;
+    ck.l_rep = wk->l_rep.as<int32_t>();
+    ck.seed_off = wk->seed_off.as<uint64_t>();
+    ck.n_chain = wk->n_chain.as<int32_t>(); ck.n_reg = wk->n_reg.as<int32_t>(); ck.n_hit = wk->n_hit.as<int32_t>();
+    ck.na = wk->na.as<int32_t>(); ck.frac_rep = wk->frac_rep.as<float>();
+    ck.zarena = wk->zarena.as<uint8_t>(); ck.zcap = caps.zcap; ck.zused = wk->counters.as<unsigned long long>();
+    ck.cigpool = wk->cigpool.as<uint32_t>(); ck.cigcap = caps.cigcap; ck.cigused = wk->counters.as<unsigned long long>() + 1;
+    ck.flags = (uint32_t *)(wk->counters.as<unsigned long long>() + 2);
     ck.log_lut = al->d_loglut.as<double>(); ck.log_lut_n = 1 << 16;
-    ck.lists = al->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
+    ck.lists = wk->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
     ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
-    ck.seed_cnt = al->seed_cnt.as<unsigned long long>();
+    ck.seed_cnt = wk->seed_cnt.as<unsigned long long>();
     DevOpt dopt; dopt.o = *opt;
     DevFM<uint32_t> fm = al->fm32;
     fm.sa_dense = (al->dense_sa && al->have_dense) ? al->d_sa_dense.as<uint32_t>() : nullptr;
 
-    (void)hipEventRecord(al->ev[0], st);
+    (void)hipEventRecord(wk->ev[0], st);
     {   // encode + relative offsets
         const unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256 + 1, 65535u * 4);
-        hipLaunchKernelGGL(k_encode, dim3(g), dim3(256), 0, st, d_ascii + base0, al->codes.as<uint8_t>(), (size_t)n_bases);
-        hipLaunchKernelGGL(k_rel_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_offs + r0, al->offs_rel.as<uint64_t>(), n, base0);
+        hipLaunchKernelGGL(k_encode, dim3(g), dim3(256), 0, st, d_ascii + base0, wk->codes.as<uint8_t>(), (size_t)n_bases);
+        hipLaunchKernelGGL(k_rel_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_offs + r0, wk->offs_rel.as<uint64_t>(), n, base0);
     }
-    (void)hipEventRecord(al->ev[1], st);
+    (void)hipEventRecord(wk->ev[1], st);
     hipLaunchKernelGGL(k_seed<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt);
-    (void)hipEventRecord(al->ev[2], st);
+    (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
         size_t tmp_bytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (unsigned long long *)al->seed_cnt.p, (unsigned long long *)al->seed_off.p, n + 1, st);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (unsigned long long *)wk->seed_cnt.p, (unsigned long long *)wk->seed_off.p, n + 1, st);
         ENS(scan_tmp, tmp_bytes + 256);
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tmp_bytes, (unsigned long long *)al->seed_cnt.p, (unsigned long long *)al->seed_off.p, n + 1, st));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tmp_bytes, (unsigned long long *)wk->seed_cnt.p, (unsigned long long *)wk->seed_off.p, n + 1, st));
     }
     unsigned long long S = 0;
-    HIPCHK(hipMemcpyAsync(&S, al->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&S, wk->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     {
         uint32_t fl = 0;
-        HIPCHK(hipMemcpy(&fl, ck.flags, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(&fl, ck.flags, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         if (fl) { *flags_out = fl; return SLX_OK; }
     }
     const size_t S1 = (size_t)S + 1;
     ENS(s_rbeg, S1 * 8); ENS(s_ql, S1 * 4); ENS(s_next, S1 * 4); ENS(c_pos, S1 * 8); ENS(c_head, S1 * 4); ENS(c_tail, S1 * 4);
     ENS(c_n, S1 * 4); ENS(c_rid, S1 * 4); ENS(c_w, S1 * 4); ENS(c_first, S1 * 4); ENS(c_kept, S1); ENS(ia, S1 * 4); ENS(ib, S1 * 4);
     ENS(ic, S1 * 4); ENS(srt, S1 * 8); ENS(regs, S1 * sizeof(DReg)); ENS(hits, S1 * sizeof(DHit));
-    ck.s_rbeg = al->s_rbeg.as<int64_t>(); ck.s_ql = al->s_ql.as<uint32_t>(); ck.s_next = al->s_next.as<int32_t>();
-    ck.c_pos = al->c_pos.as<int64_t>(); ck.c_head = al->c_head.as<int32_t>(); ck.c_tail = al->c_tail.as<int32_t>();
-    ck.c_n = al->c_n.as<int32_t>(); ck.c_rid = al->c_rid.as<int32_t>(); ck.c_w = al->c_w.as<int32_t>();
-    ck.c_first = al->c_first.as<int32_t>(); ck.c_kept = al->c_kept.as<int8_t>();
-    ck.ia = al->ia.as<int32_t>(); ck.ib = al->ib.as<int32_t>(); ck.ic = al->ic.as<int32_t>(); ck.srt = al->srt.as<uint64_t>();
-    ck.regs = al->regs.as<DReg>(); ck.hits = al->hits.as<DHit>();
-    ENS(queues, 64);
-    HIPCHK(hipMemsetAsync(al->queues.p, 0, 64, st));
+    ck.s_rbeg = wk->s_rbeg.as<int64_t>(); ck.s_ql = wk->s_ql.as<uint32_t>(); ck.s_next = wk->s_next.as<int32_t>();
+    ck.c_pos = wk->c_pos.as<int64_t>(); ck.c_head = wk->c_head.as<int32_t>(); ck.c_tail = wk->c_tail.as<int32_t>();
+    ck.c_n = wk->c_n.as<int32_t>(); ck.c_rid = wk->c_rid.as<int32_t>(); ck.c_w = wk->c_w.as<int32_t>();
+    ck.c_first = wk->c_first.as<int32_t>(); ck.c_kept = wk->c_kept.as<int8_t>();
+    ck.ia = wk->ia.as<int32_t>(); ck.ib = wk->ib.as<int32_t>(); ck.ic = wk->ic.as<int32_t>(); ck.srt = wk->srt.as<uint64_t>();
+    ck.regs = wk->regs.as<DReg>(); ck.hits = wk->hits.as<DHit>();
+    ENS(queues, 64); ENS(counters, 64);
+    HIPCHK(hipMemsetAsync(wk->queues.p, 0, 64, st));
     if (al->sched) {   // heaviest reads first: sort read ids by their seed count, descending
         ENS(order_key_in, (size_t)n * 4); ENS(order_key_out, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
-        hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, al->seed_cnt.as<unsigned long long>(), n,
-                           al->order_key_in.as<unsigned int>(), al->order_in.as<int>());
+        hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
+                           wk->order_key_in.as<unsigned int>(), wk->order_in.as<int>());
         size_t tb = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, al->order_key_in.as<unsigned int>(), al->order_key_out.as<unsigned int>(),
-                                                            al->order_in.as<int>(), al->order_out.as<int>(), n, 0, 20, st));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
+                                                            wk->order_in.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
         ENS(sort_tmp, tb + 256);
-        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(al->sort_tmp.p, tb, al->order_key_in.as<unsigned int>(), al->order_key_out.as<unsigned int>(),
-                                                            al->order_in.as<int>(), al->order_out.as<int>(), n, 0, 20, st));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(wk->sort_tmp.p, tb, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
+                                                            wk->order_in.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
     }
-    (void)hipEventRecord(al->ev[3], st);
-    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, al->sched ? al->order_out.as<int>() : nullptr,
-                       al->queues.as<unsigned int>());
-    (void)hipEventRecord(al->ev[4], st);
-    if (max_len <= 160) launch_ext_fin<160>(al, ck, dopt, grid, bs);
-    else if (max_len <= 320) launch_ext_fin<320>(al, ck, dopt, grid, bs);
-    else launch_ext_fin<SLX_MAX_READ_LEN + 4>(al, ck, dopt, grid, bs);
-    (void)hipEventRecord(al->ev[6], st);
+    (void)hipEventRecord(wk->ev[3], st);
+    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, al->sched ? wk->order_out.as<int>() : nullptr,
+                       wk->queues.as<unsigned int>());
+    (void)hipEventRecord(wk->ev[4], st);
+    if (max_len <= 160) launch_ext_fin<160>(al, wk, ck, dopt, grid, bs);
+    else if (max_len <= 320) launch_ext_fin<320>(al, wk, ck, dopt, grid, bs);
+    else launch_ext_fin<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, grid, bs);
+    (void)hipEventRecord(wk->ev[6], st);
     // hit / cigar counts -> offsets
-    hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, al->cig_cnt.as<unsigned long long>());
+    hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, wk->cig_cnt.as<unsigned long long>());
     {
-        hipcub::TransformInputIterator<unsigned long long, CvtI32U64, const int *> it(al->n_hit.as<int>(), CvtI32U64());
+        hipcub::TransformInputIterator<unsigned long long, CvtI32U64, const int *> it(wk->n_hit.as<int>(), CvtI32U64());
         size_t tb = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, al->hit_off_c.as<unsigned long long>(), n + 1, st);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, wk->hit_off_c.as<unsigned long long>(), n + 1, st);
         ENS(scan_tmp, tb + 256);
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tb, it, al->hit_off_c.as<unsigned long long>(), n + 1, st));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, it, wk->hit_off_c.as<unsigned long long>(), n + 1, st));
         size_t tb2 = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, al->cig_cnt.as<unsigned long long>(), al->cig_off_c.as<unsigned long long>(), n + 1, st);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, wk->cig_cnt.as<unsigned long long>(), wk->cig_off_c.as<unsigned long long>(), n + 1, st);
         ENS(scan_tmp, tb2 + 256);
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(al->scan_tmp.p, tb2, al->cig_cnt.as<unsigned long long>(), al->cig_off_c.as<unsigned long long>(), n + 1, st));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb2, wk->cig_cnt.as<unsigned long long>(), wk->cig_off_c.as<unsigned long long>(), n + 1, st));
     }
     unsigned long long Hc = 0, Cc = 0;
     uint32_t fl = 0;
-    HIPCHK(hipMemcpyAsync(&Hc, al->hit_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&Cc, al->cig_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&Hc, wk->hit_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&Cc, wk->cig_off_c.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&fl, ck.flags, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (fl) { *flags_out = fl; return SLX_OK; }
     // grow the outputs and compact
     const size_t H = (size_t)*hit_base + Hc, C = (size_t)*cig_base + Cc;
-#define GROW(buf, bytes, keep) if ((rc = al->buf.grow((size_t)(bytes), (size_t)(keep), st)) != SLX_OK) return rc
+#define GROW(buf, bytes, keep) if ((rc = wk->buf.grow((size_t)(bytes), (size_t)(keep), st)) != SLX_OK) return rc
     GROW(o_rid, (H + 1) * 4, *hit_base * 4); GROW(o_pos, (H + 1) * 8, *hit_base * 8); GROW(o_flag, (H + 1) * 2, *hit_base * 2);
     GROW(o_mapq, (H + 1), *hit_base); GROW(o_score, (H + 1) * 4, *hit_base * 4); GROW(o_nm, (H + 1) * 4, *hit_base * 4);
     GROW(o_na, (H + 1) * 4, *hit_base * 4); GROW(o_ncig, (H + 1) * 4, *hit_base * 4); GROW(o_cig_off, (H + 2) * 8, *hit_base * 8);
     GROW(o_cigar, (C + 1) * 4, *cig_base * 4);
     HitsSoA so;
-    so.hit_off = al->o_hit_off.as<int64_t>(); so.rid = al->o_rid.as<int32_t>(); so.pos = al->o_pos.as<int64_t>();
-    so.flag = al->o_flag.as<uint16_t>(); so.mapq = al->o_mapq.as<uint8_t>(); so.score = al->o_score.as<int32_t>();
-    so.nm = al->o_nm.as<int32_t>(); so.na = al->o_na.as<int32_t>(); so.n_cigar_ops = al->o_ncig.as<int32_t>();
-    so.cig_off = al->o_cig_off.as<int64_t>(); so.cigar = al->o_cigar.as<uint32_t>();
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, al->hit_off_c.as<unsigned long long>(),
-                       al->cig_off_c.as<unsigned long long>(), so, r0, *hit_base, *cig_base);
-    (void)hipEventRecord(al->ev[7], st);
+    so.hit_off = wk->o_hit_off.as<int64_t>(); so.rid = wk->o_rid.as<int32_t>(); so.pos = wk->o_pos.as<int64_t>();
+    so.flag = wk->o_flag.as<uint16_t>(); so.mapq = wk->o_mapq.as<uint8_t>(); so.score = wk->o_score.as<int32_t>();
+    so.nm = wk->o_nm.as<int32_t>(); so.na = wk->o_na.as<int32_t>(); so.n_cigar_ops = wk->o_ncig.as<int32_t>();
+    so.cig_off = wk->o_cig_off.as<int64_t>(); so.cigar = wk->o_cigar.as<uint32_t>();
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, wk->hit_off_c.as<unsigned long long>(),
+                       wk->cig_off_c.as<unsigned long long>(), so, r0 - part_lo, *hit_base, *cig_base);
+    (void)hipEventRecord(wk->ev[7], st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 7; ++i) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, al->ev[i], al->ev[i + 1]) == hipSuccess) al->stage_ms[i] += ms;
+        if (hipEventElapsedTime(&ms, wk->ev[i], wk->ev[i + 1]) == hipSuccess) wk->stage_ms[i] += ms;
     }
     *hit_base += (int64_t)Hc;
     *cig_base += (int64_t)Cc;
@@ -446,52 +487,55 @@ static int run_chunk(slx_aligner *al, const slx_opt *opt, const uint8_t *d_ascii
 #undef GROW
 }
 
-extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_bases, const void *d_offs_, int64_t n_reads,
-                                      uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary,
-                                      slx_hits *out)
+__global__ void k_shift_offsets(int64_t *dst, const int64_t *src, int64_t n, int64_t add)
 {
-    if (!al || !opt || !out || n_reads < 0) { slx_set_error("slx_align_batch_device: bad argument"); return SLX_EINVAL; }
-    memset(out, 0, sizeof *out);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+
+// one worker pushes reads [r_lo, r_hi) through the pipeline (in chunks), leaving its SoA result in wk->o_*
+static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint8_t *d_bases, const uint64_t *d_offs, int64_t r_lo, int64_t r_hi,
+                      uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary)
+{
     HIPCHK(hipSetDevice(al->device));
-    if (opt->e_del <= 0 || opt->e_ins <= 0) { slx_set_error("gap extension penalty must be > 0 on the GPU path (bwa divides by it)"); return SLX_EINVAL; }
-    for (int i = 0; i < SLX_N_STAGES; ++i) al->stage_ms[i] = 0;
-    const uint64_t *d_offs = (const uint64_t *)d_offs_;
+    for (int i = 0; i < SLX_N_STAGES; ++i) wk->stage_ms[i] = 0;
     int rc;
-    if ((rc = al->o_hit_off.ensure(((size_t)n_reads + 1) * 8)) != SLX_OK) return rc;
+    const int64_t n_part = r_hi - r_lo;
+    if ((rc = wk->o_hit_off.ensure(((size_t)n_part + 1) * 8)) != SLX_OK) return rc;
     int64_t hit_base = 0, cig_base = 0;
-    hipEvent_t t0, t1;
-    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
-    HIPCHK(hipEventRecord(t0, al->stream));
-    std::vector<uint64_t> h_offs;       // chunk boundaries need host copies of a few offsets
-    for (int64_t r0 = 0; r0 < n_reads; r0 += al->chunk_reads) {
-        const int n = (int)std::min<int64_t>(al->chunk_reads, n_reads - r0);
-        // offsets of this chunk to the host: total bases and the longest read
-        h_offs.resize((size_t)n + 1);
-        HIPCHK(hipMemcpy(h_offs.data(), d_offs + r0, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    for (int64_t r0 = r_lo; r0 < r_hi; r0 += al->chunk_reads) {
+        const int n = (int)std::min<int64_t>(al->chunk_reads, r_hi - r0);
+        wk->h_offs.resize((size_t)n + 1);
+        HIPCHK(hipMemcpyAsync(wk->h_offs.data(), d_offs + r0, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, wk->stream));
+        HIPCHK(hipStreamSynchronize(wk->stream));
         int max_len = 0;
         for (int i = 0; i < n; ++i) {
-            if (h_offs[(size_t)i + 1] < h_offs[(size_t)i]) { slx_set_error("offsets are not monotonic at read %lld", (long long)(r0 + i)); return SLX_EINVAL; }
-            max_len = std::max<int>(max_len, (int)std::min<uint64_t>(h_offs[(size_t)i + 1] - h_offs[(size_t)i], 1u << 30));
+            if (wk->h_offs[(size_t)i + 1] < wk->h_offs[(size_t)i]) { slx_set_error("offsets are not monotonic at read %lld", (long long)(r0 + i)); return SLX_EINVAL; }
+            max_len = std::max<int>(max_len, (int)std::min<uint64_t>(wk->h_offs[(size_t)i + 1] - wk->h_offs[(size_t)i], 1u << 30));
         }
         if (max_len > SLX_MAX_READ_LEN) {
             slx_set_error("read of %d bp: the GPU path supports reads up to %d bp (longer reads enter bwa's mem_flt_chained_seeds branch)", max_len, SLX_MAX_READ_LEN);
             return SLX_EUNSUPPORTED;
         }
-        uint64_t pair[2] = {h_offs[0], h_offs[(size_t)n]};
+        uint64_t pair[2] = {wk->h_offs[0], wk->h_offs[(size_t)n]};
         ChunkCaps caps;
-        caps.cap_intv = al->cap_intv;
-        caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
-        caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096;
+        {
+            std::lock_guard<std::mutex> g(al->mu);
+            caps.cap_intv = al->cap_intv;
+            caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
+            caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096;
+        }
         for (int attempt = 0;; ++attempt) {
             uint32_t fl = 0;
             int64_t hb = hit_base, cb = cig_base;
-            rc = run_chunk(al, opt, (const uint8_t *)d_bases, d_offs, pair, r0, n, max_len, rng_state, first_ordinal, hardclip, keepSecFrac,
-                           maxSecondary, caps, &hb, &cb, &fl);
+            // hit offsets of this worker are relative to its own first read / first hit
+            rc = run_chunk(al, wk, opt, d_bases, d_offs, pair, r0, r_lo, n, max_len, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary,
+                           caps, &hb, &cb, &fl);
             if (rc != SLX_OK) return rc;
             if (!fl) {
                 hit_base = hb; cig_base = cb;
-                // remember what this workload needed so that the next batch does not pay for the retry again
-                al->cap_intv = caps.cap_intv;
+                std::lock_guard<std::mutex> g(al->mu);   // remember what this workload needed: the next batch does not pay for the retry again
+                al->cap_intv = std::max(al->cap_intv, caps.cap_intv);
                 al->z_per_read = std::max<unsigned long long>(al->z_per_read, (caps.zcap + n - 1) / (unsigned long long)n);
                 al->cig_per_read = std::max<unsigned long long>(al->cig_per_read, (caps.cigcap + n - 1) / (unsigned long long)n);
                 al->n_retries += attempt;
@@ -504,13 +548,97 @@ extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const
             if (fl & OVF_CIGAR) caps.cigcap *= 2;
         }
     }
-    // terminal offsets
-    {
+    {   // terminal offsets
         int64_t last[1] = {hit_base};
-        HIPCHK(hipMemcpyAsync(al->o_hit_off.as<int64_t>() + n_reads, last, 8, hipMemcpyHostToDevice, al->stream));
-        if ((rc = al->o_cig_off.grow(((size_t)hit_base + 2) * 8, (size_t)hit_base * 8, al->stream)) != SLX_OK) return rc;
+        HIPCHK(hipMemcpyAsync(wk->o_hit_off.as<int64_t>() + n_part, last, 8, hipMemcpyHostToDevice, wk->stream));
+        if ((rc = wk->o_cig_off.grow(((size_t)hit_base + 2) * 8, (size_t)hit_base * 8, wk->stream)) != SLX_OK) return rc;
         int64_t lastc[1] = {cig_base};
-        HIPCHK(hipMemcpyAsync(al->o_cig_off.as<int64_t>() + hit_base, lastc, 8, hipMemcpyHostToDevice, al->stream));
+        HIPCHK(hipMemcpyAsync(wk->o_cig_off.as<int64_t>() + hit_base, lastc, 8, hipMemcpyHostToDevice, wk->stream));
+        HIPCHK(hipStreamSynchronize(wk->stream));
+    }
+    wk->n_hits = hit_base; wk->n_cig = cig_base;
+    return SLX_OK;
+}
+
+extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_bases, const void *d_offs_, int64_t n_reads,
+                                      uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary,
+                                      slx_hits *out)
+{
+    if (!al || !opt || !out || n_reads < 0) { slx_set_error("slx_align_batch_device: bad argument"); return SLX_EINVAL; }
+    memset(out, 0, sizeof *out);
+    HIPCHK(hipSetDevice(al->device));
+    if (opt->e_del <= 0 || opt->e_ins <= 0) { slx_set_error("gap extension penalty must be > 0 on the GPU path (bwa divides by it)"); return SLX_EINVAL; }
+    const uint64_t *d_offs = (const uint64_t *)d_offs_;
+    const int K = (n_reads >= 2 * al->min_split) ? std::min<int>(al->n_workers, (int)al->workers.size()) : 1;
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, al->stream));
+    HIPCHK(hipStreamSynchronize(al->stream));
+    std::vector<int64_t> lo((size_t)K + 1);
+    for (int k = 0; k <= K; ++k) lo[(size_t)k] = n_reads * k / K;
+    if (K == 1) {
+        Worker *wk = al->workers[0];
+        wk->rc = worker_run(al, wk, opt, (const uint8_t *)d_bases, d_offs, 0, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary);
+        if (wk->rc != SLX_OK) return wk->rc;
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < K; ++k) {
+            Worker *wk = al->workers[(size_t)k];
+            th.emplace_back([=]() {
+                wk->rc = worker_run(al, wk, opt, (const uint8_t *)d_bases, d_offs, lo[(size_t)k], lo[(size_t)k + 1], rng_state, first_ordinal, hardclip,
+                                    keepSecFrac, maxSecondary);
+                if (wk->rc != SLX_OK) wk->err = slx_last_error();   // the message is thread-local
+            });
+        }
+        for (auto &t : th) t.join();
+        for (int k = 0; k < K; ++k)
+            if (al->workers[(size_t)k]->rc != SLX_OK) { slx_set_error("%s", al->workers[(size_t)k]->err.c_str()); return al->workers[(size_t)k]->rc; }
+    }
+    for (int i = 0; i < SLX_N_STAGES; ++i) {
+        al->stage_ms[i] = 0;
+        for (int k = 0; k < K; ++k) al->stage_ms[i] += al->workers[(size_t)k]->stage_ms[i];
+    }
+    slx_hits r;
+    memset(&r, 0, sizeof r);
+    r.n_reads = n_reads; r.on_device = 1;
+    if (K == 1) {
+        Worker *wk = al->workers[0];
+        r.n_hits = wk->n_hits; r.n_cigar = wk->n_cig;
+        r.hit_off = wk->o_hit_off.as<int64_t>(); r.rid = wk->o_rid.as<int32_t>(); r.pos = wk->o_pos.as<int64_t>();
+        r.flag = wk->o_flag.as<uint16_t>(); r.mapq = wk->o_mapq.as<uint8_t>(); r.score = wk->o_score.as<int32_t>();
+        r.nm = wk->o_nm.as<int32_t>(); r.na = wk->o_na.as<int32_t>(); r.n_cigar_ops = wk->o_ncig.as<int32_t>();
+        r.cig_off = wk->o_cig_off.as<int64_t>(); r.cigar = wk->o_cigar.as<uint32_t>();
+    } else {   // concatenate the workers' results (read order = worker order)
+        int64_t H = 0, C = 0;
+        for (int k = 0; k < K; ++k) { H += al->workers[(size_t)k]->n_hits; C += al->workers[(size_t)k]->n_cig; }
+        int rc;
+#define ENSO(buf, bytes) if ((rc = al->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
+        ENSO(o_hit_off, ((size_t)n_reads + 1) * 8); ENSO(o_rid, ((size_t)H + 1) * 4); ENSO(o_pos, ((size_t)H + 1) * 8); ENSO(o_flag, ((size_t)H + 1) * 2);
+        ENSO(o_mapq, (size_t)H + 1); ENSO(o_score, ((size_t)H + 1) * 4); ENSO(o_nm, ((size_t)H + 1) * 4); ENSO(o_na, ((size_t)H + 1) * 4);
+        ENSO(o_ncig, ((size_t)H + 1) * 4); ENSO(o_cig_off, ((size_t)H + 2) * 8); ENSO(o_cigar, ((size_t)C + 1) * 4);
+#undef ENSO
+        int64_t hb = 0, cb = 0;
+        hipStream_t st = al->stream;
+        for (int k = 0; k < K; ++k) {
+            Worker *wk = al->workers[(size_t)k];
+            const int64_t np = lo[(size_t)k + 1] - lo[(size_t)k], h = wk->n_hits, c = wk->n_cig;
+            const int last = k == K - 1 ? 1 : 0;   // the last part also carries the terminal offsets
+            hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((np + last + 255) / 256)), dim3(256), 0, st, al->o_hit_off.as<int64_t>() + lo[(size_t)k],
+                               wk->o_hit_off.as<int64_t>(), np + last, hb);
+            hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((h + last + 255) / 256)), dim3(256), 0, st, al->o_cig_off.as<int64_t>() + hb,
+                               wk->o_cig_off.as<int64_t>(), h + last, cb);
+#define CAT(buf, type, cnt, base) if ((cnt) > 0) HIPCHK(hipMemcpyAsync(al->buf.as<type>() + (base), wk->buf.as<type>(), (size_t)(cnt) * sizeof(type), hipMemcpyDeviceToDevice, st))
+            CAT(o_rid, int32_t, h, hb); CAT(o_pos, int64_t, h, hb); CAT(o_flag, uint16_t, h, hb); CAT(o_mapq, uint8_t, h, hb); CAT(o_score, int32_t, h, hb);
+            CAT(o_nm, int32_t, h, hb); CAT(o_na, int32_t, h, hb); CAT(o_ncig, int32_t, h, hb); CAT(o_cigar, uint32_t, c, cb);
+#undef CAT
+            hb += h; cb += c;
+        }
+        HIPCHK(hipGetLastError());
+        r.n_hits = H; r.n_cigar = C;
+        r.hit_off = al->o_hit_off.as<int64_t>(); r.rid = al->o_rid.as<int32_t>(); r.pos = al->o_pos.as<int64_t>();
+        r.flag = al->o_flag.as<uint16_t>(); r.mapq = al->o_mapq.as<uint8_t>(); r.score = al->o_score.as<int32_t>();
+        r.nm = al->o_nm.as<int32_t>(); r.na = al->o_na.as<int32_t>(); r.n_cigar_ops = al->o_ncig.as<int32_t>();
+        r.cig_off = al->o_cig_off.as<int64_t>(); r.cigar = al->o_cigar.as<uint32_t>();
     }
     HIPCHK(hipEventRecord(t1, al->stream));
     HIPCHK(hipStreamSynchronize(al->stream));
@@ -518,12 +646,7 @@ extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const
     (void)hipEventElapsedTime(&tot, t0, t1);
     al->stage_ms[7] = tot;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    out->n_reads = n_reads; out->n_hits = hit_base; out->n_cigar = cig_base;
-    out->hit_off = al->o_hit_off.as<int64_t>(); out->rid = al->o_rid.as<int32_t>(); out->pos = al->o_pos.as<int64_t>();
-    out->flag = al->o_flag.as<uint16_t>(); out->mapq = al->o_mapq.as<uint8_t>(); out->score = al->o_score.as<int32_t>();
-    out->nm = al->o_nm.as<int32_t>(); out->na = al->o_na.as<int32_t>(); out->n_cigar_ops = al->o_ncig.as<int32_t>();
-    out->cig_off = al->o_cig_off.as<int64_t>(); out->cigar = al->o_cigar.as<uint32_t>();
-    out->on_device = 1;
+    *out = r;
     return SLX_OK;
 }
 
