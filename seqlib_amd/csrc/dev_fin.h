@@ -219,19 +219,12 @@ __device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const 
     return mapq;
 }
 
+// mem_sort_dedup_patch + mem_mark_primary_se for one read; returns the number of regions left (their handles are
+// w.ia[0..n) in mem_mark_primary_se order).  Shared by the fused and the split finalize kernels.
 template <int MAXQ>
-__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+__device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query,
+                            int *eh_h, int *eh_e)
 {
-    const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
-        const int r = order ? order[slot] : slot;
-        ReadWS w = make_ws(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
-        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         int n = ck.n_reg[r];
         int *a = w.ia;                            // region handles
         DReg *G = w.regs;
@@ -319,6 +312,25 @@ __global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dop
                 else ai.secondary = z[k];
             }
         }
+        return n;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+{
+    const slx_opt &opt = dopt.o;
+    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
+        ReadWS w = make_ws(ck, r);
+        const uint8_t *query = ck.codes + ck.offs[r];
+        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+        int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, eh_h, eh_e);
+        int *a = w.ia;
+        DReg *G = w.regs;
         // ---------------- glue: reg2aln for every region the caller keeps (src/BWAAligner.cpp:117-129)
         int nh = 0;
         int *hh = w.ic;                           // hit handles

@@ -1,0 +1,350 @@
+// dev_fin2.h -- the finalize stage split into work lists (production path; dev_fin.h's fused one-lane-per-read
+// kernel is kept as a test reference, fin_mode=0).  Same behaviour, different mapping:
+//   k_regs      one lane per read : mem_sort_dedup_patch, mem_mark_primary_se, then for every region the glue keeps
+//                                   (/root/reference/src/BWAAligner.cpp:117-121) MAPQ + inferred band width; the
+//                                   CIGAR work of mem_reg2aln is queued as a job
+//   k_cig_fast  one lane per job  : bwa_gen_cigar2's no-DP path (equal lengths, band 0): "<len>M", NM by comparison
+//   k_cig_dp    one WAVE per job  : bwa_gen_cigar2 -> ksw_global2 with up to three growing bands, row-parallel with
+//                                   the H/E row in registers (E and F are fed by M here too, so F is a prefix max),
+//                                   direction bytes to the arena, traceback, NM
+//   k_hits      one lane per read : std::sort of the hits + the glue's secondary filters (:133-146)
+// About 86 % of the alignments take the fast path; the DP ones no longer stall 63 idle lanes of a wave.
+#pragma once
+#include "dev_fin.h"
+#include "dev_ext_reg.h"
+
+struct alignas(8) DJob {      // one pending bwa_gen_cigar2 sequence (mem_reg2aln's do/while)
+    int64_t rb, re;
+    int qb, qe;
+    int w2, truesc;
+    int r, pad;
+};
+
+struct FinLists {
+    DJob *jobs;               // per seed slot, parallel to Chunk::hits
+    uint32_t *fast_list, *dp_list;
+    unsigned int *n_fast, *n_dp, *q_dp;
+};
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue)
+{
+    const slx_opt &opt = dopt.o;
+    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
+        ReadWS w = make_ws(ck, r);
+        const uint8_t *query = ck.codes + ck.offs[r];
+        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+        const int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, eh_h, eh_e);
+        const int *a = w.ia;
+        const DReg *G = w.regs;
+        const uint64_t so = ck.seed_off[r];
+        int nh = 0;
+        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+        for (int i = 0; i < n; ++i) {
+            const DReg &ar = G[a[i]];
+            if (ar.secondary != 0 && drop_sec) continue;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
+            DHit h;
+            h.flag = ar.secondary >= 0 ? 0x100 : 0;
+            h.mapq = ar.secondary < 0 ? dev_approx_mapq_se(opt, ar, ck) : 0;
+            h.score = ar.score; h.nm = -1; h.n_cigar = 0; h.cig_start = 0; h.pos = 0; h.rid = -1;
+            const int qb = ar.qb, qe = ar.qe;
+            const int64_t rb = ar.rb, re = ar.re;
+            int tmp = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+            int w2 = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+            w2 = w2 > tmp ? w2 : tmp;
+            if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+            DJob j;
+            j.rb = rb; j.re = re; j.qb = qb; j.qe = qe; j.w2 = w2; j.truesc = ar.truesc; j.r = r; j.pad = 0;
+            w.hits[nh] = h;
+            fl.jobs[so + nh] = j;
+            const int wc = w2 < opt.w << 2 ? w2 : opt.w << 2;
+            const bool fast = (qe - qb) == (int)(re - rb) && wc == 0;
+            if (fast) fl.fast_list[atomicAdd(fl.n_fast, 1u)] = (uint32_t)(so + nh);
+            else fl.dp_list[atomicAdd(fl.n_dp, 1u)] = (uint32_t)(so + nh);
+            ++nh;
+        }
+        ck.n_hit[r] = nh;
+    }
+}
+
+// final position / rid / clipping of mem_reg2aln once the core cigar [cs, cs+nc) is in the pool with one free slot on each side
+__device__ __forceinline__ void dev_finish_hit(const DevRef &R, const Chunk &ck, const DJob &j, int l_query, DHit &h, int64_t cs, int nc)
+{
+    int is_rev;
+    int64_t pos = dev_depos(R, j.rb < R.l_pac ? j.rb : j.re - 1, &is_rev);
+    if (nc > 0) {                                 // squeeze out a leading or else a trailing deletion
+        if ((ck.cigpool[cs] & 0xf) == 2) { pos += ck.cigpool[cs] >> 4; ++cs; --nc; }
+        else if ((ck.cigpool[cs + nc - 1] & 0xf) == 2) --nc;
+    }
+    if (j.qb != 0 || j.qe != l_query) {           // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
+        const int clip5 = is_rev ? l_query - j.qe : j.qb, clip3 = is_rev ? j.qb : l_query - j.qe;
+        const uint32_t cop = ck.hardclip ? 5u : 4u;
+        if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
+        if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
+    }
+    h.rid = dev_pos2rid(R, pos);
+    h.pos = pos - R.ann_off[h.rid];
+    if (is_rev) h.flag |= 0x10;
+    h.n_cigar = nc; h.cig_start = cs;
+}
+
+__global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists fl)
+{
+    const unsigned int n = *fl.n_fast;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const uint32_t slot = fl.fast_list[t];
+        const DJob j = fl.jobs[slot];
+        DHit h = ck.hits[slot];
+        const uint8_t *query = ck.codes + ck.offs[j.r];
+        const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
+        const int lq = j.qe - j.qb;
+        // NM: mismatches along the diagonal (orientation does not matter for a count)
+        int nm = 0;
+        for (int i = 0; i < lq; ++i) {
+            const int qc = query[j.qb + i];
+            nm += qc != ref_base(R, j.rb + i);
+        }
+        h.nm = nm;
+        const unsigned long long base = atomicAdd(ck.cigused, 3ull);
+        if (base + 3 > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
+        ck.cigpool[base + 1] = (uint32_t)lq << 4;
+        dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, 1);
+        ck.hits[slot] = h;
+    }
+}
+
+// ---------------------------------------------------------------- wave-cooperative ksw_global2
+#define G_NEG (-0x7f000000)
+
+__device__ __forceinline__ int dpp_incl_max_scan_g(int v)
+{
+    v = imax(v, dpp_get<0x111, 0xf, 0xf>(G_NEG, v));
+    v = imax(v, dpp_get<0x112, 0xf, 0xf>(G_NEG, v));
+    v = imax(v, dpp_get<0x114, 0xf, 0xf>(G_NEG, v));
+    v = imax(v, dpp_get<0x118, 0xf, 0xf>(G_NEG, v));
+    v = imax(v, dpp_get<0x142, 0xa, 0xf>(G_NEG, v));
+    v = imax(v, dpp_get<0x143, 0xc, 0xf>(G_NEG, v));
+    return v;
+}
+
+template <int CPL, typename QF, typename TF>
+__device__ int wave_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, int lane)
+{
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int j0 = lane * CPL;
+    int H[CPL], E[CPL], qc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = j0 + k;
+        qc[k] = j < qlen ? qf(j) : 4;
+        H[k] = j == 0 ? 0 : (j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
+        E[k] = DEV_MINUS_INF;
+    }
+    int tb_cur = lane < tlen ? tf(lane) : 0;
+    int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = lane_read(tb_cur, i & (WAVE - 1));
+        const uint32_t rowp = mr.packed[t];
+        const int row4 = mr.q4[t];
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_MINUS_INF;
+        int M[CPL], pre[CPL], h[CPL];
+        int run = G_NEG;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int j = j0 + k;
+            const bool act = j >= beg && j < end;
+            const int q = qc[k];
+            const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            M[k] = H[k] + s;
+            const int u = act ? M[k] - oe_ins + j * e_ins : G_NEG;
+            run = imax(run, u);
+            pre[k] = run;
+        }
+        const int incl = dpp_incl_max_scan_g(run);
+        const int excl = dpp_get<0x138, 0xf, 0xf>(G_NEG, incl);
+        uint8_t *zi = z ? z + (size_t)i * n_col : nullptr;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int j = j0 + k;
+            const bool act = j >= beg && j < end;
+            const int ex = k == 0 ? excl : imax(excl, pre[k - 1]);
+            // F(i,j): the initial -inf decays by e_ins per column, exactly as the scalar recurrence carries it
+            int f = DEV_MINUS_INF - (j - beg) * e_ins;
+            if (j > beg) f = imax(f, ex - (j - 1) * e_ins);
+            const int m = M[k], e = E[k];
+            int d = m >= e ? 0 : 1;
+            int hh = m >= e ? m : e;
+            d = hh >= f ? d : 2;
+            hh = hh >= f ? hh : f;
+            h[k] = hh;
+            int tt = m - oe_del;
+            int e2 = e - e_del;
+            d |= e2 > tt ? 1 << 2 : 0;
+            e2 = e2 > tt ? e2 : tt;
+            tt = m - oe_ins;
+            const int f2 = f - e_ins;
+            d |= f2 > tt ? 2 << 4 : 0;
+            if (act) { E[k] = e2; if (zi) zi[j - beg] = (uint8_t)d; }
+        }
+        const int h_left = dpp_get<0x138, 0xf, 0xf>(0, h[CPL - 1]);
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int j = j0 + k;
+            const int hp = k == 0 ? h_left : h[k - 1];
+            if (j - 1 >= beg && j - 1 < end) H[k] = hp;
+            if (end > beg) { if (j == beg) H[k] = h1_init; if (j == end) E[k] = DEV_MINUS_INF; }
+            else if (j == end) { H[k] = h1_init; E[k] = DEV_MINUS_INF; }
+        }
+    }
+    const int src = qlen / CPL, kk = qlen - src * CPL;
+    int pick = H[0];
+#pragma unroll
+    for (int k = 1; k < CPL; ++k) pick = kk == k ? H[k] : pick;
+    return lane_read(pick, src);
+}
+
+// One CIGAR job on one wave.  Kept out of line on purpose: with the body inlined into the queue loop the compiler
+// fuses that loop, the early exits and the three-band do/while into a single loop nest (observed: a wave re-entering
+// it with a stale job index and never finishing); a call boundary keeps the queue loop a plain fetch / test / call.
+template <int MAXQ>
+__device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl,
+                                            uint32_t slot, int lane)
+{
+    constexpr int CPLMAX = (MAXQ + 1 + WAVE - 1) / WAVE;
+    const DJob j = fl.jobs[slot];
+    DHit h = ck.hits[slot];
+    const uint8_t *query = ck.codes + ck.offs[j.r];
+    const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
+    const int lq = j.qe - j.qb;
+    const int64_t rb = j.rb, re = j.re;
+    const uint8_t *qseg = query + j.qb;
+    // bwa_gen_cigar2 inside mem_reg2aln's do/while: up to three band widths
+    const bool valid = !(lq <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac));
+    const int rlen = (int)(re - rb);
+    const bool rev = rb >= R.l_pac;
+    auto qf = [&](int x) { return (int)(rev ? qseg[lq - 1 - x] : qseg[x]); };
+    auto tf = [&](int y) { return rev ? ref_base(R, re - 1 - y) : ref_base(R, rb + y); };
+    int w2 = j.w2, score = 0, last_sc = -(1 << 30), w_used = 0, n_col = 0;
+    uint8_t *z = nullptr;
+    if (valid) {
+        for (int it = 0; it < 3; ++it) {
+            w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+            int ww, max_gap, max_ins, max_del, min_w;
+            max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = rlen - lq < 0 ? lq - rlen : rlen - lq;
+            ww = (max_gap + dl + 1) >> 1;
+            ww = ww < w2 ? ww : w2;
+            min_w = dl + 3;
+            ww = ww > min_w ? ww : min_w;
+            w_used = ww;
+            n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
+            unsigned long long off = 0;
+            const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
+            if (lane == 0) off = atomicAdd(ck.zused, need);
+            off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
+            if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return; }
+            z = ck.zarena + off;
+            if (lq + 1 <= WAVE) score = wave_ksw_global2<1>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
+            else if (CPLMAX > 2 && lq + 1 <= 2 * WAVE) score = wave_ksw_global2<(CPLMAX > 2 ? 2 : CPLMAX)>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
+            else score = wave_ksw_global2<CPLMAX>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
+            // mem_reg2aln: `if (score == last_sc || w2 == opt->w<<2) break; last_sc = score; w2 <<= 1;` then `while (++i < 3 && score < truesc - a)`
+            if (score == last_sc || w2 == opt.w << 2) break;
+            last_sc = score;
+            w2 <<= 1;
+            if (!(score < j.truesc - opt.a)) break;
+        }
+    }
+    int n_ops = 0;
+    if (valid) {
+        __threadfence();                          // the direction bytes were written by other lanes of this wave
+        dev_traceback(z, n_col, lq, rlen, w_used, [&](int, int) { ++n_ops; });
+    }
+    n_ops = __builtin_amdgcn_readfirstlane(n_ops);
+    unsigned long long base = 0;
+    const unsigned long long need = (unsigned long long)n_ops + 2;
+    if (lane == 0) base = atomicAdd(ck.cigused, need);
+    base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+    if (base + need > ck.cigcap) { if (lane == 0) atomicOr(ck.flags, OVF_CIGAR); return; }
+    uint32_t *cg = ck.cigpool + base + 1;
+    if (valid) {
+        int wp = n_ops;
+        dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });   // every lane stores the same words
+        // NM: lanes share the comparisons of each M run
+        int x = 0, y = 0, n_mm = 0, n_gap = 0;
+        for (int k = 0; k < n_ops; ++k) {
+            const uint32_t cw = cg[k];
+            const int op = (int)(cw & 0xf), len = (int)(cw >> 4);
+            if (op == 0) {
+                for (int u = lane; u < len; u += WAVE) n_mm += qf(x + u) != tf(y + u);
+                x += len; y += len;
+            } else if (op == 2) { if (k > 0 && k < n_ops - 1) n_gap += len; y += len; }
+            else if (op == 1) { x += len; n_gap += len; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) n_mm += __shfl_xor(n_mm, d, WAVE);
+        h.nm = n_mm + n_gap;
+    }
+    dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, n_ops);
+    if (lane == 0) ck.hits[slot] = h;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(64) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl)
+{
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(dopt.o.mat);
+    const unsigned int n_jobs = *fl.n_dp;
+    for (;;) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_jobs) break;
+        dev_cig_dp_job<MAXQ>(R, ck, dopt.o, mr, fl, fl.dp_list[t], lane);
+    }
+}
+
+__global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsigned int *queue)
+{
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
+        ReadWS w = make_ws(ck, r);
+        const int nh = ck.n_hit[r];
+        int *hh = w.ic;
+        for (int i = 0; i < nh; ++i) hh[i] = i;
+        // std::sort(hits, aln_sort) then the secondary filters (src/BWAAligner.cpp:133-146)
+        std_sort_idx(nh, hh, [&](int x, int y) {
+            const DHit &A = w.hits[x], &B = w.hits[y];
+            if (A.mapq != B.mapq) return A.mapq > B.mapq;
+            if (A.rid != B.rid) return A.rid < B.rid;
+            return A.pos < B.pos;
+        });
+        double primaryScore = 0;
+        int n_out = 0;
+        for (int i = 0; i < nh; ++i) {
+            const DHit &h = w.hits[hh[i]];
+            const bool isSec = (h.flag & 0x100) != 0;
+            const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)h.score);
+            const bool tooMany = isSec && (i > ck.maxSecondary);
+            if (tooLow || tooMany) continue;
+            if (!isSec) primaryScore = (double)h.score;
+            hh[n_out++] = hh[i];
+        }
+        ck.n_hit[r] = n_out;
+    }
+}

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cmath>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,7 @@
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
+#include "dev_fin2.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -73,7 +75,7 @@ struct Worker {
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list;
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
     hipEvent_t ev[SLX_N_STAGES + 1];
     float stage_ms[SLX_N_STAGES];
@@ -88,7 +90,7 @@ struct Worker {
         DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
                        &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                        &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
-                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
                        &o_na, &o_ncig, &o_cig_off, &o_cigar};
         n_all = (int)(sizeof(b) / sizeof(b[0]));
         for (int i = 0; i < n_all; ++i) all[i] = b[i];
@@ -109,6 +111,8 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
+    int fin_debug = 4;
+    int fin_mode = 1;             // 1 = finalize split into work lists (fast / DP cigar jobs), 0 = fused one-lane-per-read kernel
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
     int n_workers = 2;            // concurrent halves of a large batch
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
@@ -298,6 +302,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "dense_sa")) al->dense_sa = value != 0;
     else if (!strcmp(key, "ext_mode")) al->ext_mode = (int)value;
     else if (!strcmp(key, "sched")) al->sched = (int)value;
+    else if (!strcmp(key, "fin_mode")) al->fin_mode = (int)value;
+    else if (!strcmp(key, "fin_debug")) al->fin_debug = (int)value;
     else if (!strcmp(key, "workers")) { if (value < 1 || value > 4) return SLX_EINVAL; al->n_workers = (int)value; }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
@@ -326,7 +332,16 @@ static void launch_ext_fin(slx_aligner *al, Worker *wk, const Chunk &ck, const D
         else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
     }
     (void)hipEventRecord(wk->ev[5], wk->stream);
-    hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 2);
+    if (al->fin_mode == 0) hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 2);
+    else {
+        FinLists fl;
+        fl.jobs = wk->jobs.as<DJob>(); fl.fast_list = wk->fast_list.as<uint32_t>(); fl.dp_list = wk->dp_list.as<uint32_t>();
+        fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, fl, order, q + 2);
+        if (al->fin_debug >= 2) hipLaunchKernelGGL(k_cig_fast, dim3(al->n_cu * 8), dim3(256), 0, wk->stream, al->ref, ck, fl);
+        if (al->fin_debug >= 3) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(al->n_cu * 32), dim3(64), 0, wk->stream, al->ref, ck, dopt, fl);
+        if (al->fin_debug >= 4) hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, wk->stream, ck, order, q + 3);
+    }
 }
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
@@ -411,6 +426,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(s_rbeg, S1 * 8); ENS(s_ql, S1 * 4); ENS(s_next, S1 * 4); ENS(c_pos, S1 * 8); ENS(c_head, S1 * 4); ENS(c_tail, S1 * 4);
     ENS(c_n, S1 * 4); ENS(c_rid, S1 * 4); ENS(c_w, S1 * 4); ENS(c_first, S1 * 4); ENS(c_kept, S1); ENS(ia, S1 * 4); ENS(ib, S1 * 4);
     ENS(ic, S1 * 4); ENS(srt, S1 * 8); ENS(regs, S1 * sizeof(DReg)); ENS(hits, S1 * sizeof(DHit));
+    if (al->fin_mode) { ENS(jobs, S1 * sizeof(DJob)); ENS(fast_list, S1 * 4); ENS(dp_list, S1 * 4); }
     ck.s_rbeg = wk->s_rbeg.as<int64_t>(); ck.s_ql = wk->s_ql.as<uint32_t>(); ck.s_next = wk->s_next.as<int32_t>();
     ck.c_pos = wk->c_pos.as<int64_t>(); ck.c_head = wk->c_head.as<int32_t>(); ck.c_tail = wk->c_tail.as<int32_t>();
     ck.c_n = wk->c_n.as<int32_t>(); ck.c_rid = wk->c_rid.as<int32_t>(); ck.c_w = wk->c_w.as<int32_t>();
@@ -438,6 +454,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     else if (max_len <= 320) launch_ext_fin<320>(al, wk, ck, dopt, grid, bs);
     else launch_ext_fin<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, grid, bs);
     (void)hipEventRecord(wk->ev[6], st);
+    if (al->fin_mode && al->fin_debug < 4) {   // debugging aid: stop after the selected finalize kernel, report no hits
+        HIPCHK(hipMemsetAsync(wk->n_hit.p, 0, ((size_t)n + 1) * 4, st));
+    }
     // hit / cigar counts -> offsets
     hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, wk->cig_cnt.as<unsigned long long>());
     {

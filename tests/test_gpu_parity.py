@@ -56,7 +56,7 @@ def test_fixture_reads_match_oracle_and_golden(sl, orc, tiny_gpu, tiny_index, si
         assert "\n".join(lines) + "\n" == open(os.path.join(golden_dir, fn)).read()
 
 
-@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1)])
+@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
     a tiny interval capacity that forces the overflow-retry path: identical records."""
