@@ -9,12 +9,15 @@
 
 // Reads are handed out 64 at a time (one per lane) from a device-wide queue, in heaviest-first order, so
 // that the lanes of a wave work on reads of similar weight and the heavy tail starts early.
-__device__ __forceinline__ int next_slot(unsigned int *queue)
+// per_wave != 0: ONE read per wave (lane 0 works, the others idle).  Used for the heavy reads: 64 of them in one wave
+// would all diverge from each other and run serially, whereas alone in a wave a heavy read costs only its own time.
+__device__ __forceinline__ int next_slot(unsigned int *queue, int per_wave = 0)
 {
     unsigned int base = 0;
     const int lane = threadIdx.x & 63;
-    if (lane == 0) base = atomicAdd(queue, 64u);
+    if (lane == 0) base = atomicAdd(queue, per_wave ? 1u : 64u);
     base = __shfl(base, 0, 64);
+    if (per_wave) return lane == 0 ? (int)base : 0x7fffffff;
     return (int)(base + lane);
 }
 
@@ -64,13 +67,15 @@ __device__ inline int dev_chain_weight(const ReadWS &w, int c)
 }
 
 template <typename I>
-__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
 {
     const slx_opt &opt = dopt.o;
+    const int n_todo = (int)*n_slots;
+    if (per_wave) __builtin_amdgcn_s_setprio(3);   // heavy reads are the critical path: let their waves issue first
     while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
+        const int slot = next_slot(queue, per_wave);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
         const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
@@ -177,6 +182,21 @@ __global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, 
             }
             for (; i < n_chn; ++i) if (w.c_kept[a[i]] < 3) w.c_kept[a[i]] = 0;
             for (i = 0; i < n_chn; ++i) if (w.c_kept[a[i]] != 0) a[n_out++] = a[i];
+        }
+        // Exact-match shortcut: one kept chain made of one seed that spans the whole read needs no extension at all.
+        // mem_chain2aln then yields exactly this region (no left part, no right part: score = truesc = len*a), so it is
+        // written here and the wave-per-read extension kernel skips the read (n_chain = -1).
+        if (n_out == 1 && w.c_n[a[0]] == 1) {
+            const int s0 = w.c_head[a[0]];
+            if (w.s_qbeg(s0) == 0 && w.s_len(s0) == len) {
+                DReg g;
+                g.rb = w.s_rbeg[s0]; g.re = g.rb + len; g.qb = 0; g.qe = len; g.rid = w.c_rid[a[0]];
+                g.score = g.truesc = len * opt.a; g.sub = g.csub = g.sub_n = 0; g.w = opt.w; g.seedcov = len; g.secondary = 0;
+                g.seedlen0 = len; g.n_comp = 0; g.frac_rep = ck.frac_rep[r]; g.hash = 0;
+                w.regs[0] = g;
+                ck.n_reg[r] = 1;
+                n_out = -1;
+            }
         }
         ck.n_chain[r] = n_out;                   // kept chains, in extension order, are a[0..n_out)
     }

@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(128) k_extend(DevRef R, Chunk ck, DevOpt dopt,
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_chn = ck.n_chain[r];
+        if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
         const float frac_rep = ck.frac_rep[r];
         const int64_t l_pac = R.l_pac;
         int n_av = 0;                            // regions so far (all chains of the read)

@@ -195,9 +195,13 @@ __device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int t
     return reg_ksw_extend2<CPLMAX>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
 }
 
+#ifndef EXT_MIN_WAVES
+#define EXT_MIN_WAVES 4
+#endif
 template <int MAXQ>
-__global__ void __launch_bounds__(64) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+__global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int hi_prio)
 {
+    if (hi_prio) __builtin_amdgcn_s_setprio(3);
     constexpr int CPL = (MAXQ + 1 + WAVE - 1) / WAVE;
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
@@ -206,16 +210,18 @@ __global__ void __launch_bounds__(64) k_extend_reg(DevRef R, Chunk ck, DevOpt do
     for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
     __syncthreads();
     auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
+    const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     while (true) {
         int slot = 0;
         if (lane == 0) slot = (int)atomicAdd(queue, 1u);
         slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= ck.n_reads) break;
+        if (slot >= n_todo) break;
         const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_chn = ck.n_chain[r];
+        if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
         const float frac_rep = ck.frac_rep[r];
         const int64_t l_pac = R.l_pac;
         int n_av = 0;

@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(64) k_extend_wave(DevRef R, Chunk ck, DevOpt d
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_chn = ck.n_chain[r];
+        if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
         const float frac_rep = ck.frac_rep[r];
         const int64_t l_pac = R.l_pac;
         int n_av = 0;

@@ -27,14 +27,16 @@ struct FinLists {
 };
 
 template <int MAXQ>
-__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue)
+__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
 {
     const slx_opt &opt = dopt.o;
     int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    const int n_todo = (int)*n_slots;
+    if (per_wave) __builtin_amdgcn_s_setprio(3);
     while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
+        const int slot = next_slot(queue, per_wave);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
         const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
@@ -302,9 +304,10 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
 }
 
 template <int MAXQ>
-__global__ void __launch_bounds__(64) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl)
+__global__ void __launch_bounds__(64) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, int hi_prio)
 {
     const int lane = threadIdx.x;
+    if (hi_prio) __builtin_amdgcn_s_setprio(3);
     const MatRows mr = make_matrows(dopt.o.mat);
     const unsigned int n_jobs = *fl.n_dp;
     for (;;) {
@@ -316,12 +319,14 @@ __global__ void __launch_bounds__(64) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, 
     }
 }
 
-__global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsigned int *queue)
+__global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
 {
+    const int n_todo = (int)*n_slots;
+    if (per_wave) __builtin_amdgcn_s_setprio(3);
     while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
+        const int slot = next_slot(queue, per_wave);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
         const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const int nh = ck.n_hit[r];

@@ -18,6 +18,7 @@
 #include <vector>
 #include "slx_internal.h"
 #include "dev_seed.h"
+#include "dev_seed_sm.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
@@ -75,7 +76,10 @@ struct Worker {
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t dbg_ev[2][6];
+    hipEvent_t ev_split = nullptr, ev_heavy = nullptr;
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
     hipEvent_t ev[SLX_N_STAGES + 1];
     float stage_ms[SLX_N_STAGES];
@@ -83,14 +87,14 @@ struct Worker {
     int rc = SLX_OK;
     std::string err;
     std::vector<uint64_t> h_offs;
-    DevBuf *all[64];
+    DevBuf *all[80];
     int n_all = 0;
     void collect()
     {
         DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
                        &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                        &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
-                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
                        &o_na, &o_ncig, &o_cig_off, &o_cigar};
         n_all = (int)(sizeof(b) / sizeof(b[0]));
         for (int i = 0; i < n_all; ++i) all[i] = b[i];
@@ -111,7 +115,10 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
-    int fin_debug = 4;
+    int split_heavy = 0;          // 1 = reads with >= heavy_seeds seed occurrences run as their own sub-pipeline on a second stream
+    int heavy_seeds = 64;
+    int split_min = 4096;         // chunks smaller than this are not split
+    int seed_mode = 1;            // 1 = state-machine seeding kernel (one bwt_extend per lane per trip), 0 = nested-loop kernel
     int fin_mode = 1;             // 1 = finalize split into work lists (fast / DP cigar jobs), 0 = fused one-lane-per-read kernel
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
     int n_workers = 2;            // concurrent halves of a large batch
@@ -211,18 +218,21 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     al->device = (devices && n_dev > 0) ? devices[0] : 0;
     if (!(devices && n_dev > 0)) (void)hipGetDevice(&al->device);
     HIPCHK(hipSetDevice(al->device));
-    HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, al->device));
     al->n_cu = prop.multiProcessorCount;
     al->max_threads = al->n_cu * 1024;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2; ++k) {
         Worker *wk = new Worker();
         wk->collect();
         HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&wk->ev_split, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&wk->ev_heavy, hipEventDisableTiming));
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) HIPCHK(hipEventCreate(&wk->dbg_ev[a][b]));
         for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
         al->workers.push_back(wk);
     }
+    HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     al->host_idx = idx;
     // FM-index
     int rc;
@@ -288,6 +298,9 @@ extern "C" void slx_aligner_free(slx_aligner *al)
         for (int i = 0; i < wk->n_all; ++i) wk->all[i]->release();
         for (int i = 0; i <= SLX_N_STAGES; ++i) (void)hipEventDestroy(wk->ev[i]);
         if (wk->stream) (void)hipStreamDestroy(wk->stream);
+        if (wk->stream2) (void)hipStreamDestroy(wk->stream2);
+        if (wk->ev_split) (void)hipEventDestroy(wk->ev_split);
+        if (wk->ev_heavy) (void)hipEventDestroy(wk->ev_heavy);
         delete wk;
     }
     if (al->stream) (void)hipStreamDestroy(al->stream);
@@ -303,8 +316,11 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "ext_mode")) al->ext_mode = (int)value;
     else if (!strcmp(key, "sched")) al->sched = (int)value;
     else if (!strcmp(key, "fin_mode")) al->fin_mode = (int)value;
-    else if (!strcmp(key, "fin_debug")) al->fin_debug = (int)value;
-    else if (!strcmp(key, "workers")) { if (value < 1 || value > 4) return SLX_EINVAL; al->n_workers = (int)value; }
+    else if (!strcmp(key, "seed_mode")) al->seed_mode = (int)value;
+    else if (!strcmp(key, "split_heavy")) al->split_heavy = (int)value;
+    else if (!strcmp(key, "split_min")) al->split_min = (int)value;
+    else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
+    else if (!strcmp(key, "workers")) { if (value < 1 || value > 2) return SLX_EINVAL; al->n_workers = (int)value; }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
@@ -320,29 +336,81 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 }
 
 // ---------------------------------------------------------------- one chunk
+// The post-seeding part of the pipeline for one list of reads (all reads, or the light / heavy subset) on one
+// stream: chain -> extend -> regions -> CIGAR jobs -> hit sort/filter.  q = this sub-pipeline's block of queue counters.
 template <int MAXQ>
-static void launch_ext_fin(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, int grid, int bs)
+static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, const int *order,
+                       unsigned int *q, const unsigned int *n_slots, int sub, int grid, int bs, int n_est, hipEvent_t *ev_after_chain,
+                       hipEvent_t *ev_after_ext)
 {
-    const int *order = al->sched ? wk->order_out.as<int>() : nullptr;
+    hipEvent_t *dbg = wk->dbg_ev[sub];
+    const bool dbg_on = getenv("SLX_DEBUG_SUB") != nullptr;
+    if (dbg_on) (void)hipEventRecord(dbg[0], st);
+    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, order, q + 0, n_slots, sub);
+    if (ev_after_chain) (void)hipEventRecord(*ev_after_chain, st);
+    if (dbg_on) (void)hipEventRecord(dbg[1], st);
+    const int g = std::max(1, std::min(n_est, al->n_cu * 32));
+    hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1, n_slots, sub);
+    if (ev_after_ext) (void)hipEventRecord(*ev_after_ext, st);
+    if (dbg_on) (void)hipEventRecord(dbg[2], st);
+    FinLists fl;
+    fl.jobs = wk->jobs.as<DJob>();
+    fl.fast_list = (sub ? wk->fast_list2 : wk->fast_list).as<uint32_t>();
+    fl.dp_list = (sub ? wk->dp_list2 : wk->dp_list).as<uint32_t>();
+    fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
+    hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, sub);
+    if (dbg_on) (void)hipEventRecord(dbg[3], st);
+    hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n_est / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
+    hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, sub);
+    if (dbg_on) (void)hipEventRecord(dbg[4], st);
+    hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, order, q + 3, n_slots, sub);
+    if (dbg_on) (void)hipEventRecord(dbg[5], st);
+}
+
+// reference kernels (one lane per read / LDS wave kernel / fused finalize): whole chunk, input order, one stream
+template <int MAXQ>
+static void launch_reference_modes(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, int grid, int bs,
+                                   const unsigned int *n_slots)
+{
+    hipStream_t st = wk->stream;
     unsigned int *q = wk->queues.as<unsigned int>();
-    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
-    else {
-        const int g = std::min(ck.n_reads, al->n_cu * 32);
-        if (al->ext_mode == 1) hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
-        else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, wk->stream, al->ref, ck, dopt, order, q + 1);
-    }
-    (void)hipEventRecord(wk->ev[5], wk->stream);
-    if (al->fin_mode == 0) hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, order, q + 2);
+    const int *order = al->sched ? wk->order_out.as<int>() : nullptr;
+    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, order, q + 0, n_slots, 0);
+    (void)hipEventRecord(wk->ev[4], st);
+    const int g = std::min(ck.n_reads, al->n_cu * 32);
+    if (al->ext_mode == 0) hipLaunchKernelGGL(k_extend<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, order, q + 1);
+    else if (al->ext_mode == 1) hipLaunchKernelGGL(k_extend_wave<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1);
+    else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1, n_slots, 0);
+    (void)hipEventRecord(wk->ev[5], st);
+    if (al->fin_mode == 0) hipLaunchKernelGGL(k_finalize<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, order, q + 2);
     else {
         FinLists fl;
         fl.jobs = wk->jobs.as<DJob>(); fl.fast_list = wk->fast_list.as<uint32_t>(); fl.dp_list = wk->dp_list.as<uint32_t>();
         fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
-        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, wk->stream, al->ref, ck, dopt, fl, order, q + 2);
-        if (al->fin_debug >= 2) hipLaunchKernelGGL(k_cig_fast, dim3(al->n_cu * 8), dim3(256), 0, wk->stream, al->ref, ck, fl);
-        if (al->fin_debug >= 3) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(al->n_cu * 32), dim3(64), 0, wk->stream, al->ref, ck, dopt, fl);
-        if (al->fin_debug >= 4) hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, wk->stream, ck, order, q + 3);
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, 0);
+        hipLaunchKernelGGL(k_cig_fast, dim3(al->n_cu * 8), dim3(256), 0, st, al->ref, ck, fl);
+        hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
+        hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, order, q + 3, n_slots, 0);
     }
 }
+
+// light / heavy partition of a chunk by seed count (stable for the light reads: they keep their input order and locality)
+__global__ void k_part_flags(const unsigned long long *seed_cnt, int n, unsigned int thr, unsigned int *flag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = seed_cnt[i] < thr ? 1u : 0u;
+}
+
+__global__ void k_part_scatter(const unsigned int *flag, const unsigned int *pos, int n, int *light, int *heavy, unsigned int *counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) light[pos[i]] = i;
+    else heavy[atomicAdd(counts + 1, 1u)] = i;
+    if (i == n - 1) counts[0] = pos[i] + flag[i];
+}
+
+__global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
 
@@ -371,6 +439,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(counters, 64);
     // counters: [0] zused, [1] cigused, [2] flags(u32)
     HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
+    ENS(queues, 256);
+    HIPCHK(hipMemsetAsync(wk->queues.p, 0, 256, st));
     HIPCHK(hipMemsetAsync(wk->seed_cnt.p, 0, ((size_t)n + 1) * 8, st));
 
     Chunk ck;
@@ -405,7 +475,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         hipLaunchKernelGGL(k_rel_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_offs + r0, wk->offs_rel.as<uint64_t>(), n, base0);
     }
     (void)hipEventRecord(wk->ev[1], st);
-    hipLaunchKernelGGL(k_seed<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt);
+    if (al->seed_mode == 0) hipLaunchKernelGGL(k_seed<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt);
+    else hipLaunchKernelGGL(k_seed_sm<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 28);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
         size_t tmp_bytes = 0;
@@ -433,8 +504,6 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.c_first = wk->c_first.as<int32_t>(); ck.c_kept = wk->c_kept.as<int8_t>();
     ck.ia = wk->ia.as<int32_t>(); ck.ib = wk->ib.as<int32_t>(); ck.ic = wk->ic.as<int32_t>(); ck.srt = wk->srt.as<uint64_t>();
     ck.regs = wk->regs.as<DReg>(); ck.hits = wk->hits.as<DHit>();
-    ENS(queues, 64); ENS(counters, 64);
-    HIPCHK(hipMemsetAsync(wk->queues.p, 0, 64, st));
     if (al->sched) {   // heaviest reads first: sort read ids by their seed count, descending
         ENS(order_key_in, (size_t)n * 4); ENS(order_key_out, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
         hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
@@ -447,14 +516,50 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                                                             wk->order_in.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
     }
     (void)hipEventRecord(wk->ev[3], st);
-    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, al->sched ? wk->order_out.as<int>() : nullptr,
-                       wk->queues.as<unsigned int>());
-    (void)hipEventRecord(wk->ev[4], st);
-    if (max_len <= 160) launch_ext_fin<160>(al, wk, ck, dopt, grid, bs);
-    else if (max_len <= 320) launch_ext_fin<320>(al, wk, ck, dopt, grid, bs);
-    else launch_ext_fin<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, grid, bs);
+    {
+        unsigned int *q = wk->queues.as<unsigned int>();
+        unsigned int *counts = q + 24;          // [0] light (or all) reads, [1] heavy reads
+        const bool production = al->ext_mode == 2 && al->fin_mode == 1 && !al->sched;
+        const bool split = production && al->split_heavy && n >= al->split_min;
+        auto dispatch_sub = [&](hipStream_t sst, const int *order, unsigned int *qq, const unsigned int *ns, int sub, int g2, int n_est,
+                                hipEvent_t *e1, hipEvent_t *e2) {
+            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
+            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
+            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
+        };
+        if (!production) {
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
+            if (max_len <= 160) launch_reference_modes<160>(al, wk, ck, dopt, fm, grid, bs, counts);
+            else if (max_len <= 320) launch_reference_modes<320>(al, wk, ck, dopt, fm, grid, bs, counts);
+            else launch_reference_modes<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, grid, bs, counts);
+        } else if (!split) {
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
+            dispatch_sub(st, nullptr, q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5]);
+        } else {
+            ENS(part_flag, (size_t)n * 4); ENS(part_pos, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
+            ENS(fast_list2, S1 * 4); ENS(dp_list2, S1 * 4);
+            hipLaunchKernelGGL(k_part_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
+                               (unsigned int)al->heavy_seeds, wk->part_flag.as<unsigned int>());
+            size_t tb = 0;
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
+            ENS(scan_tmp, tb + 256);
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
+            hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
+                               wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), counts);
+            if (!wk->stream2) HIPCHK(hipStreamCreateWithFlags(&wk->stream2, hipStreamNonBlocking));   // created on first use: every extra
+                                                                                                       // stream competes for the few hardware queues
+            HIPCHK(hipEventRecord(wk->ev_split, st));
+            HIPCHK(hipStreamWaitEvent(wk->stream2, wk->ev_split, 0));
+            // heavy reads (a fraction of a percent of the batch, most of the critical path) on the second stream ...
+            dispatch_sub(wk->stream2, wk->order_out.as<int>(), q + 12, counts + 1, 1, grid, std::max(64, n / 8), nullptr, nullptr);
+            HIPCHK(hipEventRecord(wk->ev_heavy, wk->stream2));
+            // ... while the light ones fill the machine from the first
+            dispatch_sub(st, wk->order_in.as<int>(), q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5]);
+            HIPCHK(hipStreamWaitEvent(st, wk->ev_heavy, 0));
+        }
+    }
     (void)hipEventRecord(wk->ev[6], st);
-    if (al->fin_mode && al->fin_debug < 4) {   // debugging aid: stop after the selected finalize kernel, report no hits
+    if (0) {
         HIPCHK(hipMemsetAsync(wk->n_hit.p, 0, ((size_t)n + 1) * 4, st));
     }
     // hit / cigar counts -> offsets
@@ -497,6 +602,15 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     for (int i = 0; i < 7; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, wk->ev[i], wk->ev[i + 1]) == hipSuccess) wk->stage_ms[i] += ms;
+    }
+    if (getenv("SLX_DEBUG_SUB")) {
+        const char *nm[5] = {"chain", "extend", "regs", "cig", "hits"};
+        for (int sub = 0; sub < 2; ++sub) {
+            fprintf(stderr, "[sub %d n=%d]", sub, n);
+            for (int i = 0; i < 5; ++i) { float ms = -1; (void)hipEventElapsedTime(&ms, wk->dbg_ev[sub][i], wk->dbg_ev[sub][i + 1]); fprintf(stderr, " %s=%.1f", nm[i], ms); }
+            float tot = -1, lag = -1; (void)hipEventElapsedTime(&tot, wk->dbg_ev[sub][0], wk->dbg_ev[sub][5]); (void)hipEventElapsedTime(&lag, wk->ev[3], wk->dbg_ev[sub][0]);
+            fprintf(stderr, " total=%.1f start_lag=%.1f\n", tot, lag);
+        }
     }
     *hit_base += (int64_t)Hc;
     *cig_base += (int64_t)Cc;
