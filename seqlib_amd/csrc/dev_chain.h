@@ -66,17 +66,10 @@ __device__ inline int dev_chain_weight(const ReadWS &w, int c)
     return wt < 1 << 30 ? wt : (1 << 30) - 1;
 }
 
+// mem_chain + mem_chain_flt for one read on ONE lane (the light-read path, and the fallback of the cooperative kernel)
 template <typename I>
-__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
+__device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk &ck, const slx_opt &opt, int r)
 {
-    const slx_opt &opt = dopt.o;
-    const int n_todo = (int)*n_slots;
-    if (per_wave) __builtin_amdgcn_s_setprio(3);   // heavy reads are the critical path: let their waves issue first
-    while (true) {
-        const int slot = next_slot(queue, per_wave);
-        if (__all(slot >= n_todo)) break;
-        if (slot >= n_todo) continue;
-        const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_intv = (int)ck.intv_n[r];
@@ -199,5 +192,19 @@ __global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, 
             }
         }
         ck.n_chain[r] = n_out;                   // kept chains, in extension order, are a[0..n_out)
+}
+
+template <typename I>
+__global__ void __launch_bounds__(128) k_chain(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
+{
+    const slx_opt &opt = dopt.o;
+    const int n_todo = (int)*n_slots;
+    if (per_wave) __builtin_amdgcn_s_setprio(3);   // heavy reads are the critical path: let their waves issue first
+    while (true) {
+        const int slot = next_slot(queue, per_wave);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
+        const int r = order ? order[slot] : slot;
+        dev_chain_read<I>(fm, R, ck, opt, r);
     }
 }

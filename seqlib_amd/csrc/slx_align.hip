@@ -23,6 +23,7 @@
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
 #include "dev_fin2.h"
+#include "dev_chain_coop.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -115,6 +116,7 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
+    int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int split_heavy = 0;          // 1 = reads with >= heavy_seeds seed occurrences run as their own sub-pipeline on a second stream
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this are not split
@@ -318,6 +320,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "fin_mode")) al->fin_mode = (int)value;
     else if (!strcmp(key, "seed_mode")) al->seed_mode = (int)value;
     else if (!strcmp(key, "split_heavy")) al->split_heavy = (int)value;
+    else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
     else if (!strcmp(key, "workers")) { if (value < 1 || value > 2) return SLX_EINVAL; al->n_workers = (int)value; }
@@ -341,12 +344,12 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 template <int MAXQ>
 static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, const int *order,
                        unsigned int *q, const unsigned int *n_slots, int sub, int grid, int bs, int n_est, hipEvent_t *ev_after_chain,
-                       hipEvent_t *ev_after_ext)
+                       hipEvent_t *ev_after_ext, bool with_chain = true)
 {
     hipEvent_t *dbg = wk->dbg_ev[sub];
     const bool dbg_on = getenv("SLX_DEBUG_SUB") != nullptr;
     if (dbg_on) (void)hipEventRecord(dbg[0], st);
-    hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, order, q + 0, n_slots, sub);
+    if (with_chain) hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, order, q + 0, n_slots, sub);
     if (ev_after_chain) (void)hipEventRecord(*ev_after_chain, st);
     if (dbg_on) (void)hipEventRecord(dbg[1], st);
     const int g = std::max(1, std::min(n_est, al->n_cu * 32));
@@ -522,22 +525,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         const bool production = al->ext_mode == 2 && al->fin_mode == 1 && !al->sched;
         const bool split = production && al->split_heavy && n >= al->split_min;
         auto dispatch_sub = [&](hipStream_t sst, const int *order, unsigned int *qq, const unsigned int *ns, int sub, int g2, int n_est,
-                                hipEvent_t *e1, hipEvent_t *e2) {
-            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
-            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
-            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2);
+                                hipEvent_t *e1, hipEvent_t *e2, bool with_chain) {
+            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
+            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
+            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
         };
-        if (!production) {
-            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
-            if (max_len <= 160) launch_reference_modes<160>(al, wk, ck, dopt, fm, grid, bs, counts);
-            else if (max_len <= 320) launch_reference_modes<320>(al, wk, ck, dopt, fm, grid, bs, counts);
-            else launch_reference_modes<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, grid, bs, counts);
-        } else if (!split) {
-            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
-            dispatch_sub(st, nullptr, q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5]);
-        } else {
+        auto partition = [&]() -> int {   // light reads (input order) -> order_in, heavy reads -> order_out, counts[0] / counts[1]
             ENS(part_flag, (size_t)n * 4); ENS(part_pos, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
-            ENS(fast_list2, S1 * 4); ENS(dp_list2, S1 * 4);
             hipLaunchKernelGGL(k_part_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
                                (unsigned int)al->heavy_seeds, wk->part_flag.as<unsigned int>());
             size_t tb = 0;
@@ -546,15 +540,36 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
             hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
                                wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), counts);
+            return SLX_OK;
+        };
+        if (!production) {
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
+            if (max_len <= 160) launch_reference_modes<160>(al, wk, ck, dopt, fm, grid, bs, counts);
+            else if (max_len <= 320) launch_reference_modes<320>(al, wk, ck, dopt, fm, grid, bs, counts);
+            else launch_reference_modes<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, grid, bs, counts);
+        } else if (!split && !(al->chain_mode == 1 && n >= al->split_min)) {
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
+            dispatch_sub(st, nullptr, q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5], true);
+        } else if (!split) {
+            // chaining: light reads one per lane, heavy reads one per wave (cooperative); everything after it over all reads in input order
+            if ((rc = partition()) != SLX_OK) return rc;
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + 2, (unsigned int)n);
+            hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
+            hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                               wk->order_out.as<int>(), q + 8, counts + 1);
+            dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false);
+        } else {
+            if ((rc = partition()) != SLX_OK) return rc;
+            ENS(fast_list2, S1 * 4); ENS(dp_list2, S1 * 4);
             if (!wk->stream2) HIPCHK(hipStreamCreateWithFlags(&wk->stream2, hipStreamNonBlocking));   // created on first use: every extra
                                                                                                        // stream competes for the few hardware queues
             HIPCHK(hipEventRecord(wk->ev_split, st));
             HIPCHK(hipStreamWaitEvent(wk->stream2, wk->ev_split, 0));
             // heavy reads (a fraction of a percent of the batch, most of the critical path) on the second stream ...
-            dispatch_sub(wk->stream2, wk->order_out.as<int>(), q + 12, counts + 1, 1, grid, std::max(64, n / 8), nullptr, nullptr);
+            dispatch_sub(wk->stream2, wk->order_out.as<int>(), q + 12, counts + 1, 1, grid, std::max(64, n / 8), nullptr, nullptr, true);
             HIPCHK(hipEventRecord(wk->ev_heavy, wk->stream2));
             // ... while the light ones fill the machine from the first
-            dispatch_sub(st, wk->order_in.as<int>(), q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5]);
+            dispatch_sub(st, wk->order_in.as<int>(), q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5], true);
             HIPCHK(hipStreamWaitEvent(st, wk->ev_heavy, 0));
         }
     }
