@@ -130,9 +130,11 @@ __device__ GenCig dev_gen_cigar2(const DevRef &R, const slx_opt &o, const Chunk 
 }
 
 // mem_patch_reg
-template <int MAXQ>
+// SC = the global-alignment scorer: sc(band, l_query, query segment, rb, re) -> bwa_gen_cigar2's score (no CIGAR).
+// One lane with private rows in the lane-per-read kernels, the wave-parallel DP in the wave-per-read one.
+template <int MAXQ, typename SC>
 __device__ int dev_patch_reg(const DevRef &R, const slx_opt &o, const Chunk &ck, const uint8_t *query, const DReg &a, const DReg &b,
-                             int *_w, int *eh_h, int *eh_e)
+                             int *_w, SC &sc)
 {
     int w, score, q_s, r_s;
     double r;
@@ -147,8 +149,7 @@ __device__ int dev_patch_reg(const DevRef &R, const slx_opt &o, const Chunk &ck,
     } else if (w > o.w << 2 || r >= (double)(0.05f * 2)) return 0;
     w += a.w + b.w;
     w = w < o.w << 2 ? w : o.w << 2;
-    GenCig g = dev_gen_cigar2<MAXQ>(R, o, ck, w, b.qe - a.qb, query + a.qb, a.rb, b.re, false, eh_h, eh_e);
-    score = g.score;
+    score = sc(w, b.qe - a.qb, query + a.qb, a.rb, b.re);
     q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
     r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (double)(b.score + a.score) + .499);
     if ((double)score / (double)(q_s > r_s ? q_s : r_s) < (double)0.90f) return 0;
@@ -221,9 +222,8 @@ __device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const 
 
 // mem_sort_dedup_patch + mem_mark_primary_se for one read; returns the number of regions left (their handles are
 // w.ia[0..n) in mem_mark_primary_se order).  Shared by the fused and the split finalize kernels.
-template <int MAXQ>
-__device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query,
-                            int *eh_h, int *eh_e)
+template <int MAXQ, typename SC>
+__device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query, SC &sc)
 {
         int n = ck.n_reg[r];
         int *a = w.ia;                            // region handles
@@ -248,7 +248,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                     if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
                         if (p.score < q.score) { p.qe = p.qb; break; }
                         else q.qe = q.qb;
-                    } else if (q.rb < p.rb && (score = dev_patch_reg<MAXQ>(R, opt, ck, query, q, p, &ww, eh_h, eh_e)) > 0) {
+                    } else if (q.rb < p.rb && (score = dev_patch_reg<MAXQ>(R, opt, ck, query, q, p, &ww, sc)) > 0) {
                         p.n_comp += q.n_comp + 1;
                         p.seedcov = p.seedcov > q.seedcov ? p.seedcov : q.seedcov;
                         p.sub = p.sub > q.sub ? p.sub : q.sub;
@@ -328,7 +328,10 @@ __global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dop
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-        int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, eh_h, eh_e);
+        auto sc = [&](int band, int lq, const uint8_t *qseg, int64_t rb, int64_t re) {
+            return dev_gen_cigar2<MAXQ>(R, opt, ck, band, lq, qseg, rb, re, false, eh_h, eh_e).score;
+        };
+        int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, sc);
         int *a = w.ia;
         DReg *G = w.regs;
         // ---------------- glue: reg2aln for every region the caller keeps (src/BWAAligner.cpp:117-129)

@@ -26,100 +26,6 @@ struct FinLists {
     unsigned int *n_fast, *n_dp, *q_dp;
 };
 
-template <int MAXQ>
-__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
-{
-    const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    const int n_todo = (int)*n_slots;
-    if (per_wave) __builtin_amdgcn_s_setprio(3);
-    while (true) {
-        const int slot = next_slot(queue, per_wave);
-        if (__all(slot >= n_todo)) break;
-        if (slot >= n_todo) continue;
-        const int r = order ? order[slot] : slot;
-        ReadWS w = make_ws(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
-        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-        const int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, eh_h, eh_e);
-        const int *a = w.ia;
-        const DReg *G = w.regs;
-        const uint64_t so = ck.seed_off[r];
-        int nh = 0;
-        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
-        for (int i = 0; i < n; ++i) {
-            const DReg &ar = G[a[i]];
-            if (ar.secondary != 0 && drop_sec) continue;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
-            DHit h;
-            h.flag = ar.secondary >= 0 ? 0x100 : 0;
-            h.mapq = ar.secondary < 0 ? dev_approx_mapq_se(opt, ar, ck) : 0;
-            h.score = ar.score; h.nm = -1; h.n_cigar = 0; h.cig_start = 0; h.pos = 0; h.rid = -1;
-            const int qb = ar.qb, qe = ar.qe;
-            const int64_t rb = ar.rb, re = ar.re;
-            int tmp = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
-            int w2 = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
-            w2 = w2 > tmp ? w2 : tmp;
-            if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
-            DJob j;
-            j.rb = rb; j.re = re; j.qb = qb; j.qe = qe; j.w2 = w2; j.truesc = ar.truesc; j.r = r; j.pad = 0;
-            w.hits[nh] = h;
-            fl.jobs[so + nh] = j;
-            const int wc = w2 < opt.w << 2 ? w2 : opt.w << 2;
-            const bool fast = (qe - qb) == (int)(re - rb) && wc == 0;
-            if (fast) fl.fast_list[atomicAdd(fl.n_fast, 1u)] = (uint32_t)(so + nh);
-            else fl.dp_list[atomicAdd(fl.n_dp, 1u)] = (uint32_t)(so + nh);
-            ++nh;
-        }
-        ck.n_hit[r] = nh;
-    }
-}
-
-// final position / rid / clipping of mem_reg2aln once the core cigar [cs, cs+nc) is in the pool with one free slot on each side
-__device__ __forceinline__ void dev_finish_hit(const DevRef &R, const Chunk &ck, const DJob &j, int l_query, DHit &h, int64_t cs, int nc)
-{
-    int is_rev;
-    int64_t pos = dev_depos(R, j.rb < R.l_pac ? j.rb : j.re - 1, &is_rev);
-    if (nc > 0) {                                 // squeeze out a leading or else a trailing deletion
-        if ((ck.cigpool[cs] & 0xf) == 2) { pos += ck.cigpool[cs] >> 4; ++cs; --nc; }
-        else if ((ck.cigpool[cs + nc - 1] & 0xf) == 2) --nc;
-    }
-    if (j.qb != 0 || j.qe != l_query) {           // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
-        const int clip5 = is_rev ? l_query - j.qe : j.qb, clip3 = is_rev ? j.qb : l_query - j.qe;
-        const uint32_t cop = ck.hardclip ? 5u : 4u;
-        if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
-        if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
-    }
-    h.rid = dev_pos2rid(R, pos);
-    h.pos = pos - R.ann_off[h.rid];
-    if (is_rev) h.flag |= 0x10;
-    h.n_cigar = nc; h.cig_start = cs;
-}
-
-__global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists fl)
-{
-    const unsigned int n = *fl.n_fast;
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-        const uint32_t slot = fl.fast_list[t];
-        const DJob j = fl.jobs[slot];
-        DHit h = ck.hits[slot];
-        const uint8_t *query = ck.codes + ck.offs[j.r];
-        const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
-        const int lq = j.qe - j.qb;
-        // NM: mismatches along the diagonal (orientation does not matter for a count)
-        int nm = 0;
-        for (int i = 0; i < lq; ++i) {
-            const int qc = query[j.qb + i];
-            nm += qc != ref_base(R, j.rb + i);
-        }
-        h.nm = nm;
-        const unsigned long long base = atomicAdd(ck.cigused, 3ull);
-        if (base + 3 > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
-        ck.cigpool[base + 1] = (uint32_t)lq << 4;
-        dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, 1);
-        ck.hits[slot] = h;
-    }
-}
-
 // ---------------------------------------------------------------- wave-cooperative ksw_global2
 #define G_NEG (-0x7f000000)
 
@@ -212,6 +118,167 @@ __device__ int wave_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
 #pragma unroll
     for (int k = 1; k < CPL; ++k) pick = kk == k ? H[k] : pick;
     return lane_read(pick, src);
+}
+
+// bwa_gen_cigar2 (score only) on one wave: the scorer the wave-per-read region kernel hands to mem_patch_reg
+template <int MAXQ>
+struct WaveScorer {
+    const DevRef &R; const slx_opt &o; const MatRows &mr; int lane;
+    __device__ int operator()(int w_, int l_query, const uint8_t *qseg, int64_t rb, int64_t re) const
+    {
+        constexpr int CPLMAX = (MAXQ + 1 + WAVE - 1) / WAVE;
+        if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return 0;
+        const int rlen = (int)(re - rb);
+        const bool rev = rb >= R.l_pac;
+        auto qf = [&](int x) { return (int)(rev ? qseg[l_query - 1 - x] : qseg[x]); };
+        auto tf = [&](int y) { return rev ? ref_base(R, re - 1 - y) : ref_base(R, rb + y); };
+        if (l_query == rlen && w_ == 0) {
+            int sc = 0;
+            for (int i = 0; i < l_query; ++i) sc += o.mat[tf(i) * 5 + qf(i)];
+            return sc;
+        }
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_ins) / o.e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_del) / o.e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
+        int w = (max_gap + dl + 1) >> 1;
+        w = w < w_ ? w : w_;
+        const int min_w = dl + 3;
+        w = w > min_w ? w : min_w;
+        if (l_query + 1 <= WAVE) return wave_ksw_global2<1>(l_query, qf, rlen, tf, o, mr, w, nullptr, 0, lane);
+        if (CPLMAX > 2 && l_query + 1 <= 2 * WAVE) return wave_ksw_global2<(CPLMAX > 2 ? 2 : CPLMAX)>(l_query, qf, rlen, tf, o, mr, w, nullptr, 0, lane);
+        return wave_ksw_global2<CPLMAX>(l_query, qf, rlen, tf, o, mr, w, nullptr, 0, lane);
+    }
+};
+
+// Regions of one read -> hits + CIGAR jobs (shared by the lane-per-read and the wave-per-read kernel; `leader` = the
+// lane that performs the list pushes: every lane in the former, lane 0 in the latter).
+template <int MAXQ, typename SC>
+__device__ void dev_regs_read(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, int r, SC &sc, bool leader)
+{
+    ReadWS w = make_ws(ck, r);
+    const uint8_t *query = ck.codes + ck.offs[r];
+    const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+    const int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, sc);
+    const int *a = w.ia;
+    const DReg *G = w.regs;
+    const uint64_t so = ck.seed_off[r];
+    int nh = 0;
+    const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+    for (int i = 0; i < n; ++i) {
+        const DReg &ar = G[a[i]];
+        if (ar.secondary != 0 && drop_sec) continue;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
+        DHit h;
+        h.flag = ar.secondary >= 0 ? 0x100 : 0;
+        h.mapq = ar.secondary < 0 ? dev_approx_mapq_se(opt, ar, ck) : 0;
+        h.score = ar.score; h.nm = -1; h.n_cigar = 0; h.cig_start = 0; h.pos = 0; h.rid = -1;
+        const int qb = ar.qb, qe = ar.qe;
+        const int64_t rb = ar.rb, re = ar.re;
+        int tmp = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+        int w2 = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+        w2 = w2 > tmp ? w2 : tmp;
+        if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+        DJob j;
+        j.rb = rb; j.re = re; j.qb = qb; j.qe = qe; j.w2 = w2; j.truesc = ar.truesc; j.r = r; j.pad = 0;
+        w.hits[nh] = h;
+        fl.jobs[so + nh] = j;
+        const int wc = w2 < opt.w << 2 ? w2 : opt.w << 2;
+        const bool fast = (qe - qb) == (int)(re - rb) && wc == 0;
+        if (leader) {
+            if (fast) fl.fast_list[atomicAdd(fl.n_fast, 1u)] = (uint32_t)(so + nh);
+            else fl.dp_list[atomicAdd(fl.n_dp, 1u)] = (uint32_t)(so + nh);
+        }
+        ++nh;
+    }
+    if (leader) ck.n_hit[r] = nh;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
+{
+    const slx_opt &opt = dopt.o;
+    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    const int n_todo = (int)*n_slots;
+    if (per_wave) __builtin_amdgcn_s_setprio(3);
+    auto sc = [&](int band, int lq, const uint8_t *qseg, int64_t rb, int64_t re) {
+        return dev_gen_cigar2<MAXQ>(R, opt, ck, band, lq, qseg, rb, re, false, eh_h, eh_e).score;
+    };
+    while (true) {
+        const int slot = next_slot(queue, per_wave);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
+        dev_regs_read<MAXQ>(R, ck, opt, fl, order ? order[slot] : slot, sc, true);
+    }
+}
+
+// reads with two or more regions: one wave per read, mem_patch_reg's global alignment runs wave-parallel
+template <int MAXQ>
+__device__ __noinline__ void dev_regs_read_wave(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl, int r, int lane)
+{
+    WaveScorer<MAXQ> sc{R, opt, mr, lane};
+    dev_regs_read<MAXQ>(R, ck, opt, fl, r, sc, lane == 0);
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
+{
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(dopt.o.mat);
+    const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = (int)atomicAdd(queue, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= n_todo) break;
+        dev_regs_read_wave<MAXQ>(R, ck, dopt.o, mr, fl, order ? order[slot] : slot, lane);
+    }
+}
+
+// final position / rid / clipping of mem_reg2aln once the core cigar [cs, cs+nc) is in the pool with one free slot on each side
+__device__ __forceinline__ void dev_finish_hit(const DevRef &R, const Chunk &ck, const DJob &j, int l_query, DHit &h, int64_t cs, int nc)
+{
+    int is_rev;
+    int64_t pos = dev_depos(R, j.rb < R.l_pac ? j.rb : j.re - 1, &is_rev);
+    if (nc > 0) {                                 // squeeze out a leading or else a trailing deletion
+        if ((ck.cigpool[cs] & 0xf) == 2) { pos += ck.cigpool[cs] >> 4; ++cs; --nc; }
+        else if ((ck.cigpool[cs + nc - 1] & 0xf) == 2) --nc;
+    }
+    if (j.qb != 0 || j.qe != l_query) {           // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
+        const int clip5 = is_rev ? l_query - j.qe : j.qb, clip3 = is_rev ? j.qb : l_query - j.qe;
+        const uint32_t cop = ck.hardclip ? 5u : 4u;
+        if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
+        if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
+    }
+    h.rid = dev_pos2rid(R, pos);
+    h.pos = pos - R.ann_off[h.rid];
+    if (is_rev) h.flag |= 0x10;
+    h.n_cigar = nc; h.cig_start = cs;
+}
+
+__global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists fl)
+{
+    const unsigned int n = *fl.n_fast;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const uint32_t slot = fl.fast_list[t];
+        const DJob j = fl.jobs[slot];
+        DHit h = ck.hits[slot];
+        const uint8_t *query = ck.codes + ck.offs[j.r];
+        const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
+        const int lq = j.qe - j.qb;
+        // NM: mismatches along the diagonal (orientation does not matter for a count)
+        int nm = 0;
+        for (int i = 0; i < lq; ++i) {
+            const int qc = query[j.qb + i];
+            nm += qc != ref_base(R, j.rb + i);
+        }
+        h.nm = nm;
+        const unsigned long long base = atomicAdd(ck.cigused, 3ull);
+        if (base + 3 > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
+        ck.cigpool[base + 1] = (uint32_t)lq << 4;
+        dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, 1);
+        ck.hits[slot] = h;
+    }
 }
 
 // One CIGAR job on one wave.  Kept out of line on purpose: with the body inlined into the queue loop the compiler

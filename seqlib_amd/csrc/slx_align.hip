@@ -116,6 +116,7 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
+    int regs_mode = 0;            // 1 = reads with >= 2 regions are de-duplicated / patched by the wave-per-read kernel
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int split_heavy = 0;          // 1 = reads with >= heavy_seeds seed occurrences run as their own sub-pipeline on a second stream
     int heavy_seeds = 64;
@@ -123,7 +124,7 @@ struct slx_aligner {
     int seed_mode = 1;            // 1 = state-machine seeding kernel (one bwt_extend per lane per trip), 0 = nested-loop kernel
     int fin_mode = 1;             // 1 = finalize split into work lists (fast / DP cigar jobs), 0 = fused one-lane-per-read kernel
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
-    int n_workers = 2;            // concurrent halves of a large batch
+    int n_workers = 3;            // concurrent parts of a large batch
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
     int max_threads = 0;
     int n_cu = 256;
@@ -224,7 +225,7 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     HIPCHK(hipGetDeviceProperties(&prop, al->device));
     al->n_cu = prop.multiProcessorCount;
     al->max_threads = al->n_cu * 1024;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         Worker *wk = new Worker();
         wk->collect();
         HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
@@ -321,9 +322,10 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "seed_mode")) al->seed_mode = (int)value;
     else if (!strcmp(key, "split_heavy")) al->split_heavy = (int)value;
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
+    else if (!strcmp(key, "regs_mode")) al->regs_mode = (int)value;
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
-    else if (!strcmp(key, "workers")) { if (value < 1 || value > 2) return SLX_EINVAL; al->n_workers = (int)value; }
+    else if (!strcmp(key, "workers")) { if (value < 1 || value > 3) return SLX_EINVAL; al->n_workers = (int)value; }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
@@ -339,6 +341,30 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 }
 
 // ---------------------------------------------------------------- one chunk
+// light / heavy partition of a chunk by seed count (stable for the light reads: they keep their input order and locality)
+__global__ void k_part_flags(const unsigned long long *seed_cnt, int n, unsigned int thr, unsigned int *flag)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = seed_cnt[i] < thr ? 1u : 0u;
+}
+
+__global__ void k_part_flags_nreg(const int *n_reg, int n, unsigned int *flag)
+{   // 1 = at most one region: nothing to de-duplicate or patch, stays on the lane-per-read kernel
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = n_reg[i] <= 1 ? 1u : 0u;
+}
+
+__global__ void k_part_scatter(const unsigned int *flag, const unsigned int *pos, int n, int *light, int *heavy, unsigned int *counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) light[pos[i]] = i;
+    else heavy[atomicAdd(counts + 1, 1u)] = i;
+    if (i == n - 1) counts[0] = pos[i] + flag[i];
+}
+
+__global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
+
 // The post-seeding part of the pipeline for one list of reads (all reads, or the light / heavy subset) on one
 // stream: chain -> extend -> regions -> CIGAR jobs -> hit sort/filter.  q = this sub-pipeline's block of queue counters.
 template <int MAXQ>
@@ -361,7 +387,20 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
     fl.fast_list = (sub ? wk->fast_list2 : wk->fast_list).as<uint32_t>();
     fl.dp_list = (sub ? wk->dp_list2 : wk->dp_list).as<uint32_t>();
     fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
-    hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, sub);
+    if (al->regs_mode == 1 && !sub && !order && n_est >= al->split_min) {
+        // reads with >= 2 regions (indels, chimeras, repeats: a few percent) go to the wave-per-read kernel, whose mem_patch_reg
+        // alignment is wave-parallel; the rest stay one per lane.  order_in / order_out are free again after chaining.
+        unsigned int *cnt2 = q + 32;
+        hipLaunchKernelGGL(k_part_flags_nreg, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, ck.n_reg, n_est, wk->part_flag.as<unsigned int>());
+        size_t tb = wk->scan_tmp.cap;
+        (void)hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n_est, st);
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
+                           wk->part_pos.as<unsigned int>(), n_est, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_in.as<int>(), q + 2, cnt2, 0);
+        hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n_est / 8 + 1, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                           wk->order_out.as<int>(), q + 9, cnt2 + 1);
+    } else
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, sub);
     if (dbg_on) (void)hipEventRecord(dbg[3], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n_est / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
     hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, sub);
@@ -397,23 +436,6 @@ static void launch_reference_modes(slx_aligner *al, Worker *wk, const Chunk &ck,
     }
 }
 
-// light / heavy partition of a chunk by seed count (stable for the light reads: they keep their input order and locality)
-__global__ void k_part_flags(const unsigned long long *seed_cnt, int n, unsigned int thr, unsigned int *flag)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = seed_cnt[i] < thr ? 1u : 0u;
-}
-
-__global__ void k_part_scatter(const unsigned int *flag, const unsigned int *pos, int n, int *light, int *heavy, unsigned int *counts)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) light[pos[i]] = i;
-    else heavy[atomicAdd(counts + 1, 1u)] = i;
-    if (i == n - 1) counts[0] = pos[i] + flag[i];
-}
-
-__global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
 
