@@ -14,8 +14,11 @@ enum SeedPhase : int {
     PH_P3_FWD, PH_FINISH, PH_DONE
 };
 
+#ifndef SEED_MIN_WAVES
+#define SEED_MIN_WAVES 6
+#endif
 template <typename I>
-__global__ void __launch_bounds__(128) k_seed_sm(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+__global__ void __launch_bounds__(128, SEED_MIN_WAVES) k_seed_sm(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -127,6 +127,7 @@ struct slx_aligner {
     int n_workers = 3;            // concurrent parts of a large batch
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
     int max_threads = 0;
+    int threads_per_cu = 1536;
     int n_cu = 256;
     unsigned long long zcap = 1ull << 26;   // floor of the traceback arena (bytes)
     unsigned long long z_per_read = 512;    // arena bytes budgeted per read (grows when a chunk overflows)
@@ -224,7 +225,7 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, al->device));
     al->n_cu = prop.multiProcessorCount;
-    al->max_threads = al->n_cu * 1024;
+    al->max_threads = al->n_cu * al->threads_per_cu;
     for (int k = 0; k < 3; ++k) {
         Worker *wk = new Worker();
         wk->collect();
