@@ -202,15 +202,27 @@ def main():
                 same += bool(ok)
             match = same / m
         # roofline of the seeding kernel: algorithmic bytes on bwa's own layout / HIP-event time
-        seed_ms = stage_acc.get("seed", 0.0) / args.steps
+        seed_ms = stage_acc.get("seed", 0.0) / args.steps       # sum over this step's launches (one per worker)
+        stage_launches = 3 if n >= (1 << 19) else 1
         roof = None
+        # HBM-side traffic of the seeding kernel from the PMC passes of the same command (profiles/, see scripts/profile_round.sh)
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        except Exception:
+            pass
         if per_read is not None and seed_ms > 0:
             seed_bytes = 64.0 * per_read["n_occ_block"] + per_read["read_bases"]
             path_bytes = (64.0 * per_read["n_occ_block"] + 64.0 * per_read["n_invpsi"] + 8.0 * per_read["n_sa"] +
                           per_read["ref_bases"] / 4.0 + per_read["read_bases"] + 32.0 * per_read["n_hits"] + 4.0 * per_read["n_cigar_ops"])
             achieved = seed_bytes * n / (seed_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="k_seed<uint32_t>", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=seed_ms,
+            n_launch = max(1, round(stage_launches)) if stage_launches else 1
+            traffic = None
+            if pmc:   # bytes per launch = (FETCH_SIZE + WRITE_SIZE) per read, as counted, x reads per launch
+                traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / n_launch
+            roof = dict(bound="hbm", kernel="k_seed_sm<uint32_t>", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=n_launch, reads_per_launch=n / n_launch,
+                        kernel_ms=seed_ms,
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,
                         path_achieved=path_bytes * n / (ms_per_step * 1e-3) / 1e9)
         out = {
