@@ -220,7 +220,7 @@ def main():
             traffic = None
             if pmc:   # bytes per launch = (FETCH_SIZE + WRITE_SIZE) per read, as counted, x reads per launch
                 traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / n_launch
-            roof = dict(bound="hbm", kernel="k_seed_sm<uint32_t>", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            roof = dict(bound="hbm", kernel="k_seed12 + k_seed3", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=n_launch, reads_per_launch=n / n_launch,
                         kernel_ms=seed_ms,
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,

@@ -11,6 +11,7 @@
 template <typename I>
 struct DevFM {
     const uint32_t *bwt;      // interleaved blocks
+    const uint4 *occ;         // occ planes (dev_seed2.h): per 64 symbols 4 x u32 counts + low/high bit planes; u32 indices only
     I primary;
     I L2[5];
     I seq_len;

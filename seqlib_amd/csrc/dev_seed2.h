@@ -1,0 +1,352 @@
+// dev_seed2.h -- production SMEM seeding (seed_mode = 2): bwa's mem_collect_intv (reached from
+// /root/reference/src/BWAAligner.cpp:104 -> mem_align1 -> mem_chain) as two kernels over a rank structure laid out
+// for the GPU.  dev_seed.h (nested loops) and dev_seed_sm.h (first state machine) stay as test references.
+//
+//   k_occ_build   bwa's interleaved .bwt image -> "occ planes": one 32-byte block per 64 BWT symbols =
+//                 4 x u32 running counts + the symbols as two 64-bit bit planes (low bit / high bit of each base).
+//                 A rank query is one 32-byte read, one 64-bit mask and six popcounts, instead of a 64-byte line and
+//                 eight masked 16-symbol words.
+//   k_seed12      passes 1 and 2 (bwt_smem1a over all start positions; re-seeding inside long rare SMEMs) as a
+//                 per-lane state machine: every trip of one wave-uniform loop does exactly one bwt_extend per lane.
+//                 The phases between two extends are straight-line blocks ordered so that a lane flows through all
+//                 of them within the trip; the backward walk keeps the head of each row in registers and prefetches
+//                 the next work-list entry one trip ahead, so no load sits between a lane and its extend; the query
+//                 is read through an 8-byte register window; read indices come from a wave-level pool that is
+//                 refilled one trip ahead.
+//   k_seed3       pass 3 (bwt_seed_strategy1: forward-only LAST-like seeds), then the per-read epilogue: sort by
+//                 (start, end), repetitive length and the seed-occurrence bound.  One lane per read, one extend per
+//                 base: lanes of a wave run in lock step for reads of equal length.
+#pragma once
+#include "dev_seed.h"
+
+// ---------------------------------------------------------------------------------------------- occ planes
+__global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, uint64_t n_blocks)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t n_data_words = (seq_len + 15) >> 4;
+    const uint64_t B = b >> 1;
+    const int half = (int)(b & 1);
+    auto data_word = [&](uint64_t d) -> uint32_t { return d < n_data_words ? bwt[(d >> 3) * 16 + 8 + (d & 7)] : 0u; };
+    uint32_t cnt[4];
+    for (int s = 0; s < 4; ++s) cnt[s] = bwt[B * 16 + 2 * s];          // low word of bwa's u64 running count
+    if (half)
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w = data_word(B * 8 + k);
+            for (int s = 0; s < 16; ++s) ++cnt[(w >> (2 * s)) & 3];
+        }
+    uint64_t lo = 0, hi = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = data_word(b * 4 + k);
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t sym = (w >> ((15 - s) << 1)) & 3;              // bwa packs 16 symbols per word, first symbol in the top bits
+            lo |= (uint64_t)(sym & 1) << (16 * k + s);
+            hi |= (uint64_t)(sym >> 1) << (16 * k + s);
+        }
+    }
+    occ[2 * b] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+    occ[2 * b + 1] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+// counts of A,C,G,T in BWT[0..k] (bwt_occ4), k already mapped past the sentinel
+__device__ __forceinline__ void occp_rank(const uint4 *occ, uint32_t kk, uint32_t t[4])
+{
+    const uint4 *blk = occ + ((size_t)(kk >> 6) << 1);
+    const uint4 c = blk[0], p = blk[1];
+    const uint32_t n = (kk & 63) + 1;
+    const uint64_t m = ~0ull >> (64 - n);
+    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+    const uint32_t l0 = p.x & m0, l1 = p.y & m1, h0 = p.z & m0, h1 = p.w & m1;
+    const uint32_t sl = __popc(l0) + __popc(l1), sh = __popc(h0) + __popc(h1), st = __popc(l0 & h0) + __popc(l1 & h1);
+    t[0] = c.x + (n + st - sl - sh); t[1] = c.y + (sl - st); t[2] = c.z + (sh - st); t[3] = c.w + st;
+}
+
+// bwt_extend for the one output symbol the caller needs (same contract as fm_extend in dev_fm.h)
+__device__ __forceinline__ void fm_extend_p(const DevFM<uint32_t> &fm, const IntvE<uint32_t> &ik, int c, int is_back, IntvE<uint32_t> &ok)
+{
+    typedef uint32_t I;
+    I tk[4], tl[4];
+    const I xin = is_back ? ik.x0 : ik.x1;
+    const I xot = is_back ? ik.x1 : ik.x0;
+    const I k = xin - 1, l = xin - 1 + ik.x2;
+    const bool k_none = (k == (I)-1), l_none = (l == (I)-1);
+    occp_rank(fm.occ, k_none ? 0 : k - (k >= fm.primary ? 1 : 0), tk);
+    occp_rank(fm.occ, l_none ? 0 : l - (l >= fm.primary ? 1 : 0), tl);
+    if (k_none) tk[0] = tk[1] = tk[2] = tk[3] = 0;
+    if (l_none) tl[0] = tl[1] = tl[2] = tl[3] = 0;
+    const I s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
+    I base = xot + ((xin <= fm.primary && xin + ik.x2 - 1 >= fm.primary) ? 1 : 0);
+    I sz = s3, nin = fm.L2[3] + 1 + tk[3];
+    if (c <= 2) { base += s3; sz = s2; nin = fm.L2[2] + 1 + tk[2]; }
+    if (c <= 1) { base += s2; sz = s1; nin = fm.L2[1] + 1 + tk[1]; }
+    if (c == 0) { base += s1; sz = s0; nin = fm.L2[0] + 1 + tk[0]; }
+    if (is_back) { ok.x0 = nin; ok.x1 = base; } else { ok.x1 = nin; ok.x0 = base; }
+    ok.x2 = sz;
+}
+
+// ---------------------------------------------------------------------------------------------- query window
+struct QWin { uint64_t bits; uint32_t chunk; };
+__device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
+{   // nt4 code at absolute offset a; the codes buffer is 8-byte aligned and padded
+    const uint32_t ch = (uint32_t)(a >> 3);
+    if (ch != w.chunk) { w.bits = *(const uint64_t *)(codes + (a & ~7ull)); w.chunk = ch; }
+    return (int)((w.bits >> ((a & 7) << 3)) & 0xff);
+}
+
+#ifndef SEED2_MIN_WAVES
+#define SEED2_MIN_WAVES 6
+#endif
+#ifndef SEED2_POOL
+#define SEED2_POOL 16
+#endif
+
+enum Seed2Phase : int { S2_FETCH = 0, S2_INIT, S2_START, S2_FWD0, S2_BEGIN_BWD, S2_ROW, S2_FWD, S2_BWD, S2_DONE };
+
+__global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+{
+    typedef uint32_t I;
+    const slx_opt &opt = dopt.o;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    WorkLists<I> wl;
+    wl.base = (IntvE<I> *)ck.lists + tid; wl.stride = (size_t)ck.n_threads; wl.cap = ck.cap_list;
+    const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+    const uint32_t n_reads = (uint32_t)ck.n_reads;
+    // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
+    uint32_t pool_next = 0, pool_end = 0, res_next = 0, res_end = 0;
+    uint32_t pend_base = 0;
+    bool pending = false, exhausted = false;
+    // ---- per-lane state
+    int phase = S2_FETCH;
+    uint32_t r = 0;
+    uint64_t o0 = 0, o1 = 0, qoff = 0;
+    int len = 0, n_out = 0;
+    bool out_ovf = false, list_ovf = false;
+    int pass = 1, x = 0, k2 = 0, old_n = 0;
+    int sx = 0, i = 0, n = 0, ret = 0, bi = 0, cb = 0, cq = 0, cur = 1, np = 0, rev = 0, j = 0, nc = 0, last_start = 0;
+    I min_intv = 1, last_sz = 0;
+    IntvE<I> ik, head, nhead, psrc, nsrc;
+    ik.x0 = ik.x1 = ik.x2 = 0; ik.info = 0;
+    head = nhead = psrc = nsrc = ik;
+    QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+
+    auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+    auto push_fwd = [&](const IntvE<I> &v) { if (n < wl.cap) wl.at(1, n) = v; else list_ovf = true; ++n; };
+    auto out_push = [&](int start, int end, I a, I s) {
+        if (n_out < ck.cap_intv) {
+            const size_t o = (size_t)r * ck.cap_intv + n_out;
+            ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
+            ++n_out;
+        } else out_ovf = true;
+    };
+    auto emit_mem = [&](const IntvE<I> &p) {       // a MEM [bi+1, p.info) ends the backward walk of entry p
+        if (bi + 1 < last_start) {                 // not contained in a longer match already reported by this call
+            last_start = bi + 1;
+            if ((int)p.info - (bi + 1) >= opt.min_seed_len) out_push(bi + 1, (int)p.info, p.x0, p.x2);
+        }
+    };
+    auto finish_read = [&]() {                     // passes 1+2 done (or abandoned on a work-list overflow)
+        ck.intv_n[r] = (uint32_t)n_out;
+        if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+        if (list_ovf) atomicOr(ck.flags, OVF_LIST);
+        phase = S2_FETCH;
+    };
+
+    for (;;) {
+        // ------------------------------------------------ read assignment (wave-uniform bookkeeping)
+        if (pending) {
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
+            pending = false;
+            if (base >= n_reads) exhausted = true;
+            else { res_next = base; res_end = base + SEED2_POOL < n_reads ? base + SEED2_POOL : n_reads; }
+        }
+        if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
+        if (res_next == res_end && !exhausted) {
+            if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED2_POOL);
+            pending = true;
+        }
+        if (phase == S2_INIT) {                     // offsets requested one trip ago
+            qoff = o0; len = (int)(o1 - o0);
+            n_out = 0; out_ovf = false; list_ovf = false;
+            if (len < opt.min_seed_len) finish_read();
+            else { pass = 1; x = 0; phase = S2_START; }
+        }
+        {
+            const unsigned long long want = __ballot(phase == S2_FETCH);
+            if (want) {
+                const uint32_t avail = pool_end - pool_next;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                if (phase == S2_FETCH) {
+                    if (rank < avail) {
+                        r = pool_next + rank;
+                        o0 = ck.offs[r]; o1 = ck.offs[r + 1];
+                        phase = S2_INIT;
+                    } else if (exhausted && !pending && res_next == res_end) phase = S2_DONE;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(want);
+                pool_next += cnt < avail ? cnt : avail;
+            }
+        }
+        // ------------------------------------------------ next bwt_smem1a call of this read
+        if (phase == S2_START) {
+            int xs = -1;
+            I mi = 1;
+            if (pass == 1) {
+                while (x < len && qb(x) > 3) ++x;
+                if (x < len) xs = x;
+                else { pass = 2; k2 = 0; old_n = n_out; }
+            }
+            if (pass == 2) {                        // re-seed from the middle of long SMEMs with few occurrences
+                while (k2 < old_n) {
+                    const size_t o = (size_t)r * ck.cap_intv + k2;
+                    const uint32_t inf = ck.intv_info[o];
+                    const I s = ((const I *)ck.intv_x2)[o];
+                    ++k2;
+                    const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+                    if (end - start < split_len || s > (I)opt.split_width) continue;
+                    const int mid = (start + end) >> 1;
+                    if (qb(mid) > 3) continue;      // bwt_smem1a returns at once on an ambiguous start
+                    xs = mid; mi = s + 1;
+                    break;
+                }
+                if (xs < 0) finish_read();
+            }
+            if (xs >= 0) {
+                sx = xs; min_intv = mi < 1 ? (I)1 : mi;
+                set_intv<I>(fm, qb(xs), ik);
+                ik.info = (uint32_t)(xs + 1);
+                i = xs + 1; n = 0;
+                phase = S2_FWD0;
+            }
+        }
+        if (phase == S2_FWD0) {                     // is there a base to extend with?
+            if (list_ovf) finish_read();
+            else if (i >= len || (cq = qb(i)) > 3) { push_fwd(ik); phase = S2_BEGIN_BWD; }
+            else phase = S2_FWD;
+        }
+        if (phase == S2_BEGIN_BWD) {
+            if (list_ovf) finish_read();
+            else {
+                ret = (int)ik.info;                 // the entry pushed last = longest forward extension = next start of pass 1
+                head = ik;
+                cur = 1; np = n; rev = 1; last_start = 0x7fffffff; bi = sx - 1;
+                phase = S2_ROW;
+            }
+        }
+        if (phase == S2_ROW) {                      // start of the backward row at query position bi
+            int t = -1;
+            if (bi >= 0) { t = qb(bi); if (t > 3) t = -1; }
+            cb = t;
+            j = 0; nc = 0; last_sz = 0;
+            if (cb < 0) {                            // beginning of the read or an ambiguous base: every entry ends here, only the first can be new
+                emit_mem(head);
+                if (pass == 1) x = ret;
+                phase = S2_START;
+            } else { psrc = head; phase = S2_BWD; }
+        }
+        if (__all(phase == S2_DONE)) break;
+        // ------------------------------------------------ the one bwt_extend of this trip
+        const bool fwd = phase == S2_FWD, bwd = phase == S2_BWD;
+        if (bwd && j + 1 < np) nsrc = wl.at(cur, rev ? np - 2 - j : j + 1);       // next trip's entry, in flight behind this trip's rank reads
+        IntvE<I> ok;
+        ok.x0 = ok.x1 = ok.x2 = 0; ok.info = 0;
+        if (fwd) fm_extend_p(fm, ik, 3 - cq, 0, ok);
+        else if (bwd) fm_extend_p(fm, psrc, cb, 1, ok);
+        // ------------------------------------------------ apply it
+        if (fwd) {
+            bool stop = false;
+            if (ok.x2 != ik.x2) {
+                push_fwd(ik);
+                if (ok.x2 < min_intv) stop = true;
+            }
+            if (stop) phase = S2_BEGIN_BWD;
+            else { ok.info = (uint32_t)(i + 1); ik = ok; ++i; phase = S2_FWD0; }
+        } else if (bwd) {
+            if (ok.x2 < min_intv) { if (nc == 0) emit_mem(psrc); }
+            else if (nc == 0 || ok.x2 != last_sz) {
+                ok.info = psrc.info;
+                if (nc == 0) nhead = ok;
+                wl.at(1 - cur, nc++) = ok;
+                last_sz = ok.x2;
+            }
+            ++j;
+            if (j >= np) {
+                if (nc == 0) { if (pass == 1) x = ret; phase = S2_START; }
+                else { cur = 1 - cur; np = nc; rev = 0; --bi; head = nhead; phase = S2_ROW; }
+            } else psrc = nsrc;
+        }
+    }
+}
+
+// pass 3 + per-read epilogue; one lane per read
+__global__ void __launch_bounds__(128) k_seed3(DevFM<uint32_t> fm, Chunk ck, DevOpt dopt)
+{
+    typedef uint32_t I;
+    const slx_opt &opt = dopt.o;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < ck.n_reads;
+    const uint64_t qoff = live ? ck.offs[r] : 0;
+    const int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
+    const size_t ob = (size_t)(live ? r : 0) * ck.cap_intv;
+    uint32_t *oinfo = ck.intv_info + ob;
+    I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
+    int n_out = live ? (int)ck.intv_n[r] : 0;
+    bool out_ovf = false;
+    QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+    auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+    if (opt.max_mem_intv > 0) {                      // bwt_seed_strategy1 from every position a seed ended at
+        int x = len >= opt.min_seed_len ? 0 : len, i = 0;
+        bool fresh = true;
+        IntvE<I> ik, ok;
+        ik.x0 = ik.x1 = ik.x2 = 0; ik.info = 0;
+        for (;;) {
+            if (fresh) {
+                while (x < len && qb(x) > 3) ++x;
+                if (x < len) { set_intv<I>(fm, qb(x), ik); i = x + 1; fresh = false; }
+            }
+            const bool act = !fresh && i < len;
+            if (!__any(act)) break;
+            if (act) {
+                const int c = qb(i);
+                if (c > 3) { x = i + 1; fresh = true; }
+                else {
+                    fm_extend_p(fm, ik, 3 - c, 0, ok);
+                    if (ok.x2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+                        if (ok.x2 > 0) {
+                            if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = ok.x0; ox2[n_out] = ok.x2; ++n_out; }
+                            else out_ovf = true;
+                        }
+                        x = i + 1; fresh = true;
+                    } else { ik = ok; ++i; }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    // sort by (start, end): entries with equal keys are identical intervals, so any exact sort matches ks_introsort
+    for (int a = 1; a < n_out; ++a) {
+        const uint32_t ki = oinfo[a]; const I k0 = ox0[a], kk2 = ox2[a];
+        int b = a - 1;
+        while (b >= 0 && oinfo[b] > ki) { oinfo[b + 1] = oinfo[b]; ox0[b + 1] = ox0[b]; ox2[b + 1] = ox2[b]; --b; }
+        oinfo[b + 1] = ki; ox0[b + 1] = k0; ox2[b + 1] = kk2;
+    }
+    // mem_chain prologue: repetitive fraction and the number of seed occurrences to look up
+    int b = 0, e = 0, l_rep = 0;
+    uint32_t cnt = 0;
+    for (int k = 0; k < n_out; ++k) {
+        const I s = ox2[k];
+        if (s > (I)opt.max_occ) {
+            const int sb = (int)(oinfo[k] >> 16), se = (int)(oinfo[k] & 0xffff);
+            if (sb > e) { l_rep += e - b; b = sb; e = se; }
+            else e = e > se ? e : se;
+            const I step = s / (I)opt.max_occ;
+            const I cc = (s + step - 1) / step;
+            cnt += (uint32_t)(cc < (I)opt.max_occ ? cc : (I)opt.max_occ);
+        } else cnt += (uint32_t)s;
+    }
+    l_rep += e - b;
+    ck.intv_n[r] = (uint32_t)n_out;
+    ck.l_rep[r] = l_rep;
+    ck.seed_cnt[r] = (unsigned long long)cnt;
+    if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+}

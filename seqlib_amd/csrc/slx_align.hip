@@ -19,6 +19,7 @@
 #include "slx_internal.h"
 #include "dev_seed.h"
 #include "dev_seed_sm.h"
+#include "dev_seed2.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
@@ -106,7 +107,7 @@ struct slx_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     // index in HBM
-    DevBuf d_bwt, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
+    DevBuf d_bwt, d_occ, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
     DevFM<uint32_t> fm32;
     DevRef ref;
     bool dense_sa = true;
@@ -121,7 +122,7 @@ struct slx_aligner {
     int split_heavy = 0;          // 1 = reads with >= heavy_seeds seed occurrences run as their own sub-pipeline on a second stream
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this are not split
-    int seed_mode = 1;            // 1 = state-machine seeding kernel (one bwt_extend per lane per trip), 0 = nested-loop kernel
+    int seed_mode = 2;            // 2 = occ-plane state machine (passes 1+2) + lock-step pass 3 (dev_seed2.h); 1 = first state machine; 0 = nested loops
     int fin_mode = 1;             // 1 = finalize split into work lists (fast / DP cigar jobs), 0 = fused one-lane-per-read kernel
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
     int n_workers = 3;            // concurrent parts of a large batch
@@ -246,6 +247,16 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     HIPCHK(hipMemcpy(al->d_sa_samp.p, idx->sa.data(), idx->sa.size() * 8, hipMemcpyHostToDevice));
     DevFM<uint32_t> &fm = al->fm32;
     fm.bwt = al->d_bwt.as<uint32_t>();
+    {   // occ planes for the seeding kernels
+        const uint64_t n_blocks = ((idx->seq_len ? idx->seq_len - 1 : 0) >> 6) + 1;
+        if ((rc = al->d_occ.ensure((n_blocks + 1) * 32)) != SLX_OK) return rc;
+        HIPCHK(hipMemsetAsync(al->d_occ.p, 0, (n_blocks + 1) * 32, al->stream));
+        hipLaunchKernelGGL(k_occ_build, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, al->stream, al->d_bwt.as<uint32_t>(), (uint64_t)idx->seq_len,
+                           al->d_occ.as<uint4>(), n_blocks);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(al->stream));
+        fm.occ = al->d_occ.as<uint4>();
+    }
     fm.primary = (uint32_t)idx->primary;
     for (int i = 0; i < 5; ++i) fm.L2[i] = (uint32_t)idx->L2[i];
     fm.seq_len = (uint32_t)idx->seq_len;
@@ -295,7 +306,7 @@ extern "C" void slx_aligner_free(slx_aligner *al)
 {
     if (!al) return;
     (void)hipSetDevice(al->device);
-    DevBuf *bufs[] = {&al->d_bwt, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
                       &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar};
     for (DevBuf *b : bufs) b->release();
     for (Worker *wk : al->workers) {
@@ -502,7 +513,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     if (al->seed_mode == 0) hipLaunchKernelGGL(k_seed<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt);
-    else hipLaunchKernelGGL(k_seed_sm<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 28);
+    else if (al->seed_mode == 2) {
+        hipLaunchKernelGGL(k_seed12, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+        hipLaunchKernelGGL(k_seed3, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    } else hipLaunchKernelGGL(k_seed_sm<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 28);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
         size_t tmp_bytes = 0;

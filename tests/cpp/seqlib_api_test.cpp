@@ -6,12 +6,21 @@
 //   seqlib_api_test gpu <index_prefix> <fastq> <n_single> <n_batch>
 //       aligns the first n_single reads one alignSequence call at a time and the next n_batch reads through
 //       alignSequences, printing "read# rec# flag rid pos mapq CIGAR AS NM NA seq" per record.
+//   seqlib_api_test fastq <file>
+//       FastqReader: one "name<TAB>comment<TAB>seq<TAB>qual" line per record, reusing one UnalignedSequence as a
+//       `while (r.GetNextSequence(s))` loop does.  No GPU call.
+//   seqlib_api_test writer <tmp_prefix> <n_records>
+//       BamWriter on hand-built records: <tmp_prefix>.sam and <tmp_prefix>.bam.  No GPU call.
+//   seqlib_api_test pipeline <index_prefix> <fastq> <n> <out_prefix>
+//       FastqReader -> alignSequences -> BamWriter (SAM and BAM), the path a SeqLib user strings together.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include "SeqLib/BWAAligner.h"
+#include "SeqLib/BamWriter.h"
+#include "SeqLib/FastqReader.h"
 
 using namespace SeqLib;
 
@@ -101,6 +110,103 @@ static int cpu_checks(const std::string &prefix, const std::string &tmp)
     return 0;
 }
 
+// a bam1_t built field by field the way src/BWAAligner.cpp:151-248 lays it out (qname, cigar, 4-bit seq, qual, aux)
+static BamRecordPtr make_record(const std::string &name, int flag, int tid, int pos, int mapq, const std::string &cigar, int mtid, int mpos,
+                                int isize, const std::string &seq, const std::string &qual)
+{
+    auto r = std::make_shared<BamRecord>();
+    bam1_t *b = r->raw();
+    Cigar cg(cigar);
+    b->core.tid = tid; b->core.pos = pos; b->core.qual = (uint8_t)mapq; b->core.flag = (uint16_t)flag; b->core.n_cigar = (uint32_t)cg.size();
+    b->core.mtid = mtid; b->core.mpos = mpos; b->core.isize = isize;
+    b->core.l_qname = (uint16_t)(name.size() + 1); b->core.l_qseq = (int32_t)seq.size();
+    b->l_data = (int)(b->core.l_qname + 4 * cg.size() + (seq.size() + 1) / 2 + seq.size());
+    b->data = (uint8_t *)std::calloc((size_t)b->l_data, 1);
+    b->m_data = (uint32_t)b->l_data;
+    std::memcpy(b->data, name.c_str(), name.size() + 1);
+    for (size_t k = 0; k < cg.size(); ++k) { uint32_t w = cg[k].raw(); std::memcpy(b->data + b->core.l_qname + 4 * k, &w, 4); }
+    uint8_t *sq = bam_get_seq(b);
+    for (size_t k = 0; k < seq.size(); ++k) {
+        const char *nt = "=ACMGRSVTWYHKDBN";
+        const char *f = std::strchr(nt, seq[k]);
+        const uint8_t v = f ? (uint8_t)(f - nt) : 15;
+        sq[k >> 1] |= (k & 1) ? v : (uint8_t)(v << 4);
+    }
+    uint8_t *q = bam_get_qual(b);
+    if (qual.empty()) { if (!seq.empty()) std::memset(q, 0xff, seq.size()); }
+    else for (size_t k = 0; k < seq.size(); ++k) q[k] = (uint8_t)(qual[k] - 33);
+    return r;
+}
+
+static int fastq_dump(const std::string &file)
+{
+    FastqReader r;
+    if (!r.Open(file)) return 3;
+    UnalignedSequence s;
+    while (r.GetNextSequence(s)) std::printf("%s\t%s\t%s\t%s\n", s.Name.c_str(), s.Com.c_str(), s.Seq.c_str(), s.Qual.c_str());
+    return 0;
+}
+
+static int writer_checks(const std::string &tmp, long n)
+{
+    CHECK_THROWS(BamWriter(99), std::invalid_argument);
+    BamHeader hdr("@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chrA\tLN:1000\n@SQ\tSN:chrB\tLN:50000000\n@PG\tID:test\n");
+    for (int fmt : {SAM, BAM}) {
+        BamWriter w(fmt);
+        CHECK(!w.IsOpen() && !w.WriteHeader() && !w.Close());
+        CHECK(!w.WriteRecord(*make_record("x", 4, -1, -1, 0, "", -1, -1, 0, "", "")));
+        CHECK(w.Open(tmp + (fmt == SAM ? ".sam" : ".bam")));
+        CHECK(!w.Open(tmp + ".again"));               // no reopen
+        CHECK(!w.WriteHeader());                      // no header yet
+        w.SetHeader(hdr);
+        CHECK(w.WriteHeader());
+        CHECK(!w.BuildIndex());                       // still open
+        for (long i = 0; i < n; ++i) {
+            std::string seq, qual;
+            for (int k = 0; k < 40 + (int)(i % 7); ++k) { seq.push_back("ACGTN"[(i * 7 + k * 3 + k / 5) % 5]); qual.push_back((char)(33 + (i + k) % 41)); }
+            const int len = (int)seq.size();
+            BamRecordPtr r;
+            switch (i % 4) {
+            case 0: r = make_record("r" + std::to_string(i), 0, 0, (int)(i % 900), 60, std::to_string(len) + "M", -1, -1, 0, seq, ""); break;
+            case 1: r = make_record("r" + std::to_string(i), 16 | 1, 1, (int)(i * 16411 % 49000000), 13,
+                                    "5S" + std::to_string(len - 10) + "M2D3I2H", 1, (int)(i * 16411 % 49000000) + 300, -350, seq, qual); break;
+            case 2: r = make_record("r" + std::to_string(i), 256, 1, 1 << 20, 0, "10M100N" + std::to_string(len - 10) + "M", 0, 7, 0, seq, qual); break;
+            default: r = make_record("r" + std::to_string(i), 4, -1, -1, 0, "", -1, -1, 0, seq, qual); break;
+            }
+            r->AddIntTag("NA", (int32_t)(i % 3)); r->AddIntTag("NM", (int32_t)(i % 11)); r->AddIntTag("AS", (int32_t)(len - i % 5));
+            if (i % 5 == 0) r->AddZTag("XA", "chrA,+" + std::to_string(i) + ",40M,0;");
+            CHECK(w.WriteRecord(*r));
+        }
+        CHECK(!w.WriteRecord(*make_record("bad", 0, 7, 1, 0, "1M", -1, -1, 0, "A", "")) || fmt == BAM);   // tid outside the header: SAM cannot name it
+        CHECK(w.Close());
+        CHECK(!w.Close() && !w.IsOpen());
+    }
+    BamWriter c(CRAM);
+    CHECK(!c.Open(tmp + ".cram"));
+    std::puts("writer checks OK");
+    return 0;
+}
+
+static int pipeline(const std::string &prefix, const std::string &fastq, long n, const std::string &outp)
+{
+    auto idx = std::make_shared<BWAIndex>();
+    idx->LoadIndex(prefix);
+    BWAAligner bwa(idx);
+    FastqReader fr(fastq);
+    UnalignedSequenceVector reads;
+    UnalignedSequence s;
+    while ((long)reads.size() < n && fr.GetNextSequence(s)) reads.push_back(s);
+    std::vector<BamRecordPtrVector> outs;
+    bwa.alignSequences(reads, outs, false, 0.9, 10);
+    BamWriter ws(SAM), wb(BAM);
+    CHECK(ws.Open(outp + ".sam") && wb.Open(outp + ".bam"));
+    ws.SetHeader(idx->HeaderFromIndex()); wb.SetHeader(idx->HeaderFromIndex());
+    CHECK(ws.WriteHeader() && wb.WriteHeader());
+    for (auto &v : outs) for (auto &r : v) CHECK(ws.WriteRecord(*r) && wb.WriteRecord(*r));
+    CHECK(ws.Close() && wb.Close());
+    return 0;
+}
+
 static void print_rec(long read_no, size_t j, const BamRecord &r)
 {
     int32_t as = 0, nm = 0, na = 0;
@@ -112,6 +218,9 @@ static void print_rec(long read_no, size_t j, const BamRecord &r)
 int main(int argc, char **argv)
 {
     if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);
+    if (argc >= 3 && std::string(argv[1]) == "fastq") return fastq_dump(argv[2]);
+    if (argc >= 4 && std::string(argv[1]) == "writer") return writer_checks(argv[2], std::atol(argv[3]));
+    if (argc >= 6 && std::string(argv[1]) == "pipeline") return pipeline(argv[2], argv[3], std::atol(argv[4]), argv[5]);
     if (argc >= 6 && std::string(argv[1]) == "gpu") {
         auto idx = std::make_shared<BWAIndex>();
         idx->LoadIndex(argv[2]);
@@ -139,6 +248,7 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "AlignSequence/BamRecordVector: %zu record(s), qname %s\n", brv.size(), brv.empty() ? "-" : brv[0].Qname().c_str());
         return 0;
     }
-    std::fprintf(stderr, "usage: %s cpu <prefix> <tmp> | gpu <prefix> <fastq> <n_single> <n_batch>\n", argv[0]);
+    std::fprintf(stderr, "usage: %s cpu <prefix> <tmp> | gpu <prefix> <fastq> <n_single> <n_batch> | fastq <file> | writer <tmp> <n> | "
+                         "pipeline <prefix> <fastq> <n> <out>\n", argv[0]);
     return 2;
 }
