@@ -155,8 +155,10 @@ def main():
     stage_acc = {}
     fence()
     t0 = time.time()
+    step_marks = [t0]
     for _ in range(args.steps):
         h, parts = step()
+        step_marks.append(time.time())            # each step ends synchronised on this rank: per-step spread for free
         for k, v in al.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     fence()
@@ -235,6 +237,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
+            "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(step_marks[:-1], step_marks[1:])],
             "index_build_s": t_index,
         }
         print(json.dumps(out))

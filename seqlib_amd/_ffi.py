@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libseqlib_amd.so")
+SO_PATH = os.environ.get("SLX_LIB") or os.path.join(HERE, "libseqlib_amd.so")   # SLX_LIB: tuning builds (scripts/build_variant.sh)
 
 SLX_OK, SLX_EINVAL, SLX_EIO, SLX_ENOMEM, SLX_ENODEVICE, SLX_EUNSUPPORTED, SLX_EINTERNAL = 0, -1, -2, -3, -4, -5, -6
 SLX_N_STAGES = 8

@@ -191,6 +191,16 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                 n_out = -1;
             }
         }
+        // seed lists of the kept chains, flattened (c_w / c_first are free once the filter is done): the wave-per-read extension
+        // kernel reads a chain's seeds as one coalesced slice  c_w[c_first[c] .. + c_n[c])  instead of chasing s_next on 64 idle lanes
+        {
+            int off = 0;
+            for (int i = 0; i < n_out; ++i) {
+                const int c = a[i];
+                w.c_first[c] = off;
+                for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) w.c_w[off++] = s;
+            }
+        }
         ck.n_chain[r] = n_out;                   // kept chains, in extension order, are a[0..n_out)
 }
 

@@ -196,6 +196,23 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                 n_out += __popcll(bal);
             }
         }
+        // flattened seed lists of the kept chains (see dev_chain_read): offsets by a wave scan, then one chain per lane
+        {
+            int carry = 0;
+            for (int base = 0; base < n_out; base += 64) {
+                const int x = base + lane;
+                const int c = x < n_out ? w.ia[x] : 0;
+                const int cn = x < n_out ? w.c_n[c] : 0;
+                int incl = cn;
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                if (x < n_out) {
+                    int off = carry + incl - cn;
+                    w.c_first[c] = off;
+                    for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) w.c_w[off++] = s;
+                }
+                carry += __shfl(incl, 63, 64);
+            }
+        }
         if (lane == 0) ck.n_chain[r] = n_out;
     }
 }

@@ -43,20 +43,64 @@ __device__ __forceinline__ int lane_read(int v, int src_lane)
     return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_lane));
 }
 
-template <int CPL, typename QF, typename TF>
-__device__ ExtResult reg_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0, int lane)
+// unsigned-max DPP steps with 0 as the identity (bound_ctrl zero fill): every value scanned below is >= 0, which lets
+// the compiler fold each step into a single v_max_u32 with a DPP operand (no identity moves)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umax_step(uint32_t v)
 {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t dpp_incl_umax_scan(uint32_t v)
+{
+    v = dpp_umax_step<0x111, 0xf>(v);
+    v = dpp_umax_step<0x112, 0xf>(v);
+    v = dpp_umax_step<0x114, 0xf>(v);
+    v = dpp_umax_step<0x118, 0xf>(v);
+    v = dpp_umax_step<0x142, 0xa>(v);
+    v = dpp_umax_step<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int dpp_shr1_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane 0 receives 0
+
+struct MatCols { uint32_t c[5]; };   // score matrix by query base: byte t of c[q] = mat[t*5+q], t = 0..3 (the reference has no N)
+__device__ __forceinline__ MatCols make_matcols(const int8_t *mat)
+{
+    MatCols m;
+    for (int q = 0; q < 5; ++q)
+        m.c[q] = (uint32_t)(uint8_t)mat[q] | (uint32_t)(uint8_t)mat[5 + q] << 8 | (uint32_t)(uint8_t)mat[10 + q] << 16 | (uint32_t)(uint8_t)mat[15 + q] << 24;
+    return m;
+}
+
+// ksw_extend2 on registers.  Per row and column: M = H ? H + s : 0;  h = max(M, E, F);  E' = max(E - e_del, M - oe_del, 0);
+// F_j = (max over k < j of  max(M_k - oe_ins, 0) + k*e_ins) - (j-1)*e_ins  -- an exclusive prefix max over columns.  All scanned
+// quantities are non-negative, so both wave scans are six unsigned-max DPP steps; the row maximum travels as (h << 10 | column),
+// whose maximum is the scalar loop's LAST arg-max.  F at the first column of the band comes out <= 0 instead of 0, which
+// cannot change h because E >= 0.  Cells outside [beg, end] keep their stale registers exactly like eh[] does.
+template <int CPL, typename QF, typename TF>
+__device__ ExtResult reg_ksw_extend2(int qlen_, QF qf, int tlen_, TF tf, const slx_opt &o, const MatRows &mr, int w_, int end_bonus_, int h0_, int lane)
+{
+    // every lane passes the same job: pin the job parameters to scalar registers so that the band / maximum / z-drop
+    // bookkeeping below is scalar code instead of 64 identical vector lanes
+    const int qlen = __builtin_amdgcn_readfirstlane(qlen_), tlen = __builtin_amdgcn_readfirstlane(tlen_);
+    const int end_bonus = __builtin_amdgcn_readfirstlane(end_bonus_), h0 = __builtin_amdgcn_readfirstlane(h0_);
+    int w = __builtin_amdgcn_readfirstlane(w_);
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int j0 = lane * CPL;
-    int H[CPL], E[CPL], qc[CPL];
+    const MatCols mc = make_matcols(o.mat);
+    int H[CPL], E[CPL], jE[CPL], jm1E[CPL];
+    uint32_t P[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int j = j0 + k;
-        qc[k] = j < qlen ? qf(j) : 4;
+        const int q = j < qlen ? qf(j) : 4;
+        P[k] = q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
         const int v = h0 - oe_ins - (j - 1) * e_ins;             // row -1: eh[0].h = h0, then the insertion ramp while positive
         H[k] = j == 0 ? h0 : (j <= qlen && v > 0 ? v : 0);
         E[k] = 0;
+        jE[k] = j * e_ins;
+        jm1E[k] = j == 0 ? 0 : (j - 1) * e_ins;
     }
     int max = 0;
     for (int i = 0; i < 25; ++i) max = max > o.mat[i] ? max : o.mat[i];
@@ -66,6 +110,7 @@ __device__ ExtResult reg_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx
     int max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
     max_del = max_del > 1 ? max_del : 1;
     w = w < max_del ? w : max_del;
+    w = __builtin_amdgcn_readfirstlane(w);                       // the f64 divisions above run on the vector unit
     max = h0;
     int max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     // target bases are fetched 64 rows at a time (lane t holds row i0+t) one block ahead, then read with v_readlane
@@ -74,71 +119,63 @@ __device__ ExtResult reg_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx
     for (int i = 0; i < tlen; ++i) {
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
-        const uint32_t rowp = mr.packed[t];
-        const int row4 = mr.q4[t];
+        const uint32_t sh = (uint32_t)t << 3;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
-        int h1_init;
+        const uint32_t wd = end > beg ? (uint32_t)(end - beg) : 0u;   // active columns [beg, beg + wd)
+        int h1_init = 0;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
-        else h1_init = 0;
         // ---- per column: M, and the lane-local inclusive prefix of u_k = max(M_k - oe_ins, 0) + k*e_ins
-        int M[CPL], pre[CPL], h[CPL], en[CPL];
-        int run = NEG_BIG;
+        int M[CPL], h[CPL], en[CPL];
+        uint32_t pre[CPL];
+        bool act[CPL];
+        uint32_t run = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int j = j0 + k;
-            const bool act = j >= beg && j < end;
-            const int q = qc[k];
-            const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            act[k] = (uint32_t)(j - beg) < wd;
+            const int s = __builtin_amdgcn_sbfe((int)P[k], sh, 8u);
             const int hd = H[k];
             M[k] = hd ? hd + s : 0;
             int tins = M[k] - oe_ins; tins = tins > 0 ? tins : 0;
-            const int u = act ? tins + j * e_ins : NEG_BIG;
-            run = imax(run, u);
+            const uint32_t u = act[k] ? (uint32_t)(tins + jE[k]) : 0u;
+            run = run > u ? run : u;
             pre[k] = run;
         }
-        // exclusive prefix over lanes of the per-lane totals
-        const int incl = dpp_incl_max_scan(run);
-        const int excl = dpp_shr1(NEG_BIG, incl);
-        int lmax = -1, larg = -1;                                  // lane-local row maximum, last arg-max
+        const uint32_t incl = dpp_incl_umax_scan(run);
+        const uint32_t excl = (uint32_t)dpp_shr1_z((int)incl);
+        uint32_t lkey = 0;                                          // lane-local row maximum as (h << 10 | column)
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int j = j0 + k;
-            const bool act = j >= beg && j < end;
-            const int ex = k == 0 ? excl : imax(excl, pre[k - 1]);
-            const int f = j == beg ? 0 : ex - (j - 1) * e_ins;
+            const uint32_t ex = k == 0 ? excl : (excl > pre[k - 1] ? excl : pre[k - 1]);
+            const int f = (int)ex - jm1E[k];
             const int e = E[k];
             int hh = M[k] > e ? M[k] : e;
             hh = hh > f ? hh : f;
             h[k] = hh;
-            int tdel = M[k] - oe_del; tdel = tdel > 0 ? tdel : 0;
-            int e2 = e - e_del; e2 = e2 > tdel ? e2 : tdel;
-            en[k] = e2;
-            if (act && hh >= lmax) { lmax = hh; larg = j; }
+            int e2 = M[k] - oe_del; e2 = e2 > 0 ? e2 : 0;
+            const int ed = e - e_del;
+            en[k] = ed > e2 ? ed : e2;
+            const uint32_t key = act[k] ? ((uint32_t)hh << 10 | (uint32_t)j) : 0u;
+            lkey = lkey > key ? lkey : key;
         }
         // ---- write back: eh[j].h <- H(i, j-1) for j in (beg, end], eh[beg].h <- h1, eh[j].e <- E' in [beg, end), eh[end].e <- 0
-        const int h_left = dpp_shr1(0, h[CPL - 1]);                // last column of the lane to the left
+        // (an empty band leaves the row maximum at 0 and the loop ends below, so its stores do not matter)
+        const int h_left = dpp_shr1_z(h[CPL - 1]);                  // last column of the lane to the left
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int j = j0 + k;
             const int hp = k == 0 ? h_left : h[k - 1];
-            if (j - 1 >= beg && j - 1 < end) H[k] = hp;
-            if (j >= beg && j < end) E[k] = en[k];
-            if (end > beg) { if (j == beg) H[k] = h1_init; if (j == end) E[k] = 0; }
-            else if (j == end) { H[k] = h1_init; E[k] = 0; }      // empty band: the scalar loop still stores h1 into eh[end]
+            if ((uint32_t)(j - 1 - beg) < wd) H[k] = hp;
+            if (j == beg) H[k] = h1_init;
+            if (act[k]) E[k] = en[k];
+            if (j == end) E[k] = 0;
         }
         // ---- row maximum (ties -> larger column)
-        int m = 0, mj = -1;
-        {
-            const int tot = dpp_incl_max_scan(lmax);
-            const int mx = __builtin_amdgcn_readlane(tot, 63);
-            if (mx >= 0) {
-                const unsigned long long bal = __ballot(lmax == mx);
-                const int src = 63 - __clzll((long long)bal);
-                m = mx; mj = lane_read(larg, src);
-            }
-        }
+        const uint32_t rkey = (uint32_t)__builtin_amdgcn_readlane((int)dpp_incl_umax_scan(lkey), 63);
+        const int m = (int)(rkey >> 10), mj = (int)(rkey & 1023u);
         const int jfin = end > beg ? end : beg;
         if (jfin == qlen) {                                        // the row reached the end of the query: h1 = eh[end].h
             int h1 = h1_init;
@@ -162,17 +199,22 @@ __device__ ExtResult reg_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx
             else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
         }
         // ---- band for the next row: first / last column in [beg, end] whose h or e is non-zero
-        int lfirst = 0x7fffffff, llast = -1;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const int j = j0 + k;
-            if (j >= beg && j <= end && (H[k] != 0 || E[k] != 0)) { if (lfirst == 0x7fffffff) lfirst = j; llast = j; }
-        }
-        const unsigned long long bal = __ballot(llast >= 0);
         int first_nz = -1, last_nz = -1;
-        if (bal) {
-            first_nz = lane_read(lfirst, __ffsll((long long)bal) - 1);
-            last_nz = lane_read(llast, 63 - __clzll((long long)bal));
+        if (CPL == 1) {
+            const unsigned long long bal = __ballot((uint32_t)(j0 - beg) <= wd && (H[0] | E[0]) != 0);
+            if (bal) { first_nz = __ffsll((long long)bal) - 1; last_nz = 63 - __clzll((long long)bal); }
+        } else {
+            int lfirst = 0x7fffffff, llast = -1;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = j0 + k;
+                if ((uint32_t)(j - beg) <= wd && (H[k] | E[k]) != 0) { if (lfirst == 0x7fffffff) lfirst = j; llast = j; }
+            }
+            const unsigned long long bal = __ballot(llast >= 0);
+            if (bal) {
+                first_nz = lane_read(lfirst, __ffsll((long long)bal) - 1);
+                last_nz = lane_read(llast, 63 - __clzll((long long)bal));
+            }
         }
         const int nbeg = (first_nz >= 0 && first_nz < end) ? first_nz : end;   // the first scan covers [beg, end) only
         const int jl = last_nz >= nbeg ? last_nz : nbeg - 1;
@@ -195,12 +237,61 @@ __device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int t
     return reg_ksw_extend2<CPLMAX>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
 }
 
+// Left + right extension of one seed (the body of mem_chain2aln's seed loop once a seed is known to need extending): the region
+// without its seedcov.  Shared by the per-read kernel and the ahead-of-time kernel for heavy reads.
+template <int CPL>
+__device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRows &mr, const uint8_t *query, int l_query, int s_qbeg, int s_len,
+                                int64_t s_rbeg, int64_t rmax0, int64_t rmax1, int rid, float frac_rep, int lane)
+{
+    DReg a;
+    a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
+    a.n_comp = 0; a.hash = 0;
+    int aw0 = opt.w, aw1 = opt.w, i;
+    a.w = opt.w; a.score = a.truesc = -1; a.rid = rid;
+    if (s_qbeg) {
+        const int64_t tmp = s_rbeg - rmax0;
+        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+        for (i = 0; i < 2; ++i) {
+            const int prev = a.score;
+            aw0 = opt.w << i;
+            er = reg_ksw_extend2_auto<CPL>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
+                                      [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5, s_len * opt.a, lane);
+            a.score = er.score;
+            if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+        }
+        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
+        else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
+    } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
+    if (s_qbeg + s_len != l_query) {
+        const int sc0 = a.score, qe = s_qbeg + s_len;
+        const int64_t re0 = s_rbeg + s_len;
+        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+        for (i = 0; i < 2; ++i) {
+            const int prev = a.score;
+            aw1 = opt.w << i;
+            er = reg_ksw_extend2_auto<CPL>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
+                                      [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, lane);
+            a.score = er.score;
+            if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+        }
+        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
+        else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
+    } else { a.qe = l_query; a.re = s_rbeg + s_len; }
+    a.w = aw0 > aw1 ? aw0 : aw1;
+    a.seedlen0 = s_len;
+    a.frac_rep = frac_rep;
+    return a;
+}
+
 #ifndef EXT_MIN_WAVES
 #define EXT_MIN_WAVES 4
 #endif
 template <int MAXQ>
-__global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int hi_prio)
+__global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int hi_prio,
+                                                                   const int *first = nullptr, const unsigned int *n_first = nullptr)
 {
+    // `first` (optional): reads to take before the ones in `order` -- the heavy reads, heaviest first, so that a read that
+    // keeps one wave busy for tens of milliseconds starts at once instead of wherever it sits in the batch
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
     constexpr int CPL = (MAXQ + 1 + WAVE - 1) / WAVE;
     const slx_opt &opt = dopt.o;
@@ -211,12 +302,14 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
     __syncthreads();
     auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
+    const int n_head = first ? __builtin_amdgcn_readfirstlane((int)*n_first) : 0;
     while (true) {
         int slot = 0;
         if (lane == 0) slot = (int)atomicAdd(queue, 1u);
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
-        const int r = order ? order[slot] : slot;
+        const int r = first ? (slot < n_head ? first[slot] : order[slot - n_head]) : (order ? order[slot] : slot);
+        const unsigned long long t_in = ck.dbg_cyc ? __builtin_readcyclecounter() : 0ull;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
@@ -224,12 +317,13 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
         const float frac_rep = ck.frac_rep[r];
         const int64_t l_pac = R.l_pac;
+        const int cand_at = ck.cand_base ? __builtin_amdgcn_readfirstlane(ck.cand_base[r]) : -1;
         int n_av = 0;
-        int *cs = w.ib, *srt_h = w.ic;
+        int *srt_h = w.ic;
         for (int ci = 0; ci < n_chn; ++ci) {
             const int c = w.ia[ci];
-            int n = 0;
-            for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) cs[n++] = s;
+            const int n = w.c_n[c];
+            const int *cs = w.c_w + w.c_first[c];                  // the chain's seeds, flattened by the chaining kernel
             if (n == 0) continue;
             int64_t rmax0 = l_pac << 1, rmax1 = 0;
             for (int i = lane; i < n; i += WAVE) {                 // lanes take seeds, then a wave min/max
@@ -311,39 +405,10 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     if (!other_diag) { srt_h[k] = -1; continue; }
                 }
                 DReg a;
-                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
-                a.n_comp = 0; a.hash = 0;
-                int aw0 = opt.w, aw1 = opt.w;
-                a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
-                if (s_qbeg) {
-                    const int64_t tmp = s_rbeg - rmax0;
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {
-                        const int prev = a.score;
-                        aw0 = opt.w << i;
-                        er = reg_ksw_extend2_auto<CPL>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
-                                                  [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5, s_len * opt.a, lane);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-                    }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
-                    else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
-                } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
-                if (s_qbeg + s_len != l_query) {
-                    const int sc0 = a.score, qe = s_qbeg + s_len;
-                    const int64_t re0 = s_rbeg + s_len;
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {
-                        const int prev = a.score;
-                        aw1 = opt.w << i;
-                        er = reg_ksw_extend2_auto<CPL>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
-                                                  [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, lane);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-                    }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
-                    else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
-                } else { a.qe = l_query; a.re = s_rbeg + s_len; }
+                const bool have_cand = cand_at >= 0;                         // heavy read: every seed was extended ahead of time (k_extend_cand)
+                if (have_cand) a = ck.cand[cand_at + s];
+                else a = dev_extend_core<CPL>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, lane);
+                if (have_cand) { w.regs[n_av++] = a; continue; }
                 int cov = 0;
                 for (i = lane; i < n; i += WAVE) {
                     const int t = cs[i];
@@ -353,12 +418,147 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 }
                 for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
                 a.seedcov = cov;
-                a.w = aw0 > aw1 ? aw0 : aw1;
-                a.seedlen0 = s_len;
-                a.frac_rep = frac_rep;
                 w.regs[n_av++] = a;                               // every lane stores the same bytes
             }
         }
         ck.n_reg[r] = n_av;
+        if (ck.dbg_cyc && lane == 0) ck.dbg_cyc[r] = __builtin_readcyclecounter() - t_in;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- heavy reads, ahead of time
+// A read from a low-complexity tract carries hundreds of seeds, most of which mem_chain2aln does extend (they sit on
+// different diagonals); on one wave that is tens of milliseconds for a single read -- the tail of the whole extension
+// stage.  What the extension of a seed yields depends only on its chain, never on the regions found before it, so for
+// the heavy reads every seed of every kept chain is extended here, CAND_PART seeds per wave and hundreds of waves per
+// read.  k_extend_reg then replays mem_chain2aln in order and takes the stored region wherever the scalar algorithm
+// does extend a seed (about half of this work goes unused; it buys the parallelism).
+#define CAND_PART 4
+
+// per heavy read: seed slots (table space) and (chain, part) jobs
+__global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt)
+{
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= *n_heavy) return;
+    const int r = heavy[s];
+    const uint64_t so = ck.seed_off[r];
+    slot_cnt[s] = (unsigned int)(ck.seed_off[r + 1] - so);
+    const int nc = ck.n_chain[r];
+    unsigned int jobs = 0;
+    for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + CAND_PART - 1) / CAND_PART;
+    job_cnt[s] = jobs;
+}
+
+__global__ void k_cand_base(const int *heavy, const unsigned int *n_heavy, const unsigned int *slot_off, unsigned int cand_cap, int32_t *cand_base)
+{
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < *n_heavy) cand_base[heavy[s]] = slot_off[s + 1] <= cand_cap ? (int32_t)slot_off[s] : -1;
+}
+
+// one (read, chain, part) job; out of line so that the queue loop of the kernel stays a plain fetch / test / call (see dev_cig_dp_job)
+template <int MAXQ>
+__device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int r, int jl,
+                                          DReg *out, int lane)
+{
+    constexpr int CPL = (MAXQ + 1 + WAVE - 1) / WAVE;
+    auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
+    const int64_t l_pac = R.l_pac;
+    ReadWS w = make_ws(ck, r);
+    const uint8_t *query = ck.codes + ck.offs[r];
+    const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+    const int n_chn = ck.n_chain[r];
+    // local job -> (chain index, part)
+    int ci = -1, part = 0;
+    {
+        int rem = jl;
+        for (int base = 0; base < n_chn && ci < 0; base += WAVE) {
+            const int x = base + lane;
+            const int cn = x < n_chn ? w.c_n[w.ia[x]] : 0;
+            const int parts = (cn + CAND_PART - 1) / CAND_PART;
+            int pin = parts;                                            // inclusive scan over the lanes
+            for (int d = 1; d < WAVE; d <<= 1) { const int a = __shfl_up(pin, d, WAVE); if (lane >= d) pin += a; }
+            const unsigned long long hit = __ballot(x < n_chn && pin > rem);
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                ci = base + l;
+                part = rem - (lane_read(pin, l) - lane_read(parts, l));
+            } else rem -= lane_read(pin, WAVE - 1);
+        }
+    }
+    if (ci < 0) return;
+    const int c = w.ia[ci];
+    const int n = w.c_n[c];
+    const int *cs = w.c_w + w.c_first[c];
+    if (n == 0) return;
+    int64_t rmax0 = l_pac << 1, rmax1 = 0;
+    for (int i = lane; i < n; i += WAVE) {
+        const int s = cs[i];
+        const int qb = w.s_qbeg(s), sl = w.s_len(s);
+        const int64_t b = w.s_rbeg[s] - (qb + max_gap_of(qb));
+        const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + max_gap_of(l_query - qb - sl));
+        rmax0 = rmax0 < b ? rmax0 : b;
+        rmax1 = rmax1 > e ? rmax1 : e;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int64_t o0 = __shfl_xor(rmax0, d, WAVE), o1 = __shfl_xor(rmax1, d, WAVE);
+        rmax0 = rmax0 < o0 ? rmax0 : o0;
+        rmax1 = rmax1 > o1 ? rmax1 : o1;
+    }
+    rmax0 = rmax0 > 0 ? rmax0 : 0;
+    rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+    const int64_t first_rbeg = w.s_rbeg[cs[0]];
+    if (rmax0 < l_pac && l_pac < rmax1) {
+        if (first_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+    }
+    {
+        int is_rev;
+        const int rid = dev_pos2rid(R, dev_depos(R, first_rbeg, &is_rev));
+        int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
+        if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+        rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+        rmax1 = rmax1 < far_end ? rmax1 : far_end;
+    }
+    const float frac_rep = ck.frac_rep[r];
+    const int rid_c = w.c_rid[c];
+    const int j_end = (part + 1) * CAND_PART < n ? (part + 1) * CAND_PART : n;
+    for (int j = part * CAND_PART; j < j_end; ++j) {
+        const int s = cs[j];
+        DReg a = dev_extend_core<CPL>(R, opt, mr, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s], rmax0, rmax1, rid_c, frac_rep, lane);
+        int cov = 0;
+        for (int i = lane; i < n; i += WAVE) {
+            const int t = cs[i];
+            const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+            const int64_t t_rbeg = w.s_rbeg[t];
+            if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
+        }
+        for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
+        a.seedcov = cov;
+        if (lane == 0) out[s] = a;
+    }
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_cand(DevRef R, Chunk ck, DevOpt dopt, const int *heavy, const unsigned int *n_heavy,
+                                                                    const unsigned int *job_off, unsigned int *queue, DReg *cand)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(opt.mat);
+    __shared__ int gap_lut[MAXQ + 2];
+    for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
+    __syncthreads();
+    const unsigned int nh = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_heavy);
+    const unsigned int n_jobs = nh ? (unsigned int)__builtin_amdgcn_readfirstlane((int)job_off[nh]) : 0u;
+    for (;;) {
+        unsigned int job = 0;
+        if (lane == 0) job = atomicAdd(queue, 1u);
+        job = (unsigned int)__builtin_amdgcn_readfirstlane((int)job);
+        if (job >= n_jobs) break;
+        unsigned int lo = 0, hi = nh;                                // last slot whose first job is <= job
+        while (hi - lo > 1) { const unsigned int mid = (lo + hi) >> 1; if (job_off[mid] <= job) lo = mid; else hi = mid; }
+        const int r = heavy[lo];
+        const int base = __builtin_amdgcn_readfirstlane(ck.cand_base[r]);
+        if (base >= 0) dev_cand_job<MAXQ>(R, ck, opt, mr, gap_lut, r, (int)(job - job_off[lo]), cand + base, lane);   // else extended in place
     }
 }

@@ -77,6 +77,10 @@ struct Chunk {
     uint64_t *srt;            // seed sort keys
     DReg *regs;
     DHit *hits;
+    // regions of heavy reads' chains extended ahead of time (k_extend_cand): cand[cand_base[r] + chain index], cand_base[r] < 0 = none
+    const DReg *cand;
+    const int32_t *cand_base;
+    unsigned long long *dbg_cyc;   // SLX_DEBUG_CYC: cycles the extension kernel spent on each read (null otherwise)
     // per-read results
     int32_t *n_chain;         // kept chains
     int32_t *n_reg;

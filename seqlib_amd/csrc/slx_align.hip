@@ -78,8 +78,9 @@ struct Worker {
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos, cand, cand_base, cand_cnt, cand_off, dbg_cyc, order_tmp;
     hipStream_t stream2 = nullptr;
+    int id = 0;
     hipEvent_t dbg_ev[2][6];
     hipEvent_t ev_split = nullptr, ev_heavy = nullptr;
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
@@ -96,7 +97,7 @@ struct Worker {
         DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
                        &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                        &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
-                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &cand, &cand_base, &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
                        &o_na, &o_ncig, &o_cig_off, &o_cigar};
         n_all = (int)(sizeof(b) / sizeof(b[0]));
         for (int i = 0; i < n_all; ++i) all[i] = b[i];
@@ -117,7 +118,13 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
-    int regs_mode = 0;            // 1 = reads with >= 2 regions are de-duplicated / patched by the wave-per-read kernel
+    int regs_mode = 2;            // 2 = reads with <= 1 region take the straight-line kernel, the rest the lane-per-read one; 1 = the rest go to
+                                  // the wave-per-read kernel; 0 = every read on the lane-per-read kernel
+    int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
+    int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
+    int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int heavy_stream = 0;         // 1 = chaining + extension of the heavy reads run on the worker's second stream, beside the light reads'
+                                  // chaining + extension; both join before the region stage (needs chain_mode = 1)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int split_heavy = 0;          // 1 = reads with >= heavy_seeds seed occurrences run as their own sub-pipeline on a second stream
     int heavy_seeds = 64;
@@ -126,6 +133,7 @@ struct slx_aligner {
     int fin_mode = 1;             // 1 = finalize split into work lists (fast / DP cigar jobs), 0 = fused one-lane-per-read kernel
     int sched = 0;                // 1 = reads handed out heaviest-first (by seed count); 0 = in input order (better locality)
     int n_workers = 3;            // concurrent parts of a large batch
+    int active_k = 1;             // workers running in the current call
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
     int max_threads = 0;
     int threads_per_cu = 1536;
@@ -229,6 +237,7 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     al->max_threads = al->n_cu * al->threads_per_cu;
     for (int k = 0; k < 3; ++k) {
         Worker *wk = new Worker();
+        wk->id = k;
         wk->collect();
         HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&wk->ev_split, hipEventDisableTiming));
@@ -334,6 +343,10 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "seed_mode")) al->seed_mode = (int)value;
     else if (!strcmp(key, "split_heavy")) al->split_heavy = (int)value;
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
+    else if (!strcmp(key, "heavy_stream")) al->heavy_stream = (int)value;
+    else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
+    else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
+    else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "regs_mode")) al->regs_mode = (int)value;
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
@@ -382,7 +395,8 @@ __global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
 template <int MAXQ>
 static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, const int *order,
                        unsigned int *q, const unsigned int *n_slots, int sub, int grid, int bs, int n_est, hipEvent_t *ev_after_chain,
-                       hipEvent_t *ev_after_ext, bool with_chain = true)
+                       hipEvent_t *ev_after_ext, bool with_chain = true, bool with_extend = true, const int *ext_light = nullptr,
+                       const int *ext_heavy = nullptr, const unsigned int *n_heavy = nullptr)
 {
     hipEvent_t *dbg = wk->dbg_ev[sub];
     const bool dbg_on = getenv("SLX_DEBUG_SUB") != nullptr;
@@ -391,7 +405,8 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
     if (ev_after_chain) (void)hipEventRecord(*ev_after_chain, st);
     if (dbg_on) (void)hipEventRecord(dbg[1], st);
     const int g = std::max(1, std::min(n_est, al->n_cu * 32));
-    hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1, n_slots, sub);
+    if (with_extend && ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, ext_light, q + 1, n_slots, sub, ext_heavy, n_heavy);
+    else if (with_extend) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1, n_slots, sub);
     if (ev_after_ext) (void)hipEventRecord(*ev_after_ext, st);
     if (dbg_on) (void)hipEventRecord(dbg[2], st);
     FinLists fl;
@@ -399,6 +414,7 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
     fl.fast_list = (sub ? wk->fast_list2 : wk->fast_list).as<uint32_t>();
     fl.dp_list = (sub ? wk->dp_list2 : wk->dp_list).as<uint32_t>();
     fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
+    bool split_hits = false;
     if (al->regs_mode == 1 && !sub && !order && n_est >= al->split_min) {
         // reads with >= 2 regions (indels, chimeras, repeats: a few percent) go to the wave-per-read kernel, whose mem_patch_reg
         // alignment is wave-parallel; the rest stay one per lane.  order_in / order_out are free again after chaining.
@@ -411,13 +427,24 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_in.as<int>(), q + 2, cnt2, 0);
         hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n_est / 8 + 1, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, fl,
                            wk->order_out.as<int>(), q + 9, cnt2 + 1);
+    } else if (al->regs_mode == 2 && !sub && !order) {
+        unsigned int *cnt2 = q + 32;
+        hipLaunchKernelGGL(k_part_flags_nreg, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, ck.n_reg, n_est, wk->part_flag.as<unsigned int>());
+        size_t tb = wk->scan_tmp.cap;
+        (void)hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n_est, st);
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
+                           wk->part_pos.as<unsigned int>(), n_est, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
+        hipLaunchKernelGGL(k_regs1, dim3(std::max(1, std::min(n_est / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, ck, dopt, fl, wk->order_in.as<int>(), cnt2);
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0);
+        split_hits = true;
     } else
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, sub);
     if (dbg_on) (void)hipEventRecord(dbg[3], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n_est / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
     hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, sub);
     if (dbg_on) (void)hipEventRecord(dbg[4], st);
-    hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, order, q + 3, n_slots, sub);
+    if (split_hits) hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, wk->order_out.as<int>(), q + 3, q + 33, 0);   // single-region reads are final already
+    else hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, order, q + 3, n_slots, sub);
     if (dbg_on) (void)hipEventRecord(dbg[5], st);
 }
 
@@ -450,6 +477,16 @@ static void launch_reference_modes(slx_aligner *al, Worker *wk, const Chunk &ck,
 
 
 struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) const { return (unsigned long long)v; } };
+
+// Second stream of a worker for its heavy reads.  HIP multiplexes streams onto 4 hardware queues in creation order
+// (worker 0, 1, 2, then al->stream), and two streams on one queue run back to back: so the heavy work goes to a stream
+// that is idle during alignment -- al->stream (shared by the three workers) or the stream of a worker that is not running.
+static hipStream_t heavy_stream_of(slx_aligner *al, Worker *wk)
+{
+    if (al->active_k >= 3) return al->stream;
+    if (al->active_k == 2) return wk->id == 0 ? al->workers[2]->stream : al->stream;
+    return al->workers[1]->stream;
+}
 
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
 
@@ -501,6 +538,19 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.lists = wk->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
     ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
     ck.seed_cnt = wk->seed_cnt.as<unsigned long long>();
+    const bool use_cand = al->cand_mode == 1 && al->ext_mode == 2 && al->fin_mode == 1 && !al->sched && !al->split_heavy && !al->heavy_stream &&
+                          al->chain_mode == 1 && n >= al->split_min;
+    if (use_cand) {
+        ENS(cand, (size_t)al->cand_cap * sizeof(DReg)); ENS(cand_base, (size_t)n * 4); ENS(cand_cnt, ((size_t)n + 2) * 8); ENS(cand_off, ((size_t)n + 2) * 8);
+        HIPCHK(hipMemsetAsync(wk->cand_base.p, 0xff, (size_t)n * 4, st));
+        HIPCHK(hipMemsetAsync(wk->cand_cnt.p, 0, ((size_t)n + 2) * 8, st));
+        ck.cand = wk->cand.as<DReg>(); ck.cand_base = wk->cand_base.as<int32_t>();
+    }
+    if (getenv("SLX_DEBUG_CYC")) {
+        ENS(dbg_cyc, (size_t)n * 8);
+        HIPCHK(hipMemsetAsync(wk->dbg_cyc.p, 0, (size_t)n * 8, st));
+        ck.dbg_cyc = wk->dbg_cyc.as<unsigned long long>();
+    }
     DevOpt dopt; dopt.o = *opt;
     DevFM<uint32_t> fm = al->fm32;
     fm.sa_dense = (al->dense_sa && al->have_dense) ? al->d_sa_dense.as<uint32_t>() : nullptr;
@@ -561,12 +611,21 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         unsigned int *counts = q + 24;          // [0] light (or all) reads, [1] heavy reads
         const bool production = al->ext_mode == 2 && al->fin_mode == 1 && !al->sched;
         const bool split = production && al->split_heavy && n >= al->split_min;
+        if (production) { ENS(part_flag, (size_t)n * 4); ENS(part_pos, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4); }
         auto dispatch_sub = [&](hipStream_t sst, const int *order, unsigned int *qq, const unsigned int *ns, int sub, int g2, int n_est,
-                                hipEvent_t *e1, hipEvent_t *e2, bool with_chain) {
-            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
-            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
-            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain);
+                                hipEvent_t *e1, hipEvent_t *e2, bool with_chain, bool with_extend = true, const int *xl = nullptr,
+                                const int *xh = nullptr, const unsigned int *nh = nullptr) {
+            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
+            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
+            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
         };
+        auto dispatch_ext = [&](hipStream_t sst, const int *order, unsigned int *qctr, const unsigned int *ns, int n_est) {
+            const int g = std::max(1, std::min(n_est, al->n_cu * 32));
+            if (max_len <= 160) hipLaunchKernelGGL(k_extend_reg<160>, dim3(g), dim3(64), 0, sst, al->ref, ck, dopt, order, qctr, ns, 0);
+            else if (max_len <= 320) hipLaunchKernelGGL(k_extend_reg<320>, dim3(g), dim3(64), 0, sst, al->ref, ck, dopt, order, qctr, ns, 0);
+            else hipLaunchKernelGGL(k_extend_reg<SLX_MAX_READ_LEN + 4>, dim3(g), dim3(64), 0, sst, al->ref, ck, dopt, order, qctr, ns, 0);
+        };
+        const bool hsort = al->heavy_sorted && al->heavy_seeds <= 0xfffff;   // k_order_keys keeps 20 bits of the seed count
         auto partition = [&]() -> int {   // light reads (input order) -> order_in, heavy reads -> order_out, counts[0] / counts[1]
             ENS(part_flag, (size_t)n * 4); ENS(part_pos, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4);
             hipLaunchKernelGGL(k_part_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
@@ -577,6 +636,18 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
             hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
                                wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), counts);
+            if (hsort) {
+                // heavy list heaviest-first: all read ids sorted by seed count, descending -- its first counts[1] entries are exactly the heavy reads
+                ENS(order_key_in, (size_t)n * 4); ENS(order_key_out, (size_t)n * 4); ENS(order_tmp, (size_t)n * 4);
+                hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
+                                   wk->order_key_in.as<unsigned int>(), wk->order_tmp.as<int>());
+                size_t tb2 = 0;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
+                                                                    wk->order_tmp.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
+                ENS(sort_tmp, tb2 + 256);
+                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(wk->sort_tmp.p, tb2, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
+                                                                    wk->order_tmp.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
+            }
             return SLX_OK;
         };
         if (!production) {
@@ -587,6 +658,23 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         } else if (!split && !(al->chain_mode == 1 && n >= al->split_min)) {
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
             dispatch_sub(st, nullptr, q, counts, 0, grid, n, &wk->ev[4], &wk->ev[5], true);
+        } else if (!split && al->heavy_stream) {
+            // light reads: chaining + extension on the worker's stream; heavy reads (wave-cooperative chaining, then their extension)
+            // on its second stream at the same time; everything after extension over all reads in input order
+            if ((rc = partition()) != SLX_OK) return rc;
+            const hipStream_t hs = heavy_stream_of(al, wk);
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + 2, (unsigned int)n);
+            HIPCHK(hipEventRecord(wk->ev_split, st));
+            HIPCHK(hipStreamWaitEvent(hs, wk->ev_split, 0));
+            hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, hs, fm, al->ref, ck,
+                               dopt, wk->order_out.as<int>(), q + 8, counts + 1);
+            dispatch_ext(hs, wk->order_out.as<int>(), q + 13, counts + 1, std::max(64, n / 8));
+            HIPCHK(hipEventRecord(wk->ev_heavy, hs));
+            hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
+            (void)hipEventRecord(wk->ev[4], st);
+            dispatch_ext(st, wk->order_in.as<int>(), q + 1, counts, n);
+            HIPCHK(hipStreamWaitEvent(st, wk->ev_heavy, 0));
+            dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, nullptr, &wk->ev[5], false, false);
         } else if (!split) {
             // chaining: light reads one per lane, heavy reads one per wave (cooperative); everything after it over all reads in input order
             if ((rc = partition()) != SLX_OK) return rc;
@@ -594,7 +682,28 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
             hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
                                wk->order_out.as<int>(), q + 8, counts + 1);
-            dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false);
+            if (use_cand) {
+                const unsigned gb = (unsigned)((n + 255) / 256);
+                unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
+                unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (n + 2);
+                hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt);
+                size_t tb = wk->scan_tmp.cap;
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, n + 1, st));
+                tb = wk->scan_tmp.cap;
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, job_cnt, job_off, n + 1, st));
+                hipLaunchKernelGGL(k_cand_base, dim3(gb), dim3(256), 0, st, wk->order_out.as<int>(), counts + 1, slot_off, (unsigned int)al->cand_cap,
+                                   wk->cand_base.as<int32_t>());
+                const int gc = al->n_cu * 16;
+                if (max_len <= 160) hipLaunchKernelGGL(k_extend_cand<160>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
+                                                       job_off, q + 14, wk->cand.as<DReg>());
+                else if (max_len <= 320) hipLaunchKernelGGL(k_extend_cand<320>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
+                                                            job_off, q + 14, wk->cand.as<DReg>());
+                else hipLaunchKernelGGL(k_extend_cand<SLX_MAX_READ_LEN + 4>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
+                                        job_off, q + 14, wk->cand.as<DReg>());
+            }
+            if (hsort) dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false, true, wk->order_in.as<int>(),
+                                               wk->order_out.as<int>(), counts + 1);
+            else dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false);
         } else {
             if ((rc = partition()) != SLX_OK) return rc;
             ENS(fast_list2, S1 * 4); ENS(dp_list2, S1 * 4);
@@ -654,6 +763,25 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     for (int i = 0; i < 7; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, wk->ev[i], wk->ev[i + 1]) == hipSuccess) wk->stage_ms[i] += ms;
+    }
+    if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
+        std::vector<unsigned long long> cyc((size_t)n), sc((size_t)n);
+        std::vector<int> nch((size_t)n), nrg((size_t)n);
+        HIPCHK(hipMemcpy(cyc.data(), wk->dbg_cyc.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(sc.data(), wk->seed_cnt.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nch.data(), wk->n_chain.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nrg.data(), wk->n_reg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<int> ord((size_t)n);
+        for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
+        const int top = std::min(n, 12);
+        std::partial_sort(ord.begin(), ord.begin() + top, ord.end(), [&](int a, int b) { return cyc[(size_t)a] > cyc[(size_t)b]; });
+        unsigned long long tot = 0, tot_heavy = 0;
+        for (int i = 0; i < n; ++i) { tot += cyc[(size_t)i]; if (sc[(size_t)i] >= (unsigned long long)al->heavy_seeds) tot_heavy += cyc[(size_t)i]; }
+        fprintf(stderr, "[ext cycles] n=%d total=%.3g (100 MHz ticks) heavy share=%.3f\n", n, (double)tot, tot ? (double)tot_heavy / (double)tot : 0.0);
+        for (int i = 0; i < top; ++i) {
+            const size_t r = (size_t)ord[(size_t)i];
+            fprintf(stderr, "  read %zu: %.2f ms  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r] / 1e5, sc[r], nch[r], nrg[r]);
+        }
     }
     if (getenv("SLX_DEBUG_SUB")) {
         const char *nm[5] = {"chain", "extend", "regs", "cig", "hits"};
@@ -755,6 +883,7 @@ extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const
     if (opt->e_del <= 0 || opt->e_ins <= 0) { slx_set_error("gap extension penalty must be > 0 on the GPU path (bwa divides by it)"); return SLX_EINVAL; }
     const uint64_t *d_offs = (const uint64_t *)d_offs_;
     const int K = (n_reads >= 2 * al->min_split) ? std::min<int>(al->n_workers, (int)al->workers.size()) : 1;
+    al->active_k = K;
     hipEvent_t t0, t1;
     HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
     HIPCHK(hipEventRecord(t0, al->stream));

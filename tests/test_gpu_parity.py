@@ -61,16 +61,24 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
     (_, s1), (_, s2) = sim_reads
     seqs = s1[:1200] + ["A" * 150, "AC" * 75, "ACG" * 50] + s2[:800]
     exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
-    for split in (0, 1):
+    for split, hs in ((0, 0), (1, 0), (0, 1)):      # hs: heavy reads chained + extended on the worker's second stream
         for thr in (1, 3, 8, 1000000):
             al = sl.BWAAligner(tiny_gpu)
             al.set("split_min", 16)
             al.set("split_heavy", split)
+            al.set("heavy_stream", hs)
             al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
-            assert_same(al.alignSequences(seqs), exp, "split=%d heavy_seeds=%d" % (split, thr))
+            assert_same(al.alignSequences(seqs), exp, "split=%d heavy_stream=%d heavy_seeds=%d" % (split, hs, thr))
+    # ahead-of-time extension of the heavy reads' chains: off, and with a table too small for most reads (in-place fallback)
+    for knob, val in (("cand_mode", 0), ("cand_cap", 7), ("heavy_sorted", 0)):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("split_min", 16)
+        al.set("heavy_seeds", 3)
+        al.set(knob, val)
+        assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("regs_mode", 1)])
+@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
     a tiny interval capacity that forces the overflow-retry path: identical records."""
