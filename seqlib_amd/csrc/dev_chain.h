@@ -31,6 +31,28 @@ struct ReadWS {               // views into the per-seed-slot arrays for one rea
     __device__ __forceinline__ int s_len(int s) const { return (int)(s_ql[s] & 0xffff); }
 };
 
+__device__ __forceinline__ uint64_t rfl_u64(uint64_t v)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+__device__ __forceinline__ ReadWS make_ws(const Chunk &ck, int r);
+
+// the same views for a wave that works on ONE read: the slot offset is pinned to scalar registers, so the sixteen
+// array bases are scalar too instead of sixteen 64-bit vector registers of identical lanes
+__device__ __forceinline__ ReadWS make_ws_uniform(const Chunk &ck, int r)
+{
+    const uint64_t o = rfl_u64(ck.seed_off[r]);
+    ReadWS w;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o;
+    w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
+    w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
+    w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
+    w.regs = ck.regs + o; w.hits = ck.hits + o;
+    w.cap = (int)(rfl_u64(ck.seed_off[r + 1]) - o);
+    return w;
+}
+
 __device__ __forceinline__ ReadWS make_ws(const Chunk &ck, int r)
 {
     const uint64_t o = ck.seed_off[r];
@@ -176,19 +198,32 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
             for (; i < n_chn; ++i) if (w.c_kept[a[i]] < 3) w.c_kept[a[i]] = 0;
             for (i = 0; i < n_chn; ++i) if (w.c_kept[a[i]] != 0) a[n_out++] = a[i];
         }
-        // Exact-match shortcut: one kept chain made of one seed that spans the whole read needs no extension at all.
-        // mem_chain2aln then yields exactly this region (no left part, no right part: score = truesc = len*a), so it is
-        // written here and the wave-per-read extension kernel skips the read (n_chain = -1).
-        if (n_out == 1 && w.c_n[a[0]] == 1) {
-            const int s0 = w.c_head[a[0]];
-            if (w.s_qbeg(s0) == 0 && w.s_len(s0) == len) {
-                DReg g;
-                g.rb = w.s_rbeg[s0]; g.re = g.rb + len; g.qb = 0; g.qe = len; g.rid = w.c_rid[a[0]];
-                g.score = g.truesc = len * opt.a; g.sub = g.csub = g.sub_n = 0; g.w = opt.w; g.seedcov = len; g.secondary = 0;
-                g.seedlen0 = len; g.n_comp = 0; g.frac_rep = ck.frac_rep[r]; g.hash = 0;
-                w.regs[0] = g;
-                ck.n_reg[r] = 1;
-                n_out = -1;
+        // Exact-match shortcut: one kept chain whose longest seed spans the whole read, every other seed of it lying inside that
+        // seed on the same diagonal (the LAST-like seeds of pass 3 and the reseeds of pass 2 of an error-free read).  mem_chain2aln
+        // then extends the spanning seed first -- no left part, no right part: score = truesc = len*a -- and finds every other
+        // seed covered by that region on its own diagonal, so the read's only region is written here and the wave-per-read
+        // extension kernel skips the read (n_chain = -1).  seedcov = total length of the chain's seeds, all of them inside.
+        if (n_out == 1 && opt.w > 0) {           // (with a zero band bwa's containment test never fires)
+            const int c0 = a[0];
+            int s_full = -1, cov = 0;
+            bool same_diag = true;
+            int64_t diag = 0;
+            for (int s = w.c_head[c0]; s >= 0; s = w.s_next[s])
+                if (w.s_qbeg(s) == 0 && w.s_len(s) == len) { s_full = s; diag = w.s_rbeg[s]; break; }
+            if (s_full >= 0) {
+                for (int s = w.c_head[c0]; s >= 0; s = w.s_next[s]) {
+                    cov += w.s_len(s);
+                    if (w.s_rbeg[s] - w.s_qbeg(s) != diag) same_diag = false;
+                }
+                if (same_diag) {
+                    DReg g;
+                    g.rb = diag; g.re = g.rb + len; g.qb = 0; g.qe = len; g.rid = w.c_rid[c0];
+                    g.score = g.truesc = len * opt.a; g.sub = g.csub = g.sub_n = 0; g.w = opt.w; g.seedcov = cov; g.secondary = 0;
+                    g.seedlen0 = len; g.n_comp = 0; g.frac_rep = ck.frac_rep[r]; g.hash = 0;
+                    w.regs[0] = g;
+                    ck.n_reg[r] = 1;
+                    n_out = -1;
+                }
             }
         }
         // seed lists of the kept chains, flattened (c_w / c_first are free once the filter is done): the wave-per-read extension

@@ -217,9 +217,12 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
     }
 }
 
+// cap_lo < seed occurrences of the read <= cap_hi selects the reads of this launch: the table size is a template parameter (LDS),
+// so the few reads with more occurrences than the common table holds get their own launch with a bigger one instead of
+// falling back to a single lane (measured: 180 ms for one 2000-occurrence read on the single-lane path)
 template <typename I, int NCMAX>
 __global__ void __launch_bounds__(64) k_chain_coop(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue,
-                                                   const unsigned int *n_slots)
+                                                   const unsigned int *n_slots, int cap_lo, int cap_hi)
 {
     __shared__ int64_t s_pos[NCMAX + 64];
     __shared__ int s_ord[NCMAX + 64];
@@ -234,6 +237,8 @@ __global__ void __launch_bounds__(64) k_chain_coop(DevFM<I> fm, DevRef R, Chunk 
         if (lane == 0) slot = (int)atomicAdd(queue, 1u);
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
-        dev_chain_read_coop<I, NCMAX>(fm, R, ck, dopt.o, order ? order[slot] : slot, T, lane);
+        const int r = order ? order[slot] : slot;
+        const int cap = __builtin_amdgcn_readfirstlane((int)(ck.seed_off[r + 1] - ck.seed_off[r]));
+        if (cap > cap_lo && cap <= cap_hi) dev_chain_read_coop<I, NCMAX>(fm, R, ck, dopt.o, r, T, lane);
     }
 }

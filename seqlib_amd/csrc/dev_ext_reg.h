@@ -226,22 +226,24 @@ __device__ ExtResult reg_ksw_extend2(int qlen_, QF qf, int tlen_, TF tf, const s
     return r;
 }
 
-// pick the narrowest register tile that holds the extension: most extensions of 150 bp reads are < 64 columns wide,
-// so one column per lane (a third of the per-row work of the widest variant) is the common case
-template <int CPLMAX, typename QF, typename TF>
+// pick the narrowest register tile that holds the extension: most extensions of 150 bp reads are < 64 columns wide, so one column
+// per lane (a third of the per-row work of the widest variant) is the common case.  Reads longer than 191 bp keep the H/E row
+// of their widest extensions in LDS instead (wave_ksw_extend2): more than three columns per lane would spill.
+template <int NCH, typename QF, typename TF>
 __device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus,
-                                                          int h0, int lane)
+                                                          int h0, int *eh_h, int *eh_e, int lane)
 {
-    if (CPLMAX > 1 && qlen + 1 <= WAVE) return reg_ksw_extend2<1>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
-    if (CPLMAX > 2 && qlen + 1 <= 2 * WAVE) return reg_ksw_extend2<2>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
-    return reg_ksw_extend2<CPLMAX>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    if (qlen + 1 <= WAVE) return reg_ksw_extend2<1>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    if (qlen + 1 <= 2 * WAVE) return reg_ksw_extend2<2>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    if (qlen + 1 <= 3 * WAVE) return reg_ksw_extend2<3>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
+    return wave_ksw_extend2<NCH>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, eh_h, eh_e, lane);
 }
 
 // Left + right extension of one seed (the body of mem_chain2aln's seed loop once a seed is known to need extending): the region
 // without its seedcov.  Shared by the per-read kernel and the ahead-of-time kernel for heavy reads.
-template <int CPL>
+template <int NCH>
 __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRows &mr, const uint8_t *query, int l_query, int s_qbeg, int s_len,
-                                int64_t s_rbeg, int64_t rmax0, int64_t rmax1, int rid, float frac_rep, int lane)
+                                int64_t s_rbeg, int64_t rmax0, int64_t rmax1, int rid, float frac_rep, int *eh_h, int *eh_e, int lane)
 {
     DReg a;
     a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
@@ -254,8 +256,8 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
         for (i = 0; i < 2; ++i) {
             const int prev = a.score;
             aw0 = opt.w << i;
-            er = reg_ksw_extend2_auto<CPL>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
-                                      [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5, s_len * opt.a, lane);
+            er = reg_ksw_extend2_auto<NCH>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
+                                      [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5, s_len * opt.a, eh_h, eh_e, lane);
             a.score = er.score;
             if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
         }
@@ -269,8 +271,8 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
         for (i = 0; i < 2; ++i) {
             const int prev = a.score;
             aw1 = opt.w << i;
-            er = reg_ksw_extend2_auto<CPL>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
-                                      [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, lane);
+            er = reg_ksw_extend2_auto<NCH>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
+                                      [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, eh_h, eh_e, lane);
             a.score = er.score;
             if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
         }
@@ -293,10 +295,11 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
     // `first` (optional): reads to take before the ones in `order` -- the heavy reads, heaviest first, so that a read that
     // keeps one wave busy for tens of milliseconds starts at once instead of wherever it sits in the batch
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
-    constexpr int CPL = (MAXQ + 1 + WAVE - 1) / WAVE;
+    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
+    __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];                // H/E row of the (rare) extensions wider than two columns per lane
     __shared__ int gap_lut[MAXQ + 2];                             // cal_max_gap(q) for every q a 0..MAXQ query distance can take
     for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
     __syncthreads();
@@ -310,20 +313,35 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         if (slot >= n_todo) break;
         const int r = first ? (slot < n_head ? first[slot] : order[slot - n_head]) : (order ? order[slot] : slot);
         const unsigned long long t_in = ck.dbg_cyc ? __builtin_readcyclecounter() : 0ull;
-        ReadWS w = make_ws(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
-        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-        const int n_chn = ck.n_chain[r];
+        const int n_chn = __builtin_amdgcn_readfirstlane(ck.n_chain[r]);
         if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
-        const float frac_rep = ck.frac_rep[r];
+        // one read per wave: everything below that is the same in all 64 lanes is pinned to scalar registers
+        ReadWS w = make_ws_uniform(ck, r);
+        const uint64_t q_off = rfl_u64(ck.offs[r]);
+        const uint8_t *query = ck.codes + q_off;
+        const int l_query = (int)(rfl_u64(ck.offs[r + 1]) - q_off);
+        const float frac_rep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ck.frac_rep[r])));
         const int64_t l_pac = R.l_pac;
         const int cand_at = ck.cand_base ? __builtin_amdgcn_readfirstlane(ck.cand_base[r]) : -1;
         int n_av = 0;
-        int *srt_h = w.ic;
+        unsigned long long t_sort = 0, t_test = 0, t_dp = 0, t_mark;
+#define DBG_T0() do { if (ck.dbg_cyc) t_mark = __builtin_readcyclecounter(); } while (0)
+#define DBG_T1(acc) do { if (ck.dbg_cyc) acc += __builtin_readcyclecounter() - t_mark; } while (0)
+        // SoA scratch in the read's (still unused) hit slots, 40 bytes per seed slot, plus the free ib list: keys of the regions found
+        // so far for the covered test, and the current chain's seeds in sorted order
+        static_assert(sizeof(DHit) == 40, "scratch layout below fills exactly one DHit per seed slot");
+        uint8_t *const hs = (uint8_t *)w.hits;
+        const size_t cap = (size_t)w.cap;
+        int64_t *const rg_rb = (int64_t *)hs, *const rg_re = (int64_t *)(hs + 8 * cap);
+        uint32_t *const rg_q = (uint32_t *)(hs + 16 * cap);
+        int *const rg_w = (int *)(hs + 20 * cap), *const rg_sl0 = (int *)(hs + 24 * cap);
+        uint32_t *const sd_ql = (uint32_t *)(hs + 28 * cap);
+        int64_t *const sd_rb = (int64_t *)(hs + 32 * cap);
+        int *const sd_s = w.ib;
         for (int ci = 0; ci < n_chn; ++ci) {
-            const int c = w.ia[ci];
-            const int n = w.c_n[c];
-            const int *cs = w.c_w + w.c_first[c];                  // the chain's seeds, flattened by the chaining kernel
+            const int c = __builtin_amdgcn_readfirstlane(w.ia[ci]);
+            const int n = __builtin_amdgcn_readfirstlane(w.c_n[c]);
+            const int *cs = w.c_w + __builtin_amdgcn_readfirstlane(w.c_first[c]);   // the chain's seeds, flattened by the chaining kernel
             if (n == 0) continue;
             int64_t rmax0 = l_pac << 1, rmax1 = 0;
             for (int i = lane; i < n; i += WAVE) {                 // lanes take seeds, then a wave min/max
@@ -352,25 +370,53 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
                 rmax1 = rmax1 < far_end ? rmax1 : far_end;
             }
-            for (int i = 0; i < n; ++i) { w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i; srt_h[i] = i; }
-            ks_introsort_idx(n, srt_h, [&](int x, int y) { return w.srt[x] < w.srt[y]; });
+            // ---- the chain's seeds in the order mem_chain2aln takes them (ascending (length, list index), walked from the top):
+            // ranks by an all-pairs count on registers (keys are distinct), records scattered to a sorted SoA scratch
+            DBG_T0();
+            for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i;
+            __threadfence_block();                                 // other lanes read these keys below
+            for (int i0 = 0; i0 < n; i0 += WAVE) {
+                const int i = i0 + lane;
+                const bool mine = i < n;
+                const int sid = mine ? cs[i] : 0;
+                const uint32_t ql = mine ? w.s_ql[sid] : 0u;
+                const int64_t rb = mine ? w.s_rbeg[sid] : 0;
+                const uint64_t key = (uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)i;
+                int rank = 0;
+                for (int b0 = 0; b0 < n; b0 += WAVE) {
+                    const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
+                    const int nb = n - b0 < WAVE ? n - b0 : WAVE;
+                    for (int j = 0; j < nb; ++j) {
+                        const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), j) << 32 |
+                                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, j);
+                        rank += kj < key ? 1 : 0;
+                    }
+                }
+                if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; }
+            }
+            __threadfence_block();
+            DBG_T1(t_sort);
             for (int k = n - 1; k >= 0; --k) {
-                const int si = (int)(uint32_t)w.srt[srt_h[k]];
-                const int s = cs[si];
-                const int s_qbeg = w.s_qbeg(s), s_len = w.s_len(s);
-                const int64_t s_rbeg = w.s_rbeg[s];
-                int i;
-                // "has this seed been covered by an earlier region?": the scalar loop stops at the FIRST region that
-                // satisfies the test, so lanes evaluate 64 regions at a time and a ballot picks the first hit.
+                DBG_T0();
+                const uint32_t s_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd_ql[k]);
+                const int s = __builtin_amdgcn_readfirstlane(sd_s[k]);
+                const int s_qbeg = (int)(s_ql >> 16), s_len = (int)(s_ql & 0xffffu);
+                const int64_t s_rbeg = (int64_t)rfl_u64((uint64_t)sd_rb[k]);
+                // "has this seed been covered by an earlier region?": only whether ANY region passes the test matters, so lanes
+                // evaluate 64 regions each, four blocks of key loads in flight at a time
                 bool covered = false;
-                for (int base = 0; base < n_av && !covered; base += WAVE) {
-                    const int ri = base + lane;
+                for (int base = 0; base < n_av && !covered; base += 4 * WAVE) {
                     bool hit = false;
-                    if (ri < n_av) {
-                        const DReg &p = w.regs[ri];
-                        const int64_t prb = p.rb, pre_ = p.re;
-                        const int pqb = p.qb, pqe = p.qe, pw = p.w, psl0 = p.seedlen0;
-                        if (!(s_rbeg < prb || s_rbeg + s_len > pre_ || s_qbeg < pqb || s_qbeg + s_len > pqe) &&
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ri0 = base + u * WAVE + lane;
+                        const bool valid = ri0 < n_av;
+                        const int ri = valid ? ri0 : n_av - 1;
+                        const int64_t prb = rg_rb[ri], pre_ = rg_re[ri];
+                        const uint32_t pq = rg_q[ri];
+                        const int pw = rg_w[ri], psl0 = rg_sl0[ri];
+                        const int pqb = (int)(pq >> 16), pqe = (int)(pq & 0xffffu);
+                        if (valid && !(s_rbeg < prb || s_rbeg + s_len > pre_ || s_qbeg < pqb || s_qbeg + s_len > pqe) &&
                             !((double)(s_len - psl0) > .1 * l_query)) {
                             int qd = s_qbeg - pqb; int64_t rd = s_rbeg - prb;
                             int mg = max_gap_of(qd < rd ? qd : (int)rd);
@@ -385,44 +431,58 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     if (__ballot(hit)) covered = true;
                 }
                 if (covered) {
-                    // extend anyway only if a long overlapping seed of this chain sits on another diagonal
+                    // extend anyway only if a long overlapping seed of this chain (one taken before and not dropped) sits on another diagonal
                     bool other_diag = false;
-                    for (int base = k + 1; base < n && !other_diag; base += WAVE) {
-                        const int ti = base + lane;
+                    for (int base = k + 1; base < n && !other_diag; base += 4 * WAVE) {
                         bool hit = false;
-                        if (ti < n && srt_h[ti] >= 0) {
-                            const uint64_t key = w.srt[srt_h[ti]];
-                            const int t = cs[(int)(uint32_t)key];
-                            const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                            const int64_t t_rbeg = w.s_rbeg[t];
-                            if (!((double)t_len < s_len * .95)) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ti0 = base + u * WAVE + lane;
+                            const bool valid = ti0 < n;
+                            const int ti = valid ? ti0 : n - 1;
+                            const uint32_t tq = sd_ql[ti];
+                            const int64_t t_rbeg = sd_rb[ti];
+                            const int t_qbeg = (int)(tq >> 16), t_len = (int)(tq & 0xffffu);       // a dropped seed has length 0 here
+                            if (valid && !((double)t_len < s_len * .95)) {
                                 if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) hit = true;
                                 if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) hit = true;
                             }
                         }
                         if (__ballot(hit)) other_diag = true;
                     }
-                    if (!other_diag) { srt_h[k] = -1; continue; }
+                    if (!other_diag) { sd_ql[k] = s_ql & 0xffff0000u; DBG_T1(t_test); continue; }      // every lane stores the same word
                 }
+                DBG_T1(t_test);
+                DBG_T0();
                 DReg a;
                 const bool have_cand = cand_at >= 0;                         // heavy read: every seed was extended ahead of time (k_extend_cand)
                 if (have_cand) a = ck.cand[cand_at + s];
-                else a = dev_extend_core<CPL>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, lane);
-                if (have_cand) { w.regs[n_av++] = a; continue; }
-                int cov = 0;
-                for (i = lane; i < n; i += WAVE) {
-                    const int t = cs[i];
-                    const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                    const int64_t t_rbeg = w.s_rbeg[t];
-                    if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
+                else {
+                    a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
+                    int cov = 0;
+                    for (int i = lane; i < n; i += WAVE) {
+                        const uint32_t tq = w.s_ql[cs[i]];
+                        const int t_qbeg = (int)(tq >> 16), t_len = (int)(tq & 0xffffu);
+                        const int64_t t_rbeg = w.s_rbeg[cs[i]];
+                        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
+                    a.seedcov = cov;
                 }
-                for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
-                a.seedcov = cov;
-                w.regs[n_av++] = a;                               // every lane stores the same bytes
+                // every lane stores the same bytes (region + its keys for the covered test), so every lane may read them back
+                w.regs[n_av] = a;
+                rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = (uint32_t)a.qb << 16 | (uint32_t)a.qe; rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;
+                ++n_av;
+                DBG_T1(t_dp);
             }
         }
         ck.n_reg[r] = n_av;
-        if (ck.dbg_cyc && lane == 0) ck.dbg_cyc[r] = __builtin_readcyclecounter() - t_in;
+        if (ck.dbg_cyc && lane == 0) {
+            ck.dbg_cyc[r] = __builtin_readcyclecounter() - t_in;
+            ck.dbg_cyc[(size_t)ck.n_reads + r] = t_sort; ck.dbg_cyc[2 * (size_t)ck.n_reads + r] = t_test; ck.dbg_cyc[3 * (size_t)ck.n_reads + r] = t_dp;
+        }
+#undef DBG_T0
+#undef DBG_T1
     }
 }
 
@@ -458,10 +518,10 @@ __global__ void k_cand_base(const int *heavy, const unsigned int *n_heavy, const
 
 // one (read, chain, part) job; out of line so that the queue loop of the kernel stays a plain fetch / test / call (see dev_cig_dp_job)
 template <int MAXQ>
-__device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int r, int jl,
-                                          DReg *out, int lane)
+__device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int *eh_h, int *eh_e,
+                                          int r, int jl, DReg *out, int lane)
 {
-    constexpr int CPL = (MAXQ + 1 + WAVE - 1) / WAVE;
+    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
     auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
     const int64_t l_pac = R.l_pac;
     ReadWS w = make_ws(ck, r);
@@ -524,7 +584,7 @@ __device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, cons
     const int j_end = (part + 1) * CAND_PART < n ? (part + 1) * CAND_PART : n;
     for (int j = part * CAND_PART; j < j_end; ++j) {
         const int s = cs[j];
-        DReg a = dev_extend_core<CPL>(R, opt, mr, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s], rmax0, rmax1, rid_c, frac_rep, lane);
+        DReg a = dev_extend_core<NCH>(R, opt, mr, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s], rmax0, rmax1, rid_c, frac_rep, eh_h, eh_e, lane);
         int cov = 0;
         for (int i = lane; i < n; i += WAVE) {
             const int t = cs[i];
@@ -545,6 +605,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_cand(DevRef R, Chu
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
+    __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
     __shared__ int gap_lut[MAXQ + 2];
     for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
     __syncthreads();
@@ -559,6 +620,6 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_cand(DevRef R, Chu
         while (hi - lo > 1) { const unsigned int mid = (lo + hi) >> 1; if (job_off[mid] <= job) lo = mid; else hi = mid; }
         const int r = heavy[lo];
         const int base = __builtin_amdgcn_readfirstlane(ck.cand_base[r]);
-        if (base >= 0) dev_cand_job<MAXQ>(R, ck, opt, mr, gap_lut, r, (int)(job - job_off[lo]), cand + base, lane);   // else extended in place
+        if (base >= 0) dev_cand_job<MAXQ>(R, ck, opt, mr, gap_lut, eh_h, eh_e, r, (int)(job - job_off[lo]), cand + base, lane);   // else extended in place
     }
 }

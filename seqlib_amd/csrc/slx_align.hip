@@ -488,6 +488,17 @@ static hipStream_t heavy_stream_of(slx_aligner *al, Worker *wk)
     return al->workers[1]->stream;
 }
 
+// wave-cooperative chaining of the heavy list: first the few reads whose seed occurrences exceed the common LDS table (own launch,
+// bigger table, one block per CU), then the rest
+static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, unsigned int *q,
+                        unsigned int *counts, int n)
+{
+    hipLaunchKernelGGL((k_chain_coop<uint32_t, 4096>), dim3(std::max(1, std::min(n / 64 + 1, al->n_cu))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                       wk->order_out.as<int>(), q + 10, counts + 1, 1536, 0x7fffffff);
+    hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                       wk->order_out.as<int>(), q + 8, counts + 1, -1, 1536);
+}
+
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
 
 // runs the pipeline on reads [r0, r0+n) whose ASCII bases are d_ascii + d_offs[r0]...; appends to the outputs.
@@ -547,8 +558,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         ck.cand = wk->cand.as<DReg>(); ck.cand_base = wk->cand_base.as<int32_t>();
     }
     if (getenv("SLX_DEBUG_CYC")) {
-        ENS(dbg_cyc, (size_t)n * 8);
-        HIPCHK(hipMemsetAsync(wk->dbg_cyc.p, 0, (size_t)n * 8, st));
+        ENS(dbg_cyc, (size_t)n * 32);
+        HIPCHK(hipMemsetAsync(wk->dbg_cyc.p, 0, (size_t)n * 32, st));
         ck.dbg_cyc = wk->dbg_cyc.as<unsigned long long>();
     }
     DevOpt dopt; dopt.o = *opt;
@@ -666,8 +677,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + 2, (unsigned int)n);
             HIPCHK(hipEventRecord(wk->ev_split, st));
             HIPCHK(hipStreamWaitEvent(hs, wk->ev_split, 0));
-            hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, hs, fm, al->ref, ck,
-                               dopt, wk->order_out.as<int>(), q + 8, counts + 1);
+            launch_coop(al, wk, ck, dopt, fm, hs, q, counts, n);
             dispatch_ext(hs, wk->order_out.as<int>(), q + 13, counts + 1, std::max(64, n / 8));
             HIPCHK(hipEventRecord(wk->ev_heavy, hs));
             hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
@@ -680,8 +690,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             if ((rc = partition()) != SLX_OK) return rc;
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + 2, (unsigned int)n);
             hipLaunchKernelGGL(k_chain<uint32_t>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
-            hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
-                               wk->order_out.as<int>(), q + 8, counts + 1);
+            launch_coop(al, wk, ck, dopt, fm, st, q, counts, n);
             if (use_cand) {
                 const unsigned gb = (unsigned)((n + 255) / 256);
                 unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
@@ -765,9 +774,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (hipEventElapsedTime(&ms, wk->ev[i], wk->ev[i + 1]) == hipSuccess) wk->stage_ms[i] += ms;
     }
     if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
-        std::vector<unsigned long long> cyc((size_t)n), sc((size_t)n);
+        std::vector<unsigned long long> cyc((size_t)n * 4), sc((size_t)n);
         std::vector<int> nch((size_t)n), nrg((size_t)n);
-        HIPCHK(hipMemcpy(cyc.data(), wk->dbg_cyc.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cyc.data(), wk->dbg_cyc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(sc.data(), wk->seed_cnt.p, (size_t)n * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(nch.data(), wk->n_chain.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(nrg.data(), wk->n_reg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -776,11 +785,20 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         const int top = std::min(n, 12);
         std::partial_sort(ord.begin(), ord.begin() + top, ord.end(), [&](int a, int b) { return cyc[(size_t)a] > cyc[(size_t)b]; });
         unsigned long long tot = 0, tot_heavy = 0;
-        for (int i = 0; i < n; ++i) { tot += cyc[(size_t)i]; if (sc[(size_t)i] >= (unsigned long long)al->heavy_seeds) tot_heavy += cyc[(size_t)i]; }
+        unsigned long long ph[3] = {0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            tot += cyc[(size_t)i];
+            if (sc[(size_t)i] >= (unsigned long long)al->heavy_seeds) tot_heavy += cyc[(size_t)i];
+            for (int k = 0; k < 3; ++k) ph[k] += cyc[(size_t)(k + 1) * (size_t)n + (size_t)i];
+        }
+        float ext_ms = 0;
+        (void)hipEventElapsedTime(&ext_ms, wk->ev[4], wk->ev[5]);
+        fprintf(stderr, "[ext phases] sort %.3g  covered tests %.3g  extend+store %.3g ticks; extension stage %.1f ms\n", (double)ph[0], (double)ph[1], (double)ph[2], ext_ms);
         fprintf(stderr, "[ext cycles] n=%d total=%.3g (100 MHz ticks) heavy share=%.3f\n", n, (double)tot, tot ? (double)tot_heavy / (double)tot : 0.0);
         for (int i = 0; i < top; ++i) {
             const size_t r = (size_t)ord[(size_t)i];
-            fprintf(stderr, "  read %zu: %.2f ms  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r] / 1e5, sc[r], nch[r], nrg[r]);
+            fprintf(stderr, "  read %zu: %.3g ticks (sort %.3g, covered tests %.3g, extend+store %.3g)  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r],
+                    (double)cyc[(size_t)n + r], (double)cyc[2 * (size_t)n + r], (double)cyc[3 * (size_t)n + r], sc[r], nch[r], nrg[r]);
         }
     }
     if (getenv("SLX_DEBUG_SUB")) {
