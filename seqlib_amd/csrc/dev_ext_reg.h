@@ -497,13 +497,15 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
 #define CAND_PART 4
 
 // per heavy read: seed slots (table space) and (chain, part) jobs
-__global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt)
+__global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= *n_heavy) return;
     const int r = heavy[s];
     const uint64_t so = ck.seed_off[r];
-    slot_cnt[s] = (unsigned int)(ck.seed_off[r + 1] - so);
+    const unsigned int cap = (unsigned int)(ck.seed_off[r + 1] - so);
+    if (cap < min_seeds) return;                    // (counts are zero-initialised) short enough to be extended in place
+    slot_cnt[s] = cap;
     const int nc = ck.n_chain[r];
     unsigned int jobs = 0;
     for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + CAND_PART - 1) / CAND_PART;
@@ -513,7 +515,7 @@ __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_h
 __global__ void k_cand_base(const int *heavy, const unsigned int *n_heavy, const unsigned int *slot_off, unsigned int cand_cap, int32_t *cand_base)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < *n_heavy) cand_base[heavy[s]] = slot_off[s + 1] <= cand_cap ? (int32_t)slot_off[s] : -1;
+    if (s < *n_heavy) cand_base[heavy[s]] = (slot_off[s + 1] > slot_off[s] && slot_off[s + 1] <= cand_cap) ? (int32_t)slot_off[s] : -1;
 }
 
 // one (read, chain, part) job; out of line so that the queue loop of the kernel stays a plain fetch / test / call (see dev_cig_dp_job)

@@ -99,6 +99,12 @@ __device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
 #ifndef SEED2_POOL
 #define SEED2_POOL 16
 #endif
+#ifndef SEED2_EV_EVERY
+#define SEED2_EV_EVERY 4      // power of two
+#endif
+#ifndef SEED2_EV_LANES
+#define SEED2_EV_LANES 8
+#endif
 
 enum Seed2Phase : int { S2_FETCH = 0, S2_INIT, S2_START, S2_FWD0, S2_BEGIN_BWD, S2_ROW, S2_FWD, S2_BWD, S2_DONE };
 
@@ -129,6 +135,7 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
     ik.x0 = ik.x1 = ik.x2 = 0; ik.info = 0;
     head = nhead = psrc = nsrc = ik;
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+    uint32_t trip = 0;
 
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
     auto push_fwd = [&](const IntvE<I> &v) { if (n < wl.cap) wl.at(1, n) = v; else list_ovf = true; ++n; };
@@ -153,70 +160,79 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
     };
 
     for (;;) {
-        // ------------------------------------------------ read assignment (wave-uniform bookkeeping)
-        if (pending) {
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
-            pending = false;
-            if (base >= n_reads) exhausted = true;
-            else { res_next = base; res_end = base + SEED2_POOL < n_reads ? base + SEED2_POOL : n_reads; }
-        }
-        if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
-        if (res_next == res_end && !exhausted) {
-            if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED2_POOL);
-            pending = true;
-        }
-        if (phase == S2_INIT) {                     // offsets requested one trip ago
-            qoff = o0; len = (int)(o1 - o0);
-            n_out = 0; out_ovf = false; list_ovf = false;
-            if (len < opt.min_seed_len) finish_read();
-            else { pass = 1; x = 0; phase = S2_START; }
-        }
-        {
-            const unsigned long long want = __ballot(phase == S2_FETCH);
-            if (want) {
-                const uint32_t avail = pool_end - pool_next;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                if (phase == S2_FETCH) {
-                    if (rank < avail) {
-                        r = pool_next + rank;
-                        o0 = ck.offs[r]; o1 = ck.offs[r + 1];
-                        phase = S2_INIT;
-                    } else if (exhausted && !pending && res_next == res_end) phase = S2_DONE;
+        // Read assignment and the start of the next bwt_smem1a call are the long, rarely needed blocks of this loop (a dozen times per
+        // read against ~300 extends), yet with 64 lanes at different points of their reads some lane wants them on nearly every trip,
+        // and every lane then pays their issue slots.  So they run every SEED2_EV_EVERY-th trip only -- or at once when enough lanes
+        // wait or no lane has an extend to do; a waiting lane idles for a trip or two.
+        const unsigned long long m_ev = __ballot(phase == S2_FETCH || phase == S2_INIT || phase == S2_START);
+        const unsigned long long m_run = __ballot(phase != S2_FETCH && phase != S2_INIT && phase != S2_START && phase != S2_DONE);
+        ++trip;
+        if ((trip & (SEED2_EV_EVERY - 1)) == 0 || m_run == 0 || __popcll(m_ev) >= SEED2_EV_LANES) {
+            // ------------------------------------------------ read assignment (wave-uniform bookkeeping)
+            if (pending) {
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
+                pending = false;
+                if (base >= n_reads) exhausted = true;
+                else { res_next = base; res_end = base + SEED2_POOL < n_reads ? base + SEED2_POOL : n_reads; }
+            }
+            if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
+            if (res_next == res_end && !exhausted) {
+                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED2_POOL);
+                pending = true;
+            }
+            if (phase == S2_INIT) {                     // offsets requested one trip ago
+                qoff = o0; len = (int)(o1 - o0);
+                n_out = 0; out_ovf = false; list_ovf = false;
+                if (len < opt.min_seed_len) finish_read();
+                else { pass = 1; x = 0; phase = S2_START; }
+            }
+            {
+                const unsigned long long want = __ballot(phase == S2_FETCH);
+                if (want) {
+                    const uint32_t avail = pool_end - pool_next;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (phase == S2_FETCH) {
+                        if (rank < avail) {
+                            r = pool_next + rank;
+                            o0 = ck.offs[r]; o1 = ck.offs[r + 1];
+                            phase = S2_INIT;
+                        } else if (exhausted && !pending && res_next == res_end) phase = S2_DONE;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(want);
+                    pool_next += cnt < avail ? cnt : avail;
                 }
-                const uint32_t cnt = (uint32_t)__popcll(want);
-                pool_next += cnt < avail ? cnt : avail;
             }
-        }
-        // ------------------------------------------------ next bwt_smem1a call of this read
-        if (phase == S2_START) {
-            int xs = -1;
-            I mi = 1;
-            if (pass == 1) {
-                while (x < len && qb(x) > 3) ++x;
-                if (x < len) xs = x;
-                else { pass = 2; k2 = 0; old_n = n_out; }
-            }
-            if (pass == 2) {                        // re-seed from the middle of long SMEMs with few occurrences
-                while (k2 < old_n) {
-                    const size_t o = (size_t)r * ck.cap_intv + k2;
-                    const uint32_t inf = ck.intv_info[o];
-                    const I s = ((const I *)ck.intv_x2)[o];
-                    ++k2;
-                    const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
-                    if (end - start < split_len || s > (I)opt.split_width) continue;
-                    const int mid = (start + end) >> 1;
-                    if (qb(mid) > 3) continue;      // bwt_smem1a returns at once on an ambiguous start
-                    xs = mid; mi = s + 1;
-                    break;
+            // ------------------------------------------------ next bwt_smem1a call of this read
+            if (phase == S2_START) {
+                int xs = -1;
+                I mi = 1;
+                if (pass == 1) {
+                    while (x < len && qb(x) > 3) ++x;
+                    if (x < len) xs = x;
+                    else { pass = 2; k2 = 0; old_n = n_out; }
                 }
-                if (xs < 0) finish_read();
-            }
-            if (xs >= 0) {
-                sx = xs; min_intv = mi < 1 ? (I)1 : mi;
-                set_intv<I>(fm, qb(xs), ik);
-                ik.info = (uint32_t)(xs + 1);
-                i = xs + 1; n = 0;
-                phase = S2_FWD0;
+                if (pass == 2) {                        // re-seed from the middle of long SMEMs with few occurrences
+                    while (k2 < old_n) {
+                        const size_t o = (size_t)r * ck.cap_intv + k2;
+                        const uint32_t inf = ck.intv_info[o];
+                        const I s = ((const I *)ck.intv_x2)[o];
+                        ++k2;
+                        const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+                        if (end - start < split_len || s > (I)opt.split_width) continue;
+                        const int mid = (start + end) >> 1;
+                        if (qb(mid) > 3) continue;      // bwt_smem1a returns at once on an ambiguous start
+                        xs = mid; mi = s + 1;
+                        break;
+                    }
+                    if (xs < 0) finish_read();
+                }
+                if (xs >= 0) {
+                    sx = xs; min_intv = mi < 1 ? (I)1 : mi;
+                    set_intv<I>(fm, qb(xs), ik);
+                    ik.info = (uint32_t)(xs + 1);
+                    i = xs + 1; n = 0;
+                    phase = S2_FWD0;
+                }
             }
         }
         if (phase == S2_FWD0) {                     // is there a base to extend with?

@@ -70,10 +70,11 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
             al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
             assert_same(al.alignSequences(seqs), exp, "split=%d heavy_stream=%d heavy_seeds=%d" % (split, hs, thr))
     # ahead-of-time extension of the heavy reads' chains: off, and with a table too small for most reads (in-place fallback)
-    for knob, val in (("cand_mode", 0), ("cand_cap", 7), ("heavy_sorted", 0)):
+    for knob, val in (("cand_mode", 0), ("cand_cap", 7), ("cand_cap", 1 << 20), ("heavy_sorted", 0)):
         al = sl.BWAAligner(tiny_gpu)
         al.set("split_min", 16)
         al.set("heavy_seeds", 3)
+        al.set("cand_seeds", 1)        # every heavy read gets its regions ahead of time (default: only the very heavy ones)
         al.set(knob, val)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
