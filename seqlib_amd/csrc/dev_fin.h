@@ -222,16 +222,43 @@ __device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const 
 
 // mem_sort_dedup_patch + mem_mark_primary_se for one read; returns the number of regions left (their handles are
 // w.ia[0..n) in mem_mark_primary_se order).  Shared by the fused and the split finalize kernels.
+// LDS staging for the three ks_introsort passes of a read with MANY regions (wave-per-read kernel only).  klib's introsort is
+// unstable and its tie order shows in the output, so the serial algorithm itself is kept; what changes is where it runs: one
+// lane sorts handles against keys held in LDS instead of chasing 96-byte region records through global memory (a
+// 1 000-region read spent ~100 ms in these sorts).
+struct SortStage {
+    int *idx;         // handles being sorted
+    int64_t *k64;     // key by handle: re / rb / hash
+    int *ka, *kb;     // keys by handle: score, qb
+    int nmax;         // capacity (handles)
+    int lane;
+};
+
 template <int MAXQ, typename SC>
-__device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query, SC &sc)
+__device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query, SC &sc,
+                            const SortStage *ss = nullptr)
 {
         int n = ck.n_reg[r];
         int *a = w.ia;                            // region handles
         DReg *G = w.regs;
+        const bool staged = ss != nullptr && n <= ss->nmax && n >= 2;
+        // sort a[0..m) with `less` over handles: in LDS by one lane when staged (fill(h) copies handle h's keys), else in place
+        auto sort_handles = [&](int m, auto fill, auto less_lds, auto less_glb) {
+            if (!staged) { ks_introsort_idx(m, a, less_glb); return; }
+            __threadfence_block();                                   // a[] and G[] were last written by other lanes' stores
+            for (int i = ss->lane; i < m; i += 64) { const int h = a[i]; ss->idx[i] = h; fill(h); }
+            __syncthreads();
+            if (ss->lane == 0) ks_introsort_idx(m, ss->idx, less_lds);
+            __syncthreads();
+            for (int i = ss->lane; i < m; i += 64) a[i] = ss->idx[i];
+            __threadfence_block();
+        };
         for (int i = 0; i < n; ++i) a[i] = i;
         // ---------------- mem_sort_dedup_patch
         if (n > 1) {
-            ks_introsort_idx(n, a, [&](int x, int y) { return G[x].re < G[y].re; });
+            sort_handles(n, [&](int h) { ss->k64[h] = G[h].re; },
+                         [&](int x, int y) { return ss->k64[x] < ss->k64[y]; },
+                         [&](int x, int y) { return G[x].re < G[y].re; });
             for (int i = 0; i < n; ++i) G[a[i]].n_comp = 1;
             for (int i = 1; i < n; ++i) {
                 DReg &p = G[a[i]];
@@ -263,10 +290,16 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             int m = 0;
             for (int i = 0; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
             n = m;
-            ks_introsort_idx(n, a, [&](int x, int y) {
-                const DReg &X = G[x], &Y = G[y];
-                return X.score > Y.score || (X.score == Y.score && (X.rb < Y.rb || (X.rb == Y.rb && X.qb < Y.qb)));
-            });
+            sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = G[h].rb; ss->kb[h] = G[h].qb; },
+                         [&](int x, int y) {
+                             const int sx = ss->ka[x], sy = ss->ka[y];
+                             const int64_t bx = ss->k64[x], by = ss->k64[y];
+                             return sx > sy || (sx == sy && (bx < by || (bx == by && ss->kb[x] < ss->kb[y])));
+                         },
+                         [&](int x, int y) {
+                             const DReg &X = G[x], &Y = G[y];
+                             return X.score > Y.score || (X.score == Y.score && (X.rb < Y.rb || (X.rb == Y.rb && X.qb < Y.qb)));
+                         });
             for (int i = 1; i < n; ++i)
                 if (G[a[i]].score == G[a[i - 1]].score && G[a[i]].rb == G[a[i - 1]].rb && G[a[i]].qb == G[a[i - 1]].qb)
                     G[a[i]].qe = G[a[i]].qb;
@@ -283,10 +316,15 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 p.sub = 0; p.secondary = -1;
                 p.hash = dev_hash_64(id + (uint64_t)i);
             }
-            ks_introsort_idx(n, a, [&](int x, int y) {
-                const DReg &X = G[x], &Y = G[y];
-                return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // is_alt is 0 for every region
-            });
+            sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
+                         [&](int x, int y) {
+                             const int sx = ss->ka[x], sy = ss->ka[y];
+                             return sx > sy || (sx == sy && (uint64_t)ss->k64[x] < (uint64_t)ss->k64[y]);
+                         },
+                         [&](int x, int y) {
+                             const DReg &X = G[x], &Y = G[y];
+                             return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // is_alt is 0 for every region
+                         });
             int tmp = opt.a + opt.b;
             tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
             tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;

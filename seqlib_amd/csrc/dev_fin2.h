@@ -41,8 +41,11 @@ __device__ __forceinline__ int dpp_incl_max_scan_g(int v)
 }
 
 template <int CPL, typename QF, typename TF>
-__device__ int wave_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, int lane)
+__device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_opt &o, const MatRows &mr, int w_, uint8_t *z, int n_col_, int lane)
 {
+    // every lane passes the same job: pin its parameters to scalar registers (band limits and the row loop become scalar code)
+    const int qlen = __builtin_amdgcn_readfirstlane(qlen_), tlen = __builtin_amdgcn_readfirstlane(tlen_);
+    const int w = __builtin_amdgcn_readfirstlane(w_), n_col = __builtin_amdgcn_readfirstlane(n_col_);
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int j0 = lane * CPL;
@@ -205,12 +208,13 @@ __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt
 // Regions of one read -> hits + CIGAR jobs (shared by the lane-per-read and the wave-per-read kernel; `leader` = the
 // lane that performs the list pushes: every lane in the former, lane 0 in the latter).
 template <int MAXQ, typename SC>
-__device__ void dev_regs_read(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, int r, SC &sc, bool leader)
+__device__ void dev_regs_read(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, int r, SC &sc, bool leader,
+                              const SortStage *ss = nullptr)
 {
     ReadWS w = make_ws(ck, r);
     const uint8_t *query = ck.codes + ck.offs[r];
     const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-    const int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, sc);
+    const int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, sc, ss);
     const int *a = w.ia;
     const DReg *G = w.regs;
     const uint64_t so = ck.seed_off[r];
@@ -243,8 +247,9 @@ __global__ void __launch_bounds__(256) k_regs1(Chunk ck, DevOpt dopt, FinLists f
 }
 
 template <int MAXQ>
-__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
-{
+__global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave,
+                                              int big_regs = 0)
+{   // big_regs > 0: reads with at least that many regions are left to k_regs_wave
     const slx_opt &opt = dopt.o;
     int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
     const int n_todo = (int)*n_slots;
@@ -256,22 +261,32 @@ __global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, F
         const int slot = next_slot(queue, per_wave);
         if (__all(slot >= n_todo)) break;
         if (slot >= n_todo) continue;
-        dev_regs_read<MAXQ>(R, ck, opt, fl, order ? order[slot] : slot, sc, true);
+        const int r = order ? order[slot] : slot;
+        if (!(big_regs > 0 && ck.n_reg[r] >= big_regs)) dev_regs_read<MAXQ>(R, ck, opt, fl, r, sc, true);
     }
 }
 
 // reads with two or more regions: one wave per read, mem_patch_reg's global alignment runs wave-parallel
 template <int MAXQ>
-__device__ __noinline__ void dev_regs_read_wave(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl, int r, int lane)
+__device__ __noinline__ void dev_regs_read_wave(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl, int r, int lane,
+                                                const SortStage *ss)
 {
     WaveScorer<MAXQ> sc{R, opt, mr, lane};
-    dev_regs_read<MAXQ>(R, ck, opt, fl, r, sc, lane == 0);
+    dev_regs_read<MAXQ>(R, ck, opt, fl, r, sc, lane == 0, ss);
 }
 
+#define REGS_BIG_N 2048      // handles the LDS sort stage of k_regs_wave holds (40 KB)
+// one wave per read, for reads with at least min_regs regions (0: every read of the list): mem_patch_reg's global alignment runs
+// wave-parallel and the region sorts run against keys staged in LDS
 template <int MAXQ>
-__global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
+__global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots,
+                                                  int min_regs)
 {
+    __shared__ int s_idx[REGS_BIG_N], s_ka[REGS_BIG_N], s_kb[REGS_BIG_N];
+    __shared__ int64_t s_k64[REGS_BIG_N];
     const int lane = threadIdx.x;
+    SortStage ss;
+    ss.idx = s_idx; ss.k64 = s_k64; ss.ka = s_ka; ss.kb = s_kb; ss.nmax = REGS_BIG_N; ss.lane = lane;
     const MatRows mr = make_matrows(dopt.o.mat);
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     for (;;) {
@@ -279,7 +294,9 @@ __global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dop
         if (lane == 0) slot = (int)atomicAdd(queue, 1u);
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
-        dev_regs_read_wave<MAXQ>(R, ck, dopt.o, mr, fl, order ? order[slot] : slot, lane);
+        const int r = order ? order[slot] : slot;
+        const bool mine = __builtin_amdgcn_readfirstlane(ck.n_reg[r]) >= min_regs;
+        if (mine) dev_regs_read_wave<MAXQ>(R, ck, dopt.o, mr, fl, r, lane, &ss);
     }
 }
 

@@ -120,6 +120,8 @@ struct slx_aligner {
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
     int regs_mode = 2;            // 2 = reads with <= 1 region take the straight-line kernel, the rest the lane-per-read one; 1 = the rest go to
                                   // the wave-per-read kernel; 0 = every read on the lane-per-read kernel
+    int regs_big = 1 << 30;       // reads with at least this many regions take the wave-per-read region kernel with LDS-staged sorts (regs_mode 2);
+                                  // measured slower than one lane per read on the C2 workload (66 vs 49 ms per 10 M reads), so off by default
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 512;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
@@ -348,6 +350,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
+    else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "regs_mode")) al->regs_mode = (int)value;
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
@@ -428,7 +431,7 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
                            wk->part_pos.as<unsigned int>(), n_est, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_in.as<int>(), q + 2, cnt2, 0);
         hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n_est / 8 + 1, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, fl,
-                           wk->order_out.as<int>(), q + 9, cnt2 + 1);
+                           wk->order_out.as<int>(), q + 9, cnt2 + 1, 0);
     } else if (al->regs_mode == 2 && !sub && !order) {
         unsigned int *cnt2 = q + 32;
         hipLaunchKernelGGL(k_part_flags_nreg, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, ck.n_reg, n_est, wk->part_flag.as<unsigned int>());
@@ -437,7 +440,11 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
         hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
                            wk->part_pos.as<unsigned int>(), n_est, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
         hipLaunchKernelGGL(k_regs1, dim3(std::max(1, std::min(n_est / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, ck, dopt, fl, wk->order_in.as<int>(), cnt2);
-        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0);
+        // reads with many regions (low-complexity tracts) first, one wave each with the sorts staged in LDS; the rest one per lane
+        if (al->regs_big < (1 << 20))
+            hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n_est / 64 + 1, al->n_cu * 4))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                               wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big);
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
         split_hits = true;
     } else
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, order, q + 2, n_slots, sub);
@@ -874,6 +881,8 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
                 al->n_retries += attempt;
                 break;
             }
+            if (getenv("SLX_DEBUG_RETRY")) fprintf(stderr, "[retry] worker %d reads %lld+%d attempt %d flags 0x%x (cap_intv %d zcap %llu cigcap %llu)\n", wk->id,
+                                                   (long long)r0, n, attempt, fl, caps.cap_intv, caps.zcap, caps.cigcap);
             if (fl & (ERR_LOGLUT | ERR_INTERNAL)) { slx_set_error("device pipeline error flags 0x%x", fl); return SLX_EINTERNAL; }
             if (attempt >= 8) { slx_set_error("chunk still overflows its work areas after %d retries (flags 0x%x)", attempt, fl); return SLX_ENOMEM; }
             if (fl & OVF_INTV) caps.cap_intv *= 2;
