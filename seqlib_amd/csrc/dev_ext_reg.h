@@ -373,31 +373,87 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
             // ---- the chain's seeds in the order mem_chain2aln takes them (ascending (length, list index), walked from the top):
             // ranks by an all-pairs count on registers (keys are distinct), records scattered to a sorted SoA scratch
             DBG_T0();
-            for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i;
-            __threadfence_block();                                 // other lanes read these keys below
-            for (int i0 = 0; i0 < n; i0 += WAVE) {
-                const int i = i0 + lane;
-                const bool mine = i < n;
-                const int sid = mine ? cs[i] : 0;
+            uint32_t my_ql = 0; int64_t my_rb = 0; int my_rank = -1;   // n <= 64: this lane's seed and its rank, for the batch test below
+            if (n <= WAVE) {                                       // the common case: keys never leave the registers
+                const bool mine = lane < n;
+                const int sid = mine ? cs[lane] : 0;
                 const uint32_t ql = mine ? w.s_ql[sid] : 0u;
                 const int64_t rb = mine ? w.s_rbeg[sid] : 0;
-                const uint64_t key = (uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)i;
+                const uint64_t key = mine ? ((uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)lane) : ~0ull;
                 int rank = 0;
-                for (int b0 = 0; b0 < n; b0 += WAVE) {
-                    const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
-                    const int nb = n - b0 < WAVE ? n - b0 : WAVE;
-                    for (int j = 0; j < nb; ++j) {
-                        const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), j) << 32 |
-                                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, j);
-                        rank += kj < key ? 1 : 0;
-                    }
+                for (int j = 0; j < n; ++j) {
+                    const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), j) << 32 |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, j);
+                    rank += kj < key ? 1 : 0;
                 }
-                if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; }
+                if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; my_ql = ql; my_rb = rb; my_rank = rank; }
+            } else {
+                for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i;
+                __threadfence_block();                                 // other lanes read these keys below
+                for (int i0 = 0; i0 < n; i0 += WAVE) {
+                    const int i = i0 + lane;
+                    const bool mine = i < n;
+                    const int sid = mine ? cs[i] : 0;
+                    const uint32_t ql = mine ? w.s_ql[sid] : 0u;
+                    const int64_t rb = mine ? w.s_rbeg[sid] : 0;
+                    const uint64_t key = (uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)i;
+                    int rank = 0;
+                    for (int b0 = 0; b0 < n; b0 += WAVE) {
+                        const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
+                        const int nb = n - b0 < WAVE ? n - b0 : WAVE;
+                        for (int j = 0; j < nb; ++j) {
+                            const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), j) << 32 |
+                                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, j);
+                            rank += kj < key ? 1 : 0;
+                        }
+                    }
+                    if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; }
+                }
             }
             __threadfence_block();
             DBG_T1(t_sort);
+            bool top_kept = false;                                 // was the chain's first (longest) seed extended?
             for (int k = n - 1; k >= 0; --k) {
                 DBG_T0();
+                if (k == n - 2 && n <= WAVE && n_av <= 4) {
+                    // The usual fate of the remaining seeds (the LAST-like seeds of pass 3, reseeds): each is covered by a region found
+                    // so far and no extended seed of the chain crosses it on another diagonal, so each is dropped in turn.  By induction
+                    // over that order only the top seed can be "extended" for the other-diagonal test, so all of them can be judged at
+                    // once, one seed per lane; if any lane disagrees the scalar order below takes over unchanged.
+                    const uint32_t f_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd_ql[n - 1]);
+                    const int64_t f_rb = (int64_t)rfl_u64((uint64_t)sd_rb[n - 1]);
+                    bool fail = false;
+                    if (my_rank >= 0 && my_rank <= n - 2) {
+                        const int q0 = (int)(my_ql >> 16), l0 = (int)(my_ql & 0xffffu);
+                        bool cov = false;
+                        for (int ri = 0; ri < n_av; ++ri) {
+                            const int64_t prb = rg_rb[ri], pre_ = rg_re[ri];
+                            const uint32_t pq = rg_q[ri];
+                            const int pw = rg_w[ri], psl0 = rg_sl0[ri];
+                            const int pqb = (int)(pq >> 16), pqe = (int)(pq & 0xffffu);
+                            if (!(my_rb < prb || my_rb + l0 > pre_ || q0 < pqb || q0 + l0 > pqe) && !((double)(l0 - psl0) > .1 * l_query)) {
+                                int qd = q0 - pqb; int64_t rd = my_rb - prb;
+                                int mg = max_gap_of(qd < rd ? qd : (int)rd);
+                                int ww = mg < pw ? mg : pw;
+                                if (qd - rd < ww && rd - qd < ww) cov = true;
+                                qd = pqe - (q0 + l0); rd = pre_ - (my_rb + l0);
+                                mg = max_gap_of(qd < rd ? qd : (int)rd);
+                                ww = mg < pw ? mg : pw;
+                                if (qd - rd < ww && rd - qd < ww) cov = true;
+                            }
+                        }
+                        bool cross = false;
+                        if (top_kept) {
+                            const int t_qbeg = (int)(f_ql >> 16), t_len = (int)(f_ql & 0xffffu);
+                            if (!((double)t_len < l0 * .95)) {
+                                if (q0 <= t_qbeg && q0 + l0 - t_qbeg >= l0 >> 2 && t_qbeg - q0 != f_rb - my_rb) cross = true;
+                                if (t_qbeg <= q0 && t_qbeg + t_len - q0 >= l0 >> 2 && q0 - t_qbeg != my_rb - f_rb) cross = true;
+                            }
+                        }
+                        fail = !cov || cross;
+                    }
+                    if (__ballot(fail) == 0) { DBG_T1(t_test); break; }
+                }
                 const uint32_t s_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd_ql[k]);
                 const int s = __builtin_amdgcn_readfirstlane(sd_s[k]);
                 const int s_qbeg = (int)(s_ql >> 16), s_len = (int)(s_ql & 0xffffu);
@@ -469,6 +525,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
                     a.seedcov = cov;
                 }
+                if (k == n - 1) top_kept = true;
                 // every lane stores the same bytes (region + its keys for the covered test), so every lane may read them back
                 w.regs[n_av] = a;
                 rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = (uint32_t)a.qb << 16 | (uint32_t)a.qe; rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;

@@ -122,6 +122,7 @@ struct slx_aligner {
                                   // the wave-per-read kernel; 0 = every read on the lane-per-read kernel
     int regs_big = 1 << 30;       // reads with at least this many regions take the wave-per-read region kernel with LDS-staged sorts (regs_mode 2);
                                   // measured slower than one lane per read on the C2 workload (66 vs 49 ms per 10 M reads), so off by default
+    int stagger = 0;              // 1 = each worker cuts its part in two at a different point (see worker_run)
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 512;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
@@ -350,6 +351,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
+    else if (!strcmp(key, "stagger")) al->stagger = (int)value;
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "regs_mode")) al->regs_mode = (int)value;
@@ -843,8 +845,14 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
     const int64_t n_part = r_hi - r_lo;
     if ((rc = wk->o_hit_off.ensure(((size_t)n_part + 1) * 8)) != SLX_OK) return rc;
     int64_t hit_base = 0, cig_base = 0;
-    for (int64_t r0 = r_lo; r0 < r_hi; r0 += al->chunk_reads) {
-        const int n = (int)std::min<int64_t>(al->chunk_reads, r_hi - r0);
+    // stagger: the workers of a batch run the same stage sequence on equal parts, so their low-occupancy stage tails coincide;
+    // with it, worker k cuts its part in two at a different point (k+1)/(K+1), which shifts the stage boundaries apart
+    int64_t first_cut = 0;
+    if (al->stagger && al->active_k > 1 && n_part >= 4 * al->min_split) first_cut = n_part * (wk->id + 1) / (al->active_k + 1);
+    for (int64_t r0 = r_lo, step = 0; r0 < r_hi; r0 += step) {
+        const int64_t want = (first_cut && r0 == r_lo) ? first_cut : al->chunk_reads;
+        const int n = (int)std::min<int64_t>(want, r_hi - r0);
+        step = n;
         wk->h_offs.resize((size_t)n + 1);
         HIPCHK(hipMemcpyAsync(wk->h_offs.data(), d_offs + r0, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, wk->stream));
         HIPCHK(hipStreamSynchronize(wk->stream));
