@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
         const int r = first ? (slot < n_head ? first[slot] : order[slot - n_head]) : (order ? order[slot] : slot);
-        const unsigned long long t_in = ck.dbg_cyc ? __builtin_readcyclecounter() : 0ull;
+        const bool dbg = ck.dbg_cyc && ck.dbg_stage == 1;
+        const unsigned long long t_in = dbg ? __builtin_readcyclecounter() : 0ull;
         const int n_chn = __builtin_amdgcn_readfirstlane(ck.n_chain[r]);
         if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
         // one read per wave: everything below that is the same in all 64 lanes is pinned to scalar registers
@@ -325,8 +326,8 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         const int cand_at = ck.cand_base ? __builtin_amdgcn_readfirstlane(ck.cand_base[r]) : -1;
         int n_av = 0;
         unsigned long long t_sort = 0, t_test = 0, t_dp = 0, t_mark;
-#define DBG_T0() do { if (ck.dbg_cyc) t_mark = __builtin_readcyclecounter(); } while (0)
-#define DBG_T1(acc) do { if (ck.dbg_cyc) acc += __builtin_readcyclecounter() - t_mark; } while (0)
+#define DBG_T0() do { if (dbg) t_mark = __builtin_readcyclecounter(); } while (0)
+#define DBG_T1(acc) do { if (dbg) acc += __builtin_readcyclecounter() - t_mark; } while (0)
         // SoA scratch in the read's (still unused) hit slots, 40 bytes per seed slot, plus the free ib list: keys of the regions found
         // so far for the covered test, and the current chain's seeds in sorted order
         static_assert(sizeof(DHit) == 40, "scratch layout below fills exactly one DHit per seed slot");
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
             }
         }
         ck.n_reg[r] = n_av;
-        if (ck.dbg_cyc && lane == 0) {
+        if (dbg && lane == 0) {
             ck.dbg_cyc[r] = __builtin_readcyclecounter() - t_in;
             ck.dbg_cyc[(size_t)ck.n_reads + r] = t_sort; ck.dbg_cyc[2 * (size_t)ck.n_reads + r] = t_test; ck.dbg_cyc[3 * (size_t)ck.n_reads + r] = t_dp;
         }

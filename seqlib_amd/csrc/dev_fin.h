@@ -132,23 +132,33 @@ __device__ GenCig dev_gen_cigar2(const DevRef &R, const slx_opt &o, const Chunk 
 // mem_patch_reg
 // SC = the global-alignment scorer: sc(band, l_query, query segment, rb, re) -> bwa_gen_cigar2's score (no CIGAR).
 // One lane with private rows in the lane-per-read kernels, the wave-parallel DP in the wave-per-read one.
+// the tests of mem_patch_reg that come before its global alignment: the band to align with, or -1 = no patch
+__device__ __forceinline__ int dev_patch_pre(const DevRef &R, const slx_opt &o, int64_t a_rb, int64_t a_re, int a_qb, int a_qe, int a_w,
+                                             int64_t b_rb, int64_t b_re, int b_qb, int b_qe, int b_w)
+{
+    int w;
+    double r;
+    if (a_rb < R.l_pac && b_rb >= R.l_pac) return -1;
+    if (a_qb >= b_qb || a_qe >= b_qe || a_re >= b_re) return -1;
+    w = (int)((a_re - b_rb) - (a_qe - b_qb));
+    w = w > 0 ? w : -w;
+    r = (double)(a_re - b_rb) / (double)(b_re - a_rb) - (double)(a_qe - b_qb) / (double)(b_qe - a_qb);
+    r = r > 0. ? r : -r;
+    if (a_re < b_rb || a_qe < b_qb) {
+        if (w > o.w << 1 || r >= (double)0.05f) return -1;
+    } else if (w > o.w << 2 || r >= (double)(0.05f * 2)) return -1;
+    w += a_w + b_w;
+    w = w < o.w << 2 ? w : o.w << 2;
+    return w;
+}
+
 template <int MAXQ, typename SC>
 __device__ int dev_patch_reg(const DevRef &R, const slx_opt &o, const Chunk &ck, const uint8_t *query, const DReg &a, const DReg &b,
                              int *_w, SC &sc)
 {
-    int w, score, q_s, r_s;
-    double r;
-    if (a.rb < R.l_pac && b.rb >= R.l_pac) return 0;
-    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
-    w = (int)((a.re - b.rb) - (a.qe - b.qb));
-    w = w > 0 ? w : -w;
-    r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
-    r = r > 0. ? r : -r;
-    if (a.re < b.rb || a.qe < b.qb) {
-        if (w > o.w << 1 || r >= (double)0.05f) return 0;
-    } else if (w > o.w << 2 || r >= (double)(0.05f * 2)) return 0;
-    w += a.w + b.w;
-    w = w < o.w << 2 ? w : o.w << 2;
+    int score, q_s, r_s;
+    const int w = dev_patch_pre(R, o, a.rb, a.re, a.qb, a.qe, a.w, b.rb, b.re, b.qb, b.qe, b.w);
+    if (w < 0) return 0;
     score = sc(w, b.qe - a.qb, query + a.qb, a.rb, b.re);
     q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
     r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (double)(b.score + a.score) + .499);
@@ -230,6 +240,8 @@ struct SortStage {
     int *idx;         // handles being sorted
     int64_t *k64;     // key by handle: re / rb / hash
     int *ka, *kb;     // keys by handle: score, qb
+    int64_t *m_rb;    // mirror of the region fields the de-duplication loop reads (by handle); re / score / qb live in k64 / ka / kb
+    int *m_qe, *m_rid, *m_w;
     int nmax;         // capacity (handles)
     int lane;
 };
@@ -242,6 +254,8 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
         int *a = w.ia;                            // region handles
         DReg *G = w.regs;
         const bool staged = ss != nullptr && n <= ss->nmax && n >= 2;
+        const bool dbg = ck.dbg_cyc && ck.dbg_stage == 2;
+        unsigned long long t0 = dbg ? __builtin_readcyclecounter() : 0ull, t1 = t0, t2 = t0, t3 = t0;
         // sort a[0..m) with `less` over handles: in LDS by one lane when staged (fill(h) copies handle h's keys), else in place
         auto sort_handles = [&](int m, auto fill, auto less_lds, auto less_glb) {
             if (!staged) { ks_introsort_idx(m, a, less_glb); return; }
@@ -259,7 +273,89 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             sort_handles(n, [&](int h) { ss->k64[h] = G[h].re; },
                          [&](int x, int y) { return ss->k64[x] < ss->k64[y]; },
                          [&](int x, int y) { return G[x].re < G[y].re; });
-            for (int i = 0; i < n; ++i) G[a[i]].n_comp = 1;
+            if (dbg) t1 = __builtin_readcyclecounter();
+            if (staged) { for (int i = ss->lane; i < n; i += 64) G[i].n_comp = 1; __threadfence_block(); }
+            else for (int i = 0; i < n; ++i) G[a[i]].n_comp = 1;
+            if (staged) {
+                // The reads that come here have ~1 000 regions from one repeat tract: the window of the scalar j-loop is "every region
+                // before i" and the loop is quadratic (41 of 56 ms for one such read on one lane).  Same decisions, 64 j's at a time:
+                // each lane classifies its q against the current p; removals of q's (which do not change p) that precede the first
+                // p-changing event in j order are applied together; that event (p removed / a patch attempt, whose alignment runs on
+                // the whole wave) is then handled alone and the scan resumes below it with the new p.
+                const int lane = ss->lane;
+                int64_t *m_re = ss->k64; int *m_sc = ss->ka, *m_qb = ss->kb;
+                for (int h = lane; h < n; h += 64) {
+                    const DReg &g = G[h];
+                    ss->m_rb[h] = g.rb; m_re[h] = g.re; m_qb[h] = g.qb; ss->m_qe[h] = g.qe; ss->m_rid[h] = g.rid; m_sc[h] = g.score; ss->m_w[h] = g.w;
+                }
+                __syncthreads();
+                for (int i = 1; i < n; ++i) {
+                    const int ph = ss->idx[i], prevh = ss->idx[i - 1];
+                    if (ss->m_rid[ph] != ss->m_rid[prevh] || ss->m_rb[ph] >= m_re[prevh] + opt.max_chain_gap) continue;
+                    int jtop = i - 1;
+                    while (jtop >= 0) {
+                        const int64_t p_rb = ss->m_rb[ph], p_re = m_re[ph];
+                        const int p_qb = m_qb[ph], p_qe = ss->m_qe[ph], p_rid = ss->m_rid[ph], p_sc = m_sc[ph], p_w = ss->m_w[ph];
+                        const int j = jtop - lane;
+                        const bool valid = j >= 0;
+                        const int qh = ss->idx[valid ? j : 0];
+                        const int64_t q_rb = ss->m_rb[qh], q_re = m_re[qh];
+                        const int q_qb = m_qb[qh], q_qe = ss->m_qe[qh], q_sc = m_sc[qh], q_w = ss->m_w[qh];
+                        const bool cond = valid && p_rid == ss->m_rid[qh] && p_rb < q_re + opt.max_chain_gap;
+                        const unsigned long long stopm = __ballot(!cond);
+                        const int first_stop = stopm ? (int)__ffsll((long long)stopm) - 1 : 64;
+                        const bool live = lane < first_stop;
+                        int cat = 0;                         // 0 nothing, 1 = q redundant, 2 = p redundant (ends the scan), 3 = patch attempt
+                        if (live && q_qe != q_qb) {
+                            const int64_t orr = q_re - p_rb;
+                            const int64_t oq = q_qb < p_qb ? q_qe - p_qb : p_qe - q_qb;
+                            const int64_t mr = q_re - q_rb < p_re - p_rb ? q_re - q_rb : p_re - p_rb;
+                            const int64_t mq = q_qe - q_qb < p_qe - p_qb ? q_qe - q_qb : p_qe - p_qb;
+                            if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) cat = p_sc < q_sc ? 2 : 1;
+                            else if (q_rb < p_rb && dev_patch_pre(R, opt, q_rb, q_re, q_qb, q_qe, q_w, p_rb, p_re, p_qb, p_qe, p_w) >= 0) cat = 3;
+                        }
+                        const unsigned long long evm = __ballot(cat >= 2);
+                        const int first_ev = evm ? (int)__ffsll((long long)evm) - 1 : 64;
+                        if (cat == 1 && lane < first_ev) { ss->m_qe[qh] = q_qb; G[qh].qe = q_qb; }        // q.qe = q.qb
+                        __syncthreads();
+                        if (first_ev == 64) {                // no p-changing event among the live lanes
+                            if (first_stop < 64) break;
+                            jtop -= 64;
+                            continue;
+                        }
+                        const int ev_cat = __builtin_amdgcn_readlane(cat, first_ev);
+                        const int ev_q = __builtin_amdgcn_readlane(qh, first_ev);
+                        if (ev_cat == 2) {                   // p.qe = p.qb; break
+                            if (lane == 0) { ss->m_qe[ph] = p_qb; G[ph].qe = p_qb; }
+                            __syncthreads();
+                            break;
+                        }
+                        {                                    // patch attempt with q = ev_q
+                            DReg &pp = G[ph];
+                            DReg &q = G[ev_q];
+                            int ww = 0;
+                            const int score = dev_patch_reg<MAXQ>(R, opt, ck, query, q, pp, &ww, sc);
+                            if (score > 0) {                 // every lane stores the same values
+                                pp.n_comp += q.n_comp + 1;
+                                pp.seedcov = pp.seedcov > q.seedcov ? pp.seedcov : q.seedcov;
+                                pp.sub = pp.sub > q.sub ? pp.sub : q.sub;
+                                pp.csub = pp.csub > q.csub ? pp.csub : q.csub;
+                                pp.qb = q.qb; pp.rb = q.rb;
+                                pp.truesc = pp.score = score;
+                                pp.w = ww;
+                                q.qb = q.qe;
+                                if (lane == 0) {
+                                    m_qb[ph] = m_qb[ev_q]; ss->m_rb[ph] = ss->m_rb[ev_q]; m_sc[ph] = score; ss->m_w[ph] = ww;
+                                    m_qb[ev_q] = ss->m_qe[ev_q];
+                                }
+                                __syncthreads();
+                            }
+                        }
+                        jtop -= first_ev + 1;                // resume just below the event with the (possibly new) p
+                    }
+                }
+                __threadfence_block();
+            } else
             for (int i = 1; i < n; ++i) {
                 DReg &p = G[a[i]];
                 if (p.rid != G[a[i - 1]].rid || p.rb >= G[a[i - 1]].re + opt.max_chain_gap) continue;
@@ -287,6 +383,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                     }
                 }
             }
+            if (dbg) t2 = __builtin_readcyclecounter();
             int m = 0;
             for (int i = 0; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
             n = m;
@@ -307,6 +404,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             for (int i = 1; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
             n = m;
         }
+        if (dbg) t3 = __builtin_readcyclecounter();
         ck.na[r] = n;
         // ---------------- mem_mark_primary_se (salt = this read's lrand48() draw)
         if (n > 0) {
@@ -349,6 +447,11 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 if (k == nz) z[nz++] = i;
                 else ai.secondary = z[k];
             }
+        }
+        if (dbg) {
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            ck.dbg_cyc[r] = t4 - t0; ck.dbg_cyc[(size_t)ck.n_reads + r] = t1 - t0; ck.dbg_cyc[2 * (size_t)ck.n_reads + r] = t2 - t1;
+            ck.dbg_cyc[3 * (size_t)ck.n_reads + r] = t3 - t2;
         }
         return n;
 }

@@ -80,7 +80,8 @@ struct Chunk {
     // regions of heavy reads' chains extended ahead of time (k_extend_cand): cand[cand_base[r] + chain index], cand_base[r] < 0 = none
     const DReg *cand;
     const int32_t *cand_base;
-    unsigned long long *dbg_cyc;   // SLX_DEBUG_CYC: cycles the extension kernel spent on each read (null otherwise)
+    unsigned long long *dbg_cyc;   // SLX_DEBUG_CYC: cycles a kernel spent on each read, 4 arrays of n_reads (null otherwise)
+    int dbg_stage;                 // 1 = the extension kernel fills them, 2 = the region kernel
     // per-read results
     int32_t *n_chain;         // kept chains
     int32_t *n_reg;

@@ -120,8 +120,8 @@ struct slx_aligner {
     int ext_mode = 2;             // 2 = register-resident wave-cooperative extension, 1 = LDS variant, 0 = one lane per read
     int regs_mode = 2;            // 2 = reads with <= 1 region take the straight-line kernel, the rest the lane-per-read one; 1 = the rest go to
                                   // the wave-per-read kernel; 0 = every read on the lane-per-read kernel
-    int regs_big = 1 << 30;       // reads with at least this many regions take the wave-per-read region kernel with LDS-staged sorts (regs_mode 2);
-                                  // measured slower than one lane per read on the C2 workload (66 vs 49 ms per 10 M reads), so off by default
+    int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
+                                  // quadratic de-duplication scan 64 candidates at a time (regs_mode 2); 1 << 30 = off
     int stagger = 0;              // 1 = each worker cuts its part in two at a different point (see worker_run)
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
@@ -572,6 +572,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         ENS(dbg_cyc, (size_t)n * 32);
         HIPCHK(hipMemsetAsync(wk->dbg_cyc.p, 0, (size_t)n * 32, st));
         ck.dbg_cyc = wk->dbg_cyc.as<unsigned long long>();
+        ck.dbg_stage = atoi(getenv("SLX_DEBUG_CYC"));
     }
     DevOpt dopt; dopt.o = *opt;
     DevFM<uint32_t> fm = al->fm32;
@@ -808,7 +809,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         fprintf(stderr, "[ext cycles] n=%d total=%.3g (100 MHz ticks) heavy share=%.3f\n", n, (double)tot, tot ? (double)tot_heavy / (double)tot : 0.0);
         for (int i = 0; i < top; ++i) {
             const size_t r = (size_t)ord[(size_t)i];
-            fprintf(stderr, "  read %zu: %.3g ticks (sort %.3g, covered tests %.3g, extend+store %.3g)  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r],
+            fprintf(stderr, "  read %zu: %.3g ticks (A %.3g, B %.3g, C %.3g; stage 1: sort, covered tests, extend+store; stage 2: sort by end, dedup/patch, second sort)  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r],
                     (double)cyc[(size_t)n + r], (double)cyc[2 * (size_t)n + r], (double)cyc[3 * (size_t)n + r], sc[r], nch[r], nrg[r]);
         }
     }

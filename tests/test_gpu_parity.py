@@ -79,7 +79,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1), ("regs_big", 2), ("regs_big", 5)])
+@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1), ("regs_big", 2), ("regs_big", 5), ("regs_big", 1073741824)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
     a tiny interval capacity that forces the overflow-retry path: identical records."""
