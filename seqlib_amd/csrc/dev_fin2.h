@@ -27,7 +27,7 @@ struct FinLists {
 };
 
 // ---------------------------------------------------------------- wave-cooperative ksw_global2
-#define G_NEG (-0x7f000000)
+#define G_NEG ((int)0x80000000)     // identity of the signed max scan: with exactly INT_MIN the compiler folds every step into one v_max_i32 with a DPP operand
 
 __device__ __forceinline__ int dpp_incl_max_scan_g(int v)
 {
@@ -49,11 +49,14 @@ __device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_op
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int j0 = lane * CPL;
-    int H[CPL], E[CPL], qc[CPL];
+    const MatCols mc = make_matcols(o.mat);
+    int H[CPL], E[CPL];
+    uint32_t P[CPL];                              // this column's scores against target base 0..3, one byte each
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int j = j0 + k;
-        qc[k] = j < qlen ? qf(j) : 4;
+        const int q = j < qlen ? qf(j) : 4;
+        P[k] = q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
         H[k] = j == 0 ? 0 : (j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
         E[k] = DEV_MINUS_INF;
     }
@@ -62,8 +65,7 @@ __device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_op
     for (int i = 0; i < tlen; ++i) {
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
-        const uint32_t rowp = mr.packed[t];
-        const int row4 = mr.q4[t];
+        const uint32_t sh = (uint32_t)t << 3;
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_MINUS_INF;
@@ -73,8 +75,7 @@ __device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_op
         for (int k = 0; k < CPL; ++k) {
             const int j = j0 + k;
             const bool act = j >= beg && j < end;
-            const int q = qc[k];
-            const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            const int s = __builtin_amdgcn_sbfe((int)P[k], sh, 8u);
             M[k] = H[k] + s;
             const int u = act ? M[k] - oe_ins + j * e_ins : G_NEG;
             run = imax(run, u);
@@ -332,10 +333,41 @@ __global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists f
         const uint8_t *query = ck.codes + ck.offs[j.r];
         const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
         const int lq = j.qe - j.qb;
-        // NM: mismatches along the diagonal (orientation does not matter for a count)
-        int nm = 0;
-        for (int i = 0; i < lq; ++i) {
-            const int qc = query[j.qb + i];
+        // NM: mismatches along the diagonal (orientation does not matter for a count), eight bases per step: the query as one
+        // unaligned 8-byte load, the reference as one 8-byte window of the 2-bit pac expanded to a base per byte
+        typedef uint64_t __attribute__((aligned(1))) u64u;
+        int nm = 0, i = 0;
+        const uint8_t *qp = query + j.qb;
+        const bool rev = j.rb >= R.l_pac;
+        for (; i + 8 <= lq; i += 8) {
+            const uint64_t qw = *(const u64u *)(qp + i);
+            uint64_t rw = 0;
+            if (!rev) {
+                const int64_t p0 = j.rb + i;
+                const uint64_t L = *(const u64u *)(R.pac + (p0 >> 2));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int64_t pk = p0 + k;
+                    const int sh = (int)(((pk >> 2) - (p0 >> 2)) << 3) + (int)((~pk & 3) << 1);
+                    rw |= ((L >> sh) & 3ull) << (8 * k);
+                }
+            } else {
+                const int64_t f0 = (R.l_pac << 1) - 1 - (j.rb + i);          // mirror position of base 0; base k sits at f0 - k
+                const int64_t fb = (f0 - 7) >> 2;                          // first byte of the window (f0 >= lq - 1 - i >= 7)
+                const uint64_t L = *(const u64u *)(R.pac + fb);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int64_t fk = f0 - k;
+                    const int sh = (int)(((fk >> 2) - fb) << 3) + (int)((~fk & 3) << 1);
+                    rw |= (3ull - ((L >> sh) & 3ull)) << (8 * k);
+                }
+            }
+            uint64_t d = qw ^ rw;                                          // non-zero byte = mismatch (codes are 0..4)
+            d |= d >> 4; d |= d >> 2; d |= d >> 1;
+            nm += __popcll(d & 0x0101010101010101ull);
+        }
+        for (; i < lq; ++i) {
+            const int qc = qp[i];
             nm += qc != ref_base(R, j.rb + i);
         }
         h.nm = nm;
