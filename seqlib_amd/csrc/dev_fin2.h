@@ -379,6 +379,37 @@ __global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists f
     }
 }
 
+// dev_traceback for a wave that walks ONE alignment (every lane gets the same calls of emit): while the walk is in the H state,
+// lane t looks at the cell t steps further up the diagonal -- exactly the cells the scalar walk would read next -- and a ballot
+// gives the length of the diagonal run, so an alignment costs a few dependent reads per gap instead of one per base.
+template <typename F>
+__device__ void dev_traceback_wave(const uint8_t *z, int n_col, int qlen, int tlen, int w, int lane, F emit)
+{
+    int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+    int cur_op = -1, cur_len = 0;
+    auto unit = [&](int op, int len) {
+        if (op == cur_op) cur_len += len;
+        else { if (cur_op >= 0) emit(cur_op, cur_len); cur_op = op; cur_len = len; }
+    };
+    while (i >= 0 && k >= 0) {
+        if (which == 0) {
+            const int it = i - lane, kt = k - lane;
+            int d = 1;
+            if (it >= 0 && kt >= 0) d = z[(size_t)it * n_col + (kt - (it > w ? it - w : 0))] & 3;
+            const unsigned long long stop = __ballot(d != 0);
+            const int run = stop ? (int)__ffsll((long long)stop) - 1 : WAVE;
+            if (run > 0) { unit(0, run); i -= run; k -= run; continue; }
+        }
+        which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+        if (which == 0) { unit(0, 1); --i; --k; }
+        else if (which == 1) { unit(2, 1); --i; }
+        else { unit(1, 1); --k; }
+    }
+    if (i >= 0) unit(2, i + 1);
+    if (k >= 0) unit(1, k + 1);
+    if (cur_op >= 0) emit(cur_op, cur_len);
+}
+
 // One CIGAR job on one wave.  Kept out of line on purpose: with the body inlined into the queue loop the compiler
 // fuses that loop, the early exits and the three-band do/while into a single loop nest (observed: a wave re-entering
 // it with a stale job index and never finishing); a call boundary keeps the queue loop a plain fetch / test / call.
@@ -437,7 +468,7 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
     int n_ops = 0;
     if (valid) {
         __threadfence();                          // the direction bytes were written by other lanes of this wave
-        dev_traceback(z, n_col, lq, rlen, w_used, [&](int, int) { ++n_ops; });
+        dev_traceback_wave(z, n_col, lq, rlen, w_used, lane, [&](int, int) { ++n_ops; });
     }
     n_ops = __builtin_amdgcn_readfirstlane(n_ops);
     unsigned long long base = 0;
@@ -449,7 +480,7 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
     uint32_t *cg = ck.cigpool + base + 1;
     if (valid) {
         int wp = n_ops;
-        dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });   // every lane stores the same words
+        dev_traceback_wave(z, n_col, lq, rlen, w_used, lane, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });   // every lane stores the same words
         // NM: lanes share the comparisons of each M run
         int x = 0, y = 0, n_mm = 0, n_gap = 0;
         for (int k = 0; k < n_ops; ++k) {
