@@ -124,6 +124,84 @@ __device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_op
     return lane_read(pick, src);
 }
 
+// ksw_global2 for a band that fits the wave (2w+1 <= 64): lane b holds band offset b, i.e. column j = i - w + b of row i.
+// A read-length global alignment has ~20-40 cells per row; with lanes on absolute columns (wave_ksw_global2) a 150-column
+// query needs three columns per lane of which a fifth is inside the band.  In band coordinates the diagonal input H(i-1,j-1)
+// is the lane's own value from the previous row (no shuffle), E comes from the lane above (one wave_shl), F is the same
+// prefix max over lanes, and the query slides past the lanes one position per row (scores packed per lane, shifted by DPP, the
+// new top column injected from a register block).  Direction bytes go to the same band-relative z layout.
+template <int NCH, typename QF, typename TF>
+__device__ int wave_ksw_global2_band(int qlen_, QF qf, int tlen_, TF tf, const slx_opt &o, int w_, uint8_t *z, int n_col_, int lane)
+{
+    const int qlen = __builtin_amdgcn_readfirstlane(qlen_), tlen = __builtin_amdgcn_readfirstlane(tlen_);
+    const int w = __builtin_amdgcn_readfirstlane(w_), n_col = __builtin_amdgcn_readfirstlane(n_col_);
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const MatCols mc = make_matcols(o.mat);
+    auto pack_of = [&](int j) -> uint32_t {
+        const int q = j >= 0 && j < qlen ? qf(j) : 4;
+        return q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
+    };
+    uint32_t Pblk[NCH];                           // packed scores of query position 64*c + lane: the feed for the sliding window
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) Pblk[c] = pack_of(c * WAVE + lane);
+    const int b = lane, bE = b * e_ins;
+    // row 0: column j = b - w
+    uint32_t P = pack_of(b - w);
+    int H, E = DEV_MINUS_INF;
+    {
+        const int j = b - w;
+        H = j == 0 ? 0 : (j > 0 && j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
+    }
+    int tb_cur = lane < tlen ? tf(lane) : 0;
+    int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = lane_read(tb_cur, i & (WAVE - 1));
+        const uint32_t sh = (uint32_t)t << 3;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int b_lo = beg - (i - w), b_hi = end - (i - w);     // active offsets [b_lo, b_hi)
+        const bool act = b >= b_lo && b < b_hi;
+        const int s = __builtin_amdgcn_sbfe((int)P, sh, 8u);
+        const int m = H + s;
+        const int u = act ? m - oe_ins + bE : G_NEG;
+        const int incl = dpp_incl_max_scan_g(u);
+        const int ex = dpp_get<0x138, 0xf, 0xf>(G_NEG, incl);
+        // F(i,j): the initial -inf decays by e_ins per column, exactly as the scalar recurrence carries it
+        int f = DEV_MINUS_INF - (b - b_lo) * e_ins;
+        if (b > b_lo) f = imax(f, ex - (b - 1) * e_ins);
+        const int e = E;
+        int d = m >= e ? 0 : 1;
+        int hh = m >= e ? m : e;
+        d = hh >= f ? d : 2;
+        hh = hh >= f ? hh : f;
+        int tt = m - oe_del;
+        int e2 = e - e_del;
+        d |= e2 > tt ? 1 << 2 : 0;
+        e2 = e2 > tt ? e2 : tt;
+        tt = m - oe_ins;
+        const int f2 = f - e_ins;
+        d |= f2 > tt ? 2 << 4 : 0;
+        if (act && z) z[(size_t)i * n_col + (b - b_lo)] = (uint8_t)d;
+        // next row: H stays in place (H(i, j) is the diagonal input of (i+1, j+1), same offset); the lane whose column becomes 0 gets
+        // the first-column boundary; E'(i+1, j) moves one offset down; the query window slides by one position
+        if (act) H = hh;
+        if (b == w - (i + 1)) H = -(o_del + e_del * (i + 1));
+        const int e_up = dpp_get<0x130, 0xf, 0xf>(DEV_MINUS_INF, act ? e2 : DEV_MINUS_INF);     // wave_shl:1 -- from lane b + 1
+        E = e_up;
+        const int jn = i + 1 + w;                                    // query position entering at the top offset 2w
+        uint32_t pin = Pblk[0];
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) pin = (jn >> 6) == c ? Pblk[c] : pin;
+        const uint32_t p_new = jn < qlen ? (uint32_t)lane_read((int)pin, jn & (WAVE - 1)) : mc.c[4];
+        const uint32_t p_up = (uint32_t)dpp_get<0x130, 0xf, 0xf>(0, (int)P);
+        P = b == 2 * w ? p_new : p_up;
+    }
+    // H(tlen-1, qlen-1) sits at offset qlen-1 - (tlen-1-w)
+    return lane_read(H, qlen - 1 - (tlen - 1 - w));
+}
+
 // bwa_gen_cigar2 (score only) on one wave: the scorer the wave-per-read region kernel hands to mem_patch_reg
 template <int MAXQ>
 struct WaveScorer {
@@ -455,7 +533,9 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
                   (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
             if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return; }
             z = ck.zarena + off;
-            if (lq + 1 <= WAVE) score = wave_ksw_global2<1>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
+            if (2 * ww + 1 <= WAVE && lq <= (MAXQ + 2 + WAVE - 1) / WAVE * WAVE)
+                score = wave_ksw_global2_band<(MAXQ + 2 + WAVE - 1) / WAVE>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            else if (lq + 1 <= WAVE) score = wave_ksw_global2<1>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
             else if (CPLMAX > 2 && lq + 1 <= 2 * WAVE) score = wave_ksw_global2<(CPLMAX > 2 ? 2 : CPLMAX)>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
             else score = wave_ksw_global2<CPLMAX>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
             // mem_reg2aln: `if (score == last_sc || w2 == opt->w<<2) break; last_sc = score; w2 <<= 1;` then `while (++i < 3 && score < truesc - a)`
