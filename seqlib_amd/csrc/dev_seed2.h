@@ -48,9 +48,58 @@ __global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, u
     occ[2 * b + 1] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
+#ifndef SEED2_OCC192
+#define SEED2_OCC192 0        // 1 = 64-byte blocks of 192 symbols (index 1.5x smaller: more of it stays in the 4 MB L2 of an XCD)
+#endif
+
+// the 192-symbol variant of the occ planes: 4 x u32 counts + three (low, high) plane pairs of 64 symbols = 64 bytes
+__global__ void k_occ_build192(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, uint64_t n_blocks)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t n_data_words = (seq_len + 15) >> 4;
+    auto data_word = [&](uint64_t d) -> uint32_t { return d < n_data_words ? bwt[(d >> 3) * 16 + 8 + (d & 7)] : 0u; };
+    const uint64_t first = b * 192, B = first >> 7, rem_words = (first & 127) >> 4;      // bwa block holding symbol `first`, words before it
+    uint32_t cnt[4];
+    for (int s = 0; s < 4; ++s) cnt[s] = (B * 16 + 2 * s) < ((n_data_words + 7) / 8 + 1) * 16 ? bwt[B * 16 + 2 * s] : 0u;
+    for (uint64_t k = 0; k < rem_words; ++k) {
+        const uint32_t w = data_word(B * 8 + k);
+        for (int s = 0; s < 16; ++s) ++cnt[(w >> (2 * s)) & 3];
+    }
+    occ[4 * b] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+    for (int part = 0; part < 3; ++part) {
+        uint64_t lo = 0, hi = 0;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w = data_word(b * 12 + part * 4 + k);
+            for (int s = 0; s < 16; ++s) {
+                const uint32_t sym = (w >> ((15 - s) << 1)) & 3;
+                lo |= (uint64_t)(sym & 1) << (16 * k + s);
+                hi |= (uint64_t)(sym >> 1) << (16 * k + s);
+            }
+        }
+        occ[4 * b + 1 + part] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    }
+}
+
 // counts of A,C,G,T in BWT[0..k] (bwt_occ4), k already mapped past the sentinel
 __device__ __forceinline__ void occp_rank(const uint4 *occ, uint32_t kk, uint32_t t[4])
 {
+#if SEED2_OCC192
+    const uint32_t bi = __umulhi(kk, 0xAAAAAAABu) >> 7;           // kk / 192
+    const uint4 *blk = occ + ((size_t)bi << 2);
+    const uint4 c = blk[0], p0 = blk[1], p1 = blk[2], p2 = blk[3];
+    const uint32_t n = kk - bi * 192u + 1;                         // 1..192 symbols of the block count
+    uint32_t sl = 0, sh = 0, st = 0;
+    auto part = [&](const uint4 &p, int cnt) {                     // cnt (may be <= 0 or >= 64) leading symbols of this 64-symbol part
+        const int cc = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
+        const uint64_t m = cc ? ~0ull >> (64 - cc) : 0ull;
+        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+        const uint32_t l0 = p.x & m0, l1 = p.y & m1, h0 = p.z & m0, h1 = p.w & m1;
+        sl += __popc(l0) + __popc(l1); sh += __popc(h0) + __popc(h1); st += __popc(l0 & h0) + __popc(l1 & h1);
+    };
+    part(p0, (int)n); part(p1, (int)n - 64); part(p2, (int)n - 128);
+    t[0] = c.x + (n + st - sl - sh); t[1] = c.y + (sl - st); t[2] = c.z + (sh - st); t[3] = c.w + st;
+#else
     const uint4 *blk = occ + ((size_t)(kk >> 6) << 1);
     const uint4 c = blk[0], p = blk[1];
     const uint32_t n = (kk & 63) + 1;
@@ -59,6 +108,7 @@ __device__ __forceinline__ void occp_rank(const uint4 *occ, uint32_t kk, uint32_
     const uint32_t l0 = p.x & m0, l1 = p.y & m1, h0 = p.z & m0, h1 = p.w & m1;
     const uint32_t sl = __popc(l0) + __popc(l1), sh = __popc(h0) + __popc(h1), st = __popc(l0 & h0) + __popc(l1 & h1);
     t[0] = c.x + (n + st - sl - sh); t[1] = c.y + (sl - st); t[2] = c.z + (sh - st); t[3] = c.w + st;
+#endif
 }
 
 // bwt_extend for the one output symbol the caller needs (same contract as fm_extend in dev_fm.h)
@@ -266,8 +316,12 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
         if (bwd && j + 1 < np) nsrc = wl.at(cur, rev ? np - 2 - j : j + 1);       // next trip's entry, in flight behind this trip's rank reads
         IntvE<I> ok;
         ok.x0 = ok.x1 = ok.x2 = 0; ok.info = 0;
-        if (fwd) fm_extend_p(fm, ik, 3 - cq, 0, ok);
-        else if (bwd) fm_extend_p(fm, psrc, cb, 1, ok);
+        if (fwd || bwd) {                           // ONE inlined copy of the extend for both directions: a wave nearly always holds both kinds of lane
+            IntvE<I> src = psrc;
+            int c = cb;
+            if (fwd) { src = ik; c = 3 - cq; }
+            fm_extend_p(fm, src, c, bwd ? 1 : 0, ok);
+        }
         // ------------------------------------------------ apply it
         if (fwd) {
             bool stop = false;

@@ -261,11 +261,22 @@ extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int 
     DevFM<uint32_t> &fm = al->fm32;
     fm.bwt = al->d_bwt.as<uint32_t>();
     {   // occ planes for the seeding kernels
+#if SEED2_OCC192
+        const uint64_t n_blocks = (idx->seq_len ? idx->seq_len - 1 : 0) / 192 + 1;
+        const size_t occ_bytes = (n_blocks + 1) * 64;
+#else
         const uint64_t n_blocks = ((idx->seq_len ? idx->seq_len - 1 : 0) >> 6) + 1;
-        if ((rc = al->d_occ.ensure((n_blocks + 1) * 32)) != SLX_OK) return rc;
-        HIPCHK(hipMemsetAsync(al->d_occ.p, 0, (n_blocks + 1) * 32, al->stream));
+        const size_t occ_bytes = (n_blocks + 1) * 32;
+#endif
+        if ((rc = al->d_occ.ensure(occ_bytes)) != SLX_OK) return rc;
+        HIPCHK(hipMemsetAsync(al->d_occ.p, 0, occ_bytes, al->stream));
+#if SEED2_OCC192
+        hipLaunchKernelGGL(k_occ_build192, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, al->stream, al->d_bwt.as<uint32_t>(), (uint64_t)idx->seq_len,
+                           al->d_occ.as<uint4>(), n_blocks);
+#else
         hipLaunchKernelGGL(k_occ_build, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, al->stream, al->d_bwt.as<uint32_t>(), (uint64_t)idx->seq_len,
                            al->d_occ.as<uint4>(), n_blocks);
+#endif
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(al->stream));
         fm.occ = al->d_occ.as<uint4>();
