@@ -28,17 +28,17 @@ struct CoopTables {            // LDS tables of one wave
 };
 
 // one heavy read on one wave; out of line so that the queue loop of the kernel stays a plain fetch / test / call
-template <typename I, int NCMAX>
-__device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRef &R, const Chunk &ck, const slx_opt &opt, int r, const CoopTables &T, int lane)
+template <typename I, int NCMAX, bool FINAL>
+__device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRef &R, const Chunk &ck, const slx_opt &opt, int r, const CoopTables &T, int lane,
+                                                 int nc_limit)
 {
     int64_t *s_pos = T.s_pos; int *s_ord = T.s_ord, *s_w = T.s_w, *s_cb = T.s_cb, *s_ce = T.s_ce, *s_first = T.s_first, *s_kept = T.s_kept;
     signed char *s_kf = T.s_kf;
     {
         ReadWS w = make_ws(ck, r);
-        if (w.cap > NCMAX) {                    // does not fit the LDS table: one lane, global memory
-            if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r);
-            return;
-        }
+        // The LDS table bounds the number of CHAINS, which is usually far below the number of seed occurrences (2 000 occurrences in
+        // 45 chains is typical of a repeat tract), so a read is only turned away when a chain would not fit any more: n_chain = -2
+        // hands it to the launch with the bigger table, and past that one to a single lane on global memory.
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_intv = (int)ck.intv_n[r];
         const uint32_t *iinfo = ck.intv_info + (size_t)r * ck.cap_intv;
@@ -95,6 +95,11 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                             }
                             to_add = !res;
                         }
+                    }
+                    if (to_add && nc == nc_limit) {  // table full (uniform; nc_limit <= NCMAX, lower only in tests): give the read up, see above
+                        if (FINAL) { if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r); }
+                        else if (lane == 0) ck.n_chain[r] = -2;
+                        return;
                     }
                     if (to_add) {
                         const int s = ns++, c = nc;
@@ -217,12 +222,11 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
     }
 }
 
-// cap_lo < seed occurrences of the read <= cap_hi selects the reads of this launch: the table size is a template parameter (LDS),
-// so the few reads with more occurrences than the common table holds get their own launch with a bigger one instead of
-// falling back to a single lane (measured: 180 ms for one 2000-occurrence read on the single-lane path)
-template <typename I, int NCMAX>
+// FINAL = false: every read of the list, reads whose chains outgrow the table are flagged (n_chain = -2); FINAL = true: the flagged
+// reads only, with a bigger table (135 KB of LDS: one block per CU; there are normally none) and a single-lane last resort
+template <typename I, int NCMAX, bool FINAL>
 __global__ void __launch_bounds__(64) k_chain_coop(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue,
-                                                   const unsigned int *n_slots, int cap_lo, int cap_hi)
+                                                   const unsigned int *n_slots, int nc_limit)
 {
     __shared__ int64_t s_pos[NCMAX + 64];
     __shared__ int s_ord[NCMAX + 64];
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(64) k_chain_coop(DevFM<I> fm, DevRef R, Chunk 
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
         const int r = order ? order[slot] : slot;
-        const int cap = __builtin_amdgcn_readfirstlane((int)(ck.seed_off[r + 1] - ck.seed_off[r]));
-        if (cap > cap_lo && cap <= cap_hi) dev_chain_read_coop<I, NCMAX>(fm, R, ck, dopt.o, r, T, lane);
+        const bool mine = !FINAL || __builtin_amdgcn_readfirstlane(ck.n_chain[r]) == -2;
+        if (mine) dev_chain_read_coop<I, NCMAX, FINAL>(fm, R, ck, dopt.o, r, T, lane, nc_limit < NCMAX ? nc_limit : NCMAX);
     }
 }

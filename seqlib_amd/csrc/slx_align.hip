@@ -122,6 +122,7 @@ struct slx_aligner {
                                   // the wave-per-read kernel; 0 = every read on the lane-per-read kernel
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
                                   // quadratic de-duplication scan 64 candidates at a time (regs_mode 2); 1 << 30 = off
+    int coop_lim1 = 1 << 30, coop_lim2 = 1 << 30;   // test hooks: chains the two LDS tables of k_chain_coop take before giving a read up
     int stagger = 0;              // 1 = each worker cuts its part in two at a different point (see worker_run)
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
@@ -363,6 +364,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
     else if (!strcmp(key, "stagger")) al->stagger = (int)value;
+    else if (!strcmp(key, "coop_lim1")) { if (value < 1) return SLX_EINVAL; al->coop_lim1 = (int)value; }
+    else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "regs_mode")) al->regs_mode = (int)value;
@@ -510,15 +513,14 @@ static hipStream_t heavy_stream_of(slx_aligner *al, Worker *wk)
     return al->workers[1]->stream;
 }
 
-// wave-cooperative chaining of the heavy list: first the few reads whose seed occurrences exceed the common LDS table (own launch,
-// bigger table, one block per CU), then the rest
+// wave-cooperative chaining of the heavy list, then (a few blocks, normally nothing to do) the reads whose chains outgrew the LDS table
 static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, unsigned int *q,
                         unsigned int *counts, int n)
 {
-    hipLaunchKernelGGL((k_chain_coop<uint32_t, 4096>), dim3(std::max(1, std::min(n / 64 + 1, al->n_cu))), dim3(64), 0, st, fm, al->ref, ck, dopt,
-                       wk->order_out.as<int>(), q + 10, counts + 1, 1536, 0x7fffffff);
-    hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
-                       wk->order_out.as<int>(), q + 8, counts + 1, -1, 1536);
+    hipLaunchKernelGGL((k_chain_coop<uint32_t, 1536, false>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                       wk->order_out.as<int>(), q + 8, counts + 1, al->coop_lim1);
+    hipLaunchKernelGGL((k_chain_coop<uint32_t, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                       wk->order_out.as<int>(), q + 10, counts + 1, al->coop_lim2);
 }
 
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };

@@ -70,6 +70,14 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
             al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
             assert_same(al.alignSequences(seqs), exp, "split=%d heavy_stream=%d heavy_seeds=%d" % (split, hs, thr))
     # ahead-of-time extension of the heavy reads' chains: off, and with a table too small for most reads (in-place fallback)
+    # chains outgrowing the LDS table of the cooperative chaining kernel: second launch, then the single-lane last resort
+    for lim1, lim2 in ((2, 1 << 30), (2, 3)):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("split_min", 16)
+        al.set("heavy_seeds", 3)
+        al.set("coop_lim1", lim1)
+        al.set("coop_lim2", lim2)
+        assert_same(al.alignSequences(seqs), exp, "coop_lim1=%d coop_lim2=%d" % (lim1, lim2))
     for knob, val in (("cand_mode", 0), ("cand_cap", 7), ("cand_cap", 1 << 20), ("heavy_sorted", 0)):
         al = sl.BWAAligner(tiny_gpu)
         al.set("split_min", 16)
