@@ -77,21 +77,18 @@ __device__ ExtResult dev_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx
     return r;
 }
 
-template <int MAXQ>
-__global__ void __launch_bounds__(128) k_extend(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+// mem_chain2aln for one read on one lane.  REPLAY = false: the reference kernel of ext_mode 0 (extensions run on the lane, H/E rows
+// in lane-private scratch).  REPLAY = true: the decision sequence only -- the region of each chain's top (longest) seed was
+// computed ahead of time by k_ext_first (one wave per chain) and is taken from `first`; if any OTHER seed turns out to need an
+// extension the read is given up (returns false, nothing stored) and the wave-per-read kernel redoes it.
+template <int MAXQ, bool REPLAY>
+__device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt &opt, int r, int *eh_h, int *eh_e, const DReg *first)
 {
-    const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
-        const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_chn = ck.n_chain[r];
-        if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
+        if (n_chn < 0) return true;               // exact full-length match: region already written by the chaining kernel
         const float frac_rep = ck.frac_rep[r];
         const int64_t l_pac = R.l_pac;
         int n_av = 0;                            // regions so far (all chains of the read)
@@ -163,53 +160,72 @@ __global__ void __launch_bounds__(128) k_extend(DevRef R, Chunk ck, DevOpt dopt,
                     if (i == n) { srt_h[k] = -1; continue; }
                 }
                 DReg a;
-                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
-                a.n_comp = 0; a.hash = 0;
-                int aw0 = opt.w, aw1 = opt.w;
-                a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
-                if (s_qbeg) {                    // left extension: both sequences reversed
-                    const int64_t tmp = s_rbeg - rmax0;
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {    // MAX_BAND_TRY
-                        const int prev = a.score;
-                        aw0 = opt.w << i;
-                        er = dev_ksw_extend2<MAXQ>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
-                                                   [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, aw0, opt.pen_clip5,
-                                                   s_len * opt.a, eh_h, eh_e);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+                if (REPLAY) {
+                    if (k != n - 1) return false;            // a seed other than the chain's top seed needs extending: not precomputed
+                    a = first[ci];
+                } else {
+                    a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
+                    a.n_comp = 0; a.hash = 0;
+                    int aw0 = opt.w, aw1 = opt.w;
+                    a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
+                    if (s_qbeg) {                    // left extension: both sequences reversed
+                        const int64_t tmp = s_rbeg - rmax0;
+                        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+                        for (i = 0; i < 2; ++i) {    // MAX_BAND_TRY
+                            const int prev = a.score;
+                            aw0 = opt.w << i;
+                            er = dev_ksw_extend2<MAXQ>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
+                                                       [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, aw0, opt.pen_clip5,
+                                                       s_len * opt.a, eh_h, eh_e);
+                            a.score = er.score;
+                            if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+                        }
+                        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
+                        else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
+                    } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
+                    if (s_qbeg + s_len != l_query) { // right extension
+                        const int sc0 = a.score, qe = s_qbeg + s_len;
+                        const int64_t re0 = s_rbeg + s_len;      // = rmax0 + re in bwa's local coordinates
+                        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
+                        for (i = 0; i < 2; ++i) {
+                            const int prev = a.score;
+                            aw1 = opt.w << i;
+                            er = dev_ksw_extend2<MAXQ>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
+                                                       [&](int t) { return ref_base(R, re0 + t); }, opt, aw1, opt.pen_clip3, sc0, eh_h, eh_e);
+                            a.score = er.score;
+                            if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+                        }
+                        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
+                        else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
+                    } else { a.qe = l_query; a.re = s_rbeg + s_len; }
+                    a.seedcov = 0;
+                    for (i = 0; i < n; ++i) {
+                        const int t = cs[i];
+                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+                        const int64_t t_rbeg = w.s_rbeg[t];
+                        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
                     }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
-                    else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
-                } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
-                if (s_qbeg + s_len != l_query) { // right extension
-                    const int sc0 = a.score, qe = s_qbeg + s_len;
-                    const int64_t re0 = s_rbeg + s_len;      // = rmax0 + re in bwa's local coordinates
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {
-                        const int prev = a.score;
-                        aw1 = opt.w << i;
-                        er = dev_ksw_extend2<MAXQ>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
-                                                   [&](int t) { return ref_base(R, re0 + t); }, opt, aw1, opt.pen_clip3, sc0, eh_h, eh_e);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-                    }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
-                    else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
-                } else { a.qe = l_query; a.re = s_rbeg + s_len; }
-                a.seedcov = 0;
-                for (i = 0; i < n; ++i) {
-                    const int t = cs[i];
-                    const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                    const int64_t t_rbeg = w.s_rbeg[t];
-                    if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
+                    a.w = aw0 > aw1 ? aw0 : aw1;
+                    a.seedlen0 = s_len;
+                    a.frac_rep = frac_rep;
                 }
-                a.w = aw0 > aw1 ? aw0 : aw1;
-                a.seedlen0 = s_len;
-                a.frac_rep = frac_rep;
                 w.regs[n_av++] = a;
             }
         }
         ck.n_reg[r] = n_av;
+        return true;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_extend(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
+{
+    const slx_opt &opt = dopt.o;
+    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    while (true) {
+        const int slot = next_slot(queue);
+        if (__all(slot >= ck.n_reads)) break;
+        if (slot >= ck.n_reads) continue;
+        const int r = order ? order[slot] : slot;
+        dev_extend_lane<MAXQ, false>(R, ck, opt, r, eh_h, eh_e, nullptr);
     }
 }

@@ -285,6 +285,9 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
     return a;
 }
 
+#ifndef EXT_JOB_WAVES
+#define EXT_JOB_WAVES 6       // waves/SIMD of the job kernels (k_ext_first, k_extend_cand): DP only, no per-read bookkeeping
+#endif
 #ifndef EXT_MIN_WAVES
 #define EXT_MIN_WAVES 4
 #endif
@@ -659,7 +662,7 @@ __device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, cons
 }
 
 template <int MAXQ>
-__global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_cand(DevRef R, Chunk ck, DevOpt dopt, const int *heavy, const unsigned int *n_heavy,
+__global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_extend_cand(DevRef R, Chunk ck, DevOpt dopt, const int *heavy, const unsigned int *n_heavy,
                                                                     const unsigned int *job_off, unsigned int *queue, DReg *cand)
 {
     const slx_opt &opt = dopt.o;
@@ -681,5 +684,140 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_cand(DevRef R, Chu
         const int r = heavy[lo];
         const int base = __builtin_amdgcn_readfirstlane(ck.cand_base[r]);
         if (base >= 0) dev_cand_job<MAXQ>(R, ck, opt, mr, gap_lut, eh_h, eh_e, r, (int)(job - job_off[lo]), cand + base, lane);   // else extended in place
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- light reads, split in two
+// k_extend_reg is bound by wave-time: one wave per read at 4 waves/SIMD, of which the DP is about half and the rest is the
+// per-read decision sequence of mem_chain2aln, a chain of dependent loads that leaves 63 lanes idle.  For the light reads
+// (the bulk) the two are separated: k_ext_first extends the top (longest) seed of every kept chain, one wave per chain --
+// that is the only extension such a read normally needs -- and k_ext_replay runs the decision sequence one read per LANE,
+// taking those regions from the table.  A read that turns out to need any other extension is put on a list and redone by
+// k_extend_reg together with the heavy reads.
+__global__ void k_first_count(Chunk ck, int n, unsigned int heavy_seeds, unsigned int *cnt)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int nc = ck.n_chain[r];
+    cnt[r] = (ck.seed_cnt[r] < heavy_seeds && nc > 0) ? (unsigned int)nc : 0u;
+}
+
+__global__ void k_add_u32(const unsigned int *a, const unsigned int *b, unsigned int *out) { *out = *a + *b; }
+
+// the top seed of chain ci of read r: region -> *out
+template <int MAXQ>
+__device__ __noinline__ void dev_first_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int *eh_h, int *eh_e,
+                                           int r, int ci, DReg *out, int lane)
+{
+    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
+    auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
+    const int64_t l_pac = R.l_pac;
+    ReadWS w = make_ws_uniform(ck, r);
+    const uint64_t q_off = rfl_u64(ck.offs[r]);
+    const uint8_t *query = ck.codes + q_off;
+    const int l_query = (int)(rfl_u64(ck.offs[r + 1]) - q_off);
+    const int c = __builtin_amdgcn_readfirstlane(w.ia[ci]);
+    const int n = __builtin_amdgcn_readfirstlane(w.c_n[c]);
+    const int *cs = w.c_w + __builtin_amdgcn_readfirstlane(w.c_first[c]);
+    if (n == 0) return;
+    int64_t rmax0 = l_pac << 1, rmax1 = 0;
+    uint64_t best = 0;                               // (length << 32 | list index), then the seed's slot id in a second word
+    int best_s = 0;
+    for (int i = lane; i < n; i += WAVE) {
+        const int s = cs[i];
+        const int qb = w.s_qbeg(s), sl = w.s_len(s);
+        const int64_t b = w.s_rbeg[s] - (qb + max_gap_of(qb));
+        const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + max_gap_of(l_query - qb - sl));
+        rmax0 = rmax0 < b ? rmax0 : b;
+        rmax1 = rmax1 > e ? rmax1 : e;
+        const uint64_t key = (uint64_t)(uint32_t)sl << 32 | (uint64_t)(uint32_t)i;
+        if (key >= best) { best = key; best_s = s; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int64_t o0 = __shfl_xor(rmax0, d, WAVE), o1 = __shfl_xor(rmax1, d, WAVE);
+        rmax0 = rmax0 < o0 ? rmax0 : o0;
+        rmax1 = rmax1 > o1 ? rmax1 : o1;
+        const uint64_t ob = __shfl_xor(best, d, WAVE);
+        const int os = __shfl_xor(best_s, d, WAVE);
+        if (ob > best) { best = ob; best_s = os; }
+    }
+    rmax0 = rmax0 > 0 ? rmax0 : 0;
+    rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+    const int64_t first_rbeg = w.s_rbeg[cs[0]];
+    if (rmax0 < l_pac && l_pac < rmax1) {
+        if (first_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+    }
+    {
+        int is_rev;
+        const int rid = dev_pos2rid(R, dev_depos(R, first_rbeg, &is_rev));
+        int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
+        if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+        rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+        rmax1 = rmax1 < far_end ? rmax1 : far_end;
+    }
+    const int s = __builtin_amdgcn_readfirstlane(best_s);
+    DReg a = dev_extend_core<NCH>(R, opt, mr, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s], rmax0, rmax1, w.c_rid[c], ck.frac_rep[r], eh_h, eh_e, lane);
+    int cov = 0;
+    for (int i = lane; i < n; i += WAVE) {
+        const int t = cs[i];
+        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+        const int64_t t_rbeg = w.s_rbeg[t];
+        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
+    }
+    for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
+    a.seedcov = cov;
+    if (lane == 0) *out = a;
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_ext_first(DevRef R, Chunk ck, DevOpt dopt, int n, const unsigned int *first_off, unsigned int cap,
+                                                                  unsigned int *queue, DReg *first)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(opt.mat);
+    __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    __shared__ int gap_lut[MAXQ + 2];
+    for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
+    __syncthreads();
+    for (;;) {                                       // a wave-full of reads per fetch; the reads with nothing to do cost one ballot
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(queue, (unsigned int)WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const int x = base + lane;
+        const unsigned int off_l = x < n ? first_off[x] : 0u;
+        const unsigned int cnt_l = x < n ? first_off[x + 1] - off_l : 0u;
+        unsigned long long todo = __ballot(cnt_l > 0 && off_l + cnt_l <= cap);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int nch = __builtin_amdgcn_readlane((int)cnt_l, l);
+            const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)off_l, l);
+            for (int ci = 0; ci < nch; ++ci) dev_first_job<MAXQ>(R, ck, opt, mr, gap_lut, eh_h, eh_e, base + l, ci, first + off + ci, lane);
+        }
+    }
+}
+
+template <int MAXQ>
+__global__ void __launch_bounds__(128) k_ext_replay(DevRef R, Chunk ck, DevOpt dopt, int n, unsigned int heavy_seeds, const unsigned int *first_off,
+                                                    unsigned int cap, const DReg *first, unsigned int *queue, int *fb_list, unsigned int *n_fb)
+{
+    const slx_opt &opt = dopt.o;
+    while (true) {
+        const int r = next_slot(queue);
+        if (__all(r >= n)) break;
+        if (r >= n) continue;
+        if (ck.seed_cnt[r] >= heavy_seeds) continue;                  // heavy: k_extend_reg has it on its list
+        const int nc = ck.n_chain[r];
+        if (nc < 0) continue;                                         // finished by the chaining kernel
+        bool done;
+        if (nc == 0) { ck.n_reg[r] = 0; done = true; }
+        else {
+            const unsigned int off = first_off[r];
+            done = off + (unsigned int)nc <= cap && dev_extend_lane<MAXQ, true>(R, ck, opt, r, nullptr, nullptr, first + off);
+        }
+        if (!done) fb_list[wave_fetch_inc(n_fb)] = r;
     }
 }

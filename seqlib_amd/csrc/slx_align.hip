@@ -78,7 +78,7 @@ struct Worker {
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos, cand, cand_base, cand_cnt, cand_off, dbg_cyc, order_tmp;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos, cand, cand_base, cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list;
     hipStream_t stream2 = nullptr;
     int id = 0;
     hipEvent_t dbg_ev[2][6];
@@ -97,7 +97,7 @@ struct Worker {
         DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
                        &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                        &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
-                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &cand, &cand_base, &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &cand, &cand_base, &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
                        &o_na, &o_ncig, &o_cig_off, &o_cigar};
         n_all = (int)(sizeof(b) / sizeof(b[0]));
         for (int i = 0; i < n_all; ++i) all[i] = b[i];
@@ -123,6 +123,8 @@ struct slx_aligner {
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
                                   // quadratic de-duplication scan 64 candidates at a time (regs_mode 2); 1 << 30 = off
     int coop_lim1 = 1 << 30, coop_lim2 = 1 << 30;   // test hooks: chains the two LDS tables of k_chain_coop take before giving a read up
+    int ext_split = 1;            // 1 = light reads: top-seed extensions one wave per chain (k_ext_first) + decision sequence one read per lane
+                                  // (k_ext_replay); k_extend_reg keeps the heavy reads and the reads that need more
     int stagger = 0;              // 1 = each worker cuts its part in two at a different point (see worker_run)
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
@@ -364,6 +366,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
     else if (!strcmp(key, "stagger")) al->stagger = (int)value;
+    else if (!strcmp(key, "ext_split")) al->ext_split = (int)value;
     else if (!strcmp(key, "coop_lim1")) { if (value < 1) return SLX_EINVAL; al->coop_lim1 = (int)value; }
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
@@ -417,7 +420,7 @@ template <int MAXQ>
 static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<uint32_t> &fm, hipStream_t st, const int *order,
                        unsigned int *q, const unsigned int *n_slots, int sub, int grid, int bs, int n_est, hipEvent_t *ev_after_chain,
                        hipEvent_t *ev_after_ext, bool with_chain = true, bool with_extend = true, const int *ext_light = nullptr,
-                       const int *ext_heavy = nullptr, const unsigned int *n_heavy = nullptr)
+                       const int *ext_heavy = nullptr, const unsigned int *n_heavy = nullptr, const unsigned int *ext_slots = nullptr)
 {
     hipEvent_t *dbg = wk->dbg_ev[sub];
     const bool dbg_on = getenv("SLX_DEBUG_SUB") != nullptr;
@@ -426,7 +429,8 @@ static void launch_sub(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOp
     if (ev_after_chain) (void)hipEventRecord(*ev_after_chain, st);
     if (dbg_on) (void)hipEventRecord(dbg[1], st);
     const int g = std::max(1, std::min(n_est, al->n_cu * 32));
-    if (with_extend && ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, ext_light, q + 1, n_slots, sub, ext_heavy, n_heavy);
+    if (with_extend && ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, ext_light, q + 1, ext_slots ? ext_slots : n_slots, sub,
+                                                     ext_heavy, n_heavy);
     else if (with_extend) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, order, q + 1, n_slots, sub);
     if (ev_after_ext) (void)hipEventRecord(*ev_after_ext, st);
     if (dbg_on) (void)hipEventRecord(dbg[2], st);
@@ -650,10 +654,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (production) { ENS(part_flag, (size_t)n * 4); ENS(part_pos, (size_t)n * 4); ENS(order_in, (size_t)n * 4); ENS(order_out, (size_t)n * 4); }
         auto dispatch_sub = [&](hipStream_t sst, const int *order, unsigned int *qq, const unsigned int *ns, int sub, int g2, int n_est,
                                 hipEvent_t *e1, hipEvent_t *e2, bool with_chain, bool with_extend = true, const int *xl = nullptr,
-                                const int *xh = nullptr, const unsigned int *nh = nullptr) {
-            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
-            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
-            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh);
+                                const int *xh = nullptr, const unsigned int *nh = nullptr, const unsigned int *xs = nullptr) {
+            if (max_len <= 160) launch_sub<160>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh, xs);
+            else if (max_len <= 320) launch_sub<320>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh, xs);
+            else launch_sub<SLX_MAX_READ_LEN + 4>(al, wk, ck, dopt, fm, sst, order, qq, ns, sub, g2, bs, n_est, e1, e2, with_chain, with_extend, xl, xh, nh, xs);
         };
         auto dispatch_ext = [&](hipStream_t sst, const int *order, unsigned int *qctr, const unsigned int *ns, int n_est) {
             const int g = std::max(1, std::min(n_est, al->n_cu * 32));
@@ -727,7 +731,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, job_cnt, job_off, n + 1, st));
                 hipLaunchKernelGGL(k_cand_base, dim3(gb), dim3(256), 0, st, wk->order_out.as<int>(), counts + 1, slot_off, (unsigned int)al->cand_cap,
                                    wk->cand_base.as<int32_t>());
-                const int gc = al->n_cu * 16;
+                const int gc = al->n_cu * 32;
                 if (max_len <= 160) hipLaunchKernelGGL(k_extend_cand<160>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
                                                        job_off, q + 14, wk->cand.as<DReg>());
                 else if (max_len <= 320) hipLaunchKernelGGL(k_extend_cand<320>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
@@ -735,7 +739,33 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 else hipLaunchKernelGGL(k_extend_cand<SLX_MAX_READ_LEN + 4>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
                                         job_off, q + 14, wk->cand.as<DReg>());
             }
-            if (hsort) dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false, true, wk->order_in.as<int>(),
+            if (hsort && al->ext_split) {
+                // light reads: top seed of every chain extended one wave per chain, decision sequence one read per lane; what is left
+                // (reads needing another extension) joins the heavy reads in the wave-per-read kernel
+                ENS(first_tab, (size_t)n * sizeof(DReg)); ENS(first_cnt, ((size_t)n + 2) * 4); ENS(first_off, ((size_t)n + 2) * 4); ENS(fb_list, (size_t)n * 4);
+                unsigned int *n_fb = q + 20, *ext_tot = q + 21;
+                HIPCHK(hipMemsetAsync(wk->first_cnt.p, 0, ((size_t)n + 2) * 4, st));
+                hipLaunchKernelGGL(k_first_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, n, (unsigned int)al->heavy_seeds, wk->first_cnt.as<unsigned int>());
+                size_t tb = wk->scan_tmp.cap;
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->first_cnt.as<unsigned int>(), wk->first_off.as<unsigned int>(), n + 1, st));
+                const int gf = al->n_cu * 32;
+                if (max_len <= 160) {
+                    hipLaunchKernelGGL(k_ext_first<160>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22, wk->first_tab.as<DReg>());
+                    hipLaunchKernelGGL(k_ext_replay<160>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
+                                       (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
+                } else if (max_len <= 320) {
+                    hipLaunchKernelGGL(k_ext_first<320>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22, wk->first_tab.as<DReg>());
+                    hipLaunchKernelGGL(k_ext_replay<320>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
+                                       (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
+                } else {
+                    hipLaunchKernelGGL(k_ext_first<SLX_MAX_READ_LEN + 4>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22,
+                                       wk->first_tab.as<DReg>());
+                    hipLaunchKernelGGL(k_ext_replay<SLX_MAX_READ_LEN + 4>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds,
+                                       wk->first_off.as<unsigned int>(), (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
+                }
+                hipLaunchKernelGGL(k_add_u32, dim3(1), dim3(1), 0, st, counts + 1, n_fb, ext_tot);
+                dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false, true, wk->fb_list.as<int>(), wk->order_out.as<int>(), counts + 1, ext_tot);
+            } else if (hsort) dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false, true, wk->order_in.as<int>(),
                                                wk->order_out.as<int>(), counts + 1);
             else dispatch_sub(st, nullptr, q, counts + 2, 0, grid, n, &wk->ev[4], &wk->ev[5], false);
         } else {

@@ -70,6 +70,12 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
             al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
             assert_same(al.alignSequences(seqs), exp, "split=%d heavy_stream=%d heavy_seeds=%d" % (split, hs, thr))
     # ahead-of-time extension of the heavy reads' chains: off, and with a table too small for most reads (in-place fallback)
+    # split extension of the light reads off (every read on the wave-per-read kernel)
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("split_min", 16)
+    al.set("heavy_seeds", 8)
+    al.set("ext_split", 0)
+    assert_same(al.alignSequences(seqs), exp, "ext_split=0")
     # chains outgrowing the LDS table of the cooperative chaining kernel: second launch, then the single-lane last resort
     for lim1, lim2 in ((2, 1 << 30), (2, 3)):
         al = sl.BWAAligner(tiny_gpu)
@@ -87,7 +93,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1), ("regs_big", 2), ("regs_big", 5), ("regs_big", 1073741824)])
+@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1), ("regs_big", 2), ("regs_big", 5), ("regs_big", 1073741824), ("ext_split", 0)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
     a tiny interval capacity that forces the overflow-retry path: identical records."""
