@@ -162,7 +162,14 @@ __device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt 
                 DReg a;
                 if (REPLAY) {
                     if (k != n - 1) return false;            // a seed other than the chain's top seed needs extending: not precomputed
-                    a = first[ci];
+                    a = first[ci];                           // (k_ext_first leaves seedcov to this kernel, which has the chain's seeds at hand)
+                    a.seedcov = 0;
+                    for (i = 0; i < n; ++i) {
+                        const int t = cs[i];
+                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+                        const int64_t t_rbeg = w.s_rbeg[t];
+                        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
+                    }
                 } else {
                     a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
                     a.n_comp = 0; a.hash = 0;

@@ -705,98 +705,96 @@ __global__ void k_first_count(Chunk ck, int n, unsigned int heavy_seeds, unsigne
 
 __global__ void k_add_u32(const unsigned int *a, const unsigned int *b, unsigned int *out) { *out = *a + *b; }
 
-// the top seed of chain ci of read r: region -> *out
-template <int MAXQ>
-__device__ __noinline__ void dev_first_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int *eh_h, int *eh_e,
-                                           int r, int ci, DReg *out, int lane)
+// one lane per read: a job descriptor for the top seed of every kept chain of a light read -- the seed itself, the reference window
+// of its chain (rmax, clipped to the contig) and where the read's bases are -- so that the extension kernel starts from ONE load
+// instead of the chain of dependent loads that leads from a read to its chains to their seeds
+__global__ void __launch_bounds__(128) k_first_prep(DevRef R, Chunk ck, DevOpt dopt, int n, const unsigned int *first_off, unsigned int cap, FirstJob *jobs)
 {
-    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
-    auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
+    const slx_opt &opt = dopt.o;
     const int64_t l_pac = R.l_pac;
-    ReadWS w = make_ws_uniform(ck, r);
-    const uint64_t q_off = rfl_u64(ck.offs[r]);
-    const uint8_t *query = ck.codes + q_off;
-    const int l_query = (int)(rfl_u64(ck.offs[r + 1]) - q_off);
-    const int c = __builtin_amdgcn_readfirstlane(w.ia[ci]);
-    const int n = __builtin_amdgcn_readfirstlane(w.c_n[c]);
-    const int *cs = w.c_w + __builtin_amdgcn_readfirstlane(w.c_first[c]);
-    if (n == 0) return;
-    int64_t rmax0 = l_pac << 1, rmax1 = 0;
-    uint64_t best = 0;                               // (length << 32 | list index), then the seed's slot id in a second word
-    int best_s = 0;
-    for (int i = lane; i < n; i += WAVE) {
-        const int s = cs[i];
-        const int qb = w.s_qbeg(s), sl = w.s_len(s);
-        const int64_t b = w.s_rbeg[s] - (qb + max_gap_of(qb));
-        const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + max_gap_of(l_query - qb - sl));
-        rmax0 = rmax0 < b ? rmax0 : b;
-        rmax1 = rmax1 > e ? rmax1 : e;
-        const uint64_t key = (uint64_t)(uint32_t)sl << 32 | (uint64_t)(uint32_t)i;
-        if (key >= best) { best = key; best_s = s; }
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const unsigned int off = first_off[r], cnt = first_off[r + 1] - off;
+        if (cnt == 0) continue;
+        if (off + cnt > cap) {                          // does not fit the table: the read is redone by k_extend_reg; its slots below the
+            FirstJob z;                                 // table end get an empty job (nothing to extend) so that no wave runs on garbage
+            z.s_rbeg = z.rmax0 = z.rmax1 = 0; z.q_off = 0; z.l_query = z.s_qbeg = z.s_len = z.rid = 0; z.frac_rep = 0.f; z.pad = 0;
+            for (unsigned int k = off; k < cap; ++k) jobs[k] = z;
+            continue;
+        }
+        ReadWS w = make_ws(ck, r);
+        const uint64_t q_off = ck.offs[r];
+        const int l_query = (int)(ck.offs[r + 1] - q_off);
+        const float frac_rep = ck.frac_rep[r];
+        for (unsigned int ci = 0; ci < cnt; ++ci) {
+            const int c = w.ia[ci];
+            const int nn = w.c_n[c];
+            const int *cs = w.c_w + w.c_first[c];
+            int64_t rmax0 = l_pac << 1, rmax1 = 0;
+            uint64_t best = 0;
+            int best_s = cs[0];
+            for (int i = 0; i < nn; ++i) {
+                const int s = cs[i];
+                const int qb = w.s_qbeg(s), sl = w.s_len(s);
+                const int64_t b = w.s_rbeg[s] - (qb + dev_cal_max_gap(opt, qb));
+                const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + dev_cal_max_gap(opt, l_query - qb - sl));
+                rmax0 = rmax0 < b ? rmax0 : b;
+                rmax1 = rmax1 > e ? rmax1 : e;
+                const uint64_t key = (uint64_t)(uint32_t)sl << 32 | (uint64_t)(uint32_t)i;       // the sorted loop takes the largest (length, list index) first
+                if (key >= best) { best = key; best_s = s; }
+            }
+            rmax0 = rmax0 > 0 ? rmax0 : 0;
+            rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+            const int64_t first_rbeg = w.s_rbeg[cs[0]];
+            if (rmax0 < l_pac && l_pac < rmax1) {
+                if (first_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+            }
+            int is_rev;
+            const int rid = dev_pos2rid(R, dev_depos(R, first_rbeg, &is_rev));
+            int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
+            if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+            rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+            rmax1 = rmax1 < far_end ? rmax1 : far_end;
+            FirstJob j;
+            j.s_rbeg = w.s_rbeg[best_s]; j.rmax0 = rmax0; j.rmax1 = rmax1; j.q_off = q_off; j.l_query = l_query;
+            j.s_qbeg = w.s_qbeg(best_s); j.s_len = w.s_len(best_s); j.rid = w.c_rid[c]; j.frac_rep = frac_rep; j.pad = 0;
+            jobs[off + ci] = j;
+        }
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int64_t o0 = __shfl_xor(rmax0, d, WAVE), o1 = __shfl_xor(rmax1, d, WAVE);
-        rmax0 = rmax0 < o0 ? rmax0 : o0;
-        rmax1 = rmax1 > o1 ? rmax1 : o1;
-        const uint64_t ob = __shfl_xor(best, d, WAVE);
-        const int os = __shfl_xor(best_s, d, WAVE);
-        if (ob > best) { best = ob; best_s = os; }
-    }
-    rmax0 = rmax0 > 0 ? rmax0 : 0;
-    rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-    const int64_t first_rbeg = w.s_rbeg[cs[0]];
-    if (rmax0 < l_pac && l_pac < rmax1) {
-        if (first_rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
-    }
-    {
-        int is_rev;
-        const int rid = dev_pos2rid(R, dev_depos(R, first_rbeg, &is_rev));
-        int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
-        if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
-        rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
-        rmax1 = rmax1 < far_end ? rmax1 : far_end;
-    }
-    const int s = __builtin_amdgcn_readfirstlane(best_s);
-    DReg a = dev_extend_core<NCH>(R, opt, mr, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s], rmax0, rmax1, w.c_rid[c], ck.frac_rep[r], eh_h, eh_e, lane);
-    int cov = 0;
-    for (int i = lane; i < n; i += WAVE) {
-        const int t = cs[i];
-        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-        const int64_t t_rbeg = w.s_rbeg[t];
-        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
-    }
-    for (int d = 32; d >= 1; d >>= 1) cov += __shfl_xor(cov, d, WAVE);
-    a.seedcov = cov;
-    if (lane == 0) *out = a;
 }
 
+// one top-seed extension; out of line so that the queue loop of the kernel stays a plain fetch / test / call
+template <int MAXQ>
+__device__ __noinline__ void dev_first_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, int *eh_h, int *eh_e, const FirstJob *jp,
+                                           DReg *out, int lane)
+{
+    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
+    const FirstJob j = *jp;                          // every lane reads the same 64 bytes
+    const int64_t s_rbeg = (int64_t)rfl_u64((uint64_t)j.s_rbeg), rmax0 = (int64_t)rfl_u64((uint64_t)j.rmax0), rmax1 = (int64_t)rfl_u64((uint64_t)j.rmax1);
+    const uint8_t *query = ck.codes + rfl_u64(j.q_off);
+    const int l_query = __builtin_amdgcn_readfirstlane(j.l_query), s_qbeg = __builtin_amdgcn_readfirstlane(j.s_qbeg);
+    const int s_len = __builtin_amdgcn_readfirstlane(j.s_len), rid = __builtin_amdgcn_readfirstlane(j.rid);
+    const DReg a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, rid, j.frac_rep, eh_h, eh_e, lane);
+    if (lane == 0) *out = a;                         // seedcov is filled in by k_ext_replay
+}
+
+#define FIRST_BATCH 8        // jobs per queue fetch of k_ext_first (one fetch-add on a shared address costs ~10 ns device-wide)
 template <int MAXQ>
 __global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_ext_first(DevRef R, Chunk ck, DevOpt dopt, int n, const unsigned int *first_off, unsigned int cap,
-                                                                  unsigned int *queue, DReg *first)
+                                                                  unsigned int *queue, const FirstJob *jobs, DReg *first)
 {
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
     __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    __shared__ int gap_lut[MAXQ + 2];
-    for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
-    __syncthreads();
-    for (;;) {                                       // a wave-full of reads per fetch; the reads with nothing to do cost one ballot
-        int base = 0;
-        if (lane == 0) base = (int)atomicAdd(queue, (unsigned int)WAVE);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const int x = base + lane;
-        const unsigned int off_l = x < n ? first_off[x] : 0u;
-        const unsigned int cnt_l = x < n ? first_off[x + 1] - off_l : 0u;
-        unsigned long long todo = __ballot(cnt_l > 0 && off_l + cnt_l <= cap);
-        while (todo) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int nch = __builtin_amdgcn_readlane((int)cnt_l, l);
-            const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)off_l, l);
-            for (int ci = 0; ci < nch; ++ci) dev_first_job<MAXQ>(R, ck, opt, mr, gap_lut, eh_h, eh_e, base + l, ci, first + off + ci, lane);
-        }
+    unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)first_off[n]);
+    if (n_jobs > cap) n_jobs = cap;                  // (reads whose slots pass the table end are not prepared either)
+    for (;;) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(queue, (unsigned int)FIRST_BATCH);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_jobs) break;
+        const unsigned int end = base + FIRST_BATCH < n_jobs ? base + FIRST_BATCH : n_jobs;
+        for (unsigned int job = base; job < end; ++job) dev_first_job<MAXQ>(R, ck, opt, mr, eh_h, eh_e, jobs + job, first + job, lane);
     }
 }
 

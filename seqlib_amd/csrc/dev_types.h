@@ -50,6 +50,14 @@ struct alignas(8) DHit {      // mem_aln_t after reg2aln
     int64_t cig_start;        // word offset in the cigar pool
 };
 
+struct alignas(8) FirstJob {   // one top-seed extension of a light read (k_first_prep -> k_ext_first)
+    int64_t s_rbeg, rmax0, rmax1;
+    uint64_t q_off;             // the read's codes
+    int l_query, s_qbeg, s_len, rid;
+    float frac_rep;
+    int pad;
+};
+
 // one chunk of reads, all device pointers
 struct Chunk {
     int n_reads;

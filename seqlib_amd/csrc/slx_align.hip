@@ -78,7 +78,7 @@ struct Worker {
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
-    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos, cand, cand_base, cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list;
+    DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, fast_list2, dp_list2, part_flag, part_pos, cand, cand_base, cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs;
     hipStream_t stream2 = nullptr;
     int id = 0;
     hipEvent_t dbg_ev[2][6];
@@ -97,7 +97,7 @@ struct Worker {
         DevBuf *b[] = {&codes, &offs_rel, &intv_n, &intv_info, &intv_x0, &intv_x2, &l_rep, &seed_cnt, &seed_off, &scan_tmp, &s_rbeg, &s_ql, &s_next,
                        &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                        &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
-                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &cand, &cand_base, &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
+                       &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &fast_list2, &dp_list2, &part_flag, &part_pos, &cand, &cand_base, &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm,
                        &o_na, &o_ncig, &o_cig_off, &o_cigar};
         n_all = (int)(sizeof(b) / sizeof(b[0]));
         for (int i = 0; i < n_all; ++i) all[i] = b[i];
@@ -749,17 +749,22 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 size_t tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->first_cnt.as<unsigned int>(), wk->first_off.as<unsigned int>(), n + 1, st));
                 const int gf = al->n_cu * 32;
+                ENS(first_jobs, (size_t)n * sizeof(FirstJob));
+                hipLaunchKernelGGL(k_first_prep, dim3(std::max(1, std::min(n / 128 + 1, al->n_cu * 12))), dim3(128), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(),
+                                   (unsigned int)n, wk->first_jobs.as<FirstJob>());
                 if (max_len <= 160) {
-                    hipLaunchKernelGGL(k_ext_first<160>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22, wk->first_tab.as<DReg>());
+                    hipLaunchKernelGGL(k_ext_first<160>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22,
+                                       wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
                     hipLaunchKernelGGL(k_ext_replay<160>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
                                        (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
                 } else if (max_len <= 320) {
-                    hipLaunchKernelGGL(k_ext_first<320>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22, wk->first_tab.as<DReg>());
+                    hipLaunchKernelGGL(k_ext_first<320>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22,
+                                       wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
                     hipLaunchKernelGGL(k_ext_replay<320>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
                                        (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
                 } else {
                     hipLaunchKernelGGL(k_ext_first<SLX_MAX_READ_LEN + 4>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22,
-                                       wk->first_tab.as<DReg>());
+                                       wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
                     hipLaunchKernelGGL(k_ext_replay<SLX_MAX_READ_LEN + 4>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds,
                                        wk->first_off.as<unsigned int>(), (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
                 }
