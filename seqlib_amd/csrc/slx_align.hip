@@ -128,7 +128,7 @@ struct slx_aligner {
     int stagger = 0;              // 1 = each worker cuts its part in two at a different point (see worker_run)
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
-    int cand_seeds = 512;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
+    int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
     int heavy_stream = 0;         // 1 = chaining + extension of the heavy reads run on the worker's second stream, beside the light reads'
                                   // chaining + extension; both join before the region stage (needs chain_mode = 1)
