@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
     head = nhead = psrc = nsrc = ik;
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
     uint32_t trip = 0;
+    unsigned long long dbg_ext = 0, dbg_ev = 0, dbg_done = 0;
 
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
     auto push_fwd = [&](const IntvE<I> &v) { if (n < wl.cap) wl.at(1, n) = v; else list_ovf = true; ++n; };
@@ -313,6 +314,11 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
         if (__all(phase == S2_DONE)) break;
         // ------------------------------------------------ the one bwt_extend of this trip
         const bool fwd = phase == S2_FWD, bwd = phase == S2_BWD;
+        if (ck.dbg_cyc && ck.dbg_stage == 3) {       // SLX_DEBUG_CYC=3: lanes extending / waiting for an event block / done, per trip
+            dbg_ext += (unsigned long long)__popcll(__ballot(fwd || bwd));
+            dbg_ev += (unsigned long long)__popcll(__ballot(phase == S2_FETCH || phase == S2_INIT || phase == S2_START));
+            dbg_done += (unsigned long long)__popcll(__ballot(phase == S2_DONE));
+        }
         if (bwd && j + 1 < np) nsrc = wl.at(cur, rev ? np - 2 - j : j + 1);       // next trip's entry, in flight behind this trip's rank reads
         IntvE<I> ok;
         ok.x0 = ok.x1 = ok.x2 = 0; ok.info = 0;
@@ -345,6 +351,9 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
                 else { cur = 1 - cur; np = nc; rev = 0; --bi; head = nhead; phase = S2_ROW; }
             } else psrc = nsrc;
         }
+    }
+    if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
+        atomicAdd(ck.dbg_cyc + 0, (unsigned long long)trip); atomicAdd(ck.dbg_cyc + 1, dbg_ext); atomicAdd(ck.dbg_cyc + 2, dbg_ev); atomicAdd(ck.dbg_cyc + 3, dbg_done);
     }
 }
 

@@ -833,7 +833,12 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         float ms = 0;
         if (hipEventElapsedTime(&ms, wk->ev[i], wk->ev[i + 1]) == hipSuccess) wk->stage_ms[i] += ms;
     }
-    if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
+    if (ck.dbg_cyc && ck.dbg_stage == 3) {
+        unsigned long long c4[4];
+        HIPCHK(hipMemcpy(c4, wk->dbg_cyc.p, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[seed12] wave-trips %.4g; per trip of 64 lanes: %.1f extending, %.1f waiting for an event block, %.1f done\n", (double)c4[0],
+                (double)c4[1] / (double)c4[0], (double)c4[2] / (double)c4[0], (double)c4[3] / (double)c4[0]);
+    } else if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
         std::vector<unsigned long long> cyc((size_t)n * 4), sc((size_t)n);
         std::vector<int> nch((size_t)n), nrg((size_t)n);
         HIPCHK(hipMemcpy(cyc.data(), wk->dbg_cyc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
