@@ -149,6 +149,9 @@ __device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
 #ifndef SEED2_POOL
 #define SEED2_POOL 16
 #endif
+#ifndef SEED2_DEBUG
+#define SEED2_DEBUG 0
+#endif
 #ifndef SEED2_EV_EVERY
 #define SEED2_EV_EVERY 4      // power of two
 #endif
@@ -186,7 +189,9 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
     head = nhead = psrc = nsrc = ik;
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
     uint32_t trip = 0;
-    unsigned long long dbg_ext = 0, dbg_ev = 0, dbg_done = 0;
+#if SEED2_DEBUG
+    unsigned long long dbg_ext = 0, dbg_ev = 0, dbg_done = 0;   // (three more live values cost this kernel a register tier: off in production)
+#endif
 
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
     auto push_fwd = [&](const IntvE<I> &v) { if (n < wl.cap) wl.at(1, n) = v; else list_ovf = true; ++n; };
@@ -314,11 +319,13 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
         if (__all(phase == S2_DONE)) break;
         // ------------------------------------------------ the one bwt_extend of this trip
         const bool fwd = phase == S2_FWD, bwd = phase == S2_BWD;
-        if (ck.dbg_cyc && ck.dbg_stage == 3) {       // SLX_DEBUG_CYC=3: lanes extending / waiting for an event block / done, per trip
+#if SEED2_DEBUG
+        if (ck.dbg_cyc && ck.dbg_stage == 3) {       // -DSEED2_DEBUG=1 + SLX_DEBUG_CYC=3: lanes extending / waiting for an event block / done, per trip
             dbg_ext += (unsigned long long)__popcll(__ballot(fwd || bwd));
             dbg_ev += (unsigned long long)__popcll(__ballot(phase == S2_FETCH || phase == S2_INIT || phase == S2_START));
             dbg_done += (unsigned long long)__popcll(__ballot(phase == S2_DONE));
         }
+#endif
         if (bwd && j + 1 < np) nsrc = wl.at(cur, rev ? np - 2 - j : j + 1);       // next trip's entry, in flight behind this trip's rank reads
         IntvE<I> ok;
         ok.x0 = ok.x1 = ok.x2 = 0; ok.info = 0;
@@ -352,9 +359,11 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
             } else psrc = nsrc;
         }
     }
+#if SEED2_DEBUG
     if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
         atomicAdd(ck.dbg_cyc + 0, (unsigned long long)trip); atomicAdd(ck.dbg_cyc + 1, dbg_ext); atomicAdd(ck.dbg_cyc + 2, dbg_ev); atomicAdd(ck.dbg_cyc + 3, dbg_done);
     }
+#endif
 }
 
 // pass 3 + per-read epilogue; one lane per read
