@@ -558,8 +558,11 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
     if (lane == 0) ck.hits[slot] = h;
 }
 
+#ifndef CIG_MIN_WAVES
+#define CIG_MIN_WAVES 2
+#endif
 template <int MAXQ>
-__global__ void __launch_bounds__(64) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, int hi_prio)
+__global__ void __launch_bounds__(64, CIG_MIN_WAVES) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, int hi_prio)
 {
     const int lane = threadIdx.x;
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
