@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- aligned 150 bp reads/s through the BWAAligner hot path on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
-by torch.distributed.run with one rank per GPU (backend "nccl" = RCCL).  A step = one pass of the whole path
-(encode -> SMEM seeding -> chaining -> extension -> CIGAR/MAPQ -> hit filters -> SoA result) over one batch of
-synthetic reads that is already resident in HBM, plus -- when N > 1 -- the single RCCL gather of the packed
-hits to rank 0.  Workload at N = 1: BASELINE.json configs[1] ("C2": E. coli-sized 4.6 Mb synthetic reference,
-10 M synthetic 150 bp reads); with N ranks every rank aligns its own 10 M-read shard (weak scaling, reads
-sharded by contiguous ordinal range, index replicated).  Rank 0 prints ONE JSON line.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no
+WORLD_SIZE in the environment it starts the N ranks itself (a torch.distributed.run child, before anything
+touches the GPU) and exits with the child's code; under torch.distributed.run it is one rank per GPU
+(backend "nccl" = RCCL).  A step = one pass of the whole path (encode -> SMEM seeding -> chaining ->
+extension -> CIGAR/MAPQ -> hit filters -> SoA result) over one batch of synthetic reads that is already
+resident in HBM, plus -- when N > 1 -- the single RCCL gather of the packed hits to rank 0.
+
+Workload at N = 1: the largest single-GPU configuration of BASELINE.json, configs[2] ("C3": chr20-sized
+64.4 Mb synthetic reference, 50 M synthetic 150 bp reads = 25 M pairs, a pair being two single-end reads
+as the API has no paired mode; the batch is aligned in chunks of 8 M reads per worker).  `--config C2`
+(E. coli-sized, 10 M reads), `C1` and `C4` (GRCh38-sized, u64 index) select the other configurations.
+With N ranks every rank aligns its own shard of that size (weak scaling, reads sharded by contiguous
+ordinal range, index replicated).  Rank 0 prints ONE JSON line.
+
+Beside `value` (reads resident in HBM -> hits resident in HBM) the line carries the metric as SURVEY 8d words
+it: `value_host_to_host` (pinned host reads -> host SoA hits through slx_align_batch) and `value_bamrecords`
+(the C++ class: UnalignedSequenceVector -> BamRecordPtrVector, on a bounded sample, tools/bamrec_bench.cpp).
 """
 import argparse
 import ctypes as C
 import json
+import mmap
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -24,46 +37,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CU x 4 SIMD x 16 lanes/cycle x 2.4 GHz = 39.3 T int32 lane-ops/s
+DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000}
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+
+_G = {}
 
 
-def _gen_block(args):
+def _gen_block(job):
     from seqlib_amd import synth
-    genome, b, read_len, seed = args
-    return synth.make_reads_block(genome, b, synth.BLOCK, read_len, seed)[0]
+    b, lo, m = job
+    cfg, refs, out = _G["cfg"], _G["refs"], _G["out"]
+    out[lo:lo + m] = synth.make_config_block(cfg, refs, b)[:m]
+    return m
 
 
-def gen_reads(genome, n_reads, read_len, seed, first_block):
+def gen_reads(cfg, refs, n_reads, first_block, share=1):
+    """n_reads reads of the config's read set from block first_block on, generated block-parallel by forked workers that
+    write straight into one anonymous shared mapping.  Runs BEFORE this process touches the GPU."""
     from seqlib_amd import synth
+    read_len = cfg["read_len"]
+    if n_reads < synth.BLOCK:
+        return synth.make_config_reads(cfg, refs, n_reads, first_block)
+    buf = mmap.mmap(-1, n_reads * read_len)
+    out = np.frombuffer(buf, dtype=np.uint8).reshape(n_reads, read_len)
     nb = (n_reads + synth.BLOCK - 1) // synth.BLOCK
-    out = np.empty((n_reads, read_len), dtype=np.uint8)
-    procs = max(1, min(nb, (os.cpu_count() or 8), 32))
-    jobs = [(genome, first_block + b, read_len, seed) for b in range(nb)]
+    jobs = [(first_block + b, b * synth.BLOCK, min(synth.BLOCK, n_reads - b * synth.BLOCK)) for b in range(nb)]
+    procs = max(1, min(nb, (os.cpu_count() or 8) // max(1, share), 48))
+    _G.update(cfg=cfg, refs=refs, out=out)
     if procs > 1:
         with mp.get_context("fork").Pool(procs) as pool:
-            for b, blk in enumerate(pool.imap(_gen_block, jobs)):
-                lo = b * synth.BLOCK
-                m = min(synth.BLOCK, n_reads - lo)
-                out[lo:lo + m] = blk[:m]
+            for _ in pool.imap_unordered(_gen_block, jobs, chunksize=1):
+                pass
     else:
-        for b, j in enumerate(jobs):
-            lo = b * synth.BLOCK
-            m = min(synth.BLOCK, n_reads - lo)
-            out[lo:lo + m] = _gen_block(j)[:m]
+        for j in jobs:
+            _gen_block(j)
+    _G.clear()
     return out
 
 
-def cpu_baseline(prefix, reads_ascii, budget_s=12.0):
-    """The CPU oracle (a port of the reference path: it cannot be built from /root/reference) timed on
-    this box's host cores on a bounded sample of the same reads.  Also returns the oracle-counted algorithmic
-    bytes per read that the roofline figure is computed from."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=12.0):
+    """The CPU oracle (a port of the reference path: it cannot be built from /root/reference) timed on this box's
+    host cores on a bounded sample of the same reads: one oracle process per core (python -m oracle.cpu_bench, started fresh --
+    nothing of this process is forked), each timing its own slice after loading the index.  Also returns the oracle-counted
+    algorithmic bytes / DP cells per read that the roofline figures are computed from."""
     from oracle import orc
     idx = orc.Index.load(prefix)
     opt = orc.default_opt()
     read_len = reads_ascii.shape[1]
-    cores = os.cpu_count() or 1
-    # calibrate on one thread
-    cal = 2000
+    cores = min(os.cpu_count() or 1, 64)
+    cal = min(2000, len(reads_ascii))
     offs = (np.arange(cal + 1, dtype=np.uint64) * np.uint64(read_len))
     orc.lib().orc_counters_reset()
     t0 = time.time()
@@ -72,22 +95,58 @@ def cpu_baseline(prefix, reads_ascii, budget_s=12.0):
     cnt = orc.counters()
     per_read = {k: v / cal for k, v in cnt.items()}
     rate1 = cal / dt1
-    per_thread = int(max(1000, min(rate1 * budget_s, (len(reads_ascii) - cal) // max(cores, 1))))
-    if per_thread * cores + cal > len(reads_ascii):
-        per_thread = max(1, (len(reads_ascii) - cal) // cores)
-
-    def work(t):
-        lo = cal + t * per_thread
-        o = (np.arange(per_thread + 1, dtype=np.uint64) * np.uint64(read_len))
-        orc.align_batch_flat(opt, idx, reads_ascii[lo:lo + per_thread].tobytes(), o, first_ordinal=lo)
-        return per_thread
-    t0 = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        done = sum(ex.map(work, range(cores)))
-    dt = time.time() - t0
-    return dict(value=done / dt, unit="reads/s", cores=cores, kind="port",
-                sample="%d reads x %d threads of the same synthetic C2 reads (single thread: %.0f reads/s)" % (per_thread, cores, rate1),
+    del idx
+    per_proc = int(max(500, min(rate1 * budget_s, (len(reads_ascii) - cal) // max(cores, 1))))
+    if per_proc * cores + cal > len(reads_ascii):
+        per_proc = max(1, (len(reads_ascii) - cal) // cores)
+    tmp = tempfile.mkdtemp(prefix="slx_cpu_")
+    sample = os.path.join(tmp, "sample.bin")
+    reads_ascii[cal:cal + per_proc * cores].tofile(sample)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", prefix, sample, str(read_len), str(t * per_proc), str(per_proc), str(cal + t * per_proc)],
+                           stdout=subprocess.PIPE, env=env, cwd=ROOT) for t in range(cores)]
+    secs, done = [], 0
+    for p in ps:
+        o = p.communicate()[0].decode().strip().splitlines()
+        if p.returncode == 0 and o:
+            r = json.loads(o[-1])
+            secs.append(r["seconds"]); done += r["reads"]
+    os.remove(sample)
+    rate = done / max(secs) if secs else 0.0
+    return dict(value=rate, unit="reads/s", cores=len(secs), kind="port",
+                sample="%d reads x %d oracle processes of the same synthetic %s reads (single thread: %.0f reads/s; the oracle is scalar, "
+                       "malloc-heavy C and scales sub-linearly with the core count)" % (per_proc, len(secs), cfg_name, rate1),
                 single_thread=rate1), per_read
+
+
+def compare(got, exp, m):
+    same = 0
+    for i in range(m):
+        a0, a1 = got["hit_off"][i], got["hit_off"][i + 1]
+        b0, b1 = exp["hit_off"][i], exp["hit_off"][i + 1]
+        ok = (a1 - a0) == (b1 - b0)
+        if ok:
+            for k in ("rid", "pos", "flag", "mapq", "score", "nm", "na", "n_cigar"):
+                ok = ok and np.array_equal(got[k][a0:a1], exp[k][b0:b1])
+            ok = ok and np.array_equal(got["cigar"][got["cig_off"][a0]:got["cig_off"][a1]] if a1 > a0 else got["cigar"][:0],
+                                       exp["cigar"][exp["cig_off"][b0]:exp["cig_off"][b1]] if b1 > b0 else exp["cigar"][:0])
+        same += bool(ok)
+    return same / max(m, 1)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child job and relay its exit code.  Runs before
+    any HIP call of this process (device_count() does not initialise the GPU on this image); never re-execs."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to report a %d-GPU number from fewer devices\n" % (n, have, n))
+        sys.exit(2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -95,17 +154,38 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (C2 = 10 M)")
-    ap.add_argument("--config", default="C2")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's size: C3 = 50 M, C2 = 10 M)")
+    ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / value_bamrecords")
     ap.add_argument("--verify", type=int, default=20000, help="reads of the timed batch checked bit-for-bit against the oracle")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
+
+    # ---- workload, generated before this process touches the GPU (forked generator workers)
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS[args.config]
+    read_len = cfg["read_len"]
+    n = args.reads or DEFAULT_READS[args.config]
+    if cfg.get("pairs"):
+        n -= n % 2
+    t_setup = time.time()
+    refs = synth.make_reference(cfg)
+    blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
+    reads = gen_reads(cfg, refs, n, first_block=rank * blocks_per_rank, share=world)
+    t_gen = time.time() - t_setup
+    first_ordinal = rank * n
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the BWAAligner path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -115,28 +195,24 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import seqlib_amd
-    from seqlib_amd import synth, gather
-    cfg = synth.CONFIGS[args.config]
-    read_len = cfg["read_len"]
-    t_setup = time.time()
-    genome = synth.make_genome(cfg["length"])
+    from seqlib_amd import gather
+    t0 = time.time()
     idx = seqlib_amd.BWAIndex()
-    idx.ConstructIndex([(cfg["name"], synth.genome_ascii(genome))])     # suffix sort + BWT/Occ/SA on the GPU
-    t_index = time.time() - t_setup
+    idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])     # suffix sort + BWT/Occ/SA on the GPU
+    t_index = time.time() - t0
     al = seqlib_amd.BWAAligner(idx, device=local_rank)
-    for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=workers=4,sched=1
+    per_worker = (n + 2) // 3
+    if per_worker > (1 << 23):
+        al.set("chunk_reads", 1 << 23)       # 50 M reads: each of the three workers takes its part in chunks of 8 M reads
+    for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=workers=2
         k, v = kv.split("=")
         al.set(k, int(v))
-    n = args.reads
-    blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
-    reads = gen_reads(genome, n, read_len, cfg["read_seed"], first_block=rank * blocks_per_rank)
-    first_ordinal = rank * n
     d_bases = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offs = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * read_len
     torch.cuda.synchronize()
 
-    def step():
-        h = al.align_device(d_bases.data_ptr(), d_offs.data_ptr(), n, first_ordinal=first_ordinal)
+    def step(m=n):
+        h = al.align_device(d_bases.data_ptr(), d_offs.data_ptr(), m, first_ordinal=first_ordinal)
         if world > 1:
             sz = al.packed_size(h)
             buf = torch.empty(sz, dtype=torch.uint8, device=dev)
@@ -152,7 +228,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    stage_acc = {}
+    stage_acc, probe_acc = {}, {}
     fence()
     t0 = time.time()
     step_marks = [t0]
@@ -161,6 +237,8 @@ def main():
         step_marks.append(time.time())            # each step ends synchronised on this rank: per-step spread for free
         for k, v in al.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+        for k, v in al.probe_ms()[0].items():
+            probe_acc[k] = probe_acc.get(k, 0.0) + v
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -171,16 +249,32 @@ def main():
     total_reads = n * world
     value = total_reads / (dt / args.steps)
 
-    out = None
+    # ---- N > 1: the merged gather of a sample equals what one process computes for the same reads
+    gather_ok = None
+    if world > 1:
+        m = min(4096, n)
+        _, parts = step(m)
+        if rank == 0:
+            gather_ok = True
+            for r in range(world):
+                got_r = gather.unpack(parts[r].cpu().numpy())
+                blk = (synth.make_config_block(cfg, refs, r * blocks_per_rank) if n >= synth.BLOCK
+                       else synth.make_config_reads(cfg, refs, n, r * blocks_per_rank))[:m]
+                db = torch.from_numpy(np.ascontiguousarray(blk).reshape(-1)).to(dev)
+                hv = al.align_device(db.data_ptr(), d_offs.data_ptr(), m, first_ordinal=r * n)
+                sz = al.packed_size(hv)
+                buf = torch.empty(sz, dtype=torch.uint8, device=dev)
+                al.pack_into(hv, buf.data_ptr(), sz)
+                one = gather.unpack(buf.cpu().numpy())
+                gather_ok = gather_ok and all(np.array_equal(got_r[k], one[k]) for k in ("hit_off", "pos", "cig_off", "rid", "score", "nm", "na", "n_cigar", "cigar", "flag", "mapq"))
+
     if rank == 0:
-        # parity spot check of the timed batch against the oracle + CPU baseline + algorithmic bytes
         tmp = tempfile.mkdtemp(prefix="slx_bench_")
         prefix = os.path.join(tmp, cfg["name"])
         idx.WriteIndex(prefix)
-        per_read, cpu = None, None
-        match = None
+        per_read, cpu, match = None, None, None
         if not args.no_cpu_baseline:
-            cpu, per_read = cpu_baseline(prefix, reads)
+            cpu, per_read = cpu_baseline(prefix, reads, args.config)
         if args.verify > 0:
             from oracle import orc
             m = min(args.verify, n)
@@ -191,59 +285,102 @@ def main():
             got = gather.unpack(buf.cpu().numpy())
             oidx = orc.Index.load(prefix)
             exp = orc.align_batch_flat(orc.default_opt(), oidx, reads[:m].tobytes(), synth.offsets_for(m, read_len), first_ordinal=first_ordinal)
-            same = 0
-            for i in range(m):
-                a0, a1 = got["hit_off"][i], got["hit_off"][i + 1]
-                b0, b1 = exp["hit_off"][i], exp["hit_off"][i + 1]
-                ok = (a1 - a0) == (b1 - b0)
-                if ok:
-                    for k in ("rid", "pos", "flag", "mapq", "score", "nm", "na", "n_cigar"):
-                        ok = ok and np.array_equal(got[k][a0:a1], exp[k][b0:b1])
-                    ok = ok and np.array_equal(got["cigar"][got["cig_off"][a0]:got["cig_off"][a1]] if a1 > a0 else got["cigar"][:0],
-                                               exp["cigar"][exp["cig_off"][b0]:exp["cig_off"][b1]] if b1 > b0 else exp["cigar"][:0])
-                same += bool(ok)
-            match = same / m
-        # roofline of the seeding kernel: algorithmic bytes on bwa's own layout / HIP-event time
-        seed_ms = stage_acc.get("seed", 0.0) / args.steps       # sum over this step's launches (one per worker)
-        stage_launches = 3 if n >= (1 << 19) else 1
-        roof = None
-        # HBM-side traffic of the seeding kernel from the PMC passes of the same command (profiles/, see scripts/profile_round.sh)
+            match = compare(got, exp, m)
+            del oidx
+        # ---- the metric as SURVEY 8d words it: host reads -> host hits, and the C++ class with BamRecord materialisation
+        h2h, bam = None, None
+        if not args.no_extras:
+            pin = torch.from_numpy(reads.reshape(-1)).pin_memory()
+            offs_pin = (torch.arange(0, n + 1, dtype=torch.int64) * read_len).pin_memory()
+            best = None
+            for _ in range(2):
+                t0 = time.time()
+                hh = al.align_host_raw(pin.data_ptr(), offs_pin.data_ptr(), n, first_ordinal=first_ordinal)
+                d = time.time() - t0
+                nh = hh.n_hits
+                al.free_hits(hh)
+                best = d if best is None or d < best else best
+            h2h = dict(value=n / best, unit="reads/s", ms=best * 1e3, hits=int(nh),
+                       path="slx_align_batch: pinned host reads -> three per-worker H2D copies on the workers' streams -> pipeline -> one packed D2H into a recycled pinned block")
+            del pin, offs_pin
+            tool = os.path.join(ROOT, "seqlib_amd", "bamrec_bench")
+            if os.path.exists(tool):
+                m = min(n, 2_000_000)
+                sample = os.path.join(tmp, "bam_sample.bin")
+                reads[:m].tofile(sample)
+                try:
+                    o = subprocess.run([tool, prefix, sample, str(read_len), str(m)], stdout=subprocess.PIPE, timeout=600, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank)))
+                    if o.returncode == 0:
+                        bam = json.loads(o.stdout.decode().strip().splitlines()[-1])
+                except Exception as e:          # the extra must not take the bench line down
+                    bam = dict(error=str(e))
+                os.remove(sample)
+        # ---- rooflines
+        launches = al_launches(n)
+        roof, roof_ext = None, None
         pmc = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
         except Exception:
             pass
+        seed_ms = probe_acc.get("seed", 0.0) / args.steps        # summed over this step's launches
+        ext_ms = probe_acc.get("extend", 0.0) / args.steps
+        cig_ms = probe_acc.get("cigar", 0.0) / args.steps
         if per_read is not None and seed_ms > 0:
             seed_bytes = 64.0 * per_read["n_occ_block"] + per_read["read_bases"]
             path_bytes = (64.0 * per_read["n_occ_block"] + 64.0 * per_read["n_invpsi"] + 8.0 * per_read["n_sa"] +
                           per_read["ref_bases"] / 4.0 + per_read["read_bases"] + 32.0 * per_read["n_hits"] + 4.0 * per_read["n_cigar_ops"])
-            achieved = seed_bytes * n / (seed_ms * 1e-3) / 1e9
-            n_launch = max(1, round(stage_launches)) if stage_launches else 1
-            traffic = None
-            if pmc:   # bytes per launch = (FETCH_SIZE + WRITE_SIZE) per read, as counted, x reads per launch
-                traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / n_launch
+            achieved = seed_bytes * n / (seed_ms * 1e-3) / 1e9        # = bytes per launch / mean launch duration
+            traffic, src = None, None
+            if pmc and pmc.get("config") == args.config:
+                traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / launches
+                src = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % PMC_SUMMARY
             roof = dict(bound="hbm", kernel="k_seed12 + k_seed3", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=n_launch, reads_per_launch=n / n_launch,
-                        kernel_ms=seed_ms,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src, launches_per_step=launches, reads_per_launch=n / launches,
+                        kernel_ms=seed_ms, kernel_ms_mean_launch=seed_ms / launches, timing="HIP events on each worker's own stream around the two kernels, summed over the step's launches",
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,
                         path_achieved=path_bytes * n / (ms_per_step * 1e-3) / 1e9)
+            cells = per_read.get("ext_cells", 0.0) + per_read.get("glb_cells", 0.0)
+            if cells > 0 and ext_ms + cig_ms > 0:
+                ops = 14.0 * cells * n
+                ach = ops / ((ext_ms + cig_ms) * 1e-3)
+                roof_ext = dict(bound="valu", kernel="extension family (k_extend_cand, k_ext_first, k_ext_replay, k_extend_reg) + k_cig_fast/k_cig_dp",
+                                cells_per_read=cells, ext_cells_per_read=per_read.get("ext_cells"), glb_cells_per_read=per_read.get("glb_cells"), ops_per_cell=14,
+                                kernel_ms=ext_ms + cig_ms, extend_ms=ext_ms, cigar_ms=cig_ms, achieved=ach / 1e12, peak=VALU_PEAK_LANE_OPS / 1e12,
+                                unit="T int32 lane-op/s", frac=ach / VALU_PEAK_LANE_OPS,
+                                valu_busy=(pmc or {}).get("ext_valu_busy") if pmc and pmc.get("config") == args.config else None,
+                                valu_busy_source=("%s: SQ_ACTIVE_INST_VALU x 4 / (n_simd x GRBM_GUI_ACTIVE); formula and units in that file" % PMC_SUMMARY)
+                                if pmc and pmc.get("config") == args.config else None)
         out = {
             "metric": "aligned reads/sec (150 bp) via BWAAligner", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%s: %s %d bp synthetic reference (GPU-built BWAIndex), %d synthetic %d bp reads per GPU, "
-                                   "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], cfg["length"], n, read_len),
+            "config": {"workload": "%s: %s %d bp synthetic reference in %d contig(s) (GPU-built BWAIndex, %s index), %d synthetic %d bp reads per GPU%s, "
+                                   "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], sum(len(g) for _, g in refs), len(refs),
+                                                                                      "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
+                                                                                      " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
                        "reads_per_gpu": n, "read_len": read_len, "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_ext": roof_ext, "cpu_baseline": cpu,
+            "value_host_to_host": h2h, "value_bamrecords": bam,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
+            "gather_equals_single_process": gather_ok,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
             "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(step_marks[:-1], step_marks[1:])],
-            "index_build_s": t_index,
+            "index_build_s": t_index, "read_generation_s": t_gen,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def al_launches(n):
+    """seeding launches per step: three workers (batches >= 2^19 reads), each in chunks of at most 2^23 reads"""
+    if n < (1 << 19):
+        return 1
+    per = (n + 2) // 3
+    return 3 * max(1, -(-per // (1 << 23)))
 
 
 if __name__ == "__main__":

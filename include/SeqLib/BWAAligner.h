@@ -10,12 +10,23 @@
 // where read i behaves exactly as the i-th successive alignSequence call, including its lrand48() draw
 // (the process's real libc stream is read with seed48 and advanced by the number of reads).
 // The north-star spelling AlignSequence(...) and a BamRecordVector overload are provided as aliases.
+//
+// Threads: as in the reference, alignSequence is const and one BWAAligner may be shared by any number of host
+// threads.  The device handle is created once (std::call_once), each call reserves its lrand48() draws under a
+// process-wide lock (peek + advance of the libc state is one step), and the C-ABI serves the calls of one handle
+// one after another (the aligner's own lock): concurrent callers get correct results, not concurrent GPU work --
+// use alignSequences for throughput.
+// Limits of the GPU path, both reported by exceptions: reads longer than SLX_MAX_READ_LEN; indexes with ALT contigs.
 #pragma once
+#include <algorithm>
 #include <cassert>
+#include <exception>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 #include "seqlib_amd.h"
 #include "SeqLib/BWAIndex.h"
@@ -126,17 +137,22 @@ private:
     BWAIndexPtr index_;
     slx_opt memopt_;
     mutable slx_aligner *al_ = nullptr;
+    mutable std::once_flag al_once_;
     bool copyComment_ = false;
 
     slx_aligner *handle() const
-    {
-        if (!al_) {
-            const int rc = slx_aligner_create(index_->idx_, nullptr, 0, &al_);
+    {   // created on first use, once, whichever thread gets here first (a failed creation throws and may be retried)
+        std::call_once(al_once_, [this]() {
+            slx_aligner *al = nullptr;
+            const int rc = slx_aligner_create(index_->idx_, nullptr, 0, &al);
             if (rc == SLX_ENOMEM) throw std::bad_alloc();
             if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner: ") + slx_last_error());
-        }
+            al_ = al;
+        });
         return al_;
     }
+
+    static std::mutex &rng_mutex() { static std::mutex m; return m; }
 
     // record construction of src/BWAAligner.cpp:151-248 for hit k of `h`
     static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, bool hardclip)
@@ -199,23 +215,45 @@ private:
     void run(const char *bases, const uint64_t *offs, int64_t n, const char *const *names, const UnalignedSequenceVector *reads, bool hardclip,
              double keepSecFrac, int maxSecondary, BamRecordPtrVector *single_out, std::vector<BamRecordPtrVector> *batch_out) const
     {
-        // the reference's mem_align1 draws lrand48() once per call from the process-global libc stream
-        const uint64_t state = slx_lrand48_peek_libc();
+        // the reference's mem_align1 draws lrand48() once per call from the process-global libc stream: this call reserves
+        // its n draws in one step, so that concurrent callers never share an ordinal
+        slx_aligner *al = handle();
+        uint64_t state;
+        {
+            std::lock_guard<std::mutex> g(rng_mutex());
+            state = slx_lrand48_peek_libc();
+            slx_lrand48_skip_libc((uint64_t)n);
+        }
         slx_hits h;
-        const int rc = slx_align_batch(handle(), &memopt_, bases, offs, n, state, 0, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &h);
+        const int rc = slx_align_batch(al, &memopt_, bases, offs, n, state, 0, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &h);
         if (rc == SLX_ENOMEM) throw std::bad_alloc();
         if (rc == SLX_EINVAL) throw std::invalid_argument(slx_last_error());
         if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner::alignSequence: ") + slx_last_error());
-        slx_lrand48_skip_libc((uint64_t)n);
-        try {
-            for (int64_t i = 0; i < n; ++i) {
+        // record construction (src/BWAAligner.cpp:151-248): reads [a, b) -- every read owns its own output vector, so a large
+        // batch is materialised by several host threads (the step is malloc- and shared_ptr-bound, SURVEY hard part 7)
+        auto materialise = [&](int64_t a, int64_t b) {
+            for (int64_t i = a; i < b; ++i) {
                 const std::string_view seq(bases + offs[i], (size_t)(offs[i + 1] - offs[i]));
                 BamRecordPtrVector &dst = single_out ? *single_out : (*batch_out)[(size_t)i];
                 for (int64_t k = h.hit_off[i]; k < h.hit_off[i + 1]; ++k) {
-                    BamRecordPtr b = make_record(h, k, seq, names[i], hardclip);
-                    if (reads && copyComment_) b->AddZTag("BC", (*reads)[(size_t)i].Com);
-                    dst.push_back(b);                       // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
+                    BamRecordPtr rec = make_record(h, k, seq, names[i], hardclip);
+                    if (reads && copyComment_) rec->AddZTag("BC", (*reads)[(size_t)i].Com);
+                    dst.push_back(rec);                     // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
                 }
+            }
+        };
+        try {
+            unsigned T = (single_out || n < 8192) ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+            if (T <= 1) materialise(0, n);
+            else {
+                std::vector<std::thread> th;
+                std::vector<std::exception_ptr> err(T);
+                for (unsigned t = 0; t < T; ++t)
+                    th.emplace_back([&, t]() {
+                        try { materialise(n * (int64_t)t / (int64_t)T, n * (int64_t)(t + 1) / (int64_t)T); } catch (...) { err[t] = std::current_exception(); }
+                    });
+                for (auto &x : th) x.join();
+                for (auto &e : err) if (e) std::rethrow_exception(e);
             }
         } catch (...) { slx_hits_free(&h); throw; }
         slx_hits_free(&h);

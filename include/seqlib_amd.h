@@ -116,11 +116,16 @@ typedef struct {
     int64_t  *cig_off;      /* n_hits + 1 */
     uint32_t *cigar;
     int       on_device;    /* 1: pointers are device pointers owned by the aligner (valid until its next call) */
+    void     *block;        /* host results: the one allocation every array above points into (layout of slx_hits_pack) */
+    int       block_pinned; /* 1: block is pinned host memory (recycled by slx_hits_free); 0: malloc */
+    uint64_t  block_bytes;
 } slx_hits;
 
 /* bases/offs on the HOST: read i is bases[offs[i] .. offs[i+1]) in ASCII.  Read i behaves as the
  * i-th successive alignSequence call: it consumes lrand48 draw number first_ordinal+i of the stream
- * whose state before draw 0 is rng_state (0 = unseeded glibc).  Results copied to malloc'd host arrays. */
+ * whose state before draw 0 is rng_state (0 = unseeded glibc).  The reads go up in parts, each on the stream of the
+ * worker that aligns it (pin the caller's buffers for the full PCIe rate); the result comes back as ONE packed image
+ * (layout of slx_hits_pack) in one device-to-host copy, and the arrays of *out are views into it (out->block). */
 int  slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
                      uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary,
                      slx_hits *out);
@@ -138,10 +143,20 @@ void slx_hits_free(slx_hits *h);          /* host results only */
 uint64_t slx_hits_packed_size(const slx_hits *h);
 int  slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_bytes);
 
+/* Thread safety: an aligner runs ONE batch at a time -- slx_align_batch / slx_align_batch_device / slx_hits_pack /
+ * slx_aligner_set take the aligner's lock, so any number of host threads may share one handle (the reference's
+ * alignSequence is const and re-entrant, SeqLib/BWAAligner.h:51-63); their calls are served one after another.
+ * A device-resident result (on_device = 1) is only valid until the next call on the same aligner by ANY thread. */
+
 /* per-stage kernel time of the last batch, measured with HIP events on the aligner's stream (ms) */
 #define SLX_N_STAGES 8
 int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
 const char *slx_stage_name(int i);
+/* kernel groups of the last batch: duration summed over the workers' launches, from HIP events recorded on the worker's own
+ * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12 + k_seed3), [1] the extension
+ * family (k_extend_cand, k_first_prep, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_dp) */
+#define SLX_N_PROBES 3
+int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
 
 /* libc lrand48 stream helpers */
 uint64_t slx_lrand48_advance(uint64_t state, uint64_t n);   /* state after n draws */

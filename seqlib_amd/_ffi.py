@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("SLX_LIB") or os.path.join(HERE, "libseqlib_amd.so")   
 
 SLX_OK, SLX_EINVAL, SLX_EIO, SLX_ENOMEM, SLX_ENODEVICE, SLX_EUNSUPPORTED, SLX_EINTERNAL = 0, -1, -2, -3, -4, -5, -6
 SLX_N_STAGES = 8
+SLX_N_PROBES = 3
 SLX_MAX_READ_LEN = 700
 
 # every symbol include/seqlib_amd.h declares (checked by tests/test_abi.py against the header text)
@@ -19,7 +20,7 @@ EXPORTS = [
     "slx_opt_init", "slx_fill_scmat", "slx_index_build", "slx_index_load", "slx_index_write", "slx_index_free",
     "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_aligner_create",
     "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free", "slx_hits_packed_size", "slx_hits_pack",
-    "slx_aligner_stage_ms", "slx_stage_name", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
+    "slx_aligner_stage_ms", "slx_stage_name", "slx_aligner_probe_ms", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
     "slx_last_error", "slx_version",
 ]
 
@@ -38,7 +39,8 @@ class Hits(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_hits", C.c_int64), ("n_cigar", C.c_int64), ("hit_off", C.c_void_p),
                 ("rid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
                 ("score", C.c_void_p), ("nm", C.c_void_p), ("na", C.c_void_p), ("n_cigar_ops", C.c_void_p),
-                ("cig_off", C.c_void_p), ("cigar", C.c_void_p), ("on_device", C.c_int)]
+                ("cig_off", C.c_void_p), ("cigar", C.c_void_p), ("on_device", C.c_int), ("block", C.c_void_p),
+                ("block_pinned", C.c_int), ("block_bytes", C.c_uint64)]
 
 
 _LIB = None
@@ -79,6 +81,7 @@ def lib():
     L.slx_hits_packed_size.restype = C.c_uint64
     L.slx_hits_pack.argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_uint64]
     L.slx_aligner_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.slx_aligner_probe_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     L.slx_stage_name.argtypes = [C.c_int]
     L.slx_stage_name.restype = C.c_char_p
     L.slx_lrand48_advance.argtypes = [C.c_uint64, C.c_uint64]

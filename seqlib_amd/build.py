@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libseqlib_amd.so")
-SOURCES = ["slx_index.cpp", "slx_index_gpu.hip", "slx_align.hip"]
+SOURCES = ["slx_index.cpp", "slx_index_gpu.hip", "slx_index_gpu64.hip", "slx_align.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -23,19 +23,32 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
               [os.path.join(ROOT, "include", "seqlib_amd.h")]
-    objs = []
+    objs, procs = [], []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for s in SOURCES:
+    for s in SOURCES:                      # the translation units compile side by side
         src = os.path.join(CSRC, s)
         obj = os.path.join(HERE, "build", s + ".o")
         if force or _stale(obj, [src] + headers):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     if force or _stale(SO, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    # tools/bamrec_bench: the C++ drop-in class timed end to end (bench.py's value_bamrecords); host-only code over the C-ABI
+    tool_src = os.path.join(ROOT, "tools", "bamrec_bench.cpp")
+    tool = os.path.join(HERE, "bamrec_bench")
+    hdrs = [os.path.join(ROOT, "include", "SeqLib", f) for f in os.listdir(os.path.join(ROOT, "include", "SeqLib"))]
+    if force or _stale(tool, [tool_src, SO] + hdrs):
+        cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), tool_src, "-o", tool, "-L" + HERE, "-lseqlib_amd",
+               "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

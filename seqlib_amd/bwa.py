@@ -55,7 +55,7 @@ class BWAIndex:
                 raise ValueError("BWAIndex::Construct each reference must have non-empty Name and Seq")
         n = len(refs)
         names = (C.c_char_p * n)(*[r[0].encode() for r in refs])
-        seqs = (C.c_char_p * n)(*[r[1].encode() for r in refs])
+        seqs = (C.c_char_p * n)(*[r[1] if isinstance(r[1], bytes) else r[1].encode() for r in refs])   # bytes are passed without a copy
         lens = (C.c_int64 * n)(*[len(r[1]) for r in refs])
         h = C.c_void_p()
         rc = _ffi.lib().slx_index_build(names, seqs, lens, n, C.byref(h))
@@ -184,6 +184,22 @@ class BWAAligner:
         _ffi.lib().slx_hits_free(C.byref(h))
         return res
 
+    def align_host_raw(self, bases_ptr, offs_ptr, n_reads, first_ordinal=None, hardclip=False, keepSecFrac=0.9, maxSecondary=10):
+        """Host-buffer entry on raw pointers (e.g. pinned torch tensors): returns the ctypes Hits struct whose arrays are views
+        into one packed host block; release it with free_hits()."""
+        h = _ffi.Hits()
+        fo = self.ordinal if first_ordinal is None else first_ordinal
+        rc = _ffi.lib().slx_align_batch(self._handle(), C.byref(self.opt), C.c_char_p(bases_ptr), offs_ptr, n_reads, self.rng_state, fo,
+                                        int(hardclip), float(keepSecFrac), int(maxSecondary), C.byref(h))
+        _ffi.check(rc)
+        if first_ordinal is None:
+            self.ordinal += n_reads
+        return h
+
+    @staticmethod
+    def free_hits(h):
+        _ffi.lib().slx_hits_free(C.byref(h))
+
     def align_device(self, d_bases_ptr, d_offs_ptr, n_reads, first_ordinal=None, hardclip=False, keepSecFrac=0.9,
                      maxSecondary=10):
         """Device-resident batch: bases (ASCII) and uint64 offsets already in HBM; results stay in HBM.
@@ -209,6 +225,13 @@ class BWAAligner:
         """One read -> list of dict records (flag, rid, pos, mapq, cigar words, AS, NM, NA)."""
         r = self.alignSequences([seq], hardclip, keepSecFrac, maxSecondary)
         return [] if r is None else records_of(r, 0)
+
+    def probe_ms(self):
+        """({"seed", "extend", "cigar"} -> ms, reads): summed launch durations of three kernel groups of the last batch
+        (HIP events on the workers' own streams)"""
+        ms, n = (C.c_float * _ffi.SLX_N_PROBES)(), C.c_int64()
+        _ffi.check(_ffi.lib().slx_aligner_probe_ms(self._handle(), ms, C.byref(n)))
+        return dict(seed=ms[0], extend=ms[1], cigar=ms[2]), n.value
 
     def stage_ms(self):
         ms = (C.c_float * _ffi.SLX_N_STAGES)()

@@ -223,16 +223,3 @@ __device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt 
         return true;
 }
 
-template <int MAXQ>
-__global__ void __launch_bounds__(128) k_extend(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
-{
-    const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
-        const int r = order ? order[slot] : slot;
-        dev_extend_lane<MAXQ, false>(R, ck, opt, r, eh_h, eh_e, nullptr);
-    }
-}

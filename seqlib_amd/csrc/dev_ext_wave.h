@@ -169,138 +169,3 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     return r;
 }
 
-template <int MAXQ>
-__global__ void __launch_bounds__(64) k_extend_wave(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
-{
-    constexpr int NCH = (MAXQ + WAVE - 1) / WAVE;
-    __shared__ int eh_h[MAXQ + 2 + WAVE], eh_e[MAXQ + 2 + WAVE];
-    const slx_opt &opt = dopt.o;
-    const int lane = threadIdx.x;
-    const MatRows mr = make_matrows(opt.mat);
-    while (true) {
-        int slot = 0;
-        if (lane == 0) slot = (int)atomicAdd(queue, 1u);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= ck.n_reads) break;
-        const int r = order ? order[slot] : slot;
-        ReadWS w = make_ws(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
-        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-        const int n_chn = ck.n_chain[r];
-        if (n_chn < 0) continue;                  // exact full-length match: region already written by the chaining kernel
-        const float frac_rep = ck.frac_rep[r];
-        const int64_t l_pac = R.l_pac;
-        int n_av = 0;
-        int *cs = w.ib, *srt_h = w.ic;
-        for (int ci = 0; ci < n_chn; ++ci) {
-            const int c = w.ia[ci];
-            int n = 0;
-            for (int s = w.c_head[c]; s >= 0; s = w.s_next[s]) cs[n++] = s;
-            if (n == 0) continue;
-            int64_t rmax0 = l_pac << 1, rmax1 = 0;
-            for (int i = 0; i < n; ++i) {
-                const int s = cs[i];
-                const int qb = w.s_qbeg(s), sl = w.s_len(s);
-                const int64_t b = w.s_rbeg[s] - (qb + dev_cal_max_gap(opt, qb));
-                const int64_t e = w.s_rbeg[s] + sl + ((l_query - qb - sl) + dev_cal_max_gap(opt, l_query - qb - sl));
-                rmax0 = rmax0 < b ? rmax0 : b;
-                rmax1 = rmax1 > e ? rmax1 : e;
-            }
-            rmax0 = rmax0 > 0 ? rmax0 : 0;
-            rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
-            if (rmax0 < l_pac && l_pac < rmax1) {
-                if (w.s_rbeg[cs[0]] < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
-            }
-            {
-                int is_rev;
-                const int rid = dev_pos2rid(R, dev_depos(R, w.s_rbeg[cs[0]], &is_rev));
-                int64_t far_beg = R.ann_off[rid], far_end = far_beg + R.ann_len[rid];
-                if (is_rev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
-                rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
-                rmax1 = rmax1 < far_end ? rmax1 : far_end;
-            }
-            for (int i = 0; i < n; ++i) { w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i; srt_h[i] = i; }
-            ks_introsort_idx(n, srt_h, [&](int x, int y) { return w.srt[x] < w.srt[y]; });
-            for (int k = n - 1; k >= 0; --k) {
-                const int si = (int)(uint32_t)w.srt[srt_h[k]];
-                const int s = cs[si];
-                const int s_qbeg = w.s_qbeg(s), s_len = w.s_len(s);
-                const int64_t s_rbeg = w.s_rbeg[s];
-                int i;
-                for (i = 0; i < n_av; ++i) {
-                    const DReg &p = w.regs[i];
-                    if (s_rbeg < p.rb || s_rbeg + s_len > p.re || s_qbeg < p.qb || s_qbeg + s_len > p.qe) continue;
-                    if ((double)(s_len - p.seedlen0) > .1 * l_query) continue;
-                    int qd = s_qbeg - p.qb; int64_t rd = s_rbeg - p.rb;
-                    int max_gap = dev_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-                    int ww = max_gap < p.w ? max_gap : p.w;
-                    if (qd - rd < ww && rd - qd < ww) break;
-                    qd = p.qe - (s_qbeg + s_len); rd = p.re - (s_rbeg + s_len);
-                    max_gap = dev_cal_max_gap(opt, qd < rd ? qd : (int)rd);
-                    ww = max_gap < p.w ? max_gap : p.w;
-                    if (qd - rd < ww && rd - qd < ww) break;
-                }
-                if (i < n_av) {
-                    for (i = k + 1; i < n; ++i) {
-                        if (srt_h[i] < 0) continue;
-                        const uint64_t key = w.srt[srt_h[i]];
-                        const int t = cs[(int)(uint32_t)key];
-                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                        const int64_t t_rbeg = w.s_rbeg[t];
-                        if ((double)t_len < s_len * .95) continue;
-                        if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
-                        if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) break;
-                    }
-                    if (i == n) { srt_h[k] = -1; continue; }
-                }
-                DReg a;
-                a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
-                a.n_comp = 0; a.hash = 0;
-                int aw0 = opt.w, aw1 = opt.w;
-                a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
-                if (s_qbeg) {
-                    const int64_t tmp = s_rbeg - rmax0;
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {
-                        const int prev = a.score;
-                        aw0 = opt.w << i;
-                        er = wave_ksw_extend2<NCH>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
-                                                   [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, mr, aw0, opt.pen_clip5,
-                                                   s_len * opt.a, eh_h, eh_e, lane);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-                    }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
-                    else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
-                } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
-                if (s_qbeg + s_len != l_query) {
-                    const int sc0 = a.score, qe = s_qbeg + s_len;
-                    const int64_t re0 = s_rbeg + s_len;
-                    ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                    for (i = 0; i < 2; ++i) {
-                        const int prev = a.score;
-                        aw1 = opt.w << i;
-                        er = wave_ksw_extend2<NCH>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
-                                                   [&](int t) { return ref_base(R, re0 + t); }, opt, mr, aw1, opt.pen_clip3, sc0, eh_h, eh_e, lane);
-                        a.score = er.score;
-                        if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-                    }
-                    if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
-                    else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
-                } else { a.qe = l_query; a.re = s_rbeg + s_len; }
-                a.seedcov = 0;
-                for (i = 0; i < n; ++i) {
-                    const int t = cs[i];
-                    const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                    const int64_t t_rbeg = w.s_rbeg[t];
-                    if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
-                }
-                a.w = aw0 > aw1 ? aw0 : aw1;
-                a.seedlen0 = s_len;
-                a.frac_rep = frac_rep;
-                w.regs[n_av++] = a;                  // every lane stores the same bytes
-            }
-        }
-        ck.n_reg[r] = n_av;
-    }
-}

@@ -456,126 +456,6 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
         return n;
 }
 
-template <int MAXQ>
-__global__ void __launch_bounds__(128) k_finalize(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue)
-{
-    const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
-    while (true) {
-        const int slot = next_slot(queue);
-        if (__all(slot >= ck.n_reads)) break;
-        if (slot >= ck.n_reads) continue;
-        const int r = order ? order[slot] : slot;
-        ReadWS w = make_ws(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
-        const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
-        auto sc = [&](int band, int lq, const uint8_t *qseg, int64_t rb, int64_t re) {
-            return dev_gen_cigar2<MAXQ>(R, opt, ck, band, lq, qseg, rb, re, false, eh_h, eh_e).score;
-        };
-        int n = dev_fin_regs<MAXQ>(R, ck, opt, w, r, query, l_query, sc);
-        int *a = w.ia;
-        DReg *G = w.regs;
-        // ---------------- glue: reg2aln for every region the caller keeps (src/BWAAligner.cpp:117-129)
-        int nh = 0;
-        int *hh = w.ic;                           // hit handles
-        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
-        for (int i = 0; i < n; ++i) {
-            const DReg &ar = G[a[i]];
-            if (ar.secondary != 0 && drop_sec) continue;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
-            DHit h;
-            h.flag = 0; h.n_cigar = 0; h.cig_start = 0; h.nm = -1;
-            const int qb = ar.qb, qe = ar.qe;
-            const int64_t rb = ar.rb, re = ar.re;
-            h.mapq = ar.secondary < 0 ? dev_approx_mapq_se(opt, ar, ck) : 0;
-            if (ar.secondary >= 0) h.flag |= 0x100;
-            int tmp = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
-            int w2 = dev_infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
-            w2 = w2 > tmp ? w2 : tmp;
-            if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
-            int it = 0, score, last_sc = -(1 << 30);
-            GenCig g;
-            do {
-                w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
-                g = dev_gen_cigar2<MAXQ>(R, opt, ck, w2, qe - qb, query + qb, rb, re, true, eh_h, eh_e);
-                score = g.score;
-                if (score == last_sc || w2 == opt.w << 2) break;
-                last_sc = score;
-                w2 <<= 1;
-            } while (++it < 3 && score < ar.truesc - opt.a);
-            int is_rev;
-            int64_t pos = dev_depos(R, rb < R.l_pac ? rb : re - 1, &is_rev);
-            // cigar: [slot for 5' clip][ops][slot for 3' clip] in the pool
-            int n_ops = 0;
-            if (g.valid) {
-                if (g.fast) n_ops = 1;
-                else dev_traceback(g.z, g.n_col, g.qlen, g.tlen, g.w, [&](int, int) { ++n_ops; });
-            }
-            const unsigned long long need = (unsigned long long)n_ops + 2;
-            const unsigned long long base = atomicAdd(ck.cigused, need);
-            if (base + need > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
-            uint32_t *cg = ck.cigpool + base + 1;
-            if (g.valid) {
-                if (g.fast) cg[0] = (uint32_t)g.qlen << 4;
-                else { int wp = n_ops; dev_traceback(g.z, g.n_col, g.qlen, g.tlen, g.w, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; }); }
-                // NM = mismatches in M + inserted + deleted bases (a D that is the first or last op is not counted)
-                const bool rev = g.rev;
-                const uint8_t *qseg = query + qb;
-                const int lq = qe - qb;
-                int x = 0, y = 0, n_mm = 0, n_gap = 0;
-                for (int k = 0; k < n_ops; ++k) {
-                    const int op = (int)(cg[k] & 0xf), len = (int)(cg[k] >> 4);
-                    if (op == 0) {
-                        for (int u = 0; u < len; ++u) {
-                            const int qc = rev ? qseg[lq - 1 - (x + u)] : qseg[x + u];
-                            const int tc = rev ? ref_base(R, re - 1 - (y + u)) : ref_base(R, rb + y + u);
-                            if (qc != tc) ++n_mm;
-                        }
-                        x += len; y += len;
-                    } else if (op == 2) { if (k > 0 && k < n_ops - 1) n_gap += len; y += len; }
-                    else if (op == 1) { x += len; n_gap += len; }
-                }
-                h.nm = n_mm + n_gap;
-            }
-            int64_t cs = (int64_t)base + 1;
-            int nc = n_ops;
-            if (nc > 0) {                         // squeeze out a leading or else a trailing deletion
-                if ((ck.cigpool[cs] & 0xf) == 2) { pos += ck.cigpool[cs] >> 4; ++cs; --nc; }
-                else if ((ck.cigpool[cs + nc - 1] & 0xf) == 2) --nc;
-            }
-            if (qb != 0 || qe != l_query) {       // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
-                const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
-                const uint32_t cop = ck.hardclip ? 5u : 4u;
-                if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
-                if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
-            }
-            h.rid = dev_pos2rid(R, pos);
-            h.pos = pos - R.ann_off[h.rid];
-            h.score = ar.score;
-            if (is_rev) h.flag |= 0x10;
-            h.n_cigar = nc; h.cig_start = cs;
-            w.hits[nh] = h; hh[nh] = nh; ++nh;
-        }
-        // ---------------- std::sort(hits, aln_sort) then the secondary filters (src/BWAAligner.cpp:133-146)
-        std_sort_idx(nh, hh, [&](int x, int y) {
-            const DHit &A = w.hits[x], &B = w.hits[y];
-            if (A.mapq != B.mapq) return A.mapq > B.mapq;
-            if (A.rid != B.rid) return A.rid < B.rid;
-            return A.pos < B.pos;
-        });
-        double primaryScore = 0;
-        int n_out = 0;
-        for (int i = 0; i < nh; ++i) {
-            const DHit &h = w.hits[hh[i]];
-            const bool isSec = (h.flag & 0x100) != 0;
-            const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)h.score);
-            const bool tooMany = isSec && (i > ck.maxSecondary);
-            if (tooLow || tooMany) continue;
-            if (!isSec) primaryScore = (double)h.score;
-            hh[n_out++] = hh[i];
-        }
-        ck.n_hit[r] = n_out;
-    }
-}
 
 // ---------------------------------------------------------------- compaction into the SoA result
 struct HitsSoA {

@@ -1,6 +1,6 @@
 // dev_seed2.h -- production SMEM seeding (seed_mode = 2): bwa's mem_collect_intv (reached from
 // /root/reference/src/BWAAligner.cpp:104 -> mem_align1 -> mem_chain) as two kernels over a rank structure laid out
-// for the GPU.  dev_seed.h (nested loops) and dev_seed_sm.h (first state machine) stay as test references.
+// for the GPU.  Templated on the index type: u32 for indexes below 2^32 BWT symbols, u64 above (GRCh38).
 //
 //   k_occ_build   bwa's interleaved .bwt image -> "occ planes": one 32-byte block per 64 BWT symbols =
 //                 4 x u32 running counts + the symbols as two 64-bit bit planes (low bit / high bit of each base).
@@ -20,7 +20,18 @@
 #include "dev_seed.h"
 
 // ---------------------------------------------------------------------------------------------- occ planes
-__global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, uint64_t n_blocks)
+// Indexes with >= 2^32 symbols (GRCh38: 6.2 G) keep the same 32-byte blocks: the u32 counts are then relative to the
+// block's SUPER-BLOCK (2^32 symbols), whose four u64 base counts sit in a table of a few entries (`sup`, filled by
+// k_occ_sup from bwa's own u64 block headers) that stays in cache.  sup == nullptr: plain u32 counts.
+__global__ void k_occ_sup(const uint32_t *bwt, uint64_t n_sup, uint64_t *sup)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_sup * 4) return;
+    const uint64_t sb = t >> 2, c = t & 3, B = sb << 25;           // bwa block (128 symbols) that starts super-block sb
+    sup[t] = (uint64_t)bwt[B * 16 + 2 * c] | (uint64_t)bwt[B * 16 + 2 * c + 1] << 32;
+}
+
+__global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, uint64_t n_blocks, const uint64_t *sup)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
@@ -29,7 +40,10 @@ __global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, u
     const int half = (int)(b & 1);
     auto data_word = [&](uint64_t d) -> uint32_t { return d < n_data_words ? bwt[(d >> 3) * 16 + 8 + (d & 7)] : 0u; };
     uint32_t cnt[4];
-    for (int s = 0; s < 4; ++s) cnt[s] = bwt[B * 16 + 2 * s];          // low word of bwa's u64 running count
+    for (int s = 0; s < 4; ++s) {                                      // bwa's u64 running count, relative to the super-block
+        const uint64_t full = (uint64_t)bwt[B * 16 + 2 * s] | (uint64_t)bwt[B * 16 + 2 * s + 1] << 32;
+        cnt[s] = (uint32_t)(full - (sup ? sup[(b >> 26) * 4 + s] : 0ull));
+    }
     if (half)
         for (int k = 0; k < 4; ++k) {
             const uint32_t w = data_word(B * 8 + k);
@@ -48,80 +62,37 @@ __global__ void k_occ_build(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, u
     occ[2 * b + 1] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
-#ifndef SEED2_OCC192
-#define SEED2_OCC192 0        // 1 = 64-byte blocks of 192 symbols (index 1.5x smaller: more of it stays in the 4 MB L2 of an XCD)
-#endif
-
-// the 192-symbol variant of the occ planes: 4 x u32 counts + three (low, high) plane pairs of 64 symbols = 64 bytes
-__global__ void k_occ_build192(const uint32_t *bwt, uint64_t seq_len, uint4 *occ, uint64_t n_blocks)
-{
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    const uint64_t n_data_words = (seq_len + 15) >> 4;
-    auto data_word = [&](uint64_t d) -> uint32_t { return d < n_data_words ? bwt[(d >> 3) * 16 + 8 + (d & 7)] : 0u; };
-    const uint64_t first = b * 192, B = first >> 7, rem_words = (first & 127) >> 4;      // bwa block holding symbol `first`, words before it
-    uint32_t cnt[4];
-    for (int s = 0; s < 4; ++s) cnt[s] = (B * 16 + 2 * s) < ((n_data_words + 7) / 8 + 1) * 16 ? bwt[B * 16 + 2 * s] : 0u;
-    for (uint64_t k = 0; k < rem_words; ++k) {
-        const uint32_t w = data_word(B * 8 + k);
-        for (int s = 0; s < 16; ++s) ++cnt[(w >> (2 * s)) & 3];
-    }
-    occ[4 * b] = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
-    for (int part = 0; part < 3; ++part) {
-        uint64_t lo = 0, hi = 0;
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t w = data_word(b * 12 + part * 4 + k);
-            for (int s = 0; s < 16; ++s) {
-                const uint32_t sym = (w >> ((15 - s) << 1)) & 3;
-                lo |= (uint64_t)(sym & 1) << (16 * k + s);
-                hi |= (uint64_t)(sym >> 1) << (16 * k + s);
-            }
-        }
-        occ[4 * b + 1 + part] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-    }
-}
-
 // counts of A,C,G,T in BWT[0..k] (bwt_occ4), k already mapped past the sentinel
-__device__ __forceinline__ void occp_rank(const uint4 *occ, uint32_t kk, uint32_t t[4])
+template <typename I>
+__device__ __forceinline__ void occp_rank(const DevFM<I> &fm, I kk, I t[4])
 {
-#if SEED2_OCC192
-    const uint32_t bi = __umulhi(kk, 0xAAAAAAABu) >> 7;           // kk / 192
-    const uint4 *blk = occ + ((size_t)bi << 2);
-    const uint4 c = blk[0], p0 = blk[1], p1 = blk[2], p2 = blk[3];
-    const uint32_t n = kk - bi * 192u + 1;                         // 1..192 symbols of the block count
-    uint32_t sl = 0, sh = 0, st = 0;
-    auto part = [&](const uint4 &p, int cnt) {                     // cnt (may be <= 0 or >= 64) leading symbols of this 64-symbol part
-        const int cc = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
-        const uint64_t m = cc ? ~0ull >> (64 - cc) : 0ull;
-        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-        const uint32_t l0 = p.x & m0, l1 = p.y & m1, h0 = p.z & m0, h1 = p.w & m1;
-        sl += __popc(l0) + __popc(l1); sh += __popc(h0) + __popc(h1); st += __popc(l0 & h0) + __popc(l1 & h1);
-    };
-    part(p0, (int)n); part(p1, (int)n - 64); part(p2, (int)n - 128);
-    t[0] = c.x + (n + st - sl - sh); t[1] = c.y + (sl - st); t[2] = c.z + (sh - st); t[3] = c.w + st;
-#else
-    const uint4 *blk = occ + ((size_t)(kk >> 6) << 1);
+    const uint4 *blk = fm.occ + ((size_t)(kk >> 6) << 1);
     const uint4 c = blk[0], p = blk[1];
-    const uint32_t n = (kk & 63) + 1;
+    I b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (sizeof(I) == 8) {                                            // super-block base: a cached 32-byte table row, in flight with the block
+        const ulonglong2 *sp = (const ulonglong2 *)(fm.sup + ((uint64_t)kk >> 32) * 4);
+        const ulonglong2 s0 = sp[0], s1 = sp[1];
+        b0 = (I)s0.x; b1 = (I)s0.y; b2 = (I)s1.x; b3 = (I)s1.y;
+    }
+    const uint32_t n = ((uint32_t)kk & 63) + 1;
     const uint64_t m = ~0ull >> (64 - n);
     const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
     const uint32_t l0 = p.x & m0, l1 = p.y & m1, h0 = p.z & m0, h1 = p.w & m1;
     const uint32_t sl = __popc(l0) + __popc(l1), sh = __popc(h0) + __popc(h1), st = __popc(l0 & h0) + __popc(l1 & h1);
-    t[0] = c.x + (n + st - sl - sh); t[1] = c.y + (sl - st); t[2] = c.z + (sh - st); t[3] = c.w + st;
-#endif
+    t[0] = b0 + (I)(c.x + (n + st - sl - sh)); t[1] = b1 + (I)(c.y + (sl - st)); t[2] = b2 + (I)(c.z + (sh - st)); t[3] = b3 + (I)(c.w + st);
 }
 
 // bwt_extend for the one output symbol the caller needs (same contract as fm_extend in dev_fm.h)
-__device__ __forceinline__ void fm_extend_p(const DevFM<uint32_t> &fm, const IntvE<uint32_t> &ik, int c, int is_back, IntvE<uint32_t> &ok)
+template <typename I>
+__device__ __forceinline__ void fm_extend_p(const DevFM<I> &fm, const IntvE<I> &ik, int c, int is_back, IntvE<I> &ok)
 {
-    typedef uint32_t I;
     I tk[4], tl[4];
     const I xin = is_back ? ik.x0 : ik.x1;
     const I xot = is_back ? ik.x1 : ik.x0;
     const I k = xin - 1, l = xin - 1 + ik.x2;
     const bool k_none = (k == (I)-1), l_none = (l == (I)-1);
-    occp_rank(fm.occ, k_none ? 0 : k - (k >= fm.primary ? 1 : 0), tk);
-    occp_rank(fm.occ, l_none ? 0 : l - (l >= fm.primary ? 1 : 0), tl);
+    occp_rank<I>(fm, k_none ? (I)0 : k - (k >= fm.primary ? 1 : 0), tk);
+    occp_rank<I>(fm, l_none ? (I)0 : l - (l >= fm.primary ? 1 : 0), tl);
     if (k_none) tk[0] = tk[1] = tk[2] = tk[3] = 0;
     if (l_none) tl[0] = tl[1] = tl[2] = tl[3] = 0;
     const I s0 = tl[0] - tk[0], s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3];
@@ -161,9 +132,9 @@ __device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
 
 enum Seed2Phase : int { S2_FETCH = 0, S2_INIT, S2_START, S2_FWD0, S2_BEGIN_BWD, S2_ROW, S2_FWD, S2_BWD, S2_DONE };
 
-__global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+template <typename I>
+__global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
 {
-    typedef uint32_t I;
     const slx_opt &opt = dopt.o;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -333,7 +304,7 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
             IntvE<I> src = psrc;
             int c = cb;
             if (fwd) { src = ik; c = 3 - cq; }
-            fm_extend_p(fm, src, c, bwd ? 1 : 0, ok);
+            fm_extend_p<I>(fm, src, c, bwd ? 1 : 0, ok);
         }
         // ------------------------------------------------ apply it
         if (fwd) {
@@ -367,9 +338,9 @@ __global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<uint32_t>
 }
 
 // pass 3 + per-read epilogue; one lane per read
-__global__ void __launch_bounds__(128) k_seed3(DevFM<uint32_t> fm, Chunk ck, DevOpt dopt)
+template <typename I>
+__global__ void __launch_bounds__(128) k_seed3(DevFM<I> fm, Chunk ck, DevOpt dopt)
 {
-    typedef uint32_t I;
     const slx_opt &opt = dopt.o;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < ck.n_reads;
@@ -398,7 +369,7 @@ __global__ void __launch_bounds__(128) k_seed3(DevFM<uint32_t> fm, Chunk ck, Dev
                 const int c = qb(i);
                 if (c > 3) { x = i + 1; fresh = true; }
                 else {
-                    fm_extend_p(fm, ik, 3 - c, 0, ok);
+                    fm_extend_p<I>(fm, ik, 3 - c, 0, ok);
                     if (ok.x2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
                         if (ok.x2 > 0) {
                             if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = ok.x0; ox2[n_out] = ok.x2; ++n_out; }

@@ -120,10 +120,9 @@ extern "C" int slx_index_build(const char *const *names, const char *const *seqs
         }
         total += L[i];
     }
-    if ((uint64_t)total * 2 + 1 >= (1ULL << 32)) {
-        slx_set_error("slx_index_build: %lld bp exceeds this round's 32-bit suffix sorter (the reference's in-memory builder is limited to 2^31-1 BWT symbols too)", (long long)total);
-        return SLX_EUNSUPPORTED;
-    }
+    // (the reference's in-memory builder stops at 2^31 - 1 BWT symbols -- is_bwt takes an int; larger indexes reach it as files
+    // made by `bwa index`.  Here texts of 2^32 - 1 symbols and more take the 64-bit suffix sorter, slx_index_gpu64.hip.)
+    const bool wide = (uint64_t)total * 2 + 1 >= (1ULL << 32) || getenv("SLX_BUILD64") != nullptr;
     slx_index *idx = new slx_index();
     idx->l_pac = total;
     // forward pac (first pass over the sequences; every N draws lrand48()&3)
@@ -145,7 +144,8 @@ extern "C" int slx_index_build(const char *const *names, const char *const *seqs
             text[(size_t)l] = (uint8_t)c;
         }
     for (int64_t k = total - 1; k >= 0; --k, ++l) text[(size_t)l] = (uint8_t)(3 - text[(size_t)k]);
-    int rc = slx_gpu_build_fm(idx, text.data(), (uint64_t)total * 2);
+    int rc = wide ? slx_gpu_build_fm64(idx, text.data(), (uint64_t)total * 2) : slx_gpu_build_fm(idx, text.data(), (uint64_t)total * 2);
+    std::vector<uint8_t>().swap(text);
     if (rc != SLX_OK) { delete idx; return rc; }
     idx->seed = 11;
     int64_t off = 0;
@@ -263,6 +263,20 @@ extern "C" int slx_index_load(const char *prefix_, slx_index **out)
         idx->anns.push_back(an);
     }
     fclose(fp);
+    fp = fopen((prefix + ".alt").c_str(), "r");   // bns_restore: the first field of every non-header line names an ALT contig
+    if (fp) {
+        std::string tok;
+        int c;
+        while ((c = fgetc(fp)) != EOF) {
+            if (c == '\t' || c == '\n' || c == '\r') {
+                if (!tok.empty() && tok[0] != '@')
+                    for (slx_ann &an : idx->anns) if (an.name == tok) { an.is_alt = 1; break; }
+                while (c != '\n' && c != EOF) c = fgetc(fp);
+                tok.clear();
+            } else tok.push_back((char)c);
+        }
+        fclose(fp);
+    }
     fp = fopen((prefix + ".amb").c_str(), "r");
     if (!fp) return fail(".amb");
     if (fscanf(fp, "%lld%d%d", &ll, &a, &b) != 3) { fclose(fp); return fail(".amb"); }

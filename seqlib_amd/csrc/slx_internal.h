@@ -42,3 +42,5 @@ void slx_set_error(const char *fmt, ...);
 
 // device-side index construction (slx_index_gpu.hip): text T[0..n) over {0..3} -> fills bwt/sa/primary/L2
 int slx_gpu_build_fm(slx_index *idx, const uint8_t *text, uint64_t n);
+// the same for texts of 2^32 - 1 symbols and more (slx_index_gpu64.hip); also taken for small texts when SLX_BUILD64 is set (test hook)
+int slx_gpu_build_fm64(slx_index *idx, const uint8_t *text, uint64_t n);

@@ -15,10 +15,17 @@ BLOCK = 1 << 17            # reads per independently seeded block
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 
+GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+          ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+          ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+
 CONFIGS = {                 # BASELINE.json configs
     "C1": dict(name="plumbing_1kb", length=1000, read_len=100, read_seed=43),
     "C2": dict(name="ecoli_syn", length=4641652, read_len=150, read_seed=44),
-    "C3": dict(name="chr20_syn", length=64444167, read_len=150, read_seed=45),
+    "C3": dict(name="chr20_syn", length=64444167, read_len=150, read_seed=45, pairs=True),
+    # full GRCh38-sized reference: 24 contigs with the primary assembly's lengths (3.09 Gbp, 6.2 G BWT symbols)
+    "C4": dict(name="grch38_syn", length=sum(l for _, l in GRCH38), read_len=150, read_seed=46, contigs=[(n + "_syn", l) for n, l in GRCH38]),
 }
 
 
@@ -56,15 +63,21 @@ def genome_ascii(g):
     return ACGT[g].tobytes().decode()
 
 
-def make_reads_block(genome, block_idx, n, read_len, seed):
-    """Reads of block `block_idx` (deterministic, independent of other blocks) -> (uint8 ASCII [n, read_len], start, strand)"""
-    rng = np.random.Generator(np.random.PCG64([seed, block_idx]))
-    G = len(genome)
-    slack = 32
-    frag = read_len + slack
-    start = rng.integers(0, G - frag, size=n)
-    strand = rng.integers(0, 2, size=n, dtype=np.uint8)
-    seq = np.lib.stride_tricks.sliding_window_view(genome, frag)[start]      # [n, frag] copy
+def genome_ascii_bytes(g):
+    """ASCII as bytes (no str round trip: a 2 Gbp contig would be copied twice more)"""
+    return ACGT[g].tobytes()
+
+
+def make_reference(cfg):
+    """-> [(contig name, uint8 codes)]: one contig named after the config, or cfg["contigs"] = [(name, length)] with one
+    generator stream per contig (seed = GENOME_SEED + contig ordinal) so that any prefix of the list can be made alone"""
+    if "contigs" not in cfg:
+        return [(cfg["name"], make_genome(cfg["length"]))]
+    return [(nm, make_genome(L, seed=GENOME_SEED + i)) for i, (nm, L) in enumerate(cfg["contigs"])]
+
+
+def _mutate(seq, n, frag, read_len, strand, rng):
+    """wgsim-like edits of `seq` [n, frag] in place -> ASCII [n, read_len] (shared by every read generator below)"""
     # mutations (0.1 %/base): 85 % substitutions, 15 % indels with geometric extension
     n_mut = int(rng.binomial(n * frag, 0.001))
     mpos = rng.integers(0, n * frag, size=n_mut)
@@ -92,7 +105,87 @@ def make_reads_block(genome, block_idx, n, read_len, seed):
     ep = rng.integers(0, n * read_len, size=n_err)
     flat = seq.reshape(-1)
     flat[ep] = (flat[ep] + rng.integers(1, 4, size=n_err, dtype=np.uint8)) & 3
-    return ACGT[seq], start, strand
+    return ACGT[seq]
+
+
+def make_pair_block(genome, block_idx, n, read_len, seed):
+    """Paired reads of block `block_idx` as SURVEY 8d defines them for C3 -- the API has no paired-end mode, so a pair is two
+    independent single-end reads: mates 2k, 2k+1 come from one fragment of 300 +- 30 bp, opposite strands (which mate is
+    forward alternates at random).  -> (uint8 ASCII [n, read_len], start, strand), n even."""
+    rng = np.random.Generator(np.random.PCG64([seed, block_idx, 2]))
+    G = len(genome)
+    slack = 32
+    frag = read_len + slack
+    npair = n // 2
+    isz = np.clip(np.rint(rng.normal(300.0, 30.0, size=npair)).astype(np.int64), read_len, 450)
+    fstart = rng.integers(0, G - 450 - frag, size=npair)
+    flip = rng.integers(0, 2, size=npair, dtype=np.uint8)
+    start = np.empty(n, dtype=np.int64)
+    strand = np.empty(n, dtype=np.uint8)
+    # the forward mate starts at the fragment's start; the reverse mate is the reverse complement of the window that ENDS at the
+    # fragment's end (its window starts slack bases earlier so that deletions still leave read_len bases after trimming)
+    start[0::2] = np.where(flip == 0, fstart, fstart + isz - read_len)
+    start[1::2] = np.where(flip == 0, fstart + isz - read_len, fstart)
+    strand[0::2] = flip
+    strand[1::2] = 1 - flip
+    seq = np.lib.stride_tricks.sliding_window_view(genome, frag)[start]
+    return _mutate(seq, n, frag, read_len, strand, rng), start, strand
+
+
+def make_multi_block(genomes, cum, block_idx, n, read_len, seed):
+    """Single-end reads over several contigs: uniform start on a contig picked with probability proportional to its length
+    (SURVEY 8d).  genomes = list of code arrays, cum = cumulative lengths (len + 1 entries)."""
+    rng = np.random.Generator(np.random.PCG64([seed, block_idx, 3]))
+    slack = 32
+    frag = read_len + slack
+    pos = rng.integers(0, int(cum[-1]), size=n)
+    cid = np.searchsorted(cum, pos, side="right") - 1
+    strand = rng.integers(0, 2, size=n, dtype=np.uint8)
+    seq = np.empty((n, frag), dtype=np.uint8)
+    start = np.empty(n, dtype=np.int64)
+    for c in np.unique(cid):
+        sel = np.nonzero(cid == c)[0]
+        g = genomes[int(c)]
+        st = np.minimum(pos[sel] - int(cum[c]), len(g) - frag)          # keep the window inside its contig
+        start[sel] = st
+        seq[sel] = np.lib.stride_tricks.sliding_window_view(g, frag)[st]
+    return _mutate(seq, n, frag, read_len, strand, rng), start, strand
+
+
+def make_config_block(cfg, refs, block_idx, n=None):
+    """block `block_idx` of the read set of a BASELINE config -> uint8 ASCII [n, read_len]"""
+    n = BLOCK if n is None else n
+    if "contigs" in cfg:
+        genomes = [g for _, g in refs]
+        cum = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
+        return make_multi_block(genomes, cum, block_idx, n, cfg["read_len"], cfg["read_seed"])[0]
+    if cfg.get("pairs"):
+        return make_pair_block(refs[0][1], block_idx, n, cfg["read_len"], cfg["read_seed"])[0]
+    return make_reads_block(refs[0][1], block_idx, n, cfg["read_len"], cfg["read_seed"])[0]
+
+
+def make_config_reads(cfg, refs, n_reads, first_block=0):
+    """the first n_reads reads (from block first_block on) of a config's read set"""
+    out = np.empty((n_reads, cfg["read_len"]), dtype=np.uint8)
+    done, b = 0, first_block
+    while done < n_reads:
+        m = min(BLOCK, n_reads - done)
+        out[done:done + m] = make_config_block(cfg, refs, b, BLOCK if n_reads >= BLOCK else max(2, (n_reads + 1) // 2 * 2))[:m]
+        done += m
+        b += 1
+    return out
+
+
+def make_reads_block(genome, block_idx, n, read_len, seed):
+    """Reads of block `block_idx` (deterministic, independent of other blocks) -> (uint8 ASCII [n, read_len], start, strand)"""
+    rng = np.random.Generator(np.random.PCG64([seed, block_idx]))
+    G = len(genome)
+    slack = 32
+    frag = read_len + slack
+    start = rng.integers(0, G - frag, size=n)
+    strand = rng.integers(0, 2, size=n, dtype=np.uint8)
+    seq = np.lib.stride_tricks.sliding_window_view(genome, frag)[start]      # [n, frag] copy
+    return _mutate(seq, n, frag, read_len, strand, rng), start, strand
 
 
 def make_reads(genome, n_reads, read_len, seed, first_block=0):

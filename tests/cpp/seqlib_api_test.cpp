@@ -11,6 +11,11 @@
 //       `while (r.GetNextSequence(s))` loop does.  No GPU call.
 //   seqlib_api_test writer <tmp_prefix> <n_records>
 //       BamWriter on hand-built records: <tmp_prefix>.sam and <tmp_prefix>.bam.  No GPU call.
+//   seqlib_api_test threads <index_prefix> <fastq> <n> <T>
+//       ONE BWAAligner shared by T host threads, each calling the const alignSequence on its own reads (what the reference allows,
+//       SeqLib/BWAAligner.h:51-63): every read must come out as in a serial pass.  A read's lrand48 ordinal depends on the order
+//       the threads arrive in, so reads whose records depend on the tie-breaking draw (found by two serial passes with different
+//       ordinals) are left out of the comparison.
 //   seqlib_api_test pipeline <index_prefix> <fastq> <n> <out_prefix>
 //       FastqReader -> alignSequences -> BamWriter (SAM and BAM), the path a SeqLib user strings together.
 #include <cstdio>
@@ -18,6 +23,8 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
+#include <atomic>
 #include "SeqLib/BWAAligner.h"
 #include "SeqLib/BamWriter.h"
 #include "SeqLib/FastqReader.h"
@@ -215,11 +222,68 @@ static void print_rec(long read_no, size_t j, const BamRecord &r)
                 r.CigarString().c_str(), as, nm, na, r.Sequence().c_str());
 }
 
+static std::string rec_key(const BamRecordPtrVector &v)
+{
+    std::ostringstream o;
+    for (auto &r : v) {
+        int32_t as = 0, nm = 0, na = 0;
+        r->GetIntTag("AS", as); r->GetIntTag("NM", nm); r->GetIntTag("NA", na);
+        o << r->AlignmentFlag() << ':' << r->ChrID() << ':' << r->Position() << ':' << r->MapQuality() << ':' << r->CigarString() << ':' << as << ':' << nm << ':' << na
+          << ':' << r->Sequence() << ';';
+    }
+    return o.str();
+}
+
+static int thread_checks(const std::string &prefix, const std::string &fastq, long n, int T)
+{
+    auto idx = std::make_shared<BWAIndex>();
+    idx->LoadIndex(prefix);
+    const BWAAligner bwa(idx);                      // const: only the reference's const entry points are used below
+    std::ifstream fq(fastq);
+    std::string h, s, p, q;
+    UnalignedSequenceVector reads;
+    while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q) && (long)reads.size() < n)
+        reads.emplace_back(h.substr(1), s, q);
+    n = (long)reads.size();
+    std::vector<std::string> pass1((size_t)n), pass2((size_t)n), par((size_t)n);
+    for (int rep = 0; rep < 2; ++rep)
+        for (long i = 0; i < n; ++i) {
+            BamRecordPtrVector out;
+            bwa.alignSequence(reads[(size_t)i], out, false, 0.9, 10);
+            (rep ? pass2 : pass1)[(size_t)i] = rec_key(out);
+        }
+    std::atomic<long> next(0);
+    std::atomic<int> failures(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&]() {
+            try {
+                for (long i; (i = next.fetch_add(1)) < n;) {
+                    BamRecordPtrVector out;
+                    bwa.alignSequence(reads[(size_t)i], out, false, 0.9, 10);
+                    par[(size_t)i] = rec_key(out);
+                }
+            } catch (const std::exception &e) { std::fprintf(stderr, "thread: %s\n", e.what()); ++failures; }
+        });
+    for (auto &x : th) x.join();
+    CHECK(failures == 0);
+    long stable = 0, bad = 0;
+    for (long i = 0; i < n; ++i) {
+        if (pass1[(size_t)i] != pass2[(size_t)i]) continue;        // depends on the tie-breaking draw
+        ++stable;
+        if (par[(size_t)i] != pass1[(size_t)i]) { if (!bad) std::fprintf(stderr, "read %ld differs:\n %s\n %s\n", i, par[(size_t)i].c_str(), pass1[(size_t)i].c_str()); ++bad; }
+    }
+    std::printf("threads=%d reads=%ld stable=%ld mismatches=%ld\n", T, n, stable, bad);
+    CHECK(bad == 0 && stable > n * 9 / 10);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);
     if (argc >= 3 && std::string(argv[1]) == "fastq") return fastq_dump(argv[2]);
     if (argc >= 4 && std::string(argv[1]) == "writer") return writer_checks(argv[2], std::atol(argv[3]));
+    if (argc >= 6 && std::string(argv[1]) == "threads") return thread_checks(argv[2], argv[3], std::atol(argv[4]), std::atoi(argv[5]));
     if (argc >= 6 && std::string(argv[1]) == "pipeline") return pipeline(argv[2], argv[3], std::atol(argv[4]), argv[5]);
     if (argc >= 6 && std::string(argv[1]) == "gpu") {
         auto idx = std::make_shared<BWAIndex>();

@@ -19,7 +19,7 @@ def exe(tmp_path_factory):
     lib = os.path.join(ROOT, "seqlib_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "seqlib_api_test.cpp"), "-o", out, "-L" + lib, "-lseqlib_amd",
-                           "-Wl,-rpath," + lib, "-lz"])
+                           "-Wl,-rpath," + lib, "-lz", "-lpthread"])
     return out
 
 
@@ -48,6 +48,16 @@ def test_cpp_align_matches_golden(exe, golden_dir):
         else:
             assert g[10] == s
     assert "1 record(s), qname name" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_one_aligner_shared_by_threads(exe, golden_dir):
+    """one const BWAAligner called from 6 host threads at once (the reference's alignSequence is const and re-entrant):
+    every read comes out as in a serial pass"""
+    r = subprocess.run([exe, "threads", os.path.join(golden_dir, "tiny.fa"), os.path.join(golden_dir, "sim1_bcr.head3000.fq"), "400", "6"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches=0" in r.stdout
 
 
 # ---------------------------------------------------------------------------------------------- FastqReader / BamWriter

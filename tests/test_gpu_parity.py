@@ -57,18 +57,16 @@ def test_fixture_reads_match_oracle_and_golden(sl, orc, tiny_gpu, tiny_index, si
 
 
 def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads):
-    """the light / heavy sub-pipelines on two streams, forced on a small batch with a low seed-count threshold"""
+    """the production schedule (light / heavy partition, cooperative chaining, split extension) forced on a small batch
+    with low seed-count thresholds"""
     (_, s1), (_, s2) = sim_reads
     seqs = s1[:1200] + ["A" * 150, "AC" * 75, "ACG" * 50] + s2[:800]
     exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
-    for split, hs in ((0, 0), (1, 0), (0, 1)):      # hs: heavy reads chained + extended on the worker's second stream
-        for thr in (1, 3, 8, 1000000):
-            al = sl.BWAAligner(tiny_gpu)
-            al.set("split_min", 16)
-            al.set("split_heavy", split)
-            al.set("heavy_stream", hs)
-            al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
-            assert_same(al.alignSequences(seqs), exp, "split=%d heavy_stream=%d heavy_seeds=%d" % (split, hs, thr))
+    for thr in (1, 3, 8, 1000000):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("split_min", 16)
+        al.set("heavy_seeds", thr)     # thr = 1: every read goes through the wave-cooperative chaining kernel
+        assert_same(al.alignSequences(seqs), exp, "heavy_seeds=%d" % thr)
     # ahead-of-time extension of the heavy reads' chains: off, and with a table too small for most reads (in-place fallback)
     # split extension of the light reads off (every read on the wave-per-read kernel)
     al = sl.BWAAligner(tiny_gpu)
@@ -93,10 +91,11 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("ext_mode", 0), ("ext_mode", 1), ("ext_mode", 2), ("sched", 0), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("fin_mode", 0), ("seed_mode", 0), ("seed_mode", 1), ("chain_mode", 0), ("heavy_stream", 1), ("regs_mode", 0), ("regs_mode", 1), ("regs_big", 2), ("regs_big", 5), ("regs_big", 1073741824), ("ext_split", 0)])
+@pytest.mark.parametrize("knob,val", [("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
+                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 1073741824), ("ext_split", 0), ("wide_index", 1)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
-    """one-lane-per-read vs wave-cooperative extension, bwa's sampled-SA walk vs dense SA, odd chunking, and
-    a tiny interval capacity that forces the overflow-retry path: identical records."""
+    """bwa's sampled-SA walk vs dense SA, odd chunking, a tiny interval capacity that forces the overflow-retry path, the
+    routing thresholds of the region kernels, and the u64 index kernels (wide_index) on a small index: identical records."""
     (_, s1), _ = sim_reads
     seqs = s1[:1500]
     al = sl.BWAAligner(tiny_gpu)
@@ -160,7 +159,7 @@ def test_read_too_long_fails_loudly(sl, tiny_gpu):
     from seqlib_amd import _ffi
     al = sl.BWAAligner(tiny_gpu)
     with pytest.raises(_ffi.SlxError) as e:
-        al.alignSequences(["ACGT" * 200])
+        al.alignSequences(["ACGT" * (_ffi.SLX_MAX_READ_LEN // 4 + 1)])
     assert e.value.code == _ffi.SLX_EUNSUPPORTED
 
 
@@ -255,6 +254,101 @@ def test_synthetic_ecoli_block_matches_oracle(sl, orc, tmp_path):
     got = al.align_flat(reads.tobytes(), offs)
     exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
     assert_same(got, exp, "ecoli_syn")
+
+
+def test_wide_index_path_small(sl, orc, tiny_gpu, tiny_index, sim_reads):
+    """u64 index kernels (rank blocks relative to 2^32-symbol super-blocks, u64 intervals, u64 dense SA) on the fixture: the
+    production schedule and bwa's sampled-SA walk, both bit-exact"""
+    (_, s1), (_, s2) = sim_reads
+    seqs = s1[:1500] + ["A" * 150, "AC" * 75] + s2[:1500]
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    for dense in (1, 0):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("wide_index", 1)
+        al.set("dense_sa", dense)
+        al.set("split_min", 16)
+        al.set("heavy_seeds", 8)
+        assert_same(al.alignSequences(seqs), exp, "wide_index dense_sa=%d" % dense)
+
+
+def test_construct_index_64bit_builder_matches_reference_fixture(sl, orc, golden_dir, tmp_path, monkeypatch):
+    """the suffix sorter for texts >= 2^32 symbols (bucketed 27-mer sort + prefix doubling over the unresolved suffixes),
+    forced on tiny.fa: byte-identical to the reference's `bwa index` files; and on a repeat-rich text vs the oracle's builder"""
+    monkeypatch.setenv("SLX_BUILD64", "1")
+    names, seqs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    idx = sl.BWAIndex()
+    idx.ConstructIndex(list(zip(names, seqs)))
+    idx.WriteIndex(str(tmp_path / "t"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(str(tmp_path / ("t." + ext)), os.path.join(golden_dir, "tiny.fa." + ext), shallow=False), ext
+    # long exact repeats, tandem repeats and homopolymer runs: many doubling rounds
+    rng = np.random.default_rng(11)
+    unit = "".join("ACGT"[i] for i in rng.integers(0, 4, 3000))
+    ref = unit + "A" * 500 + unit[:2000] + "ACG" * 400 + unit[::-1] + "T" * 300 + unit + "AC" * 700
+    idx2 = sl.BWAIndex()
+    idx2.ConstructIndex([("rep", ref)])
+    idx2.WriteIndex(str(tmp_path / "r"))
+    oidx = orc.Index.build(["rep"], [ref])
+    oidx.write(str(tmp_path / "ro"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(str(tmp_path / ("r." + ext)), str(tmp_path / ("ro." + ext)), shallow=False), ext
+
+
+def _synth_config_vs_oracle(sl, orc, tmp_path, cfg_name, n_reads, pairs=False):
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS[cfg_name]
+    refs = synth.make_reference(cfg)
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(nm, synth.genome_ascii(g)) for nm, g in refs])
+    idx.WriteIndex(str(tmp_path / cfg_name))
+    oidx = orc.Index.load(str(tmp_path / cfg_name))
+    reads = synth.make_config_reads(cfg, refs, n_reads)
+    offs = synth.offsets_for(len(reads), cfg["read_len"])
+    al = sl.BWAAligner(idx)
+    got = al.align_flat(reads.tobytes(), offs)
+    exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
+    assert_same(got, exp, cfg["name"])
+    return got
+
+
+def test_config_C1_plumbing(sl, orc, tmp_path):
+    """BASELINE config 1: 1 kb in-memory reference, 1 000 synthetic 100 bp reads"""
+    got = _synth_config_vs_oracle(sl, orc, tmp_path, "C1", 1000)
+    assert (np.diff(got["hit_off"]) >= 1).mean() > 0.99
+
+
+def test_config_C3_chr20_block(sl, orc, tmp_path):
+    """BASELINE config 3 (the bench default): GPU-built chr20_syn index (64.4 Mb, 129 M BWT symbols), 131 072 reads =
+    65 536 pairs generated per SURVEY 8d (two single-end reads 300+-30 bp apart, opposite strands) -- bit-exact vs the
+    oracle loading the index the GPU wrote"""
+    _synth_config_vs_oracle(sl, orc, tmp_path, "C3", 1 << 17)
+
+
+def test_config_C4_wide_index(sl, orc, tmp_path):
+    """BASELINE config 4's index regime: a >= 2^32-symbol FM-index (grch38_syn: 14 contigs with GRCh38's chr1..chr14 lengths,
+    2.30 Gbp, 4.6 G BWT symbols), built by the 64-bit GPU suffix sorter, written in bwa's format, loaded by the oracle;
+    65 536 synthetic 150 bp reads through the u64 kernels, bit-exact vs the oracle.  SLX_C4_CONTIGS shrinks it for a quick run."""
+    from seqlib_amd import synth
+    cfg = dict(synth.CONFIGS["C4"])
+    k = int(os.environ.get("SLX_C4_CONTIGS", "14"))
+    cfg["contigs"] = cfg["contigs"][:k]
+    refs = synth.make_reference(cfg)
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])
+    total = sum(len(g) for _, g in refs)
+    if k >= 14:
+        assert 2 * total + 1 >= 1 << 32
+    idx.WriteIndex(str(tmp_path / "c4"))
+    reads = synth.make_config_reads(cfg, refs, 1 << 16)
+    del refs
+    offs = synth.offsets_for(len(reads), cfg["read_len"])
+    al = sl.BWAAligner(idx)
+    got = al.align_flat(reads.tobytes(), offs)
+    del al, idx
+    oidx = orc.Index.load(str(tmp_path / "c4"))
+    exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
+    assert_same(got, exp, "grch38_syn")
+    assert (np.diff(got["hit_off"]) >= 1).mean() > 0.999
 
 
 def test_full_size_properties(sl):
