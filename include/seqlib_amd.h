@@ -40,9 +40,9 @@ extern "C" {
 #define SLX_EUNSUPPORTED (-5)  /* read longer than the GPU path supports (SLX_MAX_READ_LEN) */
 #define SLX_EINTERNAL   (-6)
 
-/* Reads at or above this length enter bwa's mem_flt_chained_seeds/ksw_align2 branch (live when
- * 5.5*ln(L) <= 0.05*L, i.e. L >= ~727), which this round's GPU path does not implement. */
-#define SLX_MAX_READ_LEN 700
+/* Longest read the GPU path takes.  Reads of ~727 bp and more (5.5*ln(L) <= 0.05*L) also run bwa's
+ * mem_flt_chained_seeds/ksw_align2 seed filter and take the long-read kernels (dev_long.h). */
+#define SLX_MAX_READ_LEN 8000
 
 /* mirrors bwa's mem_opt_t (fields the single-end path reads) */
 typedef struct {

@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long wave_fetch_add_u64(unsigned long l
 }
 
 struct ReadWS {               // views into the per-seed-slot arrays for one read
-    int64_t *s_rbeg; uint32_t *s_ql; int32_t *s_next;
+    int64_t *s_rbeg; uint32_t *s_ql; int32_t *s_next; int32_t *s_score;
     int64_t *c_pos; int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first; int8_t *c_kept;
     int32_t *ia, *ib, *ic; uint64_t *srt;
     DReg *regs; DHit *hits;
@@ -65,7 +65,7 @@ __device__ __forceinline__ ReadWS make_ws_uniform(const Chunk &ck, int r)
 {
     const uint64_t o = rfl_u64(ck.seed_off[r]);
     ReadWS w;
-    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
     w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
     w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
     w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
@@ -78,7 +78,7 @@ __device__ __forceinline__ ReadWS make_ws(const Chunk &ck, int r)
 {
     const uint64_t o = ck.seed_off[r];
     ReadWS w;
-    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
     w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
     w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
     w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
@@ -152,7 +152,7 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                             const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                             if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
                                 const int s = ns++;
-                                w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                                w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                                 w.s_next[last] = s; w.c_tail[c] = s; ++w.c_n[c];
                                 res = 1;
                             } else res = 0;
@@ -162,7 +162,7 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                 }
                 if (to_add) {
                     const int s = ns++, c = nc;
-                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                     w.c_pos[c] = rbeg; w.c_head[c] = w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
                     for (int m = nc; m > lo + 1; --m) ord[m] = ord[m - 1];
                     ord[lo + 1] = c;
@@ -224,7 +224,9 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         // then extends the spanning seed first -- no left part, no right part: score = truesc = len*a -- and finds every other
         // seed covered by that region on its own diagonal, so the read's only region is written here and the wave-per-read
         // extension kernel skips the read (n_chain = -1).  seedcov = total length of the chain's seeds, all of them inside.
-        if (n_out == 1 && opt.w > 0) {           // (with a zero band bwa's containment test never fires)
+        // (not for reads the seed filter of mem_flt_chained_seeds will visit: it re-scores and may drop seeds first)
+        const bool flt = ck.s_score && len < ck.log_lut_n && flt_live(opt, len, ck.log_lut[len > 0 ? len : 1], nullptr);
+        if (n_out == 1 && opt.w > 0 && !flt) {   // (with a zero band bwa's containment test never fires)
             const int c0 = a[0];
             int s_full = -1, cov = 0;
             bool same_diag = true;

@@ -88,7 +88,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                                 const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                                 if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
                                     const int s = ns++;   // every lane stores the same bytes, so every lane may read them back
-                                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                                     w.s_next[last] = s; w.c_tail[c] = s; w.c_n[c] = w.c_n[c] + 1;
                                     res = 1;
                                 } else res = 0;
@@ -103,7 +103,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                     }
                     if (to_add) {
                         const int s = ns++, c = nc;
-                        w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1;
+                        w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                         w.c_pos[c] = rbeg; w.c_head[c] = s; w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
                         // ordered insert at rank lo+1: lanes shift the tail up by one, highest block first
                         for (int hi = nc; hi > lo + 1; hi -= 64) {

@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
     // `first` (optional): reads to take before the ones in `order` -- the heavy reads, heaviest first, so that a read that
     // keeps one wave busy for tens of milliseconds starts at once instead of wherever it sits in the batch
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
-    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
+    constexpr int NCH = MAXQ > 704 ? 0 : (MAXQ + 2 + WAVE - 1) / WAVE;   // 0: long reads, see wave_ksw_extend2
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 const int sid = mine ? cs[lane] : 0;
                 const uint32_t ql = mine ? w.s_ql[sid] : 0u;
                 const int64_t rb = mine ? w.s_rbeg[sid] : 0;
-                const uint64_t key = mine ? ((uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)lane) : ~0ull;
+                const uint32_t sc = w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (ql & 0xffffu);    // mem_seed_t::score (= length unless the seed filter ran)
+                const uint64_t key = mine ? ((uint64_t)sc << 32 | (uint64_t)(uint32_t)lane) : ~0ull;
                 int rank = 0;
                 for (int j = 0; j < n; ++j) {
                     const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), j) << 32 |
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 }
                 if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; my_ql = ql; my_rb = rb; my_rank = rank; }
             } else {
-                for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)w.s_len(cs[i]) << 32 | (uint64_t)i;
+                for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)(uint32_t)(w.s_score ? w.s_score[cs[i]] : w.s_len(cs[i])) << 32 | (uint64_t)i;
                 __threadfence_block();                                 // other lanes read these keys below
                 for (int i0 = 0; i0 < n; i0 += WAVE) {
                     const int i = i0 + lane;
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     const int sid = mine ? cs[i] : 0;
                     const uint32_t ql = mine ? w.s_ql[sid] : 0u;
                     const int64_t rb = mine ? w.s_rbeg[sid] : 0;
-                    const uint64_t key = (uint64_t)(ql & 0xffffu) << 32 | (uint64_t)(uint32_t)i;
+                    const uint64_t key = (uint64_t)(w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (ql & 0xffffu)) << 32 | (uint64_t)(uint32_t)i;
                     int rank = 0;
                     for (int b0 = 0; b0 < n; b0 += WAVE) {
                         const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
@@ -584,7 +585,7 @@ template <int MAXQ>
 __device__ __noinline__ void dev_cand_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const int *gap_lut, int *eh_h, int *eh_e,
                                           int r, int jl, DReg *out, int lane)
 {
-    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
+    constexpr int NCH = MAXQ > 704 ? 0 : (MAXQ + 2 + WAVE - 1) / WAVE;   // 0: long reads, see wave_ksw_extend2
     auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
     const int64_t l_pac = R.l_pac;
     ReadWS w = make_ws(ck, r);
@@ -767,7 +768,7 @@ template <int MAXQ>
 __device__ __noinline__ void dev_first_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, int *eh_h, int *eh_e, const FirstJob *jp,
                                            DReg *out, int lane)
 {
-    constexpr int NCH = (MAXQ + 2 + WAVE - 1) / WAVE;
+    constexpr int NCH = MAXQ > 704 ? 0 : (MAXQ + 2 + WAVE - 1) / WAVE;   // 0: long reads, see wave_ksw_extend2
     const FirstJob j = *jp;                          // every lane reads the same 64 bytes
     const int64_t s_rbeg = (int64_t)rfl_u64((uint64_t)j.s_rbeg), rmax0 = (int64_t)rfl_u64((uint64_t)j.rmax0), rmax1 = (int64_t)rfl_u64((uint64_t)j.rmax1);
     const uint8_t *query = ck.codes + rfl_u64(j.q_off);

@@ -62,7 +62,8 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     // query codes of this lane's columns, one register per 64-column tile
-    int qc[NCH];
+    // (NCH = 0: long reads -- no register tile per 64 columns, the code is fetched again for every tile of every row)
+    int qc[NCH > 0 ? NCH : 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { const int j = c * WAVE + lane; qc[c] = j < qlen ? qf(j) : 4; }
     // row -1: eh[0].h = h0, then the insertion ramp while it stays positive
@@ -103,7 +104,7 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
             if (c > c_lo && lane == 0) hd = carry_diag;
             const int nj = (c + 1) * WAVE;           // first column of the next tile
             carry_diag = nj <= qlen ? eh_h[nj] : 0;  // same address in every lane: LDS broadcast
-            const int q = qc[c < NCH ? c : NCH - 1];
+            const int q = NCH > 0 ? qc[c < NCH ? c : NCH - 1] : (j < qlen ? qf(j) : 4);
             const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
             int M = hd ? hd + s : 0;
             int tins = M - oe_ins; tins = tins > 0 ? tins : 0;

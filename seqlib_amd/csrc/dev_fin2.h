@@ -309,7 +309,14 @@ __global__ void __launch_bounds__(128) k_regs(DevRef R, Chunk ck, DevOpt dopt, F
                                               int big_regs = 0)
 {   // big_regs > 0: reads with at least that many regions are left to k_regs_wave
     const slx_opt &opt = dopt.o;
-    int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    constexpr bool LONG = MAXQ > 704;             // long reads: the H/E rows of mem_patch_reg's alignment live in a per-thread global scratch
+    int eh_hl[LONG ? 1 : MAXQ + 2], eh_el[LONG ? 1 : MAXQ + 2];
+    int *eh_h = eh_hl, *eh_e = eh_el;
+    if (LONG) {
+        const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+        if (tid >= ck.long_threads) return;
+        eh_h = ck.long_scratch + (size_t)tid * 2 * ck.long_stride; eh_e = eh_h + ck.long_stride;
+    }
     const int n_todo = (int)*n_slots;
     if (per_wave) __builtin_amdgcn_s_setprio(3);
     auto sc = [&](int band, int lq, const uint8_t *qseg, int64_t rb, int64_t re) {

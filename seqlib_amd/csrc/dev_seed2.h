@@ -117,6 +117,9 @@ __device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
 #ifndef SEED2_MIN_WAVES
 #define SEED2_MIN_WAVES 6
 #endif
+#ifndef SEED2_MIN_WAVES_U64
+#define SEED2_MIN_WAVES_U64 4      // u64 intervals: 6 waves/SIMD would spill (152 bytes of scratch); 4 keeps everything in registers
+#endif
 #ifndef SEED2_POOL
 #define SEED2_POOL 16
 #endif
@@ -133,7 +136,7 @@ __device__ __forceinline__ int q_at(const uint8_t *codes, uint64_t a, QWin &w)
 enum Seed2Phase : int { S2_FETCH = 0, S2_INIT, S2_START, S2_FWD0, S2_BEGIN_BWD, S2_ROW, S2_FWD, S2_BWD, S2_DONE };
 
 template <typename I>
-__global__ void __launch_bounds__(128, SEED2_MIN_WAVES) k_seed12(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED2_MIN_WAVES_U64 : SEED2_MIN_WAVES)) k_seed12(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;

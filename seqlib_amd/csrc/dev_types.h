@@ -78,6 +78,7 @@ struct Chunk {
     int64_t *s_rbeg;
     uint32_t *s_ql;           // qbeg << 16 | len
     int32_t *s_next;
+    int32_t *s_score;         // mem_seed_t::score, only for chunks with reads long enough for mem_flt_chained_seeds (else null: score = length)
     int64_t *c_pos;
     int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first;
     int8_t *c_kept;
@@ -104,6 +105,8 @@ struct Chunk {
     uint32_t *flags;          // OVF_* bits
     // SMEM work lists: [2 lists][cap_list][n_threads] interleaved by thread
     void *lists; int cap_list; int n_threads;
+    // long-read chunks: per-thread H/E rows of the lane-per-read alignment kernels, 2 * long_stride ints per thread
+    int *long_scratch; int long_stride; int long_threads;
     // glue parameters (src/BWAAligner.cpp:89-95)
     int hardclip; double keepSecFrac; int maxSecondary;
 };
@@ -141,6 +144,18 @@ __device__ inline int dev_intv2rid(const DevRef &R, int64_t rb, int64_t re)
     int rid_b = dev_pos2rid(R, dev_depos(R, rb, &is_rev));
     int rid_e = rb < re ? dev_pos2rid(R, dev_depos(R, re - 1, &is_rev)) : rid_b;
     return rid_b == rid_e ? rid_b : -1;
+}
+
+// mem_flt_chained_seeds' guard (bwamem.c): the seed filter runs when  min_l <= MEM_SEEDSW_COEF * l_query,
+// min_l = min_chain_weight ? MEM_HSP_COEF * min_chain_weight : MEM_MINSC_COEF * log(l_query)  (reads >= ~727 bp at the defaults).
+// C's promotions kept: float * int -> float, float * double -> double, double > float compared in double.
+#define MEM_SHORT_EXT 50
+#define MEM_SHORT_LEN 200
+__host__ __device__ __forceinline__ bool flt_live(const slx_opt &o, int l_query, double log_l, int *min_hsp_score)
+{
+    const double min_l = o.min_chain_weight ? (double)(1.1f * (float)o.min_chain_weight) : (double)5.5f * log_l;
+    if (min_hsp_score) *min_hsp_score = (int)(o.a * min_l + .499);
+    return !(min_l > (double)(0.05f * (float)l_query));
 }
 
 __device__ __forceinline__ int dev_cal_max_gap(const slx_opt &o, int qlen)

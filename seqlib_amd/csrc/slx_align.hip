@@ -26,6 +26,7 @@
 #include "dev_ext_reg.h"
 #include "dev_fin2.h"
 #include "dev_chain_coop.h"
+#include "dev_long.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -83,7 +84,7 @@ struct Worker {
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
-        cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list;
+        cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
     int id = 0;
     hipEvent_t dbg_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
@@ -101,7 +102,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar};
         for (auto &e : ev) e = nullptr;
     }
@@ -470,8 +471,9 @@ static void with_maxq(int max_len, F f)
 {
     if (max_len <= 160) f(std::integral_constant<int, 160>());
     else if (max_len <= 320) f(std::integral_constant<int, 320>());
-    else f(std::integral_constant<int, SLX_MAX_READ_LEN + 4>());
+    else f(std::integral_constant<int, 704>());
 }
+#define MAXQ_LONG (SLX_MAX_READ_LEN + 4)
 
 // extension -> regions -> CIGAR jobs -> hit sort/filter, over all reads of the chunk on the worker's stream
 template <int MAXQ>
@@ -504,14 +506,18 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
                        wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
     hipLaunchKernelGGL(k_regs1, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, ck, dopt, fl, wk->order_in.as<int>(), cnt2);
-    if (al->regs_big < (1 << 20))
-        hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n / 64 + 1, al->n_cu * 4))), dim3(64), 0, st, al->ref, ck, dopt, fl,
-                           wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big);
-    hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
+    if constexpr (MAXQ <= 704) {
+        if (al->regs_big < (1 << 20))
+            hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n / 64 + 1, al->n_cu * 4))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                               wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big);
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
+    } else   // long reads: every multi-region read on the lane-per-read kernel (its alignment rows in the per-thread scratch)
+        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, 0);
     if (dbg_on) (void)hipEventRecord(dbg[3], st);
     (void)hipEventRecord(wk->ev_probe[4], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
-    hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
+    if constexpr (MAXQ <= 704) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
+    else hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl);
     (void)hipEventRecord(wk->ev_probe[5], st);
     if (dbg_on) (void)hipEventRecord(dbg[4], st);
     hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, wk->order_out.as<int>(), q + 3, q + 33, 0);   // single-region reads are final already
@@ -543,7 +549,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     int rc;
     const uint64_t base0 = h_offs_pair[0], n_bases = h_offs_pair[1] - h_offs_pair[0];
     const int bs = 128;
-    int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)al->max_threads);
+    // chunks holding a read long enough for bwa's seed filter (mem_flt_chained_seeds, live from ~727 bp) take the long-read path
+    const bool has_long = max_len > 704 || flt_live(*opt, max_len, log((double)std::max(max_len, 1)), nullptr);
+    int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)(has_long ? std::min(al->max_threads, 16384) : al->max_threads));
     const int grid = n_threads / bs;
     const int cap_list = max_len + 1;
 #define ENS(buf, bytes) if ((rc = wk->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
@@ -582,7 +590,6 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.lists = wk->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
     ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
     ck.seed_cnt = wk->seed_cnt.as<unsigned long long>();
-    const bool has_long = false;   // (hook of the long-read path: mem_flt_chained_seeds, reads >= ~727 bp)
     const bool production = al->chain_mode == 1 && n >= al->split_min && !has_long;
     const bool use_cand = al->cand_mode == 1 && production;
     if (use_cand) {
@@ -636,6 +643,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.c_first = wk->c_first.as<int32_t>(); ck.c_kept = wk->c_kept.as<int8_t>();
     ck.ia = wk->ia.as<int32_t>(); ck.ib = wk->ib.as<int32_t>(); ck.ic = wk->ic.as<int32_t>(); ck.srt = wk->srt.as<uint64_t>();
     ck.regs = wk->regs.as<DReg>(); ck.hits = wk->hits.as<DHit>();
+    if (has_long) {   // per-seed scores (mem_seed_t::score) and the per-thread H/E rows of the lane-per-read alignment kernels
+        ENS(s_score, S1 * 4); ENS(long_list, (size_t)n * 4);
+        ck.s_score = wk->s_score.as<int32_t>();
+        ck.long_stride = max_len + 8; ck.long_threads = n_threads;
+        ENS(long_scratch, (size_t)n_threads * 2 * ck.long_stride * 4);
+        ck.long_scratch = wk->long_scratch.as<int>();
+    }
     (void)hipEventRecord(wk->ev[3], st);
     {
         unsigned int *q = wk->queues.as<unsigned int>();
@@ -654,9 +668,14 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             // chaining kernel, then the seed filter for the long ones, then every read on the wave-per-read extension kernel
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
             hipLaunchKernelGGL(k_chain<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, (const int *)nullptr, q + 0, counts, 0);
+            if (has_long) {   // mem_flt_chained_seeds
+                hipLaunchKernelGGL(k_long_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, dopt, wk->long_list.as<int>(), q + 16);
+                hipLaunchKernelGGL(k_flt_seeds, dim3(std::max(1, std::min(n, al->n_cu * 8))), dim3(64), 0, st, al->ref, ck, dopt, wk->long_list.as<int>(), q + 16, q + 17);
+            }
             (void)hipEventRecord(wk->ev_probe[2], st);
             (void)hipEventRecord(wk->ev[4], st);
-            with_maxq(max_len, [&](auto mq) {
+            if (max_len > 704) launch_tail<MAXQ_LONG>(al, wk, ck, dopt, q, counts, grid, bs, n, nullptr, nullptr, nullptr, nullptr);
+            else with_maxq(max_len, [&](auto mq) {
                 launch_tail<decltype(mq)::value>(al, wk, ck, dopt, q, counts, grid, bs, n, nullptr, nullptr, nullptr, nullptr);
             });
         } else {

@@ -155,6 +155,45 @@ def orc_revcomp(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
 
 
+def test_long_reads_seed_filter_path(sl, orc, tiny_gpu, tiny_index, golden_dir):
+    """reads of 700-5000 bp (contig-like): bwa's mem_flt_chained_seeds/ksw_align2 seed filter is live from ~727 bp, extensions are
+    thousands of columns wide, CIGAR jobs are megacell alignments -- bit-exact vs the oracle; alone, and mixed with 150 bp reads"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    rng = np.random.default_rng(5)
+    seqs = []
+    for L in (700, 726, 727, 728, 733, 800, 1000, 1500, 2500, 3999, 5000, 5000, 7999):
+        for rep in range(3):
+            ci = int(rng.integers(0, len(refs)))
+            L2 = min(L, len(refs[ci]) - 10)
+            p = int(rng.integers(0, len(refs[ci]) - L2))
+            s = list(refs[ci][p:p + L2])
+            n_sub = int(L2 * (0.0, 0.01, 0.04)[rep])
+            for _ in range(n_sub):
+                s[int(rng.integers(0, L2))] = "ACGT"[int(rng.integers(0, 4))]
+            if rep == 2:                              # an insertion, a deletion and a chimeric tail
+                q = L2 // 3
+                s[q:q] = list("ACGTTGCAAC")
+                del s[2 * q:2 * q + 7]
+                cj = (ci + 1) % len(refs)
+                s[-200:] = list(refs[cj][1000:1200])
+            t = "".join(s)
+            if rng.random() < 0.5:
+                t = orc_revcomp(t)
+            seqs.append(t)
+    seqs.append("ACGT" * 300)                      # low complexity, long
+    seqs.append(refs[0][500:1300] + "N" * 30 + refs[0][1330:2200])
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    al = sl.BWAAligner(tiny_gpu)
+    assert_same(al.alignSequences(seqs), exp, "long reads")
+    mixed = seqs[:8] + [refs[1][2000 + 150 * i:2150 + 150 * i] for i in range(40)] + seqs[8:20]
+    exp = orc.align_batch(orc.default_opt(), tiny_index, mixed)
+    al = sl.BWAAligner(tiny_gpu)
+    assert_same(al.alignSequences(mixed), exp, "long + short reads")
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("wide_index", 1)
+    assert_same(al.alignSequences(mixed), exp, "long + short reads, u64 index")
+
+
 def test_read_too_long_fails_loudly(sl, tiny_gpu):
     from seqlib_amd import _ffi
     al = sl.BWAAligner(tiny_gpu)
