@@ -407,22 +407,106 @@ static int test_and_merge(const orc_opt *opt, int64_t l_pac, orc_chain *c, const
     return 0;
 }
 
-/* Ordered chain set standing in for bwa's kbtree(chn).  Semantics of a single-leaf kbtree:
- * `lower` = first chain with pos == key if one exists, else the chain with the largest pos < key;
- * a new chain is inserted right after `lower`.  (A multi-level kbtree can differ only when two
- * chains share the same pos AND there are > 9 chains; documented in DESIGN.md.) */
+/* bwa's kbtree(chn): klib kbtree.h instantiated as KBTREE_INIT(chn, mem_chain_t, chain_cmp) and created with
+ * kb_init(chn, KB_DEFAULT_SIZE = 512): t = ((512 - 4 - sizeof(void*)) / (sizeof(void*) + sizeof(mem_chain_t)) + 1) >> 1 = 5 with the
+ * 40-byte mem_chain_t of a 64-bit build, i.e. at most 2t-1 = 9 keys per node.  Keys are the chains themselves, compared by pos;
+ * duplicates are allowed.  What is visible downstream: (a) which chain kb_intervalp returns as `lower` for a new seed -- with equal
+ * positions spread over several nodes that is whichever copy the root-to-leaf search meets first -- and (b) the in-order traversal
+ * that hands the chains to mem_chain_flt, whose unstable sort by weight sees that order.  Both depend on the tree's shape, so the
+ * tree is restated operation for operation: __kb_getp_aux, kb_intervalp, __kb_split, __kb_putp_aux, kb_putp, __kb_traverse. */
 typedef struct { int n, m; orc_chain *a; } chain_v;
 
-static int chain_lower(const chain_v *t, int64_t pos)
+#define KB_T 5
+typedef struct kbnode_s {
+    int is_internal, n;
+    orc_chain key[2 * KB_T - 1];
+    struct kbnode_s *ptr[2 * KB_T];
+} kbnode;
+
+static int kb_getp_aux(const kbnode *x, int64_t pos, int *r)
 {
-    int begin = 0, end = t->n;
+    int tr, *rr = r ? r : &tr, begin = 0, end = x->n;
+    if (x->n == 0) return -1;
     while (begin < end) {
         int mid = (begin + end) >> 1;
-        if (t->a[mid].pos < pos) begin = mid + 1; else end = mid;
+        if (x->key[mid].pos < pos) begin = mid + 1; else end = mid;   /* __cmp(key[mid], *k) < 0 */
     }
-    if (begin == t->n) return t->n - 1;
-    if (pos < t->a[begin].pos) --begin;
-    return begin; /* may be -1 */
+    if (begin == x->n) { *rr = 1; return x->n - 1; }
+    if ((*rr = (x->key[begin].pos < pos) - (pos < x->key[begin].pos)) < 0) --begin;
+    return begin;
+}
+
+static orc_chain *kb_interval_lower(kbnode *root, int64_t pos)
+{
+    int i, r = 0;
+    kbnode *x = root;
+    orc_chain *lower = 0;
+    while (x) {
+        i = kb_getp_aux(x, pos, &r);
+        if (i >= 0 && r == 0) return &x->key[i];
+        if (i >= 0) lower = &x->key[i];
+        if (!x->is_internal) return lower;
+        x = x->ptr[i + 1];
+    }
+    return lower;
+}
+
+static void kb_split(kbnode *x, int i, kbnode *y)   /* x internal, y = x->ptr[i] full */
+{
+    kbnode *z = (kbnode *)calloc(1, sizeof(kbnode));
+    z->is_internal = y->is_internal;
+    z->n = KB_T - 1;
+    memcpy(z->key, y->key + KB_T, sizeof(orc_chain) * (KB_T - 1));
+    if (y->is_internal) memcpy(z->ptr, y->ptr + KB_T, sizeof(kbnode *) * KB_T);
+    y->n = KB_T - 1;
+    memmove(x->ptr + i + 2, x->ptr + i + 1, sizeof(kbnode *) * (size_t)(x->n - i));
+    x->ptr[i + 1] = z;
+    memmove(x->key + i + 1, x->key + i, sizeof(orc_chain) * (size_t)(x->n - i));
+    x->key[i] = y->key[KB_T - 1];
+    ++x->n;
+}
+
+static void kb_putp_aux(kbnode *x, const orc_chain *k)
+{
+    int i;
+    if (!x->is_internal) {
+        i = kb_getp_aux(x, k->pos, 0);
+        if (i != x->n - 1) memmove(x->key + i + 2, x->key + i + 1, (size_t)(x->n - i - 1) * sizeof(orc_chain));
+        x->key[i + 1] = *k;
+        ++x->n;
+    } else {
+        i = kb_getp_aux(x, k->pos, 0) + 1;
+        if (x->ptr[i]->n == 2 * KB_T - 1) {
+            kb_split(x, i, x->ptr[i]);
+            if (k->pos > x->key[i].pos) ++i;                           /* __cmp(*k, key[i]) > 0 */
+        }
+        kb_putp_aux(x->ptr[i], k);
+    }
+}
+
+static kbnode *kb_put(kbnode *root, const orc_chain *k)   /* returns the (possibly new) root */
+{
+    if (root->n == 2 * KB_T - 1) {
+        kbnode *s = (kbnode *)calloc(1, sizeof(kbnode));
+        s->is_internal = 1; s->n = 0;
+        s->ptr[0] = root;
+        kb_split(s, 0, root);
+        root = s;
+    }
+    kb_putp_aux(root, k);
+    return root;
+}
+
+static void kb_traverse(kbnode *x, chain_v *out)   /* in order; frees the nodes */
+{
+    int i;
+    for (i = 0; i < x->n; ++i) {
+        if (x->is_internal) kb_traverse(x->ptr[i], out);
+        if (out->n == out->m) { out->m = out->m ? out->m << 1 : 8; out->a = (orc_chain *)realloc(out->a, (size_t)out->m * sizeof(orc_chain)); }
+        out->a[out->n++] = x->key[i];
+    }
+    if (x->is_internal) kb_traverse(x->ptr[x->n], out);
+    free(x);
 }
 
 static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const uint8_t *seq, chain_v *chain)
@@ -430,8 +514,11 @@ static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const ui
     int i, b, e, l_rep, n_intv;
     int64_t l_pac = idx->l_pac;
     orc_intv *intv = 0;
+    kbnode *root;
+    int n_keys = 0;
     chain->n = chain->m = 0; chain->a = 0;
     if (len < opt->min_seed_len) return 0;
+    root = (kbnode *)calloc(1, sizeof(kbnode));
     n_intv = orc_collect_intv(opt, idx, len, seq, &intv);
     for (i = 0, b = e = l_rep = 0; i < n_intv; ++i) { /* compute frac_rep */
         orc_intv *p = &intv[i];
@@ -448,7 +535,7 @@ static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const ui
         step = p->x[2] > (uint64_t)opt->max_occ ? (int)(p->x[2] / (uint64_t)opt->max_occ) : 1;
         for (k = count = 0; (uint64_t)k < p->x[2] && count < opt->max_occ; k += step, ++count) {
             orc_seed s;
-            int rid, to_add = 0, lo;
+            int rid, to_add = 0;
             uint64_t hops;
             s.rbeg = (int64_t)orc_sa_hops(idx, p->x[0] + (uint64_t)k, &hops);
             ++g_cnt.n_sa; g_cnt.n_invpsi += hops;
@@ -456,10 +543,9 @@ static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const ui
             s.score = s.len = slen;
             rid = bns_intv2rid(idx, s.rbeg, s.rbeg + s.len);
             if (rid < 0) continue; /* bridging contigs or the forward-reverse boundary */
-            lo = -1;
-            if (chain->n) {
-                lo = chain_lower(chain, s.rbeg);
-                if (lo < 0 || !test_and_merge(opt, l_pac, &chain->a[lo], &s, rid)) to_add = 1;
+            if (n_keys) {
+                orc_chain *lower = kb_interval_lower(root, s.rbeg);
+                if (!lower || !test_and_merge(opt, l_pac, lower, &s, rid)) to_add = 1;
             } else to_add = 1;
             if (to_add) {
                 orc_chain tmp;
@@ -470,13 +556,12 @@ static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const ui
                 tmp.seeds[0] = s;
                 tmp.rid = rid;
                 tmp.is_alt = !!idx->anns[rid].is_alt;
-                if (chain->n == chain->m) { chain->m = chain->m ? chain->m << 1 : 8; chain->a = (orc_chain *)realloc(chain->a, (size_t)chain->m * sizeof(orc_chain)); }
-                memmove(chain->a + lo + 2, chain->a + lo + 1, (size_t)(chain->n - lo - 1) * sizeof(orc_chain));
-                chain->a[lo + 1] = tmp;
-                ++chain->n;
+                root = kb_put(root, &tmp);
+                ++n_keys;
             }
         }
     }
+    kb_traverse(root, chain);
     for (i = 0; i < chain->n; ++i) chain->a[i].frac_rep = (float)l_rep / len;
     free(intv);
     return chain->n;

@@ -1,10 +1,26 @@
 """Summarises the rocprofv3 passes written by scripts/profile_round.sh:
-   python scripts/pmc_summary.py <out_dir> <reads_per_launch> > profiles/rNN_pmc_summary.json
-Per kernel: mean counter values over the full-size launches (the largest launches of each kernel).  FETCH_SIZE /
-WRITE_SIZE are reported by rocprofv3 in KB."""
+   python scripts/pmc_summary.py <out_dir> <config> > profiles/rNN_pmc_summary.json
+Per kernel: mean counter values over the full-size launches (the largest launches of each kernel).
+
+Units, as found on this gfx950 / ROCm 7.2 (cross-checked between counters of the same launches):
+  FETCH_SIZE / WRITE_SIZE   KB as rocprofv3 reports them.  FETCH_SIZE under-reports wide coalesced streams by 2x on gfx950
+                            (MI355X_MICROARCH.md); the seeding kernels issue 32-byte random reads, for which the counter is
+                            uncalibrated, so the raw value is reported.
+  SQ_ACTIVE_INST_VALU       one count per wave64 VALU instruction issued (it equals SQ_INSTS_VALU to within 3 % on every kernel
+                            here); the guide lists it in "quad-cycles".  A 32-bit wave64 VALU op occupies a SIMD-32 for 2 cycles
+                            (guide: v_fma_f32 wave64 = 2 cyc).
+  GRBM_GUI_ACTIVE           cycles, SUMMED over the 8 XCDs (GRBM_GUI_ACTIVE / 8 / kernel wall time = 2.3-2.4 GHz);
+                            SQ_BUSY_CYCLES is summed over the 32 shader engines (= 4 x GRBM_GUI_ACTIVE).
+  VALUBusy (derived here)   SQ_ACTIVE_INST_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the fraction of SIMD issue cycles this
+                            kernel's VALU instructions filled while it was resident.  With three workers' kernels overlapping on
+                            the GPU the same cycles also carry the other kernels' instructions, so the values of concurrently
+                            running kernels add up.  (The gfx94x formula of rocprof, x4 instead of x2, gives values above 100 % here.)
+  lane utilisation          SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): active lanes per VALU instruction.
+"""
 import collections, csv, glob, json, sys
 
-out_dir, reads = sys.argv[1], float(sys.argv[2])
+out_dir, config = sys.argv[1], sys.argv[2]
+N_SIMD, N_XCD = 1024, 8
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out_dir + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -12,29 +28,58 @@ for f in glob.glob(out_dir + "/pmc*/**/*counter_collection.csv", recursive=True)
         if "rocprim" in name or "rocclr" in name or "hipcub" in name:
             continue
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-kern = {}
+kern, n_launch = {}, {}
 for k, d in acc.items():
     kern[k] = {}
     for c, v in d.items():
         big = [x for x in v if x >= 0.5 * max(v)] or v       # full-size launches only
         kern[k][c] = sum(big) / len(big)
+        n_launch[k] = max(n_launch.get(k, 0), len(big))
+
+
 def g(k, c):
     return kern.get(k, {}).get(c, 0.0)
-seed = ["k_seed12", "k_seed3"]
-fetch = sum(g(k, "FETCH_SIZE") for k in seed) * 1024.0 / reads
-write = sum(g(k, "WRITE_SIZE") for k in seed) * 1024.0 / reads
+
+
+def pick(prefix):
+    return [k for k in kern if k.startswith(prefix)]
+
+
+def valu_busy(k):
+    gui = g(k, "GRBM_GUI_ACTIVE")
+    return g(k, "SQ_ACTIVE_INST_VALU") * 2.0 / (N_SIMD * gui / N_XCD) if gui else None
+
+
+def lane_util(k):
+    a = g(k, "SQ_ACTIVE_INST_VALU")
+    return g(k, "SQ_THREAD_CYCLES_VALU") / (64.0 * a) if a else None
+
+
+try:
+    bench = json.loads(open(out_dir + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
+    reads = bench["roofline"]["reads_per_launch"] if bench.get("roofline") else bench["config"]["reads_per_gpu"] / 3.0
+except Exception:
+    bench, reads = None, {"C2": 10e6 / 3, "C3": 50e6 / 6}.get(config, 1.0)
+seed12, seed3 = (pick("k_seed12") or ["k_seed12"])[0], (pick("k_seed3") or ["k_seed3"])[0]
+fetch = (g(seed12, "FETCH_SIZE") + g(seed3, "FETCH_SIZE")) * 1024.0 / reads
+write = (g(seed12, "WRITE_SIZE") + g(seed3, "WRITE_SIZE")) * 1024.0 / reads
+ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep")]
+ext_inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ext)
+ext_gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ext)
 res = {
-    "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --no-cpu-baseline --verify 0 --steps 2 (one pass per counter set; scripts/profile_round.sh)",
-    "note": "per-launch means over the full-size launches (3 workers x reads/3 each); FETCH_SIZE/WRITE_SIZE in KB as rocprofv3 reports them; on gfx950 "
-            "FETCH_SIZE is known to under-report wide coalesced streams by 2x (MI355X_MICROARCH.md) -- the seeding kernels issue 32-byte random reads, "
-            "for which the counter is uncalibrated, so the raw value is reported",
+    "config": config,
+    "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --config %s --no-cpu-baseline --no-extras --verify 0 --steps 2 --warmup 1 "
+               "(one pass per counter set; scripts/profile_round.sh)" % config,
+    "note": "per-launch means over the full-size launches; see the module docstring of scripts/pmc_summary.py for units and formulas",
     "reads_per_launch": reads,
     "seed_fetch_bytes_per_read": fetch, "seed_write_bytes_per_read": write,
-    "seed_l2_hit_rate": (g("k_seed12", "TCC_HIT_sum") / g("k_seed12", "TCC_REQ_sum")) if g("k_seed12", "TCC_REQ_sum") else None,
-    "seed_wait_frac_of_wave_cycles": (g("k_seed12", "SQ_WAIT_ANY") / g("k_seed12", "SQ_WAVE_CYCLES")) if g("k_seed12", "SQ_WAVE_CYCLES") else None,
-    "seed_valu_lane_utilisation": (g("k_seed12", "SQ_THREAD_CYCLES_VALU") / (64.0 * g("k_seed12", "SQ_ACTIVE_INST_VALU"))) if g("k_seed12", "SQ_ACTIVE_INST_VALU") else None,
-    "extend_valu_lane_utilisation": (g("k_extend_reg<160>", "SQ_THREAD_CYCLES_VALU") / (64.0 * g("k_extend_reg<160>", "SQ_ACTIVE_INST_VALU")))
-                                    if g("k_extend_reg<160>", "SQ_ACTIVE_INST_VALU") else None,
+    "seed_l2_hit_rate": (g(seed12, "TCC_HIT_sum") / g(seed12, "TCC_REQ_sum")) if g(seed12, "TCC_REQ_sum") else None,
+    "seed_wait_frac_of_wave_cycles": (g(seed12, "SQ_WAIT_ANY") / g(seed12, "SQ_WAVE_CYCLES")) if g(seed12, "SQ_WAVE_CYCLES") else None,
+    "seed_valu_lane_utilisation": lane_util(seed12), "seed_valu_busy": valu_busy(seed12), "seed_lds_instructions": g(seed12, "SQ_INSTS_LDS"),
+    # extension family: instruction-weighted over its kernels' full-size launches
+    "ext_valu_busy": (ext_inst * 2.0 / (N_SIMD * ext_gui / N_XCD)) if ext_gui else None,
+    "ext_valu_busy_by_kernel": {k: valu_busy(k) for k in ext},
+    "ext_valu_lane_utilisation_by_kernel": {k: lane_util(k) for k in ext},
     "kernels": kern,
 }
 print(json.dumps(res, indent=1))

@@ -36,6 +36,10 @@ namespace {
 constexpr int K0 = 27;   // 5^27 < 2^63
 typedef unsigned long long u64;
 
+// One element per thread over up to 2^33 elements: HIP caps gridDim.x * blockDim.x below 2^32, so large launches are folded into a
+// 2-D grid (grid_for) and every kernel derives its element index from both block coordinates.
+#define GIDX (((u64)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x)
+
 __device__ __forceinline__ u64 sym1(const uint8_t *T, u64 n, u64 p) { return p < n ? (u64)T[p] + 1 : 0; }   // 0 = the sentinel and everything past it
 
 // ---- phase A
@@ -45,7 +49,7 @@ __global__ void k_bucket_hist(const uint8_t *T, u64 n, u64 *hist)
     if (threadIdx.x < 25) h[threadIdx.x] = 0;
     __syncthreads();
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += stride) atomicAdd(&h[sym1(T, n, p) * 5 + sym1(T, n, p + 1)], 1u);
+    for (u64 p = GIDX; p <= n; p += stride) atomicAdd(&h[sym1(T, n, p) * 5 + sym1(T, n, p + 1)], 1u);
     __syncthreads();
     if (threadIdx.x < 25 && h[threadIdx.x]) atomicAdd(hist + threadIdx.x, (u64)h[threadIdx.x]);
 }
@@ -69,7 +73,7 @@ __global__ void k_bucket_gather(const uint8_t *T, u64 n, int bucket, u64 *cursor
 
 __global__ void k_keys27(const uint8_t *T, u64 n, const u64 *pos, u64 m, u64 *keys)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i >= m) return;
     const u64 p = pos[i];
     u64 key = 0;
@@ -80,7 +84,7 @@ __global__ void k_keys27(const uint8_t *T, u64 n, const u64 *pos, u64 m, u64 *ke
 // sorted bucket -> its slice of the suffix array, with a flag at the first member of every group of equal keys
 __global__ void k_emit_bucket(const u64 *keys, const u64 *pos, u64 m, u64 *sa, uint8_t *flag)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i >= m) return;
     sa[i] = pos[i];
     flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
@@ -89,17 +93,17 @@ __global__ void k_emit_bucket(const u64 *keys, const u64 *pos, u64 m, u64 *sa, u
 // ---- group bookkeeping
 __global__ void k_start_vals(const uint8_t *flag, u64 base, u64 m, u64 *val)
 {   // val[i] = own index if a group starts here (0 otherwise): the inclusive max scan turns it into the group's first index
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i < m) val[i] = flag[base + i] ? base + i : 0;
 }
 __global__ void k_apply_carry(u64 *val, u64 m, u64 carry)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i < m && val[i] < carry) val[i] = carry;
 }
 __global__ void k_scatter_grp(const u64 *sa, const u64 *start, u64 n1, u64 *grp)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i < n1) grp[sa[i]] = start[i];
 }
 // SA indices that are not yet alone in their group
@@ -107,7 +111,7 @@ __global__ void k_unres_count(const uint8_t *flag, u64 n1, u64 *count)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u64 c = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride)
+    for (u64 i = GIDX; i < n1; i += stride)
         if (!(flag[i] && (i + 1 == n1 || flag[i + 1]))) ++c;
     for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
@@ -115,7 +119,7 @@ __global__ void k_unres_count(const uint8_t *flag, u64 n1, u64 *count)
 // tile-ordered compaction of the unresolved indices (ascending order must be kept: position k of U is the k-th smallest index)
 __global__ void k_unres_tile_counts(const uint8_t *flag, u64 n1, u64 tile, u64 n_tiles, u64 *cnt)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = GIDX;
     if (t >= n_tiles) return;
     const u64 a = t * tile, b = a + tile < n1 ? a + tile : n1;
     u64 c = 0;
@@ -124,7 +128,7 @@ __global__ void k_unres_tile_counts(const uint8_t *flag, u64 n1, u64 tile, u64 n
 }
 __global__ void k_unres_tile_fill(const uint8_t *flag, u64 n1, u64 tile, u64 n_tiles, const u64 *off, u64 *uidx)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = GIDX;
     if (t >= n_tiles) return;
     const u64 a = t * tile, b = a + tile < n1 ? a + tile : n1;
     u64 o = off[t];
@@ -134,7 +138,7 @@ __global__ void k_unres_tile_fill(const uint8_t *flag, u64 n1, u64 tile, u64 n_t
 // ---- phase B, one round over the unresolved list U (m entries, ascending SA indices)
 __global__ void k_round_keys(const u64 *uidx, u64 m, const u64 *sa, const u64 *grp, u64 h, u64 *key2, u64 *pos)
 {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 k = GIDX;
     if (k >= m) return;
     const u64 p = sa[uidx[k]];
     pos[k] = p;
@@ -142,13 +146,13 @@ __global__ void k_round_keys(const u64 *uidx, u64 m, const u64 *sa, const u64 *g
 }
 __global__ void k_round_key1(const u64 *pos, u64 m, const u64 *grp, u64 *key1)
 {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 k = GIDX;
     if (k < m) key1[k] = grp[pos[k]];
 }
 // after both sorts: pos[] is ordered by (grp[p], grp[p+h]).  New group heads, read while grp still holds the old ranks.
 __global__ void k_round_flags(const u64 *uidx, const u64 *pos, u64 m, const u64 *grp, u64 h, uint8_t *nflag, u64 *val)
 {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 k = GIDX;
     if (k >= m) return;
     bool head = true;
     if (k) {
@@ -160,7 +164,7 @@ __global__ void k_round_flags(const u64 *uidx, const u64 *pos, u64 m, const u64 
 }
 __global__ void k_round_apply(const u64 *uidx, const u64 *pos, const uint8_t *nflag, const u64 *start, u64 m, u64 *sa, u64 *grp, uint8_t *flag)
 {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 k = GIDX;
     if (k >= m) return;
     const u64 i = uidx[k], p = pos[k];
     sa[i] = p;
@@ -169,7 +173,7 @@ __global__ void k_round_apply(const u64 *uidx, const u64 *pos, const uint8_t *nf
 }
 __global__ void k_round_keep(const uint8_t *nflag, u64 m, u64 tile, u64 n_tiles, u64 *cnt)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = GIDX;
     if (t >= n_tiles) return;
     const u64 a = t * tile, b = a + tile < m ? a + tile : m;
     u64 c = 0;
@@ -178,7 +182,7 @@ __global__ void k_round_keep(const uint8_t *nflag, u64 m, u64 tile, u64 n_tiles,
 }
 __global__ void k_round_compact(const uint8_t *nflag, const u64 *uidx, u64 m, u64 tile, u64 n_tiles, const u64 *off, u64 *uidx_out)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = GIDX;
     if (t >= n_tiles) return;
     const u64 a = t * tile, b = a + tile < m ? a + tile : m;
     u64 o = off[t];
@@ -188,19 +192,19 @@ __global__ void k_round_compact(const uint8_t *nflag, const u64 *uidx, u64 m, u6
 // ---- output (64-bit positions; same layout rules as slx_index_gpu.hip)
 __global__ void k_find_primary64(const u64 *sa, u64 n1, u64 *primary)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = GIDX;
     if (i < n1 && sa[i] == 0) *primary = i;
 }
 __global__ void k_bwt64(const uint8_t *T, const u64 *sa, u64 n, const u64 *primary, uint8_t *B)
 {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 k = GIDX;
     if (k >= n) return;
     const u64 i = k < *primary ? k : k + 1;
     B[k] = T[sa[i] - 1];
 }
 __global__ void k_block_counts64(const uint8_t *B, u64 n, u64 n_blk, u64 *cA, u64 *cC, u64 *cG, u64 *cT)
 {
-    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 b = GIDX;
     if (b > n_blk) return;
     u64 c[4] = {0, 0, 0, 0};
     if (b < n_blk) {
@@ -211,7 +215,7 @@ __global__ void k_block_counts64(const uint8_t *B, u64 n, u64 n_blk, u64 *cA, u6
 }
 __global__ void k_interleave64(const uint8_t *B, u64 n, u64 n_blk, const u64 *oA, const u64 *oC, const u64 *oG, const u64 *oT, uint32_t *out)
 {
-    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 b = GIDX;
     if (b > n_blk) return;
     u64 off = b * 16;
     if (b == n_blk) off = (n_blk ? n_blk - 1 : 0) * 16 + (n_blk ? 8 + (((n - (n_blk - 1) * 128) + 15) >> 4) : 0);
@@ -229,7 +233,7 @@ __global__ void k_interleave64(const uint8_t *B, u64 n, u64 n_blk, const u64 *oA
 }
 __global__ void k_sample_sa64(const u64 *sa, u64 n_sa, u64 *samp)
 {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 j = GIDX;
     if (j < n_sa) samp[j] = j == 0 ? (u64)-1 : sa[j * 32];
 }
 
@@ -243,7 +247,11 @@ struct Buf {
 
 struct MaxOp { __host__ __device__ u64 operator()(u64 a, u64 b) const { return a > b ? a : b; } };
 
-dim3 grid_for(u64 m, int bs = 256) { return dim3((unsigned)((m + bs - 1) / bs)); }
+dim3 grid_for(u64 m, int bs = 256)
+{
+    const u64 nb = (m + bs - 1) / bs, ROW = 1ull << 20;
+    return nb <= ROW ? dim3((unsigned)(nb ? nb : 1)) : dim3((unsigned)ROW, (unsigned)((nb + ROW - 1) / ROW));
+}
 
 // inclusive max scan of val[0..m) in place, in pieces of 2^30 (hipCUB scans take int-sized inputs), carrying the running maximum across pieces
 int chunked_max_scan(u64 *val, u64 m, Buf &tmp, size_t &tmp_bytes, hipStream_t st)

@@ -161,7 +161,7 @@ def test_long_reads_seed_filter_path(sl, orc, tiny_gpu, tiny_index, golden_dir):
     names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
     rng = np.random.default_rng(5)
     seqs = []
-    for L in (700, 726, 727, 728, 733, 800, 1000, 1500, 2500, 3999, 5000, 5000, 7999):
+    for L in (700, 726, 727, 728, 733, 800, 1000, 1500, 2500, 3999, 5000, 5000, 7990):
         for rep in range(3):
             ci = int(rng.integers(0, len(refs)))
             L2 = min(L, len(refs[ci]) - 10)
