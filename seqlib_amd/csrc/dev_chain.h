@@ -6,6 +6,7 @@
 #include "dev_fm.h"
 #include "dev_sort.h"
 #include "dev_types.h"
+#include "dev_kbtree.h"
 
 // Reads are handed out 64 at a time (one per lane) from a device-wide queue, in heaviest-first order, so
 // that the lanes of a wave work on reads of similar weight and the heavy tail starts early.
@@ -120,7 +121,9 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         const I *ix0 = (const I *)ck.intv_x0 + (size_t)r * ck.cap_intv;
         const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
         int ns = 0, nc = 0;                      // seeds stored, chains
-        int *ord = w.ia;                         // chain handles ordered by pos (stands in for bwa's kbtree)
+        int *ord = w.ia;                         // chain handles ordered by pos: bwa's kbtree while it is a single leaf (<= 9 chains)
+        KbTree kb;                               // ... and the tree itself from the 10th chain on (dev_kbtree.h), nodes in the region slots
+        bool tree = false;
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
             const I x2 = ix2[i];
@@ -131,15 +134,19 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                 const int rid = dev_intv2rid(R, rbeg, rbeg + slen);
                 if (rid < 0) continue;           // bridges two contigs or the forward/reverse boundary
                 // lower = first chain with pos == rbeg, else the chain with the largest pos < rbeg
-                int lo = -1;
+                int lo = -1, lower_c = -1;
                 bool to_add = true;
                 if (nc) {
-                    int b = 0, e = nc;
-                    while (b < e) { int m = (b + e) >> 1; if (w.c_pos[ord[m]] < rbeg) b = m + 1; else e = m; }
-                    if (b == nc) lo = nc - 1;
-                    else lo = rbeg < w.c_pos[ord[b]] ? b - 1 : b;
-                    if (lo >= 0) {               // test_and_merge
-                        const int c = ord[lo];
+                    if (tree) lower_c = kb.lower(rbeg);
+                    else {
+                        int b = 0, e = nc;
+                        while (b < e) { int m = (b + e) >> 1; if (w.c_pos[ord[m]] < rbeg) b = m + 1; else e = m; }
+                        if (b == nc) lo = nc - 1;
+                        else lo = rbeg < w.c_pos[ord[b]] ? b - 1 : b;
+                        lower_c = lo >= 0 ? ord[lo] : -1;
+                    }
+                    if (lower_c >= 0) {          // test_and_merge
+                        const int c = lower_c;
                         const int first = w.c_head[c], last = w.c_tail[c];
                         const int l_qbeg = w.s_qbeg(last), l_len = w.s_len(last);
                         const int64_t l_rbeg = w.s_rbeg[last];
@@ -164,12 +171,17 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                     const int s = ns++, c = nc;
                     w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                     w.c_pos[c] = rbeg; w.c_head[c] = w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
-                    for (int m = nc; m > lo + 1; --m) ord[m] = ord[m - 1];
-                    ord[lo + 1] = c;
+                    if (!tree && nc == 2 * KB_T - 1) { kb.from_array((int *)w.regs, ord, w.c_pos, nc); tree = true; }   // the leaf is full: it splits now
+                    if (tree) kb.put(rbeg, c);
+                    else {
+                        for (int m = nc; m > lo + 1; --m) ord[m] = ord[m - 1];
+                        ord[lo + 1] = c;
+                    }
                     ++nc;
                 }
             }
         }
+        if (tree) kb.traverse(ord);              // __kb_traverse: the order mem_chain_flt receives the chains in
         ck.frac_rep[r] = (float)ck.l_rep[r] / len;
         // ---------------- mem_chain_flt
         int n_chn = 0;

@@ -45,6 +45,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         const I *ix0 = (const I *)ck.intv_x0 + (size_t)r * ck.cap_intv;
         const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
         int ns = 0, nc = 0;
+        bool dup = false;                         // two chains share a position: from the 10th chain on bwa's kbtree is no longer a sorted array
         // ---------------- mem_chain: seeds in interval order, occurrences in rank order
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
@@ -95,6 +96,14 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                             }
                             to_add = !res;
                         }
+                    }
+                    if (to_add && lo >= 0 && s_pos[lo] == rbeg) dup = true;
+                    if (to_add && dup && nc >= 2 * KB_T - 1) {
+                        // equal positions in a multi-node kbtree: which chain a search meets first and the traversal order depend on the tree's
+                        // shape (dev_kbtree.h).  Rare (tandem repeats; ~2 reads per million): the read goes to the exact single-lane routine.
+                        if (FINAL) { if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r); }
+                        else if (lane == 0) ck.n_chain[r] = -2;
+                        return;
                     }
                     if (to_add && nc == nc_limit) {  // table full (uniform; nc_limit <= NCMAX, lower only in tests): give the read up, see above
                         if (FINAL) { if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r); }
