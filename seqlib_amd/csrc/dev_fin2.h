@@ -340,19 +340,21 @@ __device__ __noinline__ void dev_regs_read_wave(const DevRef &R, const Chunk &ck
     dev_regs_read<MAXQ>(R, ck, opt, fl, r, sc, lane == 0, ss);
 }
 
-#define REGS_BIG_N 2048      // handles the LDS stage of k_regs_wave holds (80 KB: sort keys + the fields the de-duplication loop reads)
+#define REGS_BIG_N 2048      // handles the LDS stage of the big-table launch of k_regs_wave holds (80 KB: sort keys + the fields the de-duplication loop reads)
+#define REGS_MID_N 640       // ... and of the first launch: 25 KB per wave, so six waves share a CU instead of two -- with max_occ = 500 nearly every
+                             // many-region read has at most ~510 regions and fits here; the ~1 000-region reads take the big table
 // one wave per read, for reads with at least min_regs regions (0: every read of the list): mem_patch_reg's global alignment runs
 // wave-parallel and the region sorts run against keys staged in LDS
-template <int MAXQ>
+template <int MAXQ, int NB>
 __global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots,
-                                                  int min_regs)
+                                                  int min_regs, int max_regs)
 {
-    __shared__ int s_idx[REGS_BIG_N], s_ka[REGS_BIG_N], s_kb[REGS_BIG_N], s_qe[REGS_BIG_N], s_rid[REGS_BIG_N], s_w[REGS_BIG_N];
-    __shared__ int64_t s_k64[REGS_BIG_N], s_rb[REGS_BIG_N];
+    __shared__ int s_idx[NB], s_ka[NB], s_kb[NB], s_qe[NB], s_rid[NB], s_w[NB];
+    __shared__ int64_t s_k64[NB], s_rb[NB];
     const int lane = threadIdx.x;
     SortStage ss;
     ss.idx = s_idx; ss.k64 = s_k64; ss.ka = s_ka; ss.kb = s_kb; ss.m_rb = s_rb; ss.m_qe = s_qe; ss.m_rid = s_rid; ss.m_w = s_w;
-    ss.nmax = REGS_BIG_N; ss.lane = lane;
+    ss.nmax = NB; ss.lane = lane;
     const MatRows mr = make_matrows(dopt.o.mat);
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     for (;;) {
@@ -361,7 +363,8 @@ __global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dop
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
         const int r = order ? order[slot] : slot;
-        const bool mine = __builtin_amdgcn_readfirstlane(ck.n_reg[r]) >= min_regs;
+        const int nr = __builtin_amdgcn_readfirstlane(ck.n_reg[r]);
+        const bool mine = nr >= min_regs && nr <= max_regs;
         if (mine) dev_regs_read_wave<MAXQ>(R, ck, dopt.o, mr, fl, r, lane, &ss);
     }
 }

@@ -21,6 +21,7 @@
 #include <vector>
 #include "slx_internal.h"
 #include "dev_seed2.h"
+#include "dev_seed3.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
@@ -132,6 +133,7 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int seed_mode = 3;            // 3 = multi-slot seeding (dev_seed3.h: up to three extends per lane and trip), 2 = one extend per trip (dev_seed2.h)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
@@ -407,6 +409,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         }
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
+    else if (!strcmp(key, "seed_mode")) { if (value != 2 && value != 3) return SLX_EINVAL; al->seed_mode = (int)value; }
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
@@ -507,9 +510,14 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
                        wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), cnt2);
     hipLaunchKernelGGL(k_regs1, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, ck, dopt, fl, wk->order_in.as<int>(), cnt2);
     if constexpr (MAXQ <= 704) {
-        if (al->regs_big < (1 << 20))
-            hipLaunchKernelGGL(k_regs_wave<MAXQ>, dim3(std::max(1, std::min(n / 64 + 1, al->n_cu * 4))), dim3(64), 0, st, al->ref, ck, dopt, fl,
-                               wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big);
+        if (al->regs_big < (1 << 20)) {   // two launches: a 640-region LDS table at six waves per CU, then the few reads beyond it on the 2 048-region table
+            const int mid = std::max(al->regs_big, REGS_MID_N);
+            if (al->regs_big <= REGS_MID_N)
+                hipLaunchKernelGGL((k_regs_wave<MAXQ, REGS_MID_N>), dim3(std::max(1, std::min(n / 64 + 1, al->n_cu * 8))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                                   wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big, REGS_MID_N);
+            hipLaunchKernelGGL((k_regs_wave<MAXQ, REGS_BIG_N>), dim3(std::max(1, std::min(n / 4096 + 1, al->n_cu))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                               wk->order_out.as<int>(), q + 15, cnt2 + 1, al->regs_big <= REGS_MID_N ? mid + 1 : al->regs_big, 1 << 30);
+        }
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
     } else   // long reads: every multi-region read on the lane-per-read kernel (its alignment rows in the per-thread scratch)
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, 0);
@@ -559,7 +567,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(intv_n, (size_t)n * 4); ENS(intv_info, (size_t)n * caps.cap_intv * 4); ENS(intv_x0, (size_t)n * caps.cap_intv * sizeof(I));
     ENS(intv_x2, (size_t)n * caps.cap_intv * sizeof(I)); ENS(l_rep, (size_t)n * 4); ENS(seed_cnt, ((size_t)n + 1) * 8); ENS(seed_off, ((size_t)n + 1) * 8);
     ENS(n_chain, (size_t)n * 4); ENS(n_reg, (size_t)n * 4); ENS(n_hit, ((size_t)n + 1) * 4); ENS(na, (size_t)n * 4); ENS(frac_rep, (size_t)n * 4);
-    ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));
+    ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));     // (the multi-slot kernel's 12-byte entries need less)
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
     ENS(counters, 64);
@@ -616,8 +624,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     (void)hipEventRecord(wk->ev_probe[0], st);
-    hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-    hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    if (al->seed_mode == 3) {
+        hipLaunchKernelGGL(k_seed_ms<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+        hipLaunchKernelGGL(k_seed_fin<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, ck, dopt);
+    } else {
+        hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+        hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    }
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
