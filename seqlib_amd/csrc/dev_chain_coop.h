@@ -46,6 +46,8 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
         int ns = 0, nc = 0;
         bool dup = false;                         // two chains share a position: from the 10th chain on bwa's kbtree is no longer a sorted array
+        KbTree kb;                                // ... then the set continues as the tree itself (dev_kbtree.h), every lane running the same steps
+        bool tree = false;                        //     on nodes kept in the read's region slots
         // ---------------- mem_chain: seeds in interval order, occurrences in rank order
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
@@ -68,15 +70,19 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                     if (rid < 0) continue;        // bridges two contigs or the forward/reverse boundary
                     const int64_t rbeg = lane_read64(rb_l, u);
                     // lower = first chain with pos == rbeg, else the chain with the largest pos < rbeg
-                    int lo = -1;
+                    int lo = -1, lower_c = -1;
                     bool to_add = true;
                     if (nc) {
-                        int b = 0, e = nc;
-                        while (b < e) { const int m = (b + e) >> 1; if (s_pos[m] < rbeg) b = m + 1; else e = m; }
-                        if (b == nc) lo = nc - 1;
-                        else lo = rbeg < s_pos[b] ? b - 1 : b;
-                        if (lo >= 0) {            // test_and_merge
-                            const int c = s_ord[lo];
+                        if (tree) lower_c = kb.lower(rbeg);
+                        else {
+                            int b = 0, e = nc;
+                            while (b < e) { const int m = (b + e) >> 1; if (s_pos[m] < rbeg) b = m + 1; else e = m; }
+                            if (b == nc) lo = nc - 1;
+                            else lo = rbeg < s_pos[b] ? b - 1 : b;
+                            lower_c = lo >= 0 ? s_ord[lo] : -1;
+                        }
+                        if (lower_c >= 0) {       // test_and_merge
+                            const int c = lower_c;
                             const int first = w.c_head[c], last = w.c_tail[c];
                             const int l_qbeg = w.s_qbeg(last), l_len = w.s_len(last);
                             const int64_t l_rbeg = w.s_rbeg[last];
@@ -97,13 +103,14 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                             to_add = !res;
                         }
                     }
-                    if (to_add && lo >= 0 && s_pos[lo] == rbeg) dup = true;
-                    if (to_add && dup && nc >= 2 * KB_T - 1) {
+                    if (to_add && !tree && lo >= 0 && s_pos[lo] == rbeg) dup = true;
+                    if (to_add && dup && !tree && nc >= 2 * KB_T - 1) {
                         // equal positions in a multi-node kbtree: which chain a search meets first and the traversal order depend on the tree's
-                        // shape (dev_kbtree.h).  Rare (tandem repeats; ~2 reads per million): the read goes to the exact single-lane routine.
-                        if (FINAL) { if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r); }
-                        else if (lane == 0) ck.n_chain[r] = -2;
-                        return;
+                        // shape (dev_kbtree.h).  Until now the sorted array and the tree agreed; the tree's shape is a function of the insertion
+                        // order, which is the chains' creation order -- so it is rebuilt by replaying those insertions, and the set goes on as the tree.
+                        kb.mem = (int *)w.regs; kb.n_nodes = 0; kb.root = kb.alloc(0);
+                        for (int h = 0; h < nc; ++h) kb.put(w.c_pos[h], h);
+                        tree = true;
                     }
                     if (to_add && nc == nc_limit) {  // table full (uniform; nc_limit <= NCMAX, lower only in tests): give the read up, see above
                         if (FINAL) { if (lane == 0) dev_chain_read<I>(fm, R, ck, opt, r); }
@@ -114,20 +121,24 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                         const int s = ns++, c = nc;
                         w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                         w.c_pos[c] = rbeg; w.c_head[c] = s; w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
-                        // ordered insert at rank lo+1: lanes shift the tail up by one, highest block first
-                        for (int hi = nc; hi > lo + 1; hi -= 64) {
-                            const int idx = hi - 1 - lane;
-                            const bool mv = idx >= lo + 1;
-                            int vo = 0; int64_t vp = 0;
-                            if (mv) { vo = s_ord[idx]; vp = s_pos[idx]; }
-                            if (mv) { s_ord[idx + 1] = vo; s_pos[idx + 1] = vp; }
+                        if (tree) kb.put(rbeg, c);
+                        else {
+                            // ordered insert at rank lo+1: lanes shift the tail up by one, highest block first
+                            for (int hi = nc; hi > lo + 1; hi -= 64) {
+                                const int idx = hi - 1 - lane;
+                                const bool mv = idx >= lo + 1;
+                                int vo = 0; int64_t vp = 0;
+                                if (mv) { vo = s_ord[idx]; vp = s_pos[idx]; }
+                                if (mv) { s_ord[idx + 1] = vo; s_pos[idx + 1] = vp; }
+                            }
+                            s_ord[lo + 1] = c; s_pos[lo + 1] = rbeg;
                         }
-                        s_ord[lo + 1] = c; s_pos[lo + 1] = rbeg;
                         ++nc;
                     }
                 }
             }
         }
+        if (tree) kb.traverse(s_ord);             // __kb_traverse: the order mem_chain_flt receives the chains in
         ck.frac_rep[r] = (float)ck.l_rep[r] / len;
         // ---------------- mem_chain_flt
         // weights, one chain per lane (handles are 0..nc-1 in creation order; s_ord gives them in pos order)

@@ -164,20 +164,41 @@ template <> DevFM<uint32_t> &fm_of<uint32_t>(slx_aligner *al) { return al->fm32;
 template <> DevFM<uint64_t> &fm_of<uint64_t>(slx_aligner *al) { return al->fm64; }
 
 // ---------------------------------------------------------------- small kernels
-__global__ void k_encode(const uint8_t *ascii, uint8_t *codes, size_t n)
+__device__ __forceinline__ uint32_t nt4_of(uint32_t b)
 {   // nst_nt4_table as mem_align1_core applies it: bytes < 4 are kept, A/C/G/T (either case) -> 0..3, else 4
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t u = b & 0xDFu;
+    const uint32_t x = (b >> 1) & 3u;                        // A 0, C 1, T 2, G 3
+    const bool letter = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+    return b < 4u ? b : (letter ? (x ^ (x >> 1)) : 4u);
+}
+
+// 16 bases per thread: four aligned 32-bit loads when the source allows it, one 16-byte store (the codes buffer is 16-byte aligned)
+__global__ void k_encode(const uint8_t *ascii, uint8_t *codes, size_t n)
+{
+    const size_t n16 = (n + 15) >> 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const uint8_t b = ascii[i];
-        uint8_t c = 4;
-        if (b < 4) c = b;
-        else {
-            const uint8_t u = b & 0xDF;
-            c = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
-            if (b < 'A') c = 4;
+    const bool aligned = ((uintptr_t)ascii & 3) == 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += stride) {
+        const size_t i = t << 4;
+        uint32_t w[4];
+        if (aligned && i + 16 <= n) {
+            const uint32_t *src = (const uint32_t *)(ascii + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = src[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w[k] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const size_t p = i + 4 * k + b; w[k] |= (uint32_t)(p < n ? ascii[p] : (uint8_t)'N') << (8 * b); }
+            }
         }
-        codes[i] = c;
+        uint4 o;
+        uint32_t *ov = &o.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            ov[k] = nt4_of(w[k] & 0xff) | nt4_of((w[k] >> 8) & 0xff) << 8 | nt4_of((w[k] >> 16) & 0xff) << 16 | nt4_of(w[k] >> 24) << 24;
+        *(uint4 *)(codes + i) = o;                           // the buffer is padded: a partial last group writes its 16 bytes
     }
 }
 
@@ -618,7 +639,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
 
     (void)hipEventRecord(wk->ev[0], st);
     {   // encode + relative offsets
-        const unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256 + 1, 65535u * 4);
+        const unsigned g = (unsigned)std::min<uint64_t>((n_bases / 16 + 255) / 256 + 1, 65535u * 4);
         hipLaunchKernelGGL(k_encode, dim3(g), dim3(256), 0, st, d_ascii + base0, wk->codes.as<uint8_t>(), (size_t)n_bases);
         hipLaunchKernelGGL(k_rel_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, d_offs + r0, wk->offs_rel.as<uint64_t>(), n, base0);
     }
