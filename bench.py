@@ -375,12 +375,12 @@ def main():
         dist.destroy_process_group()
 
 
-def al_launches(n):
-    """seeding launches per step: three workers (batches >= 2^19 reads), each in chunks of at most 2^23 reads"""
+def al_launches(n, workers=3):
+    """seeding launches per step: `workers` workers (batches >= 2^19 reads), each in chunks of at most 2^23 reads"""
     if n < (1 << 19):
         return 1
-    per = (n + 2) // 3
-    return 3 * max(1, -(-per // (1 << 23)))
+    per = (n + workers - 1) // workers
+    return workers * max(1, -(-per // (1 << 23)))
 
 
 if __name__ == "__main__":

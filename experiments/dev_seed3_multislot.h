@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED3_MIN_WAVES_U64 : S
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     WorkLists3<I> wl;
-    wl.base = (LEnt<I> *)ck.lists + tid; wl.stride = (size_t)ck.n_threads; wl.cap = ck.cap_list;
+    // the two lists of a lane-block sit in ONE contiguous region ([list][entry][128 lanes]): the entries a wave walks through then share a
+    // few pages instead of one page per (list, entry) pair spread over gigabytes
+    wl.base = (LEnt<I> *)ck.lists + (size_t)blockIdx.x * ((size_t)2 * ck.cap_list * 128) + threadIdx.x; wl.stride = 128; wl.cap = ck.cap_list;
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
     const uint32_t n_reads = (uint32_t)ck.n_reads;
     // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve

@@ -21,7 +21,6 @@
 #include <vector>
 #include "slx_internal.h"
 #include "dev_seed2.h"
-#include "dev_seed3.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
@@ -133,7 +132,6 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
-    int seed_mode = 3;            // 3 = multi-slot seeding (dev_seed3.h: up to three extends per lane and trip), 2 = one extend per trip (dev_seed2.h)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
@@ -319,6 +317,21 @@ static int upload_fm(slx_aligner *al)
     return SLX_OK;
 }
 
+#define SLX_MAX_WORKERS 8
+
+static int add_worker(slx_aligner *al)
+{
+    Worker *wk = new Worker();
+    wk->id = (int)al->workers.size();
+    wk->collect();
+    al->workers.push_back(wk);
+    HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
+    for (int b = 0; b < 6; ++b) HIPCHK(hipEventCreate(&wk->dbg_ev[b]));
+    for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
+    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&wk->ev_probe[i]));
+    return SLX_OK;
+}
+
 static int aligner_init(slx_aligner *al, const slx_index *idx, const int *devices, int n_dev)
 {
     al->device = (devices && n_dev > 0) ? devices[0] : 0;
@@ -328,16 +341,8 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     HIPCHK(hipGetDeviceProperties(&prop, al->device));
     al->n_cu = prop.multiProcessorCount;
     al->max_threads = al->n_cu * al->threads_per_cu;
-    for (int k = 0; k < 3; ++k) {
-        Worker *wk = new Worker();
-        wk->id = k;
-        wk->collect();
-        al->workers.push_back(wk);
-        HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
-        for (int b = 0; b < 6; ++b) HIPCHK(hipEventCreate(&wk->dbg_ev[b]));
-        for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
-        for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&wk->ev_probe[i]));
-    }
+    int rcw;
+    for (int k = 0; k < 3; ++k) if ((rcw = add_worker(al)) != SLX_OK) return rcw;
     HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     al->host_idx = idx;
     int rc;
@@ -430,7 +435,6 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         }
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
-    else if (!strcmp(key, "seed_mode")) { if (value != 2 && value != 3) return SLX_EINVAL; al->seed_mode = (int)value; }
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
@@ -441,7 +445,12 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
-    else if (!strcmp(key, "workers")) { if (value < 1 || value > 3) return SLX_EINVAL; al->n_workers = (int)value; }
+    else if (!strcmp(key, "workers")) {   // more than three only pays when the runtime exposes more hardware queues (GPU_MAX_HW_QUEUES)
+        if (value < 1 || value > SLX_MAX_WORKERS) return SLX_EINVAL;
+        HIPCHK(hipSetDevice(al->device));
+        while ((int)al->workers.size() < (int)value) { const int rc = add_worker(al); if (rc != SLX_OK) return rc; }
+        al->n_workers = (int)value;
+    }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
@@ -588,7 +597,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(intv_n, (size_t)n * 4); ENS(intv_info, (size_t)n * caps.cap_intv * 4); ENS(intv_x0, (size_t)n * caps.cap_intv * sizeof(I));
     ENS(intv_x2, (size_t)n * caps.cap_intv * sizeof(I)); ENS(l_rep, (size_t)n * 4); ENS(seed_cnt, ((size_t)n + 1) * 8); ENS(seed_off, ((size_t)n + 1) * 8);
     ENS(n_chain, (size_t)n * 4); ENS(n_reg, (size_t)n * 4); ENS(n_hit, ((size_t)n + 1) * 4); ENS(na, (size_t)n * 4); ENS(frac_rep, (size_t)n * 4);
-    ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));     // (the multi-slot kernel's 12-byte entries need less)
+    ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
     ENS(counters, 64);
@@ -645,13 +654,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     (void)hipEventRecord(wk->ev_probe[0], st);
-    if (al->seed_mode == 3) {
-        hipLaunchKernelGGL(k_seed_ms<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-        hipLaunchKernelGGL(k_seed_fin<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, ck, dopt);
-    } else {
-        hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-        hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
-    }
+    hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+    hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
