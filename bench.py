@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CU x 4 SIMD x 16 lanes/cycle x 2.4 GHz = 39.3 T int32 lane-ops/s
-DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000}
+DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000, "C4h": 25_000_000}
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 _G = {}

@@ -26,6 +26,9 @@ CONFIGS = {                 # BASELINE.json configs
     "C3": dict(name="chr20_syn", length=64444167, read_len=150, read_seed=45, pairs=True),
     # full GRCh38-sized reference: 24 contigs with the primary assembly's lengths (3.09 Gbp, 6.2 G BWT symbols)
     "C4": dict(name="grch38_syn", length=sum(l for _, l in GRCH38), read_len=150, read_seed=46, contigs=[(n + "_syn", l) for n, l in GRCH38]),
+    # the first 14 contigs of it (2.30 Gbp, 4.6 G BWT symbols: past 2^32, so the u64 index path): what the C4 parity test and the
+    # C4-scale bench line run on one GPU
+    "C4h": dict(name="grch38_syn_chr1-14", length=sum(l for _, l in GRCH38[:14]), read_len=150, read_seed=46, contigs=[(n + "_syn", l) for n, l in GRCH38[:14]]),
 }
 
 
