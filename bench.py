@@ -364,7 +364,9 @@ def main():
             "value_host_to_host": h2h, "value_bamrecords": bam,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
             "gather_equals_single_process": gather_ok,
+            "seed_launches_per_step": launches, "reads_per_seed_launch": n / launches,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
+            "probe_ms_per_step": {k: v / args.steps for k, v in probe_acc.items()},
             "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(step_marks[:-1], step_marks[1:])],
             "index_build_s": t_index, "read_generation_s": t_gen,
         }

@@ -158,6 +158,13 @@ const char *slx_stage_name(int i);
 #define SLX_N_PROBES 3
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
 
+/* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work
+ * areas as int64 words.  what = 0: SMEM intervals after mem_collect_intv {start, end, x0, x2}; 1: kept chains in extension order
+ * {n_chains, then per chain pos, rid, n_seeds and n_seeds x (rbeg, qbeg, len, score)}; 2: regions as mem_chain2aln left them,
+ * before mem_sort_dedup_patch {rb, re, qb, qe, rid, score, truesc, w, seedcov, seedlen0}.  Needs slx_aligner_set(al, "keep_stages", 1)
+ * and a batch small enough to run as one chunk on one worker.  Mirrors the stages of mem_align1 (src/BWAAligner.cpp:104). */
+int  slx_debug_stage(slx_aligner *al, int64_t read, int what, int64_t *buf, uint64_t cap_words, uint64_t *n_out);
+
 /* libc lrand48 stream helpers */
 uint64_t slx_lrand48_advance(uint64_t state, uint64_t n);   /* state after n draws */
 uint64_t slx_lrand48_peek_libc(void);                       /* this process's current libc state */

@@ -154,6 +154,9 @@ typedef struct {
     int score, sub, alt_sc;
 } orc_aln;                                                  /* mem_aln_t */
 
+/* per-stage results of one read (differential tests against the product's slx_debug_stage): int64 words, see orc_mem.c */
+int64_t orc_stage_dump(const orc_opt *opt, const orc_index *idx, int l_seq, const char *seq, int what, int64_t *buf, int64_t cap);
+
 /* work counters for the roofline's "algorithmic bytes" (SURVEY 8d), accumulated per thread */
 typedef struct {
     uint64_t n_extend;      /* bwt_extend calls */

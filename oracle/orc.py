@@ -107,6 +107,8 @@ def lib():
                                       C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(BatchOut)]
         L.orc_batch_free.argtypes = [C.POINTER(BatchOut)]
         L.orc_counters_get.argtypes = [C.POINTER(Counters)]
+        L.orc_stage_dump.restype = C.c_int64
+        L.orc_stage_dump.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int64]
         L.orc_free.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
@@ -214,6 +216,19 @@ def align_batch_flat(opt, index, bases, offs, hardclip=False, keep_sec_frac=0.9,
                cigar=arr(o.cigar, int(cig_off[-1]) if nh else 0, np.uint32), hit_off=arr(o.hit_off, n + 1, np.int64))
     lib().orc_batch_free(C.byref(o))
     return res
+
+
+def stage_dump(opt, index, seq, what):
+    """per-stage result of mem_align1 for one read as int64 words (0 intervals, 1 chains, 2 regions before de-duplication);
+    same layout as the product's slx_debug_stage"""
+    b = seq if isinstance(seq, bytes) else seq.encode()
+    cap = 1 << 16
+    while True:
+        buf = np.zeros(cap, dtype=np.int64)
+        n = lib().orc_stage_dump(C.byref(opt), index.h, len(b), b, int(what), buf.ctypes.data, cap)
+        if n <= cap:
+            return buf[:n].copy()
+        cap = int(n)
 
 
 def counters():

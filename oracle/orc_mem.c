@@ -1264,6 +1264,48 @@ int orc_align1(const orc_opt *opt, const orc_index *idx, int l_seq, const char *
     return (int)regs.n;
 }
 
+/* per-stage results of mem_align1 for the differential tests (same int64 layouts as the product's slx_debug_stage):
+ * what = 0: SMEM intervals {start, end, x0, x2}; 1: kept chains {n; per chain pos, rid, n_seeds, seeds (rbeg, qbeg, len, score)};
+ * 2: regions before mem_sort_dedup_patch {rb, re, qb, qe, rid, score, truesc, w, seedcov, seedlen0}.  Returns the words written. */
+int64_t orc_stage_dump(const orc_opt *opt, const orc_index *idx, int l_seq, const char *seq_, int what, int64_t *buf, int64_t cap)
+{
+    int i, j;
+    int64_t n = 0;
+    uint8_t *seq = (uint8_t *)malloc((size_t)l_seq + 1);
+#define PUT(v) do { if (n < cap) buf[n] = (int64_t)(v); ++n; } while (0)
+    for (i = 0; i < l_seq; ++i) seq[i] = (uint8_t)seq_[i] < 4 ? (uint8_t)seq_[i] : orc_nt4_table[(uint8_t)seq_[i]];
+    if (what == 0) {
+        orc_intv *intv = 0;
+        int n_intv = l_seq >= opt->min_seed_len ? orc_collect_intv(opt, idx, l_seq, seq, &intv) : 0;
+        for (i = 0; i < n_intv; ++i) { PUT(intv[i].info >> 32); PUT((uint32_t)intv[i].info); PUT(intv[i].x[0]); PUT(intv[i].x[2]); }
+        free(intv);
+    } else {
+        chain_v chn;
+        reg_v regs = {0, 0, 0};
+        mem_chain(opt, idx, l_seq, seq, &chn);
+        chn.n = mem_chain_flt(opt, chn.n, chn.a);
+        mem_flt_chained_seeds(opt, idx, l_seq, seq, chn.n, chn.a);
+        if (what == 1) PUT(chn.n);
+        for (i = 0; i < chn.n; ++i) {
+            if (what == 1) {
+                PUT(chn.a[i].pos); PUT(chn.a[i].rid); PUT(chn.a[i].n);
+                for (j = 0; j < chn.a[i].n; ++j) { const orc_seed *sd = &chn.a[i].seeds[j]; PUT(sd->rbeg); PUT(sd->qbeg); PUT(sd->len); PUT(sd->score); }
+            } else mem_chain2aln(opt, idx, l_seq, seq, &chn.a[i], &regs);
+            free(chn.a[i].seeds);
+        }
+        free(chn.a);
+        if (what == 2)
+            for (i = 0; i < (int)regs.n; ++i) {
+                const orc_reg *p = &regs.a[i];
+                PUT(p->rb); PUT(p->re); PUT(p->qb); PUT(p->qe); PUT(p->rid); PUT(p->score); PUT(p->truesc); PUT(p->w); PUT(p->seedcov); PUT(p->seedlen0);
+            }
+        free(regs.a);
+    }
+#undef PUT
+    free(seq);
+    return n;
+}
+
 /* ------------------------------------------------------------------ mem_reg2aln */
 static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
 {

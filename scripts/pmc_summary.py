@@ -57,7 +57,7 @@ def lane_util(k):
 
 try:
     bench = json.loads(open(out_dir + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
-    reads = bench["roofline"]["reads_per_launch"] if bench.get("roofline") else bench["config"]["reads_per_gpu"] / 3.0
+    reads = bench["reads_per_seed_launch"]
 except Exception:
     bench, reads = None, {"C2": 10e6 / 3, "C3": 50e6 / 6}.get(config, 1.0)
 seed12, seed3 = (pick("k_seed12") or ["k_seed12"])[0], (pick("k_seed3") or ["k_seed3"])[0]

@@ -3,9 +3,7 @@
 OUT=$1; R=$GRAFT_REPO_ROOT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 1500 python3 $R/bench.py --config C4h --steps 2 --warmup 1 --no-extras > $OUT/bench_c4.log 2>&1
-grep '^{"metric"' $OUT/bench_c4.log > $OUT/bench_c4.json
-BENCH="python3 $R/bench.py --config C4h --no-cpu-baseline --no-extras --verify 0 --steps 1 --warmup 1"
+BENCH="python3 $R/bench.py --config C4h --reads 12000000 --no-cpu-baseline --no-extras --verify 0 --steps 1 --warmup 1"
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/c4_under_rocprof.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/c4_kernel_stats.csv
 i=0

@@ -20,7 +20,7 @@ EXPORTS = [
     "slx_opt_init", "slx_fill_scmat", "slx_index_build", "slx_index_load", "slx_index_write", "slx_index_free",
     "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_aligner_create",
     "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free", "slx_hits_packed_size", "slx_hits_pack",
-    "slx_aligner_stage_ms", "slx_stage_name", "slx_aligner_probe_ms", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
+    "slx_aligner_stage_ms", "slx_stage_name", "slx_aligner_probe_ms", "slx_debug_stage", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
     "slx_last_error", "slx_version",
 ]
 
@@ -82,6 +82,7 @@ def lib():
     L.slx_hits_pack.argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_uint64]
     L.slx_aligner_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.slx_aligner_probe_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    L.slx_debug_stage.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.slx_stage_name.argtypes = [C.c_int]
     L.slx_stage_name.restype = C.c_char_p
     L.slx_lrand48_advance.argtypes = [C.c_uint64, C.c_uint64]

@@ -226,6 +226,19 @@ class BWAAligner:
         r = self.alignSequences([seq], hardclip, keepSecFrac, maxSecondary)
         return [] if r is None else records_of(r, 0)
 
+    def debug_stage(self, read, what):
+        """test hook: int64 words of stage `what` (0 intervals, 1 chains, 2 regions before de-duplication) of one read of the last batch"""
+        cap = 1 << 16
+        while True:
+            buf = np.zeros(cap, dtype=np.int64)
+            n = C.c_uint64()
+            rc = _ffi.lib().slx_debug_stage(self._handle(), int(read), int(what), buf.ctypes.data, cap, C.byref(n))
+            if rc == _ffi.SLX_ENOMEM and n.value > cap:
+                cap = int(n.value)
+                continue
+            _ffi.check(rc)
+            return buf[:n.value].copy()
+
     def probe_ms(self):
         """({"seed", "extend", "cigar"} -> ms, reads): summed launch durations of three kernel groups of the last batch
         (HIP events on the workers' own streams)"""

@@ -85,6 +85,10 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
+    DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
+    Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
+    size_t last_S1 = 0;
+    bool last_valid = false, last_wide = false;
     int id = 0;
     hipEvent_t dbg_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
@@ -102,7 +106,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar};
         for (auto &e : ev) e = nullptr;
     }
@@ -132,6 +136,7 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int keep_stages = 0;          // test hook: keep what slx_debug_stage reads (copies of the chain order / region list before de-duplication)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
@@ -435,6 +440,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         }
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
+    else if (!strcmp(key, "keep_stages")) al->keep_stages = (int)value;
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
@@ -522,6 +528,13 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
                                       ext_heavy, n_heavy);
     else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
                             (const unsigned int *)nullptr);
+    if (al->keep_stages && wk->last_S1) {      // the region stage reuses ia[] and rewrites regs[] in place
+        if (wk->snap_ia.ensure(wk->last_S1 * 4) == SLX_OK && wk->snap_regs.ensure(wk->last_S1 * sizeof(DReg)) == SLX_OK && wk->snap_nreg.ensure((size_t)n * 4) == SLX_OK) {
+            (void)hipMemcpyAsync(wk->snap_ia.p, ck.ia, wk->last_S1 * 4, hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(wk->snap_regs.p, ck.regs, wk->last_S1 * sizeof(DReg), hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(wk->snap_nreg.p, ck.n_reg, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+        }
+    }
     (void)hipEventRecord(wk->ev[5], st);
     (void)hipEventRecord(wk->ev_probe[3], st);
     if (dbg_on) (void)hipEventRecord(dbg[2], st);
@@ -681,6 +694,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.c_first = wk->c_first.as<int32_t>(); ck.c_kept = wk->c_kept.as<int8_t>();
     ck.ia = wk->ia.as<int32_t>(); ck.ib = wk->ib.as<int32_t>(); ck.ic = wk->ic.as<int32_t>(); ck.srt = wk->srt.as<uint64_t>();
     ck.regs = wk->regs.as<DReg>(); ck.hits = wk->hits.as<DHit>();
+    wk->last_S1 = S1;
     if (has_long) {   // per-seed scores (mem_seed_t::score) and the per-thread H/E rows of the lane-per-read alignment kernels
         ENS(s_score, S1 * 4); ENS(long_list, (size_t)n * 4);
         ck.s_score = wk->s_score.as<int32_t>();
@@ -878,6 +892,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         float tot = -1; (void)hipEventElapsedTime(&tot, wk->dbg_ev[0], wk->dbg_ev[5]);
         fprintf(stderr, " total=%.1f\n", tot);
     }
+    wk->last_ck = ck; wk->last_valid = true; wk->last_wide = sizeof(I) == 8;
     *hit_base += (int64_t)Hc;
     *cig_base += (int64_t)Cc;
     *flags_out = 0;
@@ -1226,4 +1241,80 @@ extern "C" int slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint
         return pack_locked(al, h, dst);
     }
     return pack_locked(al, h, dst);
+}
+
+// ---------------------------------------------------------------- test hook: per-stage results of one read
+// what = 0: SMEM intervals after mem_collect_intv, sorted          int64 [n][4] = {start, end, x0, x2}
+// what = 1: kept chains in extension order with their seeds        int64 stream: n_chains, then per chain {pos, rid, n_seeds, n_seeds x {rbeg, qbeg, len, score}}
+// what = 2: regions as mem_chain2aln left them (before mem_sort_dedup_patch)   int64 [n][10] = {rb, re, qb, qe, rid, score, truesc, w, seedcov, seedlen0}
+// Needs "keep_stages" = 1 and a batch that ran as ONE chunk on ONE worker (fewer than 2 * min_split reads); *n_out = int64 words written.
+extern "C" int slx_debug_stage(slx_aligner *al, int64_t read, int what, int64_t *buf, uint64_t cap_words, uint64_t *n_out)
+{
+    if (!al || !buf || !n_out) return SLX_EINVAL;
+    std::lock_guard<std::mutex> call(al->call_mu);
+    Worker *wk = al->workers[0];
+    if (!al->keep_stages || !wk->last_valid || al->active_k != 1) { slx_set_error("slx_debug_stage: set keep_stages = 1 and run a single-worker batch first"); return SLX_EINVAL; }
+    const Chunk &ck = wk->last_ck;
+    if (read < 0 || read >= ck.n_reads) { slx_set_error("slx_debug_stage: read %lld outside the last chunk", (long long)read); return SLX_EINVAL; }
+    HIPCHK(hipSetDevice(al->device));
+    const size_t isz = wk->last_wide ? 8 : 4;
+    uint64_t off[2];
+    HIPCHK(hipMemcpy(off, ck.seed_off + read, 16, hipMemcpyDeviceToHost));
+    const size_t o = (size_t)off[0], cap = (size_t)(off[1] - off[0]);
+    std::vector<int64_t> w;
+    auto get = [&](const void *dev, size_t count, size_t elt, std::vector<uint8_t> &dst) -> int {
+        dst.resize(count * elt + 8);
+        if (count) HIPCHK(hipMemcpy(dst.data(), dev, count * elt, hipMemcpyDeviceToHost));
+        return SLX_OK;
+    };
+    int rc;
+    if (what == 0) {
+        uint32_t n = 0;
+        HIPCHK(hipMemcpy(&n, ck.intv_n + read, 4, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> info, x0, x2;
+        if ((rc = get(ck.intv_info + (size_t)read * ck.cap_intv, n, 4, info)) != SLX_OK) return rc;
+        if ((rc = get((const uint8_t *)ck.intv_x0 + (size_t)read * ck.cap_intv * isz, n, isz, x0)) != SLX_OK) return rc;
+        if ((rc = get((const uint8_t *)ck.intv_x2 + (size_t)read * ck.cap_intv * isz, n, isz, x2)) != SLX_OK) return rc;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t inf = ((const uint32_t *)info.data())[i];
+            w.push_back(inf >> 16); w.push_back(inf & 0xffff);
+            w.push_back(wk->last_wide ? (int64_t)((const uint64_t *)x0.data())[i] : (int64_t)((const uint32_t *)x0.data())[i]);
+            w.push_back(wk->last_wide ? (int64_t)((const uint64_t *)x2.data())[i] : (int64_t)((const uint32_t *)x2.data())[i]);
+        }
+    } else if (what == 1) {
+        int32_t nch = 0;
+        HIPCHK(hipMemcpy(&nch, ck.n_chain + read, 4, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> ia, cpos, crid, cn, cfirst, cw, srb, sql, ssc;
+        if ((rc = get(wk->snap_ia.as<int32_t>() + o, cap, 4, ia)) != SLX_OK) return rc;
+        if ((rc = get(ck.c_pos + o, cap, 8, cpos)) != SLX_OK || (rc = get(ck.c_rid + o, cap, 4, crid)) != SLX_OK || (rc = get(ck.c_n + o, cap, 4, cn)) != SLX_OK ||
+            (rc = get(ck.c_first + o, cap, 4, cfirst)) != SLX_OK || (rc = get(ck.c_w + o, cap, 4, cw)) != SLX_OK || (rc = get(ck.s_rbeg + o, cap, 8, srb)) != SLX_OK ||
+            (rc = get(ck.s_ql + o, cap, 4, sql)) != SLX_OK) return rc;
+        if (ck.s_score && (rc = get(ck.s_score + o, cap, 4, ssc)) != SLX_OK) return rc;
+        w.push_back(nch);                                 // -1: the exact-match shortcut wrote the read's only region at chaining time
+        for (int32_t ci = 0; ci < nch; ++ci) {
+            const int32_t c = ((const int32_t *)ia.data())[ci];
+            const int32_t n = ((const int32_t *)cn.data())[c], f = ((const int32_t *)cfirst.data())[c];
+            w.push_back(((const int64_t *)cpos.data())[c]); w.push_back(((const int32_t *)crid.data())[c]); w.push_back(n);
+            for (int32_t k = 0; k < n; ++k) {
+                const int32_t sidx = ((const int32_t *)cw.data())[f + k];
+                const uint32_t ql = ((const uint32_t *)sql.data())[sidx];
+                w.push_back(((const int64_t *)srb.data())[sidx]); w.push_back(ql >> 16); w.push_back(ql & 0xffff);
+                w.push_back(ck.s_score ? ((const int32_t *)ssc.data())[sidx] : (int32_t)(ql & 0xffff));
+            }
+        }
+    } else if (what == 2) {
+        int32_t n = 0;
+        HIPCHK(hipMemcpy(&n, wk->snap_nreg.as<int32_t>() + read, 4, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> rg;
+        if ((rc = get(wk->snap_regs.as<DReg>() + o, (size_t)(n > 0 ? n : 0), sizeof(DReg), rg)) != SLX_OK) return rc;
+        for (int32_t i = 0; i < n; ++i) {
+            const DReg &g = ((const DReg *)rg.data())[i];
+            const int64_t v[10] = {g.rb, g.re, g.qb, g.qe, g.rid, g.score, g.truesc, g.w, g.seedcov, g.seedlen0};
+            w.insert(w.end(), v, v + 10);
+        }
+    } else { slx_set_error("slx_debug_stage: unknown stage %d", what); return SLX_EINVAL; }
+    *n_out = w.size();
+    if (w.size() > cap_words) { slx_set_error("slx_debug_stage: buffer too small (%zu words needed)", w.size()); return SLX_ENOMEM; }
+    memcpy(buf, w.data(), w.size() * 8);
+    return SLX_OK;
 }

@@ -194,6 +194,41 @@ def test_long_reads_seed_filter_path(sl, orc, tiny_gpu, tiny_index, golden_dir):
     assert_same(al.alignSequences(mixed), exp, "long + short reads, u64 index")
 
 
+def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
+    """per-stage differential check (localises a mismatch): SMEM intervals after mem_collect_intv, kept chains with their seeds in
+    extension order, and the region list as mem_chain2aln leaves it -- read by read against the oracle's stages, through the
+    slx_debug_stage test hook; on the production schedule (cooperative chaining, split extension) and the small-batch one"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    (_, s1), (_, s2) = sim_reads
+    seqs = s1[:700] + ["A" * 150, "AC" * 75, "ACG" * 50, "N" * 40 + refs[0][300:410], refs[1][100:1500], refs[2][50:900]] + s2[:300]
+    opt = orc.default_opt()
+    for knobs in ((("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1)), (("split_min", 1 << 30),)):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("keep_stages", 1)
+        for k, v in knobs:
+            al.set(k, v)
+        al.alignSequences(seqs)
+        for i, sq in enumerate(seqs):
+            for what, name in ((0, "intervals"), (1, "chains"), (2, "regions")):
+                got = al.debug_stage(i, what)
+                exp = orc.stage_dump(opt, tiny_index, sq, what)
+                if what == 1 and len(got) and got[0] == -1:
+                    continue                      # exact-match shortcut: the read's only region was written at chaining time (checked as stage 2)
+                if what == 2:                     # the order of regions is the order of extension: compare as lists
+                    got, exp = got.reshape(-1, 10), exp.reshape(-1, 10)
+                assert np.array_equal(got, exp), "read %d (%d bp): %s differ under %s\n gpu=%s\n cpu=%s" % (i, len(sq), name, knobs, got[:40], exp[:40])
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` starts its own N ranks; asked for more GPUs than are visible it must fail loudly instead of
+    reporting an N-GPU number from fewer devices"""
+    import subprocess, sys, torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "C1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '"metric"' not in r.stdout
+
+
 def test_read_too_long_fails_loudly(sl, tiny_gpu):
     from seqlib_amd import _ffi
     al = sl.BWAAligner(tiny_gpu)
