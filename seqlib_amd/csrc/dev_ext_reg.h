@@ -226,6 +226,62 @@ __device__ ExtResult reg_ksw_extend2(int qlen_, QF qf, int tlen_, TF tf, const s
     return r;
 }
 
+// ksw_extend2 without the dynamic program, for the extensions that do not need one.  Let L be what the main diagonal loses against a
+// perfect match over the whole query (sum of max(mat) - mat[t_p][q_p], p < qlen).  Any path that leaves the diagonal opens a gap
+// (>= min(o_del + e_del, o_ins + e_ins) = oe) and takes at most as many diagonal steps as the diagonal itself has at that row, so when
+// L <= oe - 1 every cell off the diagonal scores strictly below the diagonal cell of its row, the diagonal never reaches 0 (h0 > L is
+// required), and everything ksw_extend2 reports is decided by the diagonal's prefix sums S_p = h0 + sum_{q <= p} score_q:
+//     max = the largest S_p above h0 at its FIRST position (the scalar loop takes a row's maximum only when it exceeds the old one),
+//     qle = tle = that position + 1 (0 when no prefix beats h0);   gscore = S_{qlen-1}, gtle = qlen;   max_off = 0;
+// no row is all zero and z-drop never fires (the row maximum stays within L of the running maximum).  Needs tlen >= qlen.  With the
+// default scores this covers an extension through one mismatch or a few Ns: a third of all DP cells of a 150 bp workload and most
+// top-seed extensions of its light reads -- a few dozen instructions instead of ~100 per DP row.
+template <typename QF, typename TF>
+__device__ __forceinline__ bool diag_extend(int qlen_, QF qf, int tlen_, TF tf, const slx_opt &o, const MatRows &mr, int h0_, int lane, ExtResult &out)
+{
+    const int qlen = __builtin_amdgcn_readfirstlane(qlen_), tlen = __builtin_amdgcn_readfirstlane(tlen_), h0 = __builtin_amdgcn_readfirstlane(h0_);
+    if (tlen < qlen || qlen > 3 * WAVE || qlen < 1) return false;
+    int amax = 0;
+    for (int i = 0; i < 25; ++i) amax = amax > o.mat[i] ? amax : o.mat[i];
+    if ((long long)h0 + (long long)qlen * amax >= (1 << 22)) return false;          // keys below pack the score above 8 position bits
+    int sc[3], loss = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = k * WAVE + lane;
+        sc[k] = 0;
+        if (p < qlen) {
+            const int t = tf(p), q = qf(p);
+            const uint32_t rowp = t == 0 ? mr.packed[0] : t == 1 ? mr.packed[1] : t == 2 ? mr.packed[2] : mr.packed[3];
+            const int row4 = t == 0 ? mr.q4[0] : t == 1 ? mr.q4[1] : t == 2 ? mr.q4[2] : mr.q4[3];
+            sc[k] = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            loss += amax - sc[k];
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) loss += __shfl_xor(loss, d, WAVE);
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    const int oe = oe_del < oe_ins ? oe_del : oe_ins;
+    if (loss > oe - 1 || h0 <= loss) return false;
+    int run = h0;
+    uint32_t key = 0;                                   // (S_p << 8 | 255 - p) of the best prefix above h0: the maximum is the largest S_p at its first p
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v = sc[k];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const int u = __shfl_up(v, d, WAVE); if (lane >= d) v += u; }
+        const int S = run + v;
+        const int p = k * WAVE + lane;
+        if (p < qlen && S > h0) { const uint32_t kk = (uint32_t)S << 8 | (uint32_t)(255 - p); key = key > kk ? key : kk; }
+        run += __shfl(v, WAVE - 1, WAVE);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)key, d, WAVE); key = key > u ? key : u; }
+    const int idx = key ? 255 - (int)(key & 255u) : -1;
+    out.score = key ? (int)(key >> 8) : h0;
+    out.qle = idx + 1; out.tle = idx + 1;
+    out.gtle = qlen; out.gscore = run;
+    out.max_off = 0;
+    return true;
+}
+
 // pick the narrowest register tile that holds the extension: most extensions of 150 bp reads are < 64 columns wide, so one column
 // per lane (a third of the per-row work of the widest variant) is the common case.  Reads longer than 191 bp keep the H/E row
 // of their widest extensions in LDS instead (wave_ksw_extend2): more than three columns per lane would spill.
@@ -233,6 +289,10 @@ template <int NCH, typename QF, typename TF>
 __device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus,
                                                           int h0, int *eh_h, int *eh_e, int lane)
 {
+    {
+        ExtResult d;
+        if (diag_extend(qlen, qf, tlen, tf, o, mr, h0, lane, d)) return d;
+    }
     if (qlen + 1 <= WAVE) return reg_ksw_extend2<1>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
     if (qlen + 1 <= 2 * WAVE) return reg_ksw_extend2<2>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
     if (qlen + 1 <= 3 * WAVE) return reg_ksw_extend2<3>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);

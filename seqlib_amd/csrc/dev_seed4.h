@@ -1,0 +1,397 @@
+// dev_seed4.h -- SMEM seeding passes 1 + 2 (bwa's mem_collect_intv / bwt_smem1a, SURVEY.md A.3/A.4, reached from
+// /root/reference/src/BWAAligner.cpp:104 -> mem_align1 -> mem_chain) with WAVE-LEVEL MODES.
+//
+// The per-lane state machine of dev_seed2.h spends ~340 instructions around every bwt_extend, because each trip of its one loop walks
+// through every phase block that any lane of the wave is in; measurements show the kernel bound by exactly that, not by
+// the memory system, while k_seed3's plain lock-step loop costs a third per extend.  Here the lanes still own one read each and still
+// fetch the next read when theirs is done, but the wave runs TIGHT LOOPS, one kind of step at a time:
+//     F loop   forward extension steps (bwt_smem1a's first loop) for the lanes that are in one
+//     B loop   backward steps (one work-list entry against the row's base) for the lanes that are in a backward row
+//     events   read assignment and the start of the next bwt_smem1a call, between the loops
+// A loop keeps going while enough of its lanes are left; lanes of the other kind idle meanwhile, which makes the lanes of a wave fall
+// into step (forward together, then backward together).  The price is idle lanes, the gain is that a step costs little more than its
+// extend: the forward step ranks its symbol and "everything greater" (two masked popcounts per block, for both strands' interval
+// starts), the backward step ranks one symbol and never touches x[1] -- no consumer reads it.
+#pragma once
+#include "dev_seed2.h"
+
+// one rank block in flight.  Plain scalar members on purpose: selecting a vector element or an array slot by the per-lane symbol makes
+// the compiler park the struct in scratch memory.
+template <typename I>
+struct RankLd {
+    uint32_t c0, c1, c2, c3;  // running counts of A, C, G, T before the block
+    uint32_t l0, l1, h0, h1;  // low / high bit planes of its 64 symbols
+    I s0, s1, s2, s3;         // u64 index: base counts of the 2^32-symbol super-block
+    uint32_t n;               // symbols of the block that count: 1..64
+};
+
+template <typename I>
+__device__ __forceinline__ void rank_issue(const DevFM<I> &fm, I pos, RankLd<I> &r)
+{   // pos = BWT position whose inclusive rank is wanted (bwt_occ's k), not yet mapped past the sentinel
+    const I kk = pos - (pos >= fm.primary ? 1 : 0);
+    const uint4 *blk = fm.occ + ((size_t)(kk >> 6) << 1);
+    const uint4 cn = blk[0], pl = blk[1];
+    r.c0 = cn.x; r.c1 = cn.y; r.c2 = cn.z; r.c3 = cn.w;
+    r.l0 = pl.x; r.l1 = pl.y; r.h0 = pl.z; r.h1 = pl.w;
+    r.n = ((uint32_t)kk & 63) + 1;
+    if (sizeof(I) == 8) {
+        const ulonglong2 *sp = (const ulonglong2 *)(fm.sup + ((uint64_t)kk >> 32) * 4);
+        const ulonglong2 a = sp[0], b = sp[1];
+        r.s0 = (I)a.x; r.s1 = (I)a.y; r.s2 = (I)b.x; r.s3 = (I)b.y;
+    } else r.s0 = r.s1 = r.s2 = r.s3 = 0;
+}
+
+template <typename T>
+__device__ __forceinline__ T sel4(int c, T v0, T v1, T v2, T v3) { const T lo = (c & 1) ? v1 : v0, hi = (c & 1) ? v3 : v2; return (c & 2) ? hi : lo; }
+
+// occurrences of symbol c, and (GT) of the symbols greater than c, in BWT[0..pos]
+template <typename I, bool GT>
+__device__ __forceinline__ void rank_finish(const RankLd<I> &r, int c, I &cnt_c, I &cnt_gt)
+{
+    const uint64_t m = ~0ull >> (64 - r.n);
+    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+    const uint32_t a0 = (c & 1) ? r.l0 : ~r.l0, a1 = (c & 1) ? r.l1 : ~r.l1;
+    const uint32_t b0 = (c & 2) ? r.h0 : ~r.h0, b1 = (c & 2) ? r.h1 : ~r.h1;
+    cnt_c = (I)(sel4<uint32_t>(c, r.c0, r.c1, r.c2, r.c3) + (uint32_t)__popc(a0 & b0 & m0) + (uint32_t)__popc(a1 & b1 & m1));
+    if (sizeof(I) == 8) cnt_c += sel4<I>(c, r.s0, r.s1, r.s2, r.s3);
+    if (GT) {
+        // symbols > c:  c = 0: low | high,  c = 1: high,  c = 2: low & high,  c = 3: none
+        const uint32_t g0 = sel4<uint32_t>(c, r.l0 | r.h0, r.h0, r.l0 & r.h0, 0u);
+        const uint32_t g1 = sel4<uint32_t>(c, r.l1 | r.h1, r.h1, r.l1 & r.h1, 0u);
+        cnt_gt = (I)(sel4<uint32_t>(c, r.c1 + r.c2 + r.c3, r.c2 + r.c3, r.c3, 0u) + (uint32_t)__popc(g0 & m0) + (uint32_t)__popc(g1 & m1));
+        if (sizeof(I) == 8) cnt_gt += sel4<I>(c, r.s1 + r.s2 + r.s3, r.s2 + r.s3, r.s3, (I)0);
+    } else cnt_gt = 0;
+}
+
+template <typename I>
+__device__ __forceinline__ I l2_of(const DevFM<I> &fm, int c) { return sel4<I>(c, fm.L2[0], fm.L2[1], fm.L2[2], fm.L2[3]); }
+
+#ifndef SEED4_MIN_WAVES
+#define SEED4_MIN_WAVES 4
+#endif
+#ifndef SEED4_MIN_WAVES_U64
+#define SEED4_MIN_WAVES_U64 4
+#endif
+#ifndef SEED4_FLOOR_SHIFT
+#define SEED4_FLOOR_SHIFT 1   // a mode loop ends when its active lanes drop to (lanes at entry) >> this
+#endif
+#ifndef SEED4_ITERS
+#define SEED4_ITERS 24        // steps a mode loop runs at most before the wave looks at events and modes again
+#endif
+
+#ifndef SEED4_DEBUG
+#define SEED4_DEBUG 0         // 1 + SLX_DEBUG_CYC=3: loop statistics (steps and active lanes per mode) on stderr
+#endif
+
+enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_ROW, S4_BWD, S4_DONE };
+
+template <typename I>
+__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x & 63;
+    WorkLists<I> wl;
+    wl.base = (IntvE<I> *)ck.lists + (size_t)blockIdx.x * ((size_t)2 * ck.cap_list * 128) + threadIdx.x; wl.stride = 128; wl.cap = ck.cap_list;
+    const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+    const uint32_t n_reads = (uint32_t)ck.n_reads;
+    // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
+    uint32_t pool_next = 0, pool_end = 0, res_next = 0, res_end = 0;
+    uint32_t pend_base = 0;
+    bool pending = false, exhausted = false;
+    // ---- per-lane state
+    int phase = S4_FETCH;
+    uint32_t r = 0;
+    uint64_t o0 = 0, o1 = 0, qoff = 0;
+    int len = 0, n_out = 0;
+    bool out_ovf = false, list_ovf = false;
+    int pass = 1, x = 0, k2 = 0, old_n = 0;
+    int sx = 0, i = 0, n = 0, ret = 0, bi = 0, cb = 0, cur = 1, np = 0, rev = 0, j = 0, nc = 0, last_start = 0;
+    I min_intv = 1, last_sz = 0;
+    I ik0 = 0, ik1 = 0, ik2 = 0;                   // the forward interval (both strands); its end in the query is i
+    I h0 = 0, h2 = 0; uint32_t hinf = 0;           // first entry of the backward row being read
+    I nh0 = 0, nh2 = 0; uint32_t nhinf = 0;        // ... and of the row being written
+    I p0 = 0, p2 = 0; uint32_t pinf = 0;           // the entry this backward step extends
+    QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+#if SEED4_DEBUG
+    unsigned long long d_fsteps = 0, d_flanes = 0, d_bsteps = 0, d_blanes = 0, d_rounds = 0, d_ev = 0;
+#endif
+
+    auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+    auto push_fwd = [&]() {                        // the current forward interval, ending at i (x[1] is never read back)
+        if (n < wl.cap) { IntvE<I> e; e.x0 = ik0; e.x1 = 0; e.x2 = ik2; e.info = (uint32_t)i; wl.at(1, n) = e; } else list_ovf = true;
+        ++n;
+    };
+    auto out_push = [&](int start, int end, I a, I s) {
+        if (n_out < ck.cap_intv) {
+            const size_t o = (size_t)r * ck.cap_intv + n_out;
+            ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
+            ++n_out;
+        } else out_ovf = true;
+    };
+    auto emit_mem = [&](I a, I s, uint32_t end) {  // a MEM [bi+1, end) ends the backward walk of an entry
+        if (bi + 1 < last_start) {                 // not contained in a longer match already reported by this call
+            last_start = bi + 1;
+            if ((int)end - (bi + 1) >= opt.min_seed_len) out_push(bi + 1, (int)end, a, s);
+        }
+    };
+    auto finish_read = [&]() {                     // passes 1 + 2 done (or abandoned on a work-list overflow)
+        ck.intv_n[r] = (uint32_t)n_out;
+        if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+        if (list_ovf) atomicOr(ck.flags, OVF_LIST);
+        phase = S4_FETCH;
+    };
+    auto begin_bwd = [&]() {                       // the forward phase is over: its last push is the longest extension
+        if (list_ovf) { finish_read(); return; }
+        ret = i;                                    // = info of the entry pushed last = next start of pass 1
+        h0 = ik0; h2 = ik2; hinf = (uint32_t)i;
+        cur = 1; np = n; rev = 1; last_start = 0x7fffffff; bi = sx - 1;
+        phase = S4_ROW;
+    };
+
+    for (;;) {
+        // ------------------------------------------------ events: read assignment, next bwt_smem1a call
+        const unsigned long long m_ev = __ballot(phase == S4_FETCH || phase == S4_INIT || phase == S4_START);
+#if SEED4_DEBUG
+        ++d_rounds; if (m_ev) ++d_ev;
+#endif
+        if (m_ev) {
+            if (pending) {
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
+                pending = false;
+                if (base >= n_reads) exhausted = true;
+                else { res_next = base; res_end = base + SEED2_POOL < n_reads ? base + SEED2_POOL : n_reads; }
+            }
+            if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
+            if (res_next == res_end && !exhausted) {
+                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED2_POOL);
+                pending = true;
+            }
+            if (phase == S4_INIT) {                     // offsets requested one round ago
+                qoff = o0; len = (int)(o1 - o0);
+                n_out = 0; out_ovf = false; list_ovf = false;
+                if (len < opt.min_seed_len) finish_read();
+                else { pass = 1; x = 0; phase = S4_START; }
+            }
+            {
+                const unsigned long long want = __ballot(phase == S4_FETCH);
+                if (want) {
+                    const uint32_t avail = pool_end - pool_next;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (phase == S4_FETCH) {
+                        if (rank < avail) {
+                            r = pool_next + rank;
+                            o0 = ck.offs[r]; o1 = ck.offs[r + 1];
+                            phase = S4_INIT;
+                        } else if (exhausted && !pending && res_next == res_end) phase = S4_DONE;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(want);
+                    pool_next += cnt < avail ? cnt : avail;
+                }
+            }
+            if (phase == S4_START) {
+                int xs = -1;
+                I mi = 1;
+                if (pass == 1) {
+                    while (x < len && qb(x) > 3) ++x;
+                    if (x < len) xs = x;
+                    else { pass = 2; k2 = 0; old_n = n_out; }
+                }
+                if (pass == 2) {                        // re-seed from the middle of long SMEMs with few occurrences
+                    while (k2 < old_n) {
+                        const size_t o = (size_t)r * ck.cap_intv + k2;
+                        const uint32_t inf = ck.intv_info[o];
+                        const I s = ((const I *)ck.intv_x2)[o];
+                        ++k2;
+                        const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+                        if (end - start < split_len || s > (I)opt.split_width) continue;
+                        const int mid = (start + end) >> 1;
+                        if (qb(mid) > 3) continue;      // bwt_smem1a returns at once on an ambiguous start
+                        xs = mid; mi = s + 1;
+                        break;
+                    }
+                    if (xs < 0) finish_read();
+                }
+                if (xs >= 0) {
+                    sx = xs; min_intv = mi < 1 ? (I)1 : mi;
+                    const int c0 = qb(xs);
+                    ik0 = l2_of<I>(fm, c0) + 1; ik1 = l2_of<I>(fm, 3 - c0) + 1;                         // bwt_set_intv
+                    ik2 = (c0 == 3 ? fm.L2[4] : l2_of<I>(fm, c0 + 1)) - l2_of<I>(fm, c0);
+                    i = xs + 1; n = 0;
+                    phase = S4_FWD;
+                }
+            }
+        }
+        if (__all(phase == S4_DONE)) break;
+        const int nF = __popcll(__ballot(phase == S4_FWD)), nB = __popcll(__ballot(phase == S4_ROW || phase == S4_BWD));
+        if (nF == 0 && nB == 0) continue;
+        if (nF >= nB) {
+            // ------------------------------------------------ F loop: one forward extend per step
+            const int floor_ = nF >> SEED4_FLOOR_SHIFT;                 // leave when half of the lanes that entered are gone (they wait in other phases)
+            for (int it = 0; it < SEED4_ITERS; ++it) {
+                bool act = phase == S4_FWD;
+                int cq = 4;
+                if (act) {
+                    if (i >= len || (cq = qb(i)) > 3) { push_fwd(); begin_bwd(); act = false; }
+                }
+                if (__popcll(__ballot(act)) <= floor_ && it) break;
+#if SEED4_DEBUG
+                ++d_fsteps; d_flanes += (unsigned long long)__popcll(__ballot(act));
+#endif
+                if (act) {
+                    const int c = 3 - cq;
+                    RankLd<I> rk, rl;
+                    rank_issue<I>(fm, ik1 - 1, rk); rank_issue<I>(fm, ik1 - 1 + ik2, rl);
+                    I ckc, ckg, clc, clg;
+                    rank_finish<I, true>(rk, c, ckc, ckg); rank_finish<I, true>(rl, c, clc, clg);
+                    const I o2 = clc - ckc;
+                    const I o1 = l2_of<I>(fm, c) + 1 + ckc;
+                    const I o0_ = ik0 + ((ik1 <= fm.primary && ik1 + ik2 - 1 >= fm.primary) ? 1 : 0) + (clg - ckg);
+                    bool stop = false;
+                    if (o2 != ik2) {
+                        push_fwd();
+                        if (o2 < min_intv) stop = true;
+                    }
+                    if (stop) begin_bwd();
+                    else { ik0 = o0_; ik1 = o1; ik2 = o2; ++i; }
+                }
+            }
+        } else {
+            // ------------------------------------------------ B loop: one work-list entry against the row's base per step
+            const int floor_ = nB >> SEED4_FLOOR_SHIFT;
+            for (int it = 0; it < SEED4_ITERS; ++it) {
+                if (phase == S4_ROW) {                  // start of the backward row at query position bi; its first entry is in registers
+                    int t = -1;
+                    if (bi >= 0) { t = qb(bi); if (t > 3) t = -1; }
+                    cb = t;
+                    j = 0; nc = 0; last_sz = 0;
+                    p0 = h0; p2 = h2; pinf = hinf;
+                    if (cb < 0) {                       // beginning of the read or an ambiguous base: every entry ends here, only the first can be new
+                        emit_mem(p0, p2, pinf);
+                        if (pass == 1) x = ret;
+                        phase = S4_START;
+                    } else phase = S4_BWD;
+                }
+                const bool act = phase == S4_BWD;
+                if (__popcll(__ballot(act)) <= floor_ && it) break;
+#if SEED4_DEBUG
+                ++d_bsteps; d_blanes += (unsigned long long)__popcll(__ballot(act));
+#endif
+                if (act) {
+                    IntvE<I> nx; nx.x0 = 0; nx.x1 = 0; nx.x2 = 0; nx.info = 0;
+                    if (j + 1 < np) nx = wl.at(cur, rev ? np - 2 - j : j + 1);        // the next entry, in flight behind this step's rank reads
+                    RankLd<I> rk, rl;
+                    rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
+                    I ckc, clc, dummy;
+                    rank_finish<I, false>(rk, cb, ckc, dummy); rank_finish<I, false>(rl, cb, clc, dummy);
+                    const I o2 = clc - ckc;
+                    const I o0_ = l2_of<I>(fm, cb) + 1 + ckc;
+                    if (o2 < min_intv) { if (nc == 0) emit_mem(p0, p2, pinf); }
+                    else if (nc == 0 || o2 != last_sz) {
+                        if (nc == 0) { nh0 = o0_; nh2 = o2; nhinf = pinf; }
+                        IntvE<I> e; e.x0 = o0_; e.x1 = 0; e.x2 = o2; e.info = pinf;
+                        wl.at(1 - cur, nc++) = e;
+                        last_sz = o2;
+                    }
+                    ++j;
+                    if (j >= np) {
+                        if (nc == 0) { if (pass == 1) x = ret; phase = S4_START; }
+                        else { cur = 1 - cur; np = nc; rev = 0; --bi; h0 = nh0; h2 = nh2; hinf = nhinf; phase = S4_ROW; }
+                    } else { p0 = nx.x0; p2 = nx.x2; pinf = nx.info; }
+                }
+            }
+        }
+    }
+#if SEED4_DEBUG
+    if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
+        atomicAdd(ck.dbg_cyc + 0, d_fsteps); atomicAdd(ck.dbg_cyc + 1, d_flanes); atomicAdd(ck.dbg_cyc + 2, d_bsteps); atomicAdd(ck.dbg_cyc + 3, d_blanes);
+        atomicAdd(ck.dbg_cyc + 4, d_rounds); atomicAdd(ck.dbg_cyc + 5, d_ev);
+    }
+#endif
+}
+
+// pass 3 (bwt_seed_strategy1: forward-only LAST-like seeds) + the per-read epilogue of mem_collect_intv / prologue of mem_chain
+// (sort by (start, end), repetitive length, seed-occurrence bound).  One lane per read, one forward extend per base: lanes of a wave run
+// in lock step for reads of equal length.  Same loop as k_seed3 of dev_seed2.h with the forward step of this file (two masked
+// popcounts per block instead of all four symbol counts).
+template <typename I>
+__global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt dopt)
+{
+    const slx_opt &opt = dopt.o;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < ck.n_reads;
+    const uint64_t qoff = live ? ck.offs[r] : 0;
+    const int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
+    const size_t ob = (size_t)(live ? r : 0) * ck.cap_intv;
+    uint32_t *oinfo = ck.intv_info + ob;
+    I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
+    int n_out = live ? (int)ck.intv_n[r] : 0;
+    bool out_ovf = false;
+    QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+    auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+    if (opt.max_mem_intv > 0) {                      // bwt_seed_strategy1 from every position a seed ended at
+        int x = len >= opt.min_seed_len ? 0 : len, i = 0;
+        bool fresh = true;
+        I k0 = 0, k1 = 0, k2 = 0;
+        for (;;) {
+            if (fresh) {
+                while (x < len && qb(x) > 3) ++x;
+                if (x < len) {
+                    const int c0 = qb(x);
+                    k0 = l2_of<I>(fm, c0) + 1; k1 = l2_of<I>(fm, 3 - c0) + 1;
+                    k2 = (c0 == 3 ? fm.L2[4] : l2_of<I>(fm, c0 + 1)) - l2_of<I>(fm, c0);
+                    i = x + 1; fresh = false;
+                }
+            }
+            const bool act = !fresh && i < len;
+            if (!__any(act)) break;
+            if (act) {
+                const int cq = qb(i);
+                if (cq > 3) { x = i + 1; fresh = true; }
+                else {
+                    const int c = 3 - cq;
+                    RankLd<I> rk, rl;
+                    rank_issue<I>(fm, k1 - 1, rk); rank_issue<I>(fm, k1 - 1 + k2, rl);
+                    I ckc, ckg, clc, clg;
+                    rank_finish<I, true>(rk, c, ckc, ckg); rank_finish<I, true>(rl, c, clc, clg);
+                    const I o2 = clc - ckc;
+                    const I o1 = l2_of<I>(fm, c) + 1 + ckc;
+                    const I o0 = k0 + ((k1 <= fm.primary && k1 + k2 - 1 >= fm.primary) ? 1 : 0) + (clg - ckg);
+                    if (o2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+                        if (o2 > 0) {
+                            if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = o0; ox2[n_out] = o2; ++n_out; }
+                            else out_ovf = true;
+                        }
+                        x = i + 1; fresh = true;
+                    } else { k0 = o0; k1 = o1; k2 = o2; ++i; }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    // sort by (start, end): entries with equal keys are identical intervals, so any exact sort matches ks_introsort
+    for (int a = 1; a < n_out; ++a) {
+        const uint32_t ki = oinfo[a]; const I s0 = ox0[a], s2 = ox2[a];
+        int b = a - 1;
+        while (b >= 0 && oinfo[b] > ki) { oinfo[b + 1] = oinfo[b]; ox0[b + 1] = ox0[b]; ox2[b + 1] = ox2[b]; --b; }
+        oinfo[b + 1] = ki; ox0[b + 1] = s0; ox2[b + 1] = s2;
+    }
+    // mem_chain prologue: repetitive fraction and the number of seed occurrences to look up
+    int b = 0, e = 0, l_rep = 0;
+    uint32_t cnt = 0;
+    for (int k = 0; k < n_out; ++k) {
+        const I s = ox2[k];
+        if (s > (I)opt.max_occ) {
+            const int sb = (int)(oinfo[k] >> 16), se = (int)(oinfo[k] & 0xffff);
+            if (sb > e) { l_rep += e - b; b = sb; e = se; }
+            else e = e > se ? e : se;
+            const I step = s / (I)opt.max_occ;
+            const I cc = (s + step - 1) / step;
+            cnt += (uint32_t)(cc < (I)opt.max_occ ? cc : (I)opt.max_occ);
+        } else cnt += (uint32_t)s;
+    }
+    l_rep += e - b;
+    ck.intv_n[r] = (uint32_t)n_out;
+    ck.l_rep[r] = l_rep;
+    ck.seed_cnt[r] = (unsigned long long)cnt;
+    if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+}

@@ -21,6 +21,7 @@
 #include <vector>
 #include "slx_internal.h"
 #include "dev_seed2.h"
+#include "dev_seed4.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
@@ -136,6 +137,7 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int seed_mode = 4;            // 4 = wave-level mode loops (dev_seed4.h), 2 = one extend per trip of a per-lane state machine (dev_seed2.h)
     int keep_stages = 0;          // test hook: keep what slx_debug_stage reads (copies of the chain order / region list before de-duplication)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
@@ -441,6 +443,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
     else if (!strcmp(key, "keep_stages")) al->keep_stages = (int)value;
+    else if (!strcmp(key, "seed_mode")) { if (value != 2 && value != 4) return SLX_EINVAL; al->seed_mode = (int)value; }
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
@@ -667,8 +670,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     (void)hipEventRecord(wk->ev_probe[0], st);
-    hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-    hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    if (al->seed_mode == 4) hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+    else hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
+    if (al->seed_mode == 4) hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    else hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
@@ -853,10 +858,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (hipEventElapsedTime(&ms, wk->ev_probe[2 * i], wk->ev_probe[2 * i + 1]) == hipSuccess) wk->probe_ms[i] += ms;
     }
     if (ck.dbg_cyc && ck.dbg_stage == 3) {
-        unsigned long long c4[4];
-        HIPCHK(hipMemcpy(c4, wk->dbg_cyc.p, 32, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[seed12] wave-trips %.4g; per trip of 64 lanes: %.1f extending, %.1f waiting for an event block, %.1f done\n", (double)c4[0],
-                (double)c4[1] / (double)c4[0], (double)c4[2] / (double)c4[0], (double)c4[3] / (double)c4[0]);
+        unsigned long long c6[6];
+        HIPCHK(hipMemcpy(c6, wk->dbg_cyc.p, 48, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[seed12m] forward loop: %.4g wave-steps, %.1f lanes active; backward loop: %.4g wave-steps, %.1f lanes active; %.4g rounds, %.4g with events\n",
+                (double)c6[0], (double)c6[1] / (double)(c6[0] ? c6[0] : 1), (double)c6[2], (double)c6[3] / (double)(c6[2] ? c6[2] : 1), (double)c6[4], (double)c6[5]);
     } else if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
         std::vector<unsigned long long> cyc((size_t)n * 4), sc((size_t)n);
         std::vector<int> nch((size_t)n), nrg((size_t)n);
