@@ -619,10 +619,11 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
 #define CAND_PART 4
 
 // per heavy read: seed slots (table space) and (chain, part) jobs
-__global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds)
+__global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds,
+                             unsigned int top)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= *n_heavy) return;
+    if (s >= *n_heavy || s >= top) return;      // the list is heaviest-first: beyond `top` reads the in-place kernel has no tail to hide
     const int r = heavy[s];
     const uint64_t so = ck.seed_off[r];
     const unsigned int cap = (unsigned int)(ck.seed_off[r + 1] - so);

@@ -19,7 +19,12 @@ struct DevFM {
     const I *sa_dense;        // SA decompressed to interval 1 (sentinel-inclusive order), or nullptr
     const uint64_t *sa_samp;  // bwa's samples (sa[0] = -1)
     int sa_intv;
+    const void *lut;          // k-mer table (dev_seed4.h): LutE<I> per lut_k-mer, first base most significant; nullptr = none
+    int lut_k;
 };
+
+template <typename I>
+struct alignas(2 * sizeof(I)) LutE { I lo, sz; };   // SA interval [lo, lo + sz) of a k-mer (bwa's x[0], x[2]); lo = 1 where sz = 0
 
 template <typename I>
 struct alignas(16) IntvE {    // one bidirectional interval on a SMEM work list

@@ -66,6 +66,74 @@ __device__ __forceinline__ void rank_finish(const RankLd<I> &r, int c, I &cnt_c,
 template <typename I>
 __device__ __forceinline__ I l2_of(const DevFM<I> &fm, int c) { return sel4<I>(c, fm.L2[0], fm.L2[1], fm.L2[2], fm.L2[3]); }
 
+// bwt_set_intv: the bidirectional interval of the single base c
+template <typename I>
+__device__ __forceinline__ void set_intv4(const DevFM<I> &fm, int c, I &k0, I &k1, I &k2)
+{
+    k0 = l2_of<I>(fm, c) + 1; k1 = l2_of<I>(fm, 3 - c) + 1;
+    k2 = (c == 3 ? fm.L2[4] : l2_of<I>(fm, c + 1)) - l2_of<I>(fm, c);
+}
+
+// one forward extension (bwt_extend on the swapped interval with the complemented base) of (k0, k1, k2) by query base cq
+template <typename I>
+__device__ __forceinline__ void fwd_step(const DevFM<I> &fm, I k0, I k1, I k2, int cq, I &o0, I &o1, I &o2)
+{
+    const int c = 3 - cq;
+    RankLd<I> rk, rl;
+    rank_issue<I>(fm, k1 - 1, rk); rank_issue<I>(fm, k1 - 1 + k2, rl);
+    I ckc, ckg, clc, clg;
+    rank_finish<I, true>(rk, c, ckc, ckg); rank_finish<I, true>(rl, c, clc, clg);
+    o2 = clc - ckc;
+    o1 = l2_of<I>(fm, c) + 1 + ckc;
+    o0 = k0 + ((k1 <= fm.primary && k1 + k2 - 1 >= fm.primary) ? 1 : 0) + (clg - ckg);
+}
+
+// ---------------------------------------------------------------- k-mer table
+// T[W] = SA interval of the K-mer W, computed with the very forward steps the seeding loops run, so that a jump through the table and
+// K - 1 steps leave the same numbers.  What it replaces, exactly (K <= min_seed_len, checked at launch):
+//   forward:  the first K - 1 steps of a bwt_smem1a / bwt_seed_strategy1 call cannot stop (no ambiguous base among the K, the read has
+//             them, and the K-mer's interval is still >= min_intv -- sizes only shrink), so the call starts at T[W] / T[revcomp W].
+//             The entries those steps would have pushed (prefixes of 1 .. K-1 bases) become VIRTUAL: they are not on the work list.
+//   backward: a work-list entry is the SA interval of a substring, and rows extend all entries by the same base, so the prefix of k bases
+//             after t rows is the interval of q[sx-t, sx+k).  Nothing an entry does before it is K bases long can be seen: it cannot
+//             be reported (shorter than min_seed_len), `last_start` only compares within a row, and entries influence only SHORTER
+//             ones (nc == 0, last_sz).  So the prefix of k bases joins its row when it reaches K bases -- row t = K - k, as the row's last
+//             entry, straight from T -- and the tests it meets there (>= min_intv, size differs from the last kept entry's: nested
+//             intervals of equal size are equal, and stay equal) drop it exactly when bwa would have dropped it in that row or before.
+//             Rows go on while virtual entries are left even when the list is empty.
+// This removes the triangle of (prefix, row) steps every call spends on intervals of thousands of occurrences: about K (K - 1) / 2
+// backward and K - 1 forward extends per call, for K - 1 + 2 table reads.
+template <typename I>
+__global__ void k_kmer_lut(DevFM<I> fm, int K, LutE<I> *out)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (1ull << (2 * K))) return;
+    I k0, k1, k2;
+    set_intv4<I>(fm, (int)((w >> (2 * (K - 1))) & 3), k0, k1, k2);
+    for (int t = 1; t < K; ++t) {
+        I o0, o1, o2;
+        fwd_step<I>(fm, k0, k1, k2, (int)((w >> (2 * (K - 1 - t))) & 3), o0, o1, o2);
+        k0 = o0; k1 = o1; k2 = o2;
+        if (k2 == 0) break;
+    }
+    LutE<I> e; e.lo = k2 ? k0 : (I)1; e.sz = k2;
+    out[w] = e;
+}
+
+// the K-mer at q[p, p + K) as a table index and its reverse complement's; returns the offset of the first ambiguous base, or -1
+template <typename QB>
+__device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, uint32_t &rc)
+{
+    fw = 0; rc = 0;
+    for (int t = 0; t < K; ++t) {
+        const int c = qb(p + t);
+        if (c > 3) return t;
+        fw = (fw << 2) | (uint32_t)c;
+        rc |= (uint32_t)(3 - c) << (2 * t);
+    }
+    return -1;
+}
+
 #ifndef SEED4_MIN_WAVES
 #define SEED4_MIN_WAVES 4
 #endif
@@ -111,6 +179,11 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     I h0 = 0, h2 = 0; uint32_t hinf = 0;           // first entry of the backward row being read
     I nh0 = 0, nh2 = 0; uint32_t nhinf = 0;        // ... and of the row being written
     I p0 = 0, p2 = 0; uint32_t pinf = 0;           // the entry this backward step extends
+    const int K = (fm.lut && fm.lut_k <= opt.min_seed_len) ? fm.lut_k : 0;   // k-mer table (see k_kmer_lut)
+    const LutE<I> *lut = (const LutE<I> *)fm.lut;
+    int nv = 0;                                    // virtual entries of this call: K - 1 after a jump through the table
+    uint32_t vcode = 0;                            // K-mer at the backward row's position
+    I v0 = 0, v2 = 0;                              // ... and its interval, loaded at the start of the row
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
 #if SEED4_DEBUG
     unsigned long long d_fsteps = 0, d_flanes = 0, d_bsteps = 0, d_blanes = 0, d_rounds = 0, d_ev = 0;
@@ -213,10 +286,16 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 }
                 if (xs >= 0) {
                     sx = xs; min_intv = mi < 1 ? (I)1 : mi;
-                    const int c0 = qb(xs);
-                    ik0 = l2_of<I>(fm, c0) + 1; ik1 = l2_of<I>(fm, 3 - c0) + 1;                         // bwt_set_intv
-                    ik2 = (c0 == 3 ? fm.L2[4] : l2_of<I>(fm, c0 + 1)) - l2_of<I>(fm, c0);
-                    i = xs + 1; n = 0;
+                    nv = 0;
+                    if (K && xs + K <= len) {
+                        uint32_t fw, rc;
+                        if (kmer_codes(qb, xs, K, fw, rc) < 0) {
+                            const LutE<I> e = lut[fw];
+                            if (e.sz >= min_intv) { ik0 = e.lo; ik2 = e.sz; ik1 = lut[rc].lo; i = xs + K; nv = K - 1; vcode = fw; }
+                        }
+                    }
+                    if (!nv) { set_intv4<I>(fm, qb(xs), ik0, ik1, ik2); i = xs + 1; }
+                    n = 0;
                     phase = S4_FWD;
                 }
             }
@@ -238,14 +317,8 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 ++d_fsteps; d_flanes += (unsigned long long)__popcll(__ballot(act));
 #endif
                 if (act) {
-                    const int c = 3 - cq;
-                    RankLd<I> rk, rl;
-                    rank_issue<I>(fm, ik1 - 1, rk); rank_issue<I>(fm, ik1 - 1 + ik2, rl);
-                    I ckc, ckg, clc, clg;
-                    rank_finish<I, true>(rk, c, ckc, ckg); rank_finish<I, true>(rl, c, clc, clg);
-                    const I o2 = clc - ckc;
-                    const I o1 = l2_of<I>(fm, c) + 1 + ckc;
-                    const I o0_ = ik0 + ((ik1 <= fm.primary && ik1 + ik2 - 1 >= fm.primary) ? 1 : 0) + (clg - ckg);
+                    I o0_, o1, o2;
+                    fwd_step<I>(fm, ik0, ik1, ik2, cq, o0_, o1, o2);
                     bool stop = false;
                     if (o2 != ik2) {
                         push_fwd();
@@ -266,10 +339,17 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     j = 0; nc = 0; last_sz = 0;
                     p0 = h0; p2 = h2; pinf = hinf;
                     if (cb < 0) {                       // beginning of the read or an ambiguous base: every entry ends here, only the first can be new
-                        emit_mem(p0, p2, pinf);
+                        if (np > 0) emit_mem(p0, p2, pinf);   // (np == 0: only virtual entries are left, too short to report)
                         if (pass == 1) x = ret;
                         phase = S4_START;
-                    } else phase = S4_BWD;
+                    } else {
+                        if (sx - bi <= nv) {            // this row's virtual entry: the K-mer starting at bi
+                            vcode = (vcode >> 2) | ((uint32_t)cb << (2 * (K - 1)));
+                            const LutE<I> e = lut[vcode];
+                            v0 = e.lo; v2 = e.sz;
+                        }
+                        phase = S4_BWD;
+                    }
                 }
                 const bool act = phase == S4_BWD;
                 if (__popcll(__ballot(act)) <= floor_ && it) break;
@@ -279,22 +359,33 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 if (act) {
                     IntvE<I> nx; nx.x0 = 0; nx.x1 = 0; nx.x2 = 0; nx.info = 0;
                     if (j + 1 < np) nx = wl.at(cur, rev ? np - 2 - j : j + 1);        // the next entry, in flight behind this step's rank reads
-                    RankLd<I> rk, rl;
-                    rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
-                    I ckc, clc, dummy;
-                    rank_finish<I, false>(rk, cb, ckc, dummy); rank_finish<I, false>(rl, cb, clc, dummy);
-                    const I o2 = clc - ckc;
-                    const I o0_ = l2_of<I>(fm, cb) + 1 + ckc;
-                    if (o2 < min_intv) { if (nc == 0) emit_mem(p0, p2, pinf); }
-                    else if (nc == 0 || o2 != last_sz) {
-                        if (nc == 0) { nh0 = o0_; nh2 = o2; nhinf = pinf; }
-                        IntvE<I> e; e.x0 = o0_; e.x1 = 0; e.x2 = o2; e.info = pinf;
-                        wl.at(1 - cur, nc++) = e;
-                        last_sz = o2;
+                    if (j < np) {                       // (np == 0: a row of the virtual entry alone)
+                        RankLd<I> rk, rl;
+                        rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
+                        I ckc, clc, dummy;
+                        rank_finish<I, false>(rk, cb, ckc, dummy); rank_finish<I, false>(rl, cb, clc, dummy);
+                        const I o2 = clc - ckc;
+                        const I o0_ = l2_of<I>(fm, cb) + 1 + ckc;
+                        if (o2 < min_intv) { if (nc == 0) emit_mem(p0, p2, pinf); }
+                        else if (nc == 0 || o2 != last_sz) {
+                            if (nc == 0) { nh0 = o0_; nh2 = o2; nhinf = pinf; }
+                            IntvE<I> e; e.x0 = o0_; e.x1 = 0; e.x2 = o2; e.info = pinf;
+                            wl.at(1 - cur, nc++) = e;
+                            last_sz = o2;
+                        }
                     }
                     ++j;
                     if (j >= np) {
-                        if (nc == 0) { if (pass == 1) x = ret; phase = S4_START; }
+                        const int t = sx - bi;          // rows done with this one
+                        if (t <= nv && v2 >= min_intv && (nc == 0 || v2 != last_sz)) {   // the virtual entry [bi, bi + K) joins as the row's last
+                            if (nc < wl.cap) {
+                                if (nc == 0) { nh0 = v0; nh2 = v2; nhinf = (uint32_t)(bi + K); }
+                                IntvE<I> e; e.x0 = v0; e.x1 = 0; e.x2 = v2; e.info = (uint32_t)(bi + K);
+                                wl.at(1 - cur, nc++) = e;
+                            } else list_ovf = true;
+                        }
+                        if (list_ovf) finish_read();
+                        else if (nc == 0 && t >= nv) { if (pass == 1) x = ret; phase = S4_START; }
                         else { cur = 1 - cur; np = nc; rev = 0; --bi; h0 = nh0; h2 = nh2; hinf = nhinf; phase = S4_ROW; }
                     } else { p0 = nx.x0; p2 = nx.x2; pinf = nx.info; }
                 }
@@ -332,14 +423,21 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt do
         int x = len >= opt.min_seed_len ? 0 : len, i = 0;
         bool fresh = true;
         I k0 = 0, k1 = 0, k2 = 0;
+        const int K = (fm.lut && fm.lut_k <= opt.min_seed_len) ? fm.lut_k : 0;   // k-mer table (see k_kmer_lut)
+        const LutE<I> *lut = (const LutE<I> *)fm.lut;
         for (;;) {
             if (fresh) {
-                while (x < len && qb(x) > 3) ++x;
-                if (x < len) {
-                    const int c0 = qb(x);
-                    k0 = l2_of<I>(fm, c0) + 1; k1 = l2_of<I>(fm, 3 - c0) + 1;
-                    k2 = (c0 == 3 ? fm.L2[4] : l2_of<I>(fm, c0 + 1)) - l2_of<I>(fm, c0);
-                    i = x + 1; fresh = false;
+                while (x < len) {
+                    if (qb(x) > 3) { ++x; continue; }
+                    if (!K) { set_intv4<I>(fm, qb(x), k0, k1, k2); i = x + 1; fresh = false; break; }
+                    // no seed is reported before it is min_seed_len >= K bases long: the first K - 1 steps only move the interval
+                    if (x + K > len) { x = len; break; }                // fewer than K bases left: nothing more to report
+                    uint32_t fw, rc;
+                    const int bad = kmer_codes(qb, x, K, fw, rc);
+                    if (bad >= 0) { x += bad + 1; continue; }           // an ambiguous base restarts the search behind it
+                    const LutE<I> e = lut[fw];
+                    k0 = e.lo; k2 = e.sz; k1 = lut[rc].lo; i = x + K; fresh = false;
+                    break;
                 }
             }
             const bool act = !fresh && i < len;
@@ -348,14 +446,8 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt do
                 const int cq = qb(i);
                 if (cq > 3) { x = i + 1; fresh = true; }
                 else {
-                    const int c = 3 - cq;
-                    RankLd<I> rk, rl;
-                    rank_issue<I>(fm, k1 - 1, rk); rank_issue<I>(fm, k1 - 1 + k2, rl);
-                    I ckc, ckg, clc, clg;
-                    rank_finish<I, true>(rk, c, ckc, ckg); rank_finish<I, true>(rl, c, clc, clg);
-                    const I o2 = clc - ckc;
-                    const I o1 = l2_of<I>(fm, c) + 1 + ckc;
-                    const I o0 = k0 + ((k1 <= fm.primary && k1 + k2 - 1 >= fm.primary) ? 1 : 0) + (clg - ckg);
+                    I o0, o1, o2;
+                    fwd_step<I>(fm, k0, k1, k2, cq, o0, o1, o2);
                     if (o2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
                         if (o2 > 0) {
                             if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = o0; ox2[n_out] = o2; ++n_out; }

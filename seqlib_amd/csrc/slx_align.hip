@@ -117,7 +117,7 @@ struct slx_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     // index in HBM
-    DevBuf d_bwt, d_occ, d_sup, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
+    DevBuf d_bwt, d_occ, d_sup, d_lut, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
     bool wide = false;            // u64 index (>= 2^32 - 1 BWT symbols, or forced with the "wide_index" knob)
     DevFM<uint32_t> fm32;
     DevFM<uint64_t> fm64;
@@ -136,7 +136,10 @@ struct slx_aligner {
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
+    int cand_top = 512;           // ... and only for the first cand_top reads of the heaviest-first list
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int lut_k = -1;               // k-mer table of the seeding kernels (dev_seed4.h, k_kmer_lut): 4^k entries of 8 / 16 bytes; 0 = none,
+                                  // -1 = by index size (measured best where a k-mer still has a handful of occurrences: log4(symbols) - 1)
     int seed_mode = 4;            // 4 = wave-level mode loops (dev_seed4.h), 2 = one extend per trip of a per-lane state machine (dev_seed2.h)
     int keep_stages = 0;          // test hook: keep what slx_debug_stage reads (copies of the chain order / region list before de-duplication)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
@@ -274,6 +277,28 @@ __global__ void k_sa_walk(DevFM<I> fm, I *dense, uint64_t n_sa)
 
 // ---------------------------------------------------------------- create / free
 template <typename I>
+static int build_lut(slx_aligner *al)
+{
+    DevFM<I> &fm = fm_of<I>(al);
+    fm.lut = nullptr; fm.lut_k = 0;
+    int K = al->lut_k;
+    if (K < 0) {
+        int l4 = 0;
+        while ((al->host_idx->seq_len >> (2 * (l4 + 1))) != 0) ++l4;      // floor(log4(symbols))
+        K = l4 - 1 > 14 ? 14 : l4 - 1;
+    }
+    if (K < 2) return SLX_OK;
+    const uint64_t n = 1ull << (2 * K);
+    int rc;
+    if ((rc = al->d_lut.ensure(n * sizeof(LutE<I>))) != SLX_OK) return rc;
+    hipLaunchKernelGGL(k_kmer_lut<I>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, al->stream, fm, K, al->d_lut.as<LutE<I>>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(al->stream));
+    fm.lut = al->d_lut.p; fm.lut_k = K;
+    return SLX_OK;
+}
+
+template <typename I>
 static int upload_fm(slx_aligner *al)
 {
     const slx_index *idx = al->host_idx;
@@ -303,6 +328,7 @@ static int upload_fm(slx_aligner *al)
     fm.primary = (I)idx->primary;
     for (int i = 0; i < 5; ++i) fm.L2[i] = (I)idx->L2[i];
     fm.seq_len = (I)idx->seq_len;
+    if ((rc = build_lut<I>(al)) != SLX_OK) return rc;
     fm.sa_dense = nullptr;
     fm.sa_samp = al->d_sa_samp.as<uint64_t>();
     fm.sa_intv = idx->sa_intv;
@@ -409,7 +435,7 @@ extern "C" void slx_aligner_free(slx_aligner *al)
 {
     if (!al) return;
     (void)hipSetDevice(al->device);
-    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
                       &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar,
                       &al->st_bases, &al->st_offs, &al->st_pack};
     for (DevBuf *b : bufs) b->release();
@@ -443,6 +469,12 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
     else if (!strcmp(key, "keep_stages")) al->keep_stages = (int)value;
+    else if (!strcmp(key, "lut_k")) {
+        if (value != 0 && value != -1 && (value < 2 || value > 14)) return SLX_EINVAL;
+        al->lut_k = (int)value;
+        (void)hipSetDevice(al->device);
+        return al->wide ? build_lut<uint64_t>(al) : build_lut<uint32_t>(al);
+    }
     else if (!strcmp(key, "seed_mode")) { if (value != 2 && value != 4) return SLX_EINVAL; al->seed_mode = (int)value; }
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
@@ -451,6 +483,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "coop_lim1")) { if (value < 1) return SLX_EINVAL; al->coop_lim1 = (int)value; }
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
+    else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
@@ -764,7 +797,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 const unsigned gb = (unsigned)((n + 255) / 256);
                 unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
                 unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (n + 2);
-                hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds);
+                hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
+                                   hsort ? (unsigned int)al->cand_top : 0xffffffffu);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, n + 1, st));
                 tb = wk->scan_tmp.cap;

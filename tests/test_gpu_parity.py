@@ -92,7 +92,8 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
 
 
 @pytest.mark.parametrize("knob,val", [("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
-                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("ext_split", 0), ("wide_index", 1), ("seed_mode", 2)])
+                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("ext_split", 0), ("wide_index", 1), ("seed_mode", 2),
+                                      ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """bwa's sampled-SA walk vs dense SA, odd chunking, a tiny interval capacity that forces the overflow-retry path, the
     routing thresholds of the region kernels, and the u64 index kernels (wide_index) on a small index: identical records."""
@@ -153,6 +154,44 @@ def test_edge_cases(sl, orc, tiny_gpu, tiny_index, golden_dir):
 
 def orc_revcomp(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_kmer_table_jump_is_invisible(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir, wide):
+    """the seeding kernels start every bwt_smem1a / bwt_seed_strategy1 call from a k-mer table and keep the skipped prefixes off the
+    work list until they are k bases long (dev_seed4.h, k_kmer_lut): for every table size -- from k-mers with thousands of occurrences
+    to k-mers mostly absent from the index -- on reads with ambiguous bases, low-complexity reads, reads shorter than k and reads
+    around min_seed_len the records are those of the stepwise walk (the oracle's)."""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    rng = np.random.default_rng(11)
+    (_, s1), _ = sim_reads
+    seqs = list(s1[:400]) + ["", "ACGT", "ACGTACGTACG", "N" * 150, "A" * 150, "AC" * 75, "ACG" * 50, "A" * 30 + "N" + "A" * 30]
+    for L in (12, 18, 19, 20, 21, 25, 33, 75, 150, 150, 150, 150, 250):
+        for n_amb in (0, 1, 4):
+            p = int(rng.integers(0, len(refs[1]) - L))
+            s = list(refs[1][p:p + L])
+            for _ in range(n_amb):
+                s[int(rng.integers(0, L))] = "N"
+            for _ in range(L // 50):
+                s[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+            seqs.append("".join(s))
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    for k in (2, 3, 5, 7, 9, 11, 14):
+        al = sl.BWAAligner(tiny_gpu)
+        if wide:
+            al.set("wide_index", 1)
+        al.set("lut_k", k)
+        assert_same(al.alignSequences(seqs), exp, "lut_k=%d wide=%d" % (k, wide))
+    # a table wider than min_seed_len must switch itself off (its jump would skip reportable seeds): min_seed_len 10 < k = 12
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("lut_k", 12)
+    al.opt.min_seed_len = 10
+    o = orc.default_opt(); o.min_seed_len = 10
+    assert_same(al.alignSequences(seqs), orc.align_batch(o, tiny_index, seqs), "min_seed_len < lut_k")
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("lut_k", 7)
+    al.opt.min_seed_len = 10
+    assert_same(al.alignSequences(seqs), orc.align_batch(o, tiny_index, seqs), "min_seed_len 10, lut_k 7")
 
 
 def test_long_reads_seed_filter_path(sl, orc, tiny_gpu, tiny_index, golden_dir):
