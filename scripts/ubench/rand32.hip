@@ -1,5 +1,5 @@
 // rand32 -- what the memory system gives a seeding-like access pattern: every lane walks ILP independent chains of dependent
-// random 32-byte reads (two dwordx4 per read, as one rank query of dev_seed2.h) in a table of `mb` megabytes.
+// random 32-byte reads (two dwordx4 per read, as one rank query of dev_occ.h) in a table of `mb` megabytes.
 //   hipcc --offload-arch=gfx950 -O3 rand32.hip -o rand32 && ./rand32
 // Prints reads/s and GB/s per (table size, waves per SIMD, ILP).  A tuning aid, not part of the product.
 #include <hip/hip_runtime.h>

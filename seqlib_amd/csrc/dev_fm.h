@@ -11,7 +11,7 @@
 template <typename I>
 struct DevFM {
     const uint32_t *bwt;      // interleaved blocks
-    const uint4 *occ;         // occ planes (dev_seed2.h): per 64 symbols 4 x u32 counts + low/high bit planes
+    const uint4 *occ;         // occ planes (dev_occ.h): per 64 symbols 4 x u32 counts + low/high bit planes
     const uint64_t *sup;      // u64 index only: base counts of each 2^32-symbol super-block (the u32 block counts are relative to it)
     I primary;
     I L2[5];

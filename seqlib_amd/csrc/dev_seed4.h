@@ -1,19 +1,26 @@
 // dev_seed4.h -- SMEM seeding passes 1 + 2 (bwa's mem_collect_intv / bwt_smem1a, SURVEY.md A.3/A.4, reached from
 // /root/reference/src/BWAAligner.cpp:104 -> mem_align1 -> mem_chain) with WAVE-LEVEL MODES.
 //
-// The per-lane state machine of dev_seed2.h spends ~340 instructions around every bwt_extend, because each trip of its one loop walks
-// through every phase block that any lane of the wave is in; measurements show the kernel bound by exactly that, not by
-// the memory system, while k_seed3's plain lock-step loop costs a third per extend.  Here the lanes still own one read each and still
-// fetch the next read when theirs is done, but the wave runs TIGHT LOOPS, one kind of step at a time:
+// A per-lane state machine with one bwt_extend per trip of a wave-uniform loop (the first design, experiments/dev_seed2_state_machine.h)
+// spends ~340 instructions around every extend, because each trip walks through every phase block that any lane of the wave is in;
+// measurements showed that kernel bound by exactly that, not by the memory system, while a plain lock-step loop
+// costs a third per extend.  Here the lanes still own one read each and still fetch the next read when theirs is done, but the wave runs
+// TIGHT LOOPS, one kind of step at a time:
 //     F loop   forward extension steps (bwt_smem1a's first loop) for the lanes that are in one
+//     D loop   forward steps of an interval that is down to ONE occurrence: the read against the reference text, no rank (below)
 //     B loop   backward steps (one work-list entry against the row's base) for the lanes that are in a backward row
 //     events   read assignment and the start of the next bwt_smem1a call, between the loops
 // A loop keeps going while enough of its lanes are left; lanes of the other kind idle meanwhile, which makes the lanes of a wave fall
 // into step (forward together, then backward together).  The price is idle lanes, the gain is that a step costs little more than its
 // extend: the forward step ranks its symbol and "everything greater" (two masked popcounts per block, for both strands' interval
 // starts), the backward step ranks one symbol and never touches x[1] -- no consumer reads it.
+// Measured on C3 (SEED4_DEBUG): per read ~72 backward, ~12 rank-based forward and ~5 direct steps; the backward loop is 86 % of the wave
+// steps and runs with 15 of 64 lanes while ~30 wait in the forward phases.  Two schedules that keep more lanes busy were measured and
+// dropped: serving the short loops as soon as they hold half as many lanes as the backward one (3 x the rounds, same time), and ONE loop
+// in which every lane takes whichever step it is due (26 lanes per trip and a third fewer trips, but each trip pays the rank reads and
+// the text reads one after the other: 67 ms against 55).
 #pragma once
-#include "dev_seed2.h"
+#include "dev_occ.h"
 
 // one rank block in flight.  Plain scalar members on purpose: selecting a vector element or an array slot by the per-lane symbol makes
 // the compiler park the struct in scratch memory.
@@ -72,6 +79,19 @@ __device__ __forceinline__ void set_intv4(const DevFM<I> &fm, int c, I &k0, I &k
 {
     k0 = l2_of<I>(fm, c) + 1; k1 = l2_of<I>(fm, 3 - c) + 1;
     k2 = (c == 3 ? fm.L2[4] : l2_of<I>(fm, c + 1)) - l2_of<I>(fm, c);
+}
+
+// base of the indexed text T = forward ++ reverse complement (what the FM-index is over) at position p < 2 l_pac, through an 8-byte
+// window of the 2-bit pac (32 bases; the reverse strand walks the same bytes downwards)
+struct RWin { uint64_t bits; int64_t chunk; };
+__device__ __forceinline__ int text_at(const DevRef &R, int64_t p, RWin &w)
+{
+    const bool rev = p >= R.l_pac;
+    const int64_t f = rev ? (R.l_pac << 1) - 1 - p : p;
+    const int64_t ch = f >> 5;
+    if (ch != w.chunk) { w.bits = *(const uint64_t *)(R.pac + (ch << 3)); w.chunk = ch; }
+    const int b = (int)((w.bits >> ((((f >> 2) & 7) << 3) + ((~f & 3) << 1))) & 3);
+    return rev ? 3 - b : b;
 }
 
 // one forward extension (bwt_extend on the swapped interval with the complemented base) of (k0, k1, k2) by query base cq
@@ -138,7 +158,7 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #define SEED4_MIN_WAVES 4
 #endif
 #ifndef SEED4_MIN_WAVES_U64
-#define SEED4_MIN_WAVES_U64 4
+#define SEED4_MIN_WAVES_U64 3
 #endif
 #ifndef SEED4_FLOOR_SHIFT
 #define SEED4_FLOOR_SHIFT 1   // a mode loop ends when its active lanes drop to (lanes at entry) >> this
@@ -151,10 +171,19 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #define SEED4_DEBUG 0         // 1 + SLX_DEBUG_CYC=3: loop statistics (steps and active lanes per mode) on stderr
 #endif
 
-enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_ROW, S4_BWD, S4_DONE };
+// Direct forward steps.  Once a forward interval holds a single occurrence (the rule after ~14 bases of a read from unique sequence), a
+// forward extend can only keep it or empty it: x[2] stays 1 and x[0] stays put while the next base of the read equals the next base of
+// the text behind that occurrence (the sentinel adjustment and the "greater symbols" count are both 0 for a kept single occurrence), and
+// x[1] is read by nothing but the next rank-based forward step.  So from there the walk needs one suffix-array read (the occurrence's
+// position, dense SA) and the 2-bit reference -- 32 bases per 8-byte read -- instead of a rank per base.  A lane switches after two
+// consecutive steps at one occurrence (chance matches next to a mismatch die at once: not worth the two reads).
+#ifndef SEED4_DIRECT_AFTER
+#define SEED4_DIRECT_AFTER 2
+#endif
+enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW, S4_BWD, S4_DONE };
 
 template <typename I>
-__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned int *queue)
+__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x & 63;
@@ -185,8 +214,13 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     uint32_t vcode = 0;                            // K-mer at the backward row's position
     I v0 = 0, v2 = 0;                              // ... and its interval, loaded at the start of the row
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+    const bool direct_ok = fm.sa_dense != nullptr;  // (the sampled-SA walk would cost more than it saves)
+    int ones = 0;                                  // consecutive forward steps that ended at one occurrence
+    int64_t dpos = 0;                              // S4_DIR: text position of that occurrence of q[sx, i)
+    RWin rwin; rwin.bits = 0; rwin.chunk = -1;
 #if SEED4_DEBUG
-    unsigned long long d_fsteps = 0, d_flanes = 0, d_bsteps = 0, d_blanes = 0, d_rounds = 0, d_ev = 0;
+    const unsigned long long d_t0 = __builtin_readcyclecounter();
+    unsigned long long d_fsteps = 0, d_flanes = 0, d_bsteps = 0, d_blanes = 0, d_rounds = 0, d_ev = 0, d_dsteps = 0, d_dlanes = 0, d_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
@@ -232,11 +266,11 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
                 pending = false;
                 if (base >= n_reads) exhausted = true;
-                else { res_next = base; res_end = base + SEED2_POOL < n_reads ? base + SEED2_POOL : n_reads; }
+                else { res_next = base; res_end = base + SEED_POOL < n_reads ? base + SEED_POOL : n_reads; }
             }
             if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
             if (res_next == res_end && !exhausted) {
-                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED2_POOL);
+                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED_POOL);
                 pending = true;
             }
             if (phase == S4_INIT) {                     // offsets requested one round ago
@@ -295,15 +329,39 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         }
                     }
                     if (!nv) { set_intv4<I>(fm, qb(xs), ik0, ik1, ik2); i = xs + 1; }
-                    n = 0;
+                    n = 0; ones = 0;
                     phase = S4_FWD;
                 }
             }
         }
         if (__all(phase == S4_DONE)) break;
+#if SEED4_DEBUG
+        for (int ph = 0; ph < 8; ++ph) d_ph[ph] += (unsigned long long)__popcll(__ballot(phase == ph));
+#endif
         const int nF = __popcll(__ballot(phase == S4_FWD)), nB = __popcll(__ballot(phase == S4_ROW || phase == S4_BWD));
-        if (nF == 0 && nB == 0) continue;
-        if (nF >= nB) {
+        const int nD = __popcll(__ballot(phase == S4_DIR));
+        if (nF == 0 && nB == 0 && nD == 0) continue;
+        if (nD >= nF && nD >= nB) {
+            // ------------------------------------------------ D loop: up to 32 bases against the reference text per step
+            const int floor_ = nD >> SEED4_FLOOR_SHIFT;
+            for (int it = 0; it < SEED4_ITERS; ++it) {
+                if (__popcll(__ballot(phase == S4_DIR)) <= floor_ && it) break;
+#if SEED4_DEBUG
+                ++d_dsteps; d_dlanes += (unsigned long long)__popcll(__ballot(phase == S4_DIR));
+#endif
+                if (phase == S4_DIR) {
+                    for (int t = 0; t < 32; ++t) {
+                        int cq = 4;
+                        const int64_t tp = dpos + (int64_t)(i - sx);
+                        if (i < len && (cq = qb(i)) <= 3 && tp < (R.l_pac << 1) && text_at(R, tp, rwin) == cq) { ++i; continue; }
+                        // end of the read, an ambiguous base, or the occurrence ends here (mismatch / end of the text): bwt_smem1a pushes the
+                        // interval and stops -- in the last two cases because the extended interval is empty
+                        push_fwd(); begin_bwd();
+                        break;
+                    }
+                }
+            }
+        } else if (nF >= nB) {
             // ------------------------------------------------ F loop: one forward extend per step
             const int floor_ = nF >> SEED4_FLOOR_SHIFT;                 // leave when half of the lanes that entered are gone (they wait in other phases)
             for (int it = 0; it < SEED4_ITERS; ++it) {
@@ -325,7 +383,11 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         if (o2 < min_intv) stop = true;
                     }
                     if (stop) begin_bwd();
-                    else { ik0 = o0_; ik1 = o1; ik2 = o2; ++i; }
+                    else {
+                        ik0 = o0_; ik1 = o1; ik2 = o2; ++i;
+                        ones = ik2 == 1 ? ones + 1 : 0;
+                        if (direct_ok && ones >= SEED4_DIRECT_AFTER) { dpos = fm_sa<I>(fm, ik0); phase = S4_DIR; }
+                    }
                 }
             }
         } else {
@@ -394,18 +456,21 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     }
 #if SEED4_DEBUG
     if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        ck.dbg_cyc[64 + (size_t)blockIdx.x * 2 + (threadIdx.x >> 6)] = t_end - d_t0;   // this wave's lifetime
+        atomicMax(ck.dbg_cyc + 31, t_end - d_t0);
+        for (int ph = 0; ph < 8; ++ph) atomicAdd(ck.dbg_cyc + 8 + ph, d_ph[ph]);
         atomicAdd(ck.dbg_cyc + 0, d_fsteps); atomicAdd(ck.dbg_cyc + 1, d_flanes); atomicAdd(ck.dbg_cyc + 2, d_bsteps); atomicAdd(ck.dbg_cyc + 3, d_blanes);
-        atomicAdd(ck.dbg_cyc + 4, d_rounds); atomicAdd(ck.dbg_cyc + 5, d_ev);
+        atomicAdd(ck.dbg_cyc + 4, d_rounds); atomicAdd(ck.dbg_cyc + 5, d_ev); atomicAdd(ck.dbg_cyc + 6, d_dsteps); atomicAdd(ck.dbg_cyc + 7, d_dlanes);
     }
 #endif
 }
 
-// pass 3 (bwt_seed_strategy1: forward-only LAST-like seeds) + the per-read epilogue of mem_collect_intv / prologue of mem_chain
-// (sort by (start, end), repetitive length, seed-occurrence bound).  One lane per read, one forward extend per base: lanes of a wave run
-// in lock step for reads of equal length.  Same loop as k_seed3 of dev_seed2.h with the forward step of this file (two masked
-// popcounts per block instead of all four symbol counts).
+// pass 3 (bwt_seed_strategy1: forward-only LAST-like seeds); the per-read epilogue follows in k_seed_epi.  One lane per read, one forward extend per base: lanes of a wave run
+// in lock step for reads of equal length, with the forward step of this file (two masked popcounts per block instead of all four
+// symbol counts).
 template <typename I>
-__global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt)
 {
     const slx_opt &opt = dopt.o;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -421,7 +486,10 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt do
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
     if (opt.max_mem_intv > 0) {                      // bwt_seed_strategy1 from every position a seed ended at
         int x = len >= opt.min_seed_len ? 0 : len, i = 0;
-        bool fresh = true;
+        bool fresh = true, dir = false;                 // dir: the interval is one occurrence at text position dpos (see the D loop of k_seed12m)
+        int64_t dpos = 0;
+        RWin rwin; rwin.bits = 0; rwin.chunk = -1;
+        const bool direct_ok = fm.sa_dense != nullptr;
         I k0 = 0, k1 = 0, k2 = 0;
         const int K = (fm.lut && fm.lut_k <= opt.min_seed_len) ? fm.lut_k : 0;   // k-mer table (see k_kmer_lut)
         const LutE<I> *lut = (const LutE<I> *)fm.lut;
@@ -444,46 +512,97 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, Chunk ck, DevOpt do
             if (!__any(act)) break;
             if (act) {
                 const int cq = qb(i);
-                if (cq > 3) { x = i + 1; fresh = true; }
+                if (cq > 3) { x = i + 1; fresh = true; dir = false; }
                 else {
-                    I o0, o1, o2;
-                    fwd_step<I>(fm, k0, k1, k2, cq, o0, o1, o2);
+                    I o0 = k0, o1 = k1, o2 = 0;
+                    if (dir) {                          // one occurrence: kept while the text goes on like the read
+                        const int64_t tp = dpos + (int64_t)(i - x);
+                        o2 = (k2 != 0 && tp < (R.l_pac << 1) && text_at(R, tp, rwin) == cq) ? (I)1 : (I)0;
+                    } else if (k2 != 0) fwd_step<I>(fm, k0, k1, k2, cq, o0, o1, o2);      // (an empty interval stays empty: bwa walks on to min_seed_len)
                     if (o2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
                         if (o2 > 0) {
                             if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = o0; ox2[n_out] = o2; ++n_out; }
                             else out_ovf = true;
                         }
-                        x = i + 1; fresh = true;
-                    } else { k0 = o0; k1 = o1; k2 = o2; ++i; }
+                        x = i + 1; fresh = true; dir = false;
+                    } else {
+                        k0 = o0; k1 = o1; k2 = o2; ++i;
+                        if (!dir && direct_ok && k2 == 1 && x + opt.min_seed_len - i >= 2) { dpos = fm_sa<I>(fm, k0); dir = true; }
+                    }
                 }
             }
         }
     }
     if (!live) return;
-    // sort by (start, end): entries with equal keys are identical intervals, so any exact sort matches ks_introsort
-    for (int a = 1; a < n_out; ++a) {
-        const uint32_t ki = oinfo[a]; const I s0 = ox0[a], s2 = ox2[a];
-        int b = a - 1;
-        while (b >= 0 && oinfo[b] > ki) { oinfo[b + 1] = oinfo[b]; ox0[b + 1] = ox0[b]; ox2[b + 1] = ox2[b]; --b; }
-        oinfo[b + 1] = ki; ox0[b + 1] = s0; ox2[b + 1] = s2;
-    }
-    // mem_chain prologue: repetitive fraction and the number of seed occurrences to look up
+    ck.intv_n[r] = (uint32_t)n_out;
+    if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+}
+
+// per-read epilogue of mem_collect_intv / prologue of mem_chain: sort the kept intervals by (start, end) -- entries with equal keys are
+// identical intervals, so any exact sort matches ks_introsort -- then the repetitive length and the number of seed occurrences to look
+// up.  One lane per read.  A read's ~13 intervals sit in its own 3 x 160-byte slice of the interval arrays, so an insertion sort in
+// place is a chain of dependent, uncoalesced loads and read-modify-write stores (it was more than half of k_seed3m's time and 28x write
+// amplification); here the slice is loaded once (independent loads), sorted in LDS (entry e of lane l at e * 64 + l: conflict-free) and
+// written back once.  Reads with more than SEED_EPI_N intervals (repeats) sort in place as before.
+#define SEED_EPI_N 20
+template <typename I>
+__global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt)
+{
+    const slx_opt &opt = dopt.o;
+    __shared__ uint32_t s_info[SEED_EPI_N * 64];
+    __shared__ I s_x0[SEED_EPI_N * 64], s_x2[SEED_EPI_N * 64];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x * 64 + lane;
+    if (r >= ck.n_reads) return;
+    const size_t ob = (size_t)r * ck.cap_intv;
+    uint32_t *oinfo = ck.intv_info + ob;
+    I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
+    const int n_out = (int)ck.intv_n[r];
     int b = 0, e = 0, l_rep = 0;
     uint32_t cnt = 0;
-    for (int k = 0; k < n_out; ++k) {
-        const I s = ox2[k];
+    auto account = [&](uint32_t inf, I s) {          // mem_chain prologue, entries in sorted order
         if (s > (I)opt.max_occ) {
-            const int sb = (int)(oinfo[k] >> 16), se = (int)(oinfo[k] & 0xffff);
+            const int sb = (int)(inf >> 16), se = (int)(inf & 0xffff);
             if (sb > e) { l_rep += e - b; b = sb; e = se; }
             else e = e > se ? e : se;
             const I step = s / (I)opt.max_occ;
             const I cc = (s + step - 1) / step;
             cnt += (uint32_t)(cc < (I)opt.max_occ ? cc : (I)opt.max_occ);
         } else cnt += (uint32_t)s;
+    };
+    if (n_out <= SEED_EPI_N) {
+        for (int a = 0; a < n_out; a += 4) {         // four entries' loads in flight at a time
+            uint32_t ki[4]; I v0[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (a + u < n_out) { ki[u] = oinfo[a + u]; v0[u] = ox0[a + u]; v2[u] = ox2[a + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (a + u < n_out) { s_info[(a + u) * 64 + lane] = ki[u]; s_x0[(a + u) * 64 + lane] = v0[u]; s_x2[(a + u) * 64 + lane] = v2[u]; }
+        }
+        bool moved = false;
+        for (int a = 1; a < n_out; ++a) {
+            const uint32_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
+            int p = a - 1;
+            while (p >= 0 && s_info[p * 64 + lane] > ki) {
+                s_info[(p + 1) * 64 + lane] = s_info[p * 64 + lane]; s_x0[(p + 1) * 64 + lane] = s_x0[p * 64 + lane]; s_x2[(p + 1) * 64 + lane] = s_x2[p * 64 + lane];
+                --p;
+            }
+            if (p + 1 != a) { s_info[(p + 1) * 64 + lane] = ki; s_x0[(p + 1) * 64 + lane] = k0; s_x2[(p + 1) * 64 + lane] = k2; moved = true; }
+        }
+        for (int a = 0; a < n_out; ++a) {
+            const uint32_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
+            if (moved) { oinfo[a] = ki; ox0[a] = k0; ox2[a] = k2; }
+            account(ki, k2);
+        }
+    } else {
+        for (int a = 1; a < n_out; ++a) {
+            const uint32_t ki = oinfo[a]; const I s0 = ox0[a], s2 = ox2[a];
+            int p = a - 1;
+            while (p >= 0 && oinfo[p] > ki) { oinfo[p + 1] = oinfo[p]; ox0[p + 1] = ox0[p]; ox2[p + 1] = ox2[p]; --p; }
+            oinfo[p + 1] = ki; ox0[p + 1] = s0; ox2[p + 1] = s2;
+        }
+        for (int k = 0; k < n_out; ++k) account(oinfo[k], ox2[k]);
     }
     l_rep += e - b;
-    ck.intv_n[r] = (uint32_t)n_out;
     ck.l_rep[r] = l_rep;
     ck.seed_cnt[r] = (unsigned long long)cnt;
-    if (out_ovf) atomicOr(ck.flags, OVF_INTV);
 }

@@ -20,7 +20,6 @@
 #include <type_traits>
 #include <vector>
 #include "slx_internal.h"
-#include "dev_seed2.h"
 #include "dev_seed4.h"
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
@@ -140,7 +139,6 @@ struct slx_aligner {
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
     int lut_k = -1;               // k-mer table of the seeding kernels (dev_seed4.h, k_kmer_lut): 4^k entries of 8 / 16 bytes; 0 = none,
                                   // -1 = by index size (measured best where a k-mer still has a handful of occurrences: log4(symbols) - 1)
-    int seed_mode = 4;            // 4 = wave-level mode loops (dev_seed4.h), 2 = one extend per trip of a per-lane state machine (dev_seed2.h)
     int keep_stages = 0;          // test hook: keep what slx_debug_stage reads (copies of the chain order / region list before de-duplication)
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
@@ -475,7 +473,6 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         (void)hipSetDevice(al->device);
         return al->wide ? build_lut<uint64_t>(al) : build_lut<uint32_t>(al);
     }
-    else if (!strcmp(key, "seed_mode")) { if (value != 2 && value != 4) return SLX_EINVAL; al->seed_mode = (int)value; }
     else if (!strcmp(key, "cand_mode")) al->cand_mode = (int)value;
     else if (!strcmp(key, "cand_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_seeds = (int)value; }
     else if (!strcmp(key, "heavy_sorted")) al->heavy_sorted = (int)value;
@@ -703,10 +700,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     (void)hipEventRecord(wk->ev_probe[0], st);
-    if (al->seed_mode == 4) hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-    else hipLaunchKernelGGL(k_seed12<I>, dim3(grid), dim3(bs), 0, st, fm, ck, dopt, wk->queues.as<unsigned int>() + 29);
-    if (al->seed_mode == 4) hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
-    else hipLaunchKernelGGL(k_seed3<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, ck, dopt);
+    hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29);
+    hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, al->ref, ck, dopt);
+    hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, ck, dopt);
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
@@ -892,10 +888,24 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (hipEventElapsedTime(&ms, wk->ev_probe[2 * i], wk->ev_probe[2 * i + 1]) == hipSuccess) wk->probe_ms[i] += ms;
     }
     if (ck.dbg_cyc && ck.dbg_stage == 3) {
-        unsigned long long c6[6];
-        HIPCHK(hipMemcpy(c6, wk->dbg_cyc.p, 48, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[seed12m] forward loop: %.4g wave-steps, %.1f lanes active; backward loop: %.4g wave-steps, %.1f lanes active; %.4g rounds, %.4g with events\n",
-                (double)c6[0], (double)c6[1] / (double)(c6[0] ? c6[0] : 1), (double)c6[2], (double)c6[3] / (double)(c6[2] ? c6[2] : 1), (double)c6[4], (double)c6[5]);
+        unsigned long long c6[16];
+        HIPCHK(hipMemcpy(c6, wk->dbg_cyc.p, 128, hipMemcpyDeviceToHost));
+        {
+            std::vector<unsigned long long> life((size_t)grid * 2);
+            HIPCHK(hipMemcpy(life.data(), wk->dbg_cyc.as<unsigned long long>() + 64, life.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> lv;
+            for (unsigned long long v : life) if (v) lv.push_back(v);
+            std::sort(lv.begin(), lv.end());
+            if (!lv.empty()) {
+                fprintf(stderr, "[seed12m] wave lifetimes (cycle-counter ticks), %zu waves: min %.3g  p10 %.3g  p50 %.3g  p90 %.3g  p99 %.3g  max %.3g\n", lv.size(), (double)lv[0],
+                        (double)lv[lv.size() / 10], (double)lv[lv.size() / 2], (double)lv[lv.size() * 9 / 10], (double)lv[lv.size() * 99 / 100], (double)lv.back());
+            }
+        }
+        fprintf(stderr, "[seed12m] lanes per round by phase: fetch %.1f init %.1f start %.1f fwd %.1f dir %.1f row %.1f bwd %.1f done %.1f\n", (double)c6[8] / (double)c6[4],
+                (double)c6[9] / (double)c6[4], (double)c6[10] / (double)c6[4], (double)c6[11] / (double)c6[4], (double)c6[12] / (double)c6[4], (double)c6[13] / (double)c6[4],
+                (double)c6[14] / (double)c6[4], (double)c6[15] / (double)c6[4]);
+        fprintf(stderr, "[seed12m] forward loop: %.4g wave-steps, %.1f lanes active; backward loop: %.4g wave-steps, %.1f lanes active; %.4g rounds, %.4g with events; direct loop: %.4g wave-steps (32 bases each), %.1f lanes active; %d reads\n",
+                (double)c6[0], (double)c6[1] / (double)(c6[0] ? c6[0] : 1), (double)c6[2], (double)c6[3] / (double)(c6[2] ? c6[2] : 1), (double)c6[4], (double)c6[5], (double)c6[6], (double)c6[7] / (double)(c6[6] ? c6[6] : 1), n);
     } else if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
         std::vector<unsigned long long> cyc((size_t)n * 4), sc((size_t)n);
         std::vector<int> nch((size_t)n), nrg((size_t)n);
@@ -917,6 +927,17 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         float ext_ms = 0;
         (void)hipEventElapsedTime(&ext_ms, wk->ev[4], wk->ev[5]);
         fprintf(stderr, "[ext phases] sort %.3g  covered tests %.3g  extend+store %.3g ticks; extension stage %.1f ms\n", (double)ph[0], (double)ph[1], (double)ph[2], ext_ms);
+        {
+            const int lim[6] = {2, 8, 48, 128, 256, 640};
+            for (int b = 0; b < 6; ++b) {
+                long cnt = 0; unsigned long long cy = 0, a = 0, bb = 0, c = 0;
+                for (int i = 0; i < n; ++i)
+                    if (nrg[(size_t)i] >= lim[b] && (b == 5 || nrg[(size_t)i] < lim[b + 1])) {
+                        ++cnt; cy += cyc[(size_t)i]; a += cyc[(size_t)n + i]; bb += cyc[2 * (size_t)n + i]; c += cyc[3 * (size_t)n + i];
+                    }
+                fprintf(stderr, "[regions >= %d] reads %ld  ticks %.3g (A %.3g B %.3g C %.3g)\n", lim[b], cnt, (double)cy, (double)a, (double)bb, (double)c);
+            }
+        }
         fprintf(stderr, "[ext cycles] n=%d total=%.3g (100 MHz ticks) heavy share=%.3f\n", n, (double)tot, tot ? (double)tot_heavy / (double)tot : 0.0);
         for (int i = 0; i < top; ++i) {
             const size_t r = (size_t)ord[(size_t)i];
