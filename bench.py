@@ -335,7 +335,7 @@ def main():
             if pmc and pmc.get("config") == args.config:
                 traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / launches
                 src = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % PMC_SUMMARY
-            roof = dict(bound="hbm", kernel="k_seed12 + k_seed3", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            roof = dict(bound="hbm", kernel="k_seed12m + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src, launches_per_step=launches, reads_per_launch=n / launches,
                         kernel_ms=seed_ms, kernel_ms_mean_launch=seed_ms / launches, timing="HIP events on each worker's own stream around the two kernels, summed over the step's launches",
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,

@@ -60,9 +60,10 @@ try:
     reads = bench["reads_per_seed_launch"]
 except Exception:
     bench, reads = None, {"C2": 10e6 / 3, "C3": 50e6 / 6}.get(config, 1.0)
-seed12, seed3 = (pick("k_seed12") or ["k_seed12"])[0], (pick("k_seed3") or ["k_seed3"])[0]
-fetch = (g(seed12, "FETCH_SIZE") + g(seed3, "FETCH_SIZE")) * 1024.0 / reads
-write = (g(seed12, "WRITE_SIZE") + g(seed3, "WRITE_SIZE")) * 1024.0 / reads
+seed12 = (pick("k_seed12") or ["k_seed12m"])[0]
+seed_all = pick("k_seed")                     # k_seed12m, k_seed3m, k_seed_epi
+fetch = sum(g(k, "FETCH_SIZE") for k in seed_all) * 1024.0 / reads
+write = sum(g(k, "WRITE_SIZE") for k in seed_all) * 1024.0 / reads
 ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep")]
 ext_inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ext)
 ext_gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ext)

@@ -17,8 +17,8 @@
 // Measured on C3 (SEED4_DEBUG): per read ~72 backward, ~12 rank-based forward and ~5 direct steps; the backward loop is 86 % of the wave
 // steps and runs with 15 of 64 lanes while ~30 wait in the forward phases.  Two schedules that keep more lanes busy were measured and
 // dropped: serving the short loops as soon as they hold half as many lanes as the backward one (3 x the rounds, same time), and ONE loop
-// in which every lane takes whichever step it is due (26 lanes per trip and a third fewer trips, but each trip pays the rank reads and
-// the text reads one after the other: 67 ms against 55).
+// in which every lane takes whichever step it is due (28 lanes per trip and a third fewer trips, but a trip that carries all three
+// kinds of step costs 1.6 x a single-kind one even with every load issued up front: 59 ms against 55).
 #pragma once
 #include "dev_occ.h"
 
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 }
             }
         }
-    }
+        }
 #if SEED4_DEBUG
     if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
         const unsigned long long t_end = __builtin_readcyclecounter();
