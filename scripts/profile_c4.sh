@@ -5,6 +5,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --config C4h --reads 12000000 --no-cpu-baseline --no-extras --verify 0 --steps 1 --warmup 1"
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/c4_under_rocprof.log 2>&1
+grep '^{"metric"' $OUT/c4_under_rocprof.log > $OUT/bench_under_rocprof.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/c4_kernel_stats.csv
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do

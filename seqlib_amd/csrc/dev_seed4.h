@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
 // written back once.  Reads with more than SEED_EPI_N intervals (repeats) sort in place as before.
 #define SEED_EPI_N 20
 template <typename I>
-__global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned int *max_cnt)
 {
     const slx_opt &opt = dopt.o;
     __shared__ uint32_t s_info[SEED_EPI_N * 64];
@@ -605,4 +605,5 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt)
     l_rep += e - b;
     ck.l_rep[r] = l_rep;
     ck.seed_cnt[r] = (unsigned long long)cnt;
+    if (cnt > 512u) atomicMax(max_cnt, cnt);      // the host skips the big-table launches of later stages when no read can need them
 }

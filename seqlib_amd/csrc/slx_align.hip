@@ -90,6 +90,7 @@ struct Worker {
     size_t last_S1 = 0;
     bool last_valid = false, last_wide = false;
     int id = 0;
+    unsigned int max_seed_cnt = 0;       // of the chunk in flight (k_seed_epi)
     hipEvent_t dbg_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
     hipEvent_t ev[SLX_N_STAGES + 1];
@@ -591,8 +592,9 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
             if (al->regs_big <= REGS_MID_N)
                 hipLaunchKernelGGL((k_regs_wave<MAXQ, REGS_MID_N>), dim3(std::max(1, std::min(n / 64 + 1, al->n_cu * 8))), dim3(64), 0, st, al->ref, ck, dopt, fl,
                                    wk->order_out.as<int>(), q + 11, cnt2 + 1, al->regs_big, REGS_MID_N);
-            hipLaunchKernelGGL((k_regs_wave<MAXQ, REGS_BIG_N>), dim3(std::max(1, std::min(n / 4096 + 1, al->n_cu))), dim3(64), 0, st, al->ref, ck, dopt, fl,
-                               wk->order_out.as<int>(), q + 15, cnt2 + 1, al->regs_big <= REGS_MID_N ? mid + 1 : al->regs_big, 1 << 30);
+            if (mid < 512 || wk->max_seed_cnt > (unsigned int)mid)       // (regions <= seed occurrences; counts up to 512 are not tracked)
+                hipLaunchKernelGGL((k_regs_wave<MAXQ, REGS_BIG_N>), dim3(std::max(1, std::min(n / 4096 + 1, al->n_cu))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                                   wk->order_out.as<int>(), q + 15, cnt2 + 1, al->regs_big <= REGS_MID_N ? mid + 1 : al->regs_big, 1 << 30);
         }
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
     } else   // long reads: every multi-region read on the lane-per-read kernel (its alignment rows in the per-thread scratch)
@@ -617,8 +619,11 @@ static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
 {
     hipLaunchKernelGGL((k_chain_coop<I, 1536, false>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
                        wk->order_out.as<int>(), q + 8, counts + 1, al->coop_lim1);
-    hipLaunchKernelGGL((k_chain_coop<I, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
-                       wk->order_out.as<int>(), q + 10, counts + 1, al->coop_lim2);
+    // the 4 096-chain table only when a read can have more chains than the first table takes (chains <= seed occurrences): in the
+    // pipeline an empty launch of it still waited ~20 ms for a CU with that much free LDS
+    if (std::min(1536, al->coop_lim1) < 512 || wk->max_seed_cnt > (unsigned int)std::min(1536, al->coop_lim1))     // (counts up to 512 are not tracked)
+        hipLaunchKernelGGL((k_chain_coop<I, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+                           wk->order_out.as<int>(), q + 10, counts + 1, al->coop_lim2);
 }
 
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
@@ -702,7 +707,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     (void)hipEventRecord(wk->ev_probe[0], st);
     hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29);
     hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, al->ref, ck, dopt);
-    hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, ck, dopt);
+    hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, ck, dopt, wk->queues.as<unsigned int>() + 31);
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions
@@ -715,8 +720,11 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     uint32_t fl0 = 0;
     HIPCHK(hipMemcpyAsync(&S, wk->seed_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&fl0, ck.flags, 4, hipMemcpyDeviceToHost, st));
+    unsigned int max_cnt = 0;                     // largest seed-occurrence count of a read (0: none above 512): bounds its chains and regions
+    HIPCHK(hipMemcpyAsync(&max_cnt, wk->queues.as<unsigned int>() + 31, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (fl0) { *flags_out = fl0; return SLX_OK; }
+    wk->max_seed_cnt = max_cnt;
     const size_t S1 = (size_t)S + 1;
     ENS(s_rbeg, S1 * 8); ENS(s_ql, S1 * 4); ENS(s_next, S1 * 4); ENS(c_pos, S1 * 8); ENS(c_head, S1 * 4); ENS(c_tail, S1 * 4);
     ENS(c_n, S1 * 4); ENS(c_rid, S1 * 4); ENS(c_w, S1 * 4); ENS(c_first, S1 * 4); ENS(c_kept, S1); ENS(ia, S1 * 4); ENS(ib, S1 * 4);
