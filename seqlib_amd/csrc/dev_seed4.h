@@ -163,6 +163,12 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #ifndef SEED4_FLOOR_SHIFT
 #define SEED4_FLOOR_SHIFT 1   // a mode loop ends when its active lanes drop to (lanes at entry) >> this
 #endif
+#ifndef SEED4_WL_LDS
+#define SEED4_WL_LDS 6        // work-list entries per list and lane held in LDS (u32 index: 18 KB per 128-lane block, 8 blocks per CU)
+#endif
+#ifndef SEED4_WL_LDS_U64
+#define SEED4_WL_LDS_U64 4    // ... u64 index: 20 KB per block at 6 blocks per CU
+#endif
 #ifndef SEED4_ITERS
 #define SEED4_ITERS 24        // steps a mode loop runs at most before the wave looks at events and modes again
 #endif
@@ -189,6 +195,20 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     const int lane = threadIdx.x & 63;
     WorkLists<I> wl;
     wl.base = (IntvE<I> *)ck.lists + (size_t)blockIdx.x * ((size_t)2 * ck.cap_list * 128) + threadIdx.x; wl.stride = 128; wl.cap = ck.cap_list;
+    // the first SEED4_WL_LDS entries of both work lists live in LDS (entry-major: lanes at the same entry hit different banks); with the
+    // k-mer table a list rarely grows beyond a handful of entries (the forward phase only pushes where the interval size changes past the
+    // k-th base), so the global lists -- 3 KB of partial-line writes per read before -- are left to the repeats
+    constexpr int WL = sizeof(I) == 8 ? SEED4_WL_LDS_U64 : SEED4_WL_LDS;
+    __shared__ I s_wx0[2 * WL * 128], s_wx2[2 * WL * 128];
+    __shared__ uint32_t s_winf[2 * WL * 128];
+    auto wl_put = [&](int list, int e, I a, I sz, uint32_t inf) {
+        if (e < WL) { const int o = (list * WL + e) * 128 + (int)threadIdx.x; s_wx0[o] = a; s_wx2[o] = sz; s_winf[o] = inf; }
+        else { IntvE<I> v; v.x0 = a; v.x1 = 0; v.x2 = sz; v.info = inf; wl.at(list, e) = v; }
+    };
+    auto wl_get = [&](int list, int e, I &a, I &sz, uint32_t &inf) {
+        if (e < WL) { const int o = (list * WL + e) * 128 + (int)threadIdx.x; a = s_wx0[o]; sz = s_wx2[o]; inf = s_winf[o]; }
+        else { const IntvE<I> v = wl.at(list, e); a = v.x0; sz = v.x2; inf = v.info; }
+    };
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
     const uint32_t n_reads = (uint32_t)ck.n_reads;
     // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
@@ -225,7 +245,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
 
     auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
     auto push_fwd = [&]() {                        // the current forward interval, ending at i (x[1] is never read back)
-        if (n < wl.cap) { IntvE<I> e; e.x0 = ik0; e.x1 = 0; e.x2 = ik2; e.info = (uint32_t)i; wl.at(1, n) = e; } else list_ovf = true;
+        if (n < wl.cap) wl_put(1, n, ik0, ik2, (uint32_t)i); else list_ovf = true;
         ++n;
     };
     auto out_push = [&](int start, int end, I a, I s) {
@@ -419,8 +439,8 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 ++d_bsteps; d_blanes += (unsigned long long)__popcll(__ballot(act));
 #endif
                 if (act) {
-                    IntvE<I> nx; nx.x0 = 0; nx.x1 = 0; nx.x2 = 0; nx.info = 0;
-                    if (j + 1 < np) nx = wl.at(cur, rev ? np - 2 - j : j + 1);        // the next entry, in flight behind this step's rank reads
+                    I nx0 = 0, nx2 = 0; uint32_t nxinf = 0;
+                    if (j + 1 < np) wl_get(cur, rev ? np - 2 - j : j + 1, nx0, nx2, nxinf);   // the next entry, in flight behind this step's rank reads
                     if (j < np) {                       // (np == 0: a row of the virtual entry alone)
                         RankLd<I> rk, rl;
                         rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
@@ -431,8 +451,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         if (o2 < min_intv) { if (nc == 0) emit_mem(p0, p2, pinf); }
                         else if (nc == 0 || o2 != last_sz) {
                             if (nc == 0) { nh0 = o0_; nh2 = o2; nhinf = pinf; }
-                            IntvE<I> e; e.x0 = o0_; e.x1 = 0; e.x2 = o2; e.info = pinf;
-                            wl.at(1 - cur, nc++) = e;
+                            wl_put(1 - cur, nc++, o0_, o2, pinf);
                             last_sz = o2;
                         }
                     }
@@ -442,14 +461,13 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         if (t <= nv && v2 >= min_intv && (nc == 0 || v2 != last_sz)) {   // the virtual entry [bi, bi + K) joins as the row's last
                             if (nc < wl.cap) {
                                 if (nc == 0) { nh0 = v0; nh2 = v2; nhinf = (uint32_t)(bi + K); }
-                                IntvE<I> e; e.x0 = v0; e.x1 = 0; e.x2 = v2; e.info = (uint32_t)(bi + K);
-                                wl.at(1 - cur, nc++) = e;
+                                wl_put(1 - cur, nc++, v0, v2, (uint32_t)(bi + K));
                             } else list_ovf = true;
                         }
                         if (list_ovf) finish_read();
                         else if (nc == 0 && t >= nv) { if (pass == 1) x = ret; phase = S4_START; }
                         else { cur = 1 - cur; np = nc; rev = 0; --bi; h0 = nh0; h2 = nh2; hinf = nhinf; phase = S4_ROW; }
-                    } else { p0 = nx.x0; p2 = nx.x2; pinf = nx.info; }
+                    } else { p0 = nx0; p2 = nx2; pinf = nxinf; }
                 }
             }
         }
