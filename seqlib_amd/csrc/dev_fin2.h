@@ -366,6 +366,9 @@ __global__ void __launch_bounds__(64) k_regs_wave(DevRef R, Chunk ck, DevOpt dop
         const int nr = __builtin_amdgcn_readfirstlane(ck.n_reg[r]);
         const bool mine = nr >= min_regs && nr <= max_regs;
         if (mine) dev_regs_read_wave<MAXQ>(R, ck, dopt.o, mr, fl, r, lane, &ss);
+#ifdef REGS_SLEEP
+        if (mine && nr >= 256) for (int t = 0; t < REGS_SLEEP; ++t) __builtin_amdgcn_s_sleep(127);   // experiment: a slower tail
+#endif
     }
 }
 

@@ -14,11 +14,14 @@
 // into step (forward together, then backward together).  The price is idle lanes, the gain is that a step costs little more than its
 // extend: the forward step ranks its symbol and "everything greater" (two masked popcounts per block, for both strands' interval
 // starts), the backward step ranks one symbol and never touches x[1] -- no consumer reads it.
-// Measured on C3 (SEED4_DEBUG): per read ~72 backward, ~12 rank-based forward and ~5 direct steps; the backward loop is 86 % of the wave
-// steps and runs with 15 of 64 lanes while ~30 wait in the forward phases.  Two schedules that keep more lanes busy were measured and
-// dropped: serving the short loops as soon as they hold half as many lanes as the backward one (3 x the rounds, same time), and ONE loop
-// in which every lane takes whichever step it is due (28 lanes per trip and a third fewer trips, but a trip that carries all three
-// kinds of step costs 1.6 x a single-kind one even with every load issued up front: 59 ms against 55).
+// Measured on C3 (SEED4_DEBUG): per read ~72 backward, ~12 rank-based forward and ~5 direct steps.  Which loop runs next decides how many
+// lanes each step carries.  "Largest group first, each loop until half of its lanes are through" levels the three groups out at a third
+// of the wave each, and the backward loop -- 86 % of the wave steps -- ran with 15 of 64 lanes.  SEED4_SCHED = 1 works in batches: a short
+// loop (forward, direct) is entered when SEED4_BATCH lanes wait for it and runs until an eighth of them is left; the backward loop keeps
+// going until a batch is ready elsewhere (20 lanes per step, 10 % fewer wave steps, 46 -> 44 ms).  Also measured and dropped: smaller
+// batches (three times the rounds, each paying the events block), and ONE loop in which every lane takes whichever step it is due (28
+// lanes per trip and a third fewer trips, but a trip that carries all three kinds of step costs 1.6 x a single-kind one even with every
+// load issued up front: 59 ms against 55).
 #pragma once
 #include "dev_occ.h"
 
@@ -168,6 +171,19 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #endif
 #ifndef SEED4_WL_LDS_U64
 #define SEED4_WL_LDS_U64 4    // ... u64 index: 20 KB per block at 6 blocks per CU
+#endif
+#ifndef SEED4_SCHED
+#define SEED4_SCHED 1         // 1 = batches (below), 0 = largest group first, each loop until half of its lanes are through
+#endif
+#ifndef SEED4_BATCH
+#define SEED4_BATCH 20
+#endif
+#if SEED4_SCHED == 1
+#define SEED4_SHORT_FLOOR_SHIFT 3
+#define SEED4_ITERS_B 96
+#else
+#define SEED4_SHORT_FLOOR_SHIFT SEED4_FLOOR_SHIFT
+#define SEED4_ITERS_B SEED4_ITERS
 #endif
 #ifndef SEED4_ITERS
 #define SEED4_ITERS 24        // steps a mode loop runs at most before the wave looks at events and modes again
@@ -361,9 +377,19 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         const int nF = __popcll(__ballot(phase == S4_FWD)), nB = __popcll(__ballot(phase == S4_ROW || phase == S4_BWD));
         const int nD = __popcll(__ballot(phase == S4_DIR));
         if (nF == 0 && nB == 0 && nD == 0) continue;
-        if (nD >= nF && nD >= nB) {
+#if SEED4_SCHED == 1
+        // batches: the short loops (forward, direct) are entered when SEED4_BATCH lanes wait for them (or nothing else can run) and run until
+        // nearly all of their lanes are through; the backward loop -- where a read spends most of its steps -- keeps going until that many
+        // lanes are ready for something else
+        const bool goD = nD >= SEED4_BATCH || (nD && nD >= nB && nD >= nF);
+        const bool goF = !goD && (nF >= SEED4_BATCH || (nF && nF >= nB));
+#else
+        const bool goD = nD >= nF && nD >= nB;
+        const bool goF = !goD && nF >= nB;
+#endif
+        if (goD) {
             // ------------------------------------------------ D loop: up to 32 bases against the reference text per step
-            const int floor_ = nD >> SEED4_FLOOR_SHIFT;
+            const int floor_ = nD >> SEED4_SHORT_FLOOR_SHIFT;
             for (int it = 0; it < SEED4_ITERS; ++it) {
                 if (__popcll(__ballot(phase == S4_DIR)) <= floor_ && it) break;
 #if SEED4_DEBUG
@@ -381,9 +407,9 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     }
                 }
             }
-        } else if (nF >= nB) {
+        } else if (goF) {
             // ------------------------------------------------ F loop: one forward extend per step
-            const int floor_ = nF >> SEED4_FLOOR_SHIFT;                 // leave when half of the lanes that entered are gone (they wait in other phases)
+            const int floor_ = nF >> SEED4_SHORT_FLOOR_SHIFT;           // leave when that share of the lanes that entered is left (the others wait in other phases)
             for (int it = 0; it < SEED4_ITERS; ++it) {
                 bool act = phase == S4_FWD;
                 int cq = 4;
@@ -412,8 +438,8 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
             }
         } else {
             // ------------------------------------------------ B loop: one work-list entry against the row's base per step
-            const int floor_ = nB >> SEED4_FLOOR_SHIFT;
-            for (int it = 0; it < SEED4_ITERS; ++it) {
+            const int floor_ = nB >> SEED4_FLOOR_SHIFT; (void)floor_;
+            for (int it = 0; it < SEED4_ITERS_B; ++it) {
                 if (phase == S4_ROW) {                  // start of the backward row at query position bi; its first entry is in registers
                     int t = -1;
                     if (bi >= 0) { t = qb(bi); if (t > 3) t = -1; }
@@ -434,7 +460,15 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     }
                 }
                 const bool act = phase == S4_BWD;
+#if SEED4_SCHED == 1
+                {
+                    const int n_fwd = __popcll(__ballot(phase == S4_START || phase == S4_INIT || phase == S4_FWD || (phase == S4_FETCH && pool_next != pool_end)));
+                    const int n_dir = __popcll(__ballot(phase == S4_DIR));
+                    if (it && (!__any(act) || n_fwd >= SEED4_BATCH || n_dir >= SEED4_BATCH)) break;
+                }
+#else
                 if (__popcll(__ballot(act)) <= floor_ && it) break;
+#endif
 #if SEED4_DEBUG
                 ++d_bsteps; d_blanes += (unsigned long long)__popcll(__ballot(act));
 #endif
