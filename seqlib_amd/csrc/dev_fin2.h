@@ -62,6 +62,9 @@ __device__ int wave_ksw_global2(int qlen_, QF qf, int tlen_, TF tf, const slx_op
     }
     int tb_cur = lane < tlen ? tf(lane) : 0;
     int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+#ifdef CIG_NOUNROLL
+#pragma unroll 1
+#endif
     for (int i = 0; i < tlen; ++i) {
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
@@ -155,6 +158,9 @@ __device__ int wave_ksw_global2_band(int qlen_, QF qf, int tlen_, TF tf, const s
     }
     int tb_cur = lane < tlen ? tf(lane) : 0;
     int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+#ifdef CIG_NOUNROLL
+#pragma unroll 1
+#endif
     for (int i = 0; i < tlen; ++i) {
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
@@ -484,7 +490,7 @@ __device__ void dev_traceback_wave(const uint8_t *z, int n_col, int qlen, int tl
 // fuses that loop, the early exits and the three-band do/while into a single loop nest (observed: a wave re-entering
 // it with a stale job index and never finishing); a call boundary keeps the queue loop a plain fetch / test / call.
 template <int MAXQ>
-__device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl,
+static __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl,
                                             uint32_t slot, int lane)
 {
     constexpr int CPLMAX = (MAXQ + 1 + WAVE - 1) / WAVE;
@@ -572,7 +578,7 @@ __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, co
 }
 
 #ifndef CIG_MIN_WAVES
-#define CIG_MIN_WAVES 2
+#define CIG_MIN_WAVES 4
 #endif
 template <int MAXQ>
 __global__ void __launch_bounds__(64, CIG_MIN_WAVES) k_cig_dp(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, int hi_prio)
