@@ -93,8 +93,18 @@ int  slx_index_n_holes(const slx_index *idx);
  * NULL/0 = current device. */
 int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
 void slx_aligner_free(slx_aligner *al);
-/* tuning / test knobs: "chunk_reads", "cap_intv", "dense_sa" (1 = SA decompressed to sa_intv 1 in HBM,
- * 0 = bwa's sa_intv walk), "threads" */
+/* Tuning / test knobs; none of them changes a result (tests/test_gpu_parity.py runs each against the oracle).
+ *   "workers" 1..8 (3)        host workers = HIP streams a batch is split over
+ *   "chunk_reads" (1 << 24)   reads per launch of a worker;  "min_split"  smallest batch that is split over workers at all
+ *   "dense_sa" 0|1 (1)        1 = suffix array decompressed to sa_intv 1 in HBM, 0 = bwa's sampled-SA walk
+ *   "lut_k" -1|0|2..14 (-1)   width of the k-mer table of the seeding kernels (4^k x 8 or 16 bytes); -1 = by index size, 0 = none
+ *   "threads"                 lanes of the persistent seeding kernel (default 1 536 per CU)
+ *   "cap_intv"                kept SMEM intervals per read the first attempt allows (overflow -> the chunk is re-run with twice as many)
+ *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
+ *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
+ *   "wide_index" 1            test hook: run an index below 2^32 symbols through the u64 kernels
+ *   "keep_stages" 1           test hook: keep what slx_debug_stage reads
+ * Returns SLX_EINVAL for an unknown key or a value out of range. */
 int  slx_aligner_set(slx_aligner *al, const char *key, int64_t value);
 
 /* SoA result of a batch.  Hits of read i are [hit_off[i], hit_off[i+1]) in output order (after the
