@@ -262,12 +262,37 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             __threadfence_block();                                   // a[] and G[] were last written by other lanes' stores
             for (int i = ss->lane; i < m; i += 64) { const int h = a[i]; ss->idx[i] = h; fill(h); }
             __syncthreads();
-            if (ss->lane == 0) ks_introsort_idx(m, ss->idx, less_lds);
+            // When no two keys are equal every correct sort gives klib's order, so the wave counts ranks (64 elements at a time against
+            // all m, keys broadcast from LDS): ~m * m / 64 comparisons per lane instead of one lane's m log m at LDS latency.  With a tie
+            // anywhere the tie order of ks_introsort shows in the output: then the serial algorithm itself runs, on one lane as before.
+            bool tie = m > 768;                                      // (beyond that the quadratic count costs more than it saves on average)
+            if (!tie) for (int e = ss->lane; e < m; e += 64) {
+                const int he = ss->idx[e];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) {
+                    const int hj = ss->idx[j];
+                    const bool lt = less_lds(hj, he);
+                    rank += lt ? 1 : 0;
+                    if (!lt && j != e && !less_lds(he, hj)) tie = true;
+                }
+                ss->m_w[e] = rank;                                   // (m_w / m_rid are free during the three sorts)
+            }
+            if (!__any(tie)) {
+                __syncthreads();
+                for (int e = ss->lane; e < m; e += 64) ss->m_rid[ss->m_w[e]] = ss->idx[e];
+                __syncthreads();
+                for (int e = ss->lane; e < m; e += 64) { const int h = ss->m_rid[e]; ss->idx[e] = h; a[e] = h; }
+            } else {
+                __syncthreads();
+                if (ss->lane == 0) ks_introsort_idx(m, ss->idx, less_lds);
+                __syncthreads();
+                for (int i = ss->lane; i < m; i += 64) a[i] = ss->idx[i];
+            }
             __syncthreads();
-            for (int i = ss->lane; i < m; i += 64) a[i] = ss->idx[i];
             __threadfence_block();
         };
-        for (int i = 0; i < n; ++i) a[i] = i;
+        if (staged) { for (int i = ss->lane; i < n; i += 64) a[i] = i; __threadfence_block(); }
+        else for (int i = 0; i < n; ++i) a[i] = i;
         // ---------------- mem_sort_dedup_patch
         if (n > 1) {
             sort_handles(n, [&](int h) { ss->k64[h] = G[h].re; },
@@ -384,8 +409,24 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 }
             }
             if (dbg) t2 = __builtin_readcyclecounter();
+            // lane-parallel compaction of the handle list when staged: ss->idx still holds a[] and kb / m_qe mirror qb / qe
+            auto compact_staged = [&](int n_in, int first_forced) {
+                int m = 0;
+                for (int base = 0; base < n_in; base += 64) {
+                    const int i = base + ss->lane;
+                    const int h = i < n_in ? ss->idx[i] : 0;
+                    const bool keep = i < n_in && (i < first_forced || ss->m_qe[h] > ss->kb[h]);
+                    const unsigned long long km = __ballot(keep);
+                    const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                    if (keep) a[pos] = h;                          // pos <= i, and the source is the LDS copy
+                    m += (int)__popcll(km);
+                }
+                __threadfence_block();
+                return m;
+            };
             int m = 0;
-            for (int i = 0; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
+            if (staged) m = compact_staged(n, 0);
+            else for (int i = 0; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
             n = m;
             sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = G[h].rb; ss->kb[h] = G[h].qb; },
                          [&](int x, int y) {
@@ -397,19 +438,31 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                              const DReg &X = G[x], &Y = G[y];
                              return X.score > Y.score || (X.score == Y.score && (X.rb < Y.rb || (X.rb == Y.rb && X.qb < Y.qb)));
                          });
-            for (int i = 1; i < n; ++i)
-                if (G[a[i]].score == G[a[i - 1]].score && G[a[i]].rb == G[a[i - 1]].rb && G[a[i]].qb == G[a[i - 1]].qb)
-                    G[a[i]].qe = G[a[i]].qb;
-            m = n > 0 ? 1 : 0;
-            for (int i = 1; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
-            n = m;
+            if (staged) {                                         // keys of the sort are in LDS by handle; the tests do not read what they change
+                for (int i = 1 + ss->lane; i < n; i += 64) {
+                    const int h = ss->idx[i], hp = ss->idx[i - 1];
+                    if (ss->ka[h] == ss->ka[hp] && ss->k64[h] == ss->k64[hp] && ss->kb[h] == ss->kb[hp]) { G[h].qe = ss->kb[h]; ss->m_qe[h] = ss->kb[h]; }
+                }
+                __syncthreads();
+                n = compact_staged(n, 1);
+            } else {
+                for (int i = 1; i < n; ++i)
+                    if (G[a[i]].score == G[a[i - 1]].score && G[a[i]].rb == G[a[i - 1]].rb && G[a[i]].qb == G[a[i - 1]].qb)
+                        G[a[i]].qe = G[a[i]].qb;
+                m = n > 0 ? 1 : 0;
+                for (int i = 1; i < n; ++i) if (G[a[i]].qe > G[a[i]].qb) a[m++] = a[i];
+                n = m;
+            }
         }
         if (dbg) t3 = __builtin_readcyclecounter();
         ck.na[r] = n;
         // ---------------- mem_mark_primary_se (salt = this read's lrand48() draw)
         if (n > 0) {
             const uint64_t id = dev_lrand48_nth(ck.rng_state, ck.first_ordinal + (uint64_t)r + 1);
-            for (int i = 0; i < n; ++i) {
+            if (staged) {
+                for (int i = ss->lane; i < n; i += 64) { DReg &p = G[a[i]]; p.sub = 0; p.secondary = -1; p.hash = dev_hash_64(id + (uint64_t)i); }
+                __threadfence_block();
+            } else for (int i = 0; i < n; ++i) {
                 DReg &p = G[a[i]];
                 p.sub = 0; p.secondary = -1;
                 p.hash = dev_hash_64(id + (uint64_t)i);
@@ -426,6 +479,53 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             int tmp = opt.a + opt.b;
             tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
             tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
+            if (staged) {
+                // The scan over the primaries found so far (z) is the serial part: for a many-region read it is a few hundred entries
+                // long.  Region fields come from LDS (kb = qb, m_qe = qe, ka = score, by handle), 64 primaries are tested per step and a
+                // ballot finds the first that overlaps, as the scalar loop would; sub / sub_n / secondary are kept in LDS (m_rid, m_w and
+                // the two halves of k64, free after the last sort) and written back once.
+                const int lane = ss->lane;
+                int *l_sub = ss->m_rid, *l_subn = ss->m_w, *l_sec = (int *)ss->k64, *l_z = (int *)ss->k64 + ss->nmax;
+                __syncthreads();
+                for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; l_sub[h] = 0; l_subn[h] = G[h].sub_n; l_sec[h] = -1; }
+                if (lane == 0) l_z[0] = 0;
+                __syncthreads();
+                int nz = 1;
+                for (int i = 1; i < n; ++i) {
+                    const int hi = ss->idx[i];
+                    const int i_qb = ss->kb[hi], i_qe = ss->m_qe[hi], i_sc = ss->ka[hi];
+                    int found = -1;
+                    for (int kb0 = 0; kb0 < nz && found < 0; kb0 += 64) {
+                        const int k = kb0 + lane;
+                        bool hit = false;
+                        if (k < nz) {
+                            const int hj = ss->idx[l_z[k]];
+                            const int j_qb = ss->kb[hj], j_qe = ss->m_qe[hj];
+                            const int b_max = j_qb > i_qb ? j_qb : i_qb;
+                            const int e_min = j_qe < i_qe ? j_qe : i_qe;
+                            if (e_min > b_max) {
+                                const int min_l = i_qe - i_qb < j_qe - j_qb ? i_qe - i_qb : j_qe - j_qb;
+                                hit = (float)(e_min - b_max) >= (float)min_l * opt.mask_level;
+                            }
+                        }
+                        const unsigned long long hm = __ballot(hit);
+                        if (hm) found = kb0 + (int)__ffsll((long long)hm) - 1;
+                    }
+                    if (found >= 0) {
+                        if (lane == 0) {
+                            const int zi = l_z[found];
+                            const int hj = ss->idx[zi];
+                            if (l_sub[hj] == 0) l_sub[hj] = i_sc;
+                            if (ss->ka[hj] - i_sc <= tmp) ++l_subn[hj];
+                            l_sec[hi] = zi;
+                        }
+                    } else { if (lane == 0) l_z[nz] = i; ++nz; }
+                    __syncthreads();
+                }
+                for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; DReg &p = G[h]; p.sub = l_sub[h]; p.sub_n = l_subn[h]; p.secondary = l_sec[h]; }
+                __threadfence_block();
+                __syncthreads();
+            } else {
             int *z = w.ib, nz = 0;
             z[nz++] = 0;
             for (int i = 1; i < n; ++i) {
@@ -446,6 +546,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 }
                 if (k == nz) z[nz++] = i;
                 else ai.secondary = z[k];
+            }
             }
         }
         if (dbg) {

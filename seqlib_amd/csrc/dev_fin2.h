@@ -283,6 +283,21 @@ __device__ void dev_regs_read(const DevRef &R, const Chunk &ck, const slx_opt &o
     const DReg *G = w.regs;
     const uint64_t so = ck.seed_off[r];
     int nh = 0;
+    if (ss) {                                         // wave per read: one region per lane, slots by a ballot prefix
+        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + ss->lane;
+            DReg ar;
+            bool keep = false;
+            if (i < n) { ar = G[a[i]]; keep = !(ar.secondary != 0 && drop_sec); }
+            const unsigned long long km = __ballot(keep);
+            const int pos = nh + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            if (keep) dev_reg_emit(ck, opt, fl, r, so + pos, ar, true);
+            nh += (int)__popcll(km);
+        }
+        if (leader) ck.n_hit[r] = nh;
+        return;
+    }
     for (int i = 0; i < n; ++i)
         if (dev_reg_emit(ck, opt, fl, r, so + nh, G[a[i]], leader)) ++nh;
     if (leader) ck.n_hit[r] = nh;
