@@ -48,6 +48,14 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         bool dup = false;                         // two chains share a position: from the 10th chain on bwa's kbtree is no longer a sorted array
         KbTree kb;                                // ... then the set continues as the tree itself (dev_kbtree.h), every lane running the same steps
         bool tree = false;                        //     on nodes kept in the read's region slots
+        // Per-chain summary of what test_and_merge reads, by chain handle, in the LDS arrays the filter phase only needs later
+        // (s_w, s_cb, s_ce, s_first, s_kept): the chain's last seed (query start << 16 | length, reference start relative to the chain's
+        // position = its first seed's reference start), its first seed's query start << 16 | the chain's seed count, and its contig.  A seed then costs no global load
+        // while the set is a sorted array (the position comes from s_pos) and one (c_pos) once it is a tree -- it was two dependent round
+        // trips (c_head / c_tail, then the seeds), which under the seeding kernels' memory pressure made this the most stretched kernel of
+        // the pipeline.  The global arrays are still written, as the later phases and kernels read them.
+        int *l_tail = s_w, *l_lastql = s_cb, *l_lastoff = s_ce, *l_firstql = s_first, *l_rid = s_kept;
+        const bool cnt16 = ck.seed_off[r + 1] - ck.seed_off[r] < 65536;      // (the count fits 16 bits; else it is read back from c_n)
         // ---------------- mem_chain: seeds in interval order, occurrences in rank order
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
@@ -83,20 +91,25 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                         }
                         if (lower_c >= 0) {       // test_and_merge
                             const int c = lower_c;
-                            const int first = w.c_head[c], last = w.c_tail[c];
-                            const int l_qbeg = w.s_qbeg(last), l_len = w.s_len(last);
-                            const int64_t l_rbeg = w.s_rbeg[last];
+                            const int last = l_tail[c];
+                            const uint32_t lql = (uint32_t)l_lastql[c], fql = (uint32_t)l_firstql[c];
+                            const int l_qbeg = (int)(lql >> 16), l_len = (int)(lql & 0xffff);
+                            const int64_t f_rbeg = tree ? w.c_pos[c] : s_pos[lo];          // a chain's position is its first seed's reference start
+                            const int64_t l_rbeg = f_rbeg + l_lastoff[c];
                             const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
                             int res;
-                            if (rid != w.c_rid[c]) res = 0;
-                            else if (qbeg >= w.s_qbeg(first) && qbeg + slen <= qend && rbeg >= w.s_rbeg[first] && rbeg + slen <= rend) res = 1;
-                            else if ((l_rbeg < R.l_pac || w.s_rbeg[first] < R.l_pac) && rbeg >= R.l_pac) res = 0;
+                            if (rid != l_rid[c]) res = 0;
+                            else if (qbeg >= (int)(fql >> 16) && qbeg + slen <= qend && rbeg >= f_rbeg && rbeg + slen <= rend) res = 1;
+                            else if ((l_rbeg < R.l_pac || f_rbeg < R.l_pac) && rbeg >= R.l_pac) res = 0;
                             else {
                                 const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                                 if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
-                                    const int s = ns++;   // every lane stores the same bytes, so every lane may read them back
+                                    const int s = ns++;   // every lane stores the same bytes
                                     w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
-                                    w.s_next[last] = s; w.c_tail[c] = s; w.c_n[c] = w.c_n[c] + 1;
+                                    w.s_next[last] = s; w.c_tail[c] = s;
+                                    if (cnt16) { l_firstql[c] = (int)(fql + 1u); w.c_n[c] = (int)(fql & 0xffff) + 1; }     // the count rides in the low half
+                                    else w.c_n[c] = w.c_n[c] + 1;
+                                    l_tail[c] = s; l_lastql[c] = (int)(((uint32_t)qbeg << 16) | (uint32_t)slen); l_lastoff[c] = (int)(rbeg - f_rbeg);
                                     res = 1;
                                 } else res = 0;
                             }
@@ -121,6 +134,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                         const int s = ns++, c = nc;
                         w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                         w.c_pos[c] = rbeg; w.c_head[c] = s; w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
+                        l_tail[c] = s; l_lastql[c] = (int)(((uint32_t)qbeg << 16) | (uint32_t)slen); l_firstql[c] = (int)(((uint32_t)qbeg << 16) | 1u); l_lastoff[c] = 0; l_rid[c] = rid;
                         if (tree) kb.put(rbeg, c);
                         else {
                             // ordered insert at rank lo+1: lanes shift the tail up by one, highest block first
