@@ -504,9 +504,20 @@ __device__ void dev_traceback_wave(const uint8_t *z, int n_col, int qlen, int tl
 // One CIGAR job on one wave.  Kept out of line on purpose: with the body inlined into the queue loop the compiler
 // fuses that loop, the early exits and the three-band do/while into a single loop nest (observed: a wave re-entering
 // it with a stale job index and never finishing); a call boundary keeps the queue loop a plain fetch / test / call.
+// What a wave of k_cig_dp keeps between jobs, so that a job costs no fetch-add on a device-wide address (~10 ns each, serialised: with
+// three per job they, not the DP, set the kernel's time): its own stretch of the traceback arena, reused by every job that fits, and
+// the CIGAR words it has reserved ahead.
+struct CigWaveState {
+    uint8_t *z_own; unsigned long long z_own_cap;
+    unsigned long long cig_next, cig_end;
+};
+#define CIG_WAVE_Z (16u << 10)     // bytes of traceback arena per wave (a 150 bp job needs ~6 KB; larger ones allocate from the shared part)
+#define CIG_WAVE_WORDS 256u        // CIGAR words a wave reserves at a time
+#define CIG_BATCH 4                // jobs per queue fetch
+
 template <int MAXQ>
 static __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const MatRows &mr, const FinLists &fl,
-                                            uint32_t slot, int lane)
+                                            uint32_t slot, int lane, CigWaveState &ws)
 {
     constexpr int CPLMAX = (MAXQ + 1 + WAVE - 1) / WAVE;
     const DJob j = fl.jobs[slot];
@@ -539,13 +550,16 @@ static __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk 
             ww = ww > min_w ? ww : min_w;
             w_used = ww;
             n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
-            unsigned long long off = 0;
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
-            if (lane == 0) off = atomicAdd(ck.zused, need);
-            off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
-                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
-            if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return; }
-            z = ck.zarena + off;
+            if (need <= ws.z_own_cap) z = ws.z_own;                  // (a wider band of the same job overwrites the narrower one's bytes)
+            else {
+                unsigned long long off = 0;
+                if (lane == 0) off = atomicAdd(ck.zused, need);
+                off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                      (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
+                if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return; }
+                z = ck.zarena + off;
+            }
             if (2 * ww + 1 <= WAVE && lq <= (MAXQ + 2 + WAVE - 1) / WAVE * WAVE)
                 score = wave_ksw_global2_band<(MAXQ + 2 + WAVE - 1) / WAVE>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
             else if (lq + 1 <= WAVE) score = wave_ksw_global2<1>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, lane);
@@ -566,10 +580,15 @@ static __device__ __noinline__ void dev_cig_dp_job(const DevRef &R, const Chunk 
     n_ops = __builtin_amdgcn_readfirstlane(n_ops);
     unsigned long long base = 0;
     const unsigned long long need = (unsigned long long)n_ops + 2;
-    if (lane == 0) base = atomicAdd(ck.cigused, need);
-    base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-           (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
-    if (base + need > ck.cigcap) { if (lane == 0) atomicOr(ck.flags, OVF_CIGAR); return; }
+    if (ws.cig_next + need > ws.cig_end) {               // reserve ahead (what is left of the old reservation stays unused)
+        const unsigned long long take = need > CIG_WAVE_WORDS ? need : (unsigned long long)CIG_WAVE_WORDS;
+        if (lane == 0) base = atomicAdd(ck.cigused, take);
+        base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+               (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+        if (base + take > ck.cigcap) { if (lane == 0) atomicOr(ck.flags, OVF_CIGAR); return; }
+        ws.cig_next = base; ws.cig_end = base + take;
+    }
+    base = ws.cig_next; ws.cig_next += need;
     uint32_t *cg = ck.cigpool + base + 1;
     if (valid) {
         int wp = n_ops;
@@ -602,12 +621,23 @@ __global__ void __launch_bounds__(64, CIG_MIN_WAVES) k_cig_dp(DevRef R, Chunk ck
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
     const MatRows mr = make_matrows(dopt.o.mat);
     const unsigned int n_jobs = *fl.n_dp;
+    if (n_jobs == 0) return;
+    CigWaveState ws;
+    ws.z_own = nullptr; ws.z_own_cap = 0; ws.cig_next = ws.cig_end = 0;
+    if (blockIdx.x < (n_jobs + CIG_BATCH - 1) / CIG_BATCH) {   // (a wave that will find the queue empty takes nothing)
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(ck.zused, (unsigned long long)CIG_WAVE_Z);
+        off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+              (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
+        if (off + CIG_WAVE_Z <= ck.zcap) { ws.z_own = ck.zarena + off; ws.z_own_cap = CIG_WAVE_Z; }
+    }
     for (;;) {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_jobs) break;
-        dev_cig_dp_job<MAXQ>(R, ck, dopt.o, mr, fl, fl.dp_list[t], lane);
+        unsigned int t0 = 0;
+        if (lane == 0) t0 = atomicAdd(fl.q_dp, (unsigned int)CIG_BATCH);
+        t0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t0);
+        if (t0 >= n_jobs) break;
+        const unsigned int t1 = t0 + CIG_BATCH < n_jobs ? t0 + CIG_BATCH : n_jobs;
+        for (unsigned int t = t0; t < t1; ++t) dev_cig_dp_job<MAXQ>(R, ck, dopt.o, mr, fl, fl.dp_list[t], lane, ws);
     }
 }
 

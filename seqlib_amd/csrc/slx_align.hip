@@ -1015,7 +1015,8 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
             std::lock_guard<std::mutex> g(al->mu);
             caps.cap_intv = al->cap_intv;
             caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
-            caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096;
+            caps.zcap += (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_Z;      // the waves' own stretches (k_cig_dp)
+            caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096 + (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_WORDS;   // + what the waves of k_cig_dp reserve ahead
         }
         for (int attempt = 0;; ++attempt) {
             uint32_t fl = 0;
