@@ -153,6 +153,7 @@ struct slx_aligner {
     unsigned long long zcap = 1ull << 26;   // floor of the traceback arena (bytes)
     unsigned long long z_per_read = 512;    // arena bytes budgeted per read (grows when a chunk overflows)
     unsigned long long cig_per_read = 8;    // cigar-pool words per read
+    unsigned long long cig_floor = 0;       // ... and its floor (learnt from small batches that overflowed)
     int n_retries = 0;
     std::mutex mu;                // guards the capacity hints above when workers update them
     std::mutex call_mu;           // one batch at a time per aligner: the C++ mirror's alignSequence is const and may be called from many threads
@@ -1015,9 +1016,12 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
             std::lock_guard<std::mutex> g(al->mu);
             caps.cap_intv = al->cap_intv;
             caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
-            caps.zcap += (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_Z;      // the waves' own stretches (k_cig_dp)
-            caps.cigcap = (unsigned long long)n * al->cig_per_read + 4096 + (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_WORDS;   // + what the waves of k_cig_dp reserve ahead
+            caps.cigcap = std::max<unsigned long long>(al->cig_floor, (unsigned long long)n * al->cig_per_read + 4096);
         }
+        // on top of the per-read budgets: the stretches the waves of k_cig_dp take for themselves and the CIGAR words they reserve ahead
+        const unsigned long long z_waves = (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_Z;
+        const unsigned long long cig_waves = (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_WORDS;
+        caps.zcap += z_waves; caps.cigcap += cig_waves;
         for (int attempt = 0;; ++attempt) {
             uint32_t fl = 0;
             int64_t hb = hit_base, cb = cig_base;
@@ -1029,8 +1033,16 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
                 hit_base = hb; cig_base = cb;
                 std::lock_guard<std::mutex> g(al->mu);   // remember what this workload needed: the next batch does not pay for the retry again
                 al->cap_intv = std::max(al->cap_intv, caps.cap_intv);
-                al->z_per_read = std::max<unsigned long long>(al->z_per_read, (caps.zcap + n - 1) / (unsigned long long)n);
-                al->cig_per_read = std::max<unsigned long long>(al->cig_per_read, (caps.cigcap + n - 1) / (unsigned long long)n);
+                if (attempt > 0) {   // only what an overflow taught -- per read from a large chunk, as a floor from a small one (a batch
+                                     // of a few long reads says nothing about the bytes per read of the next 50 M-read batch)
+                    if (n >= 65536) {
+                        al->z_per_read = std::max<unsigned long long>(al->z_per_read, (caps.zcap - z_waves + n - 1) / (unsigned long long)n);
+                        al->cig_per_read = std::max<unsigned long long>(al->cig_per_read, (caps.cigcap - cig_waves + n - 1) / (unsigned long long)n);
+                    } else {
+                        al->zcap = std::max(al->zcap, caps.zcap - z_waves);
+                        al->cig_floor = std::max(al->cig_floor, caps.cigcap - cig_waves);
+                    }
+                }
                 al->n_retries += attempt;
                 break;
             }

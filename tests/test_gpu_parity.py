@@ -123,6 +123,23 @@ def test_ordinal_stream_matches_successive_calls(sl, orc, tiny_gpu, tiny_index, 
             for r in orc.align_sequence(orc.default_opt(), tiny_index, s1[i], ordinal=i)]
 
 
+def test_small_batch_does_not_inflate_the_budgets_of_the_next_large_one(sl, tiny_gpu, sim_reads):
+    """work-area budgets learnt from one batch carry over to the next (so that a retry is paid once): a batch of one read sits on the
+    arenas' floors, and taking `floor / 1 read` as the per-read budget made the next large batch ask for terabytes (HIP out of memory)"""
+    (_, s1), _ = sim_reads
+    big = list(s1[:2000]) * 40                        # 80 000 reads
+    al = sl.BWAAligner(tiny_gpu)
+    for i in range(3):
+        al.alignSequence(s1[i])
+    al.alignSequences(s1[:50])
+    fresh = sl.BWAAligner(tiny_gpu)
+    fresh.ordinal = al.ordinal                        # same lrand48 ordinals, so the two results must be identical
+    got = al.alignSequences(big)
+    exp = fresh.alignSequences(big)
+    assert int(got["hit_off"][-1]) > 0
+    assert_same(got, exp, "large batch after small ones")
+
+
 def test_edge_cases(sl, orc, tiny_gpu, tiny_index, golden_dir):
     """empty / too-short / all-N / N-containing / low-complexity / ragged lengths / lower case"""
     names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
