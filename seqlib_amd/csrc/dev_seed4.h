@@ -596,7 +596,9 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
 // place is a chain of dependent, uncoalesced loads and read-modify-write stores (it was more than half of k_seed3m's time and 28x write
 // amplification); here the slice is loaded once (independent loads), sorted in LDS (entry e of lane l at e * 64 + l: conflict-free) and
 // written back once.  Reads with more than SEED_EPI_N intervals (repeats) sort in place as before.
+#ifndef SEED_EPI_N
 #define SEED_EPI_N 20
+#endif
 template <typename I>
 __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned int *max_cnt)
 {
