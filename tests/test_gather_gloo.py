@@ -61,3 +61,59 @@ def test_pack_unpack_roundtrip(orc, tiny_index, sim_reads):
     # empty shard
     empty = orc.align_batch(orc.default_opt(), tiny_index, [])
     assert gather.unpack(gather.pack_numpy(empty))["n_hits"] == 0
+
+
+def _gpu_worker(rank, world, port, n, out_path):
+    """one rank of the device path: shard aligned on the GPU, slx_hits_pack into a device buffer, that image gathered to rank 0"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import seqlib_amd as sl
+    from oracle import orc
+    from seqlib_amd import gather
+    G = os.path.join(ROOT, "tests", "golden")
+    _, seqs = orc.read_fastq(os.path.join(G, "sim1_bcr.head3000.fq"), n)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(os.path.join(G, "tiny.fa"))
+    al = sl.BWAAligner(idx)
+    lo, hi = rank * n // world, (rank + 1) * n // world            # contiguous read-ordinal shard
+    shard = seqs[lo:hi]
+    dev = torch.device("cuda:0")                                    # both ranks share the box's one GPU
+    bases = np.frombuffer("".join(shard).encode(), dtype=np.uint8)
+    offs = np.zeros(len(shard) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in shard])
+    d_bases = torch.from_numpy(bases.copy()).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
+    h = al.align_device(d_bases.data_ptr(), d_offs.data_ptr(), len(shard), first_ordinal=lo)
+    sz = al.packed_size(h)
+    buf = torch.empty(sz, dtype=torch.uint8, device=dev)
+    al.pack_into(h, buf.data_ptr(), sz)
+    torch.cuda.synchronize()
+    parts = gather.gather_packed(buf.cpu(), dst=0)                  # gloo moves the image; with one GPU per rank this is the RCCL gather
+    if rank == 0:
+        merged = gather.merge([gather.unpack(p.numpy()) for p in parts])
+        np.savez(out_path, **{k: merged[k] for k in FIELDS})
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_pack_gather_merge(orc, tiny_index, sim_reads, tmp_path):
+    """N > 1 with the product's own pieces: each of two processes aligns its shard on the GPU and packs the device-resident hits with
+    slx_hits_pack; rank 0 merges the gathered images and must get what one process gets for all reads (= the oracle's records).
+    RCCL refuses two ranks on one device, so the transport here is gloo; sharding by ordinal, the packed image, unpack and merge are
+    what bench.py --gpus N runs."""
+    n = 1200
+    out = str(tmp_path / "merged_gpu.npz")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_gpu_worker, args=(2, port, n, out), nprocs=2, join=True)
+    merged = np.load(out)
+    (_, s1), _ = sim_reads
+    exp = orc.align_batch(orc.default_opt(), tiny_index, s1[:n])
+    for k in FIELDS:
+        assert np.array_equal(merged[k], exp[k]), k
