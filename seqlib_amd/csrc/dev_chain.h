@@ -124,6 +124,11 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         int *ord = w.ia;                         // chain handles ordered by pos: bwa's kbtree while it is a single leaf (<= 9 chains)
         KbTree kb;                               // ... and the tree itself from the 10th chain on (dev_kbtree.h), nodes in the region slots
         bool tree = false;
+        // the chain touched last, in registers: a read from unique sequence has one chain that every seed is tested against, and each test
+        // read c_head / c_tail and then the two seeds -- two dependent round trips per seed for values this lane wrote itself
+        int cc = -1, cc_tail = 0, cc_n = 0, cc_rid = 0;
+        uint32_t cc_fql = 0, cc_lql = 0;
+        int64_t cc_frb = 0, cc_lrb = 0;
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
             const I x2 = ix2[i];
@@ -147,20 +152,28 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                     }
                     if (lower_c >= 0) {          // test_and_merge
                         const int c = lower_c;
-                        const int first = w.c_head[c], last = w.c_tail[c];
-                        const int l_qbeg = w.s_qbeg(last), l_len = w.s_len(last);
-                        const int64_t l_rbeg = w.s_rbeg[last];
+                        if (c != cc) {               // another chain than last time: fetch its summary
+                            const int first = w.c_head[c];
+                            cc = c; cc_tail = w.c_tail[c]; cc_n = w.c_n[c]; cc_rid = w.c_rid[c];
+                            cc_fql = w.s_ql[first]; cc_frb = w.s_rbeg[first];
+                            cc_lql = w.s_ql[cc_tail]; cc_lrb = w.s_rbeg[cc_tail];
+                        }
+                        const int last = cc_tail;
+                        const int l_qbeg = (int)(cc_lql >> 16), l_len = (int)(cc_lql & 0xffff);
+                        const int64_t l_rbeg = cc_lrb;
                         const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
                         int res;
-                        if (rid != w.c_rid[c]) res = 0;
-                        else if (qbeg >= w.s_qbeg(first) && qbeg + slen <= qend && rbeg >= w.s_rbeg[first] && rbeg + slen <= rend) res = 1; // contained
-                        else if ((l_rbeg < R.l_pac || w.s_rbeg[first] < R.l_pac) && rbeg >= R.l_pac) res = 0;
+                        if (rid != cc_rid) res = 0;
+                        else if (qbeg >= (int)(cc_fql >> 16) && qbeg + slen <= qend && rbeg >= cc_frb && rbeg + slen <= rend) res = 1; // contained
+                        else if ((l_rbeg < R.l_pac || cc_frb < R.l_pac) && rbeg >= R.l_pac) res = 0;
                         else {
                             const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                             if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
                                 const int s = ns++;
-                                w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
-                                w.s_next[last] = s; w.c_tail[c] = s; ++w.c_n[c];
+                                const uint32_t ql = ((uint32_t)qbeg << 16) | (uint32_t)slen;
+                                w.s_rbeg[s] = rbeg; w.s_ql[s] = ql; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
+                                w.s_next[last] = s; w.c_tail[c] = s; w.c_n[c] = ++cc_n;
+                                cc_tail = s; cc_lql = ql; cc_lrb = rbeg;
                                 res = 1;
                             } else res = 0;
                         }
@@ -171,6 +184,7 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                     const int s = ns++, c = nc;
                     w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                     w.c_pos[c] = rbeg; w.c_head[c] = w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
+                    cc = c; cc_tail = s; cc_n = 1; cc_rid = rid; cc_fql = cc_lql = ((uint32_t)qbeg << 16) | (uint32_t)slen; cc_frb = cc_lrb = rbeg;
                     if (!tree && nc == 2 * KB_T - 1) { kb.from_array((int *)w.regs, ord, w.c_pos, nc); tree = true; }   // the leaf is full: it splits now
                     if (tree) kb.put(rbeg, c);
                     else {
