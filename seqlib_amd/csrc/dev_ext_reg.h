@@ -620,16 +620,20 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
 
 // per heavy read: seed slots (table space) and (chain, part) jobs
 __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds,
-                             unsigned int top)
+                             unsigned int top, unsigned int ratio)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= *n_heavy || s >= top) return;      // the list is heaviest-first: beyond `top` reads the in-place kernel has no tail to hide
+    if (s >= *n_heavy) return;
     const int r = heavy[s];
     const uint64_t so = ck.seed_off[r];
     const unsigned int cap = (unsigned int)(ck.seed_off[r + 1] - so);
     if (cap < min_seeds) return;                    // (counts are zero-initialised) short enough to be extended in place
-    slot_cnt[s] = cap;
     const int nc = ck.n_chain[r];
+    // The list is heaviest-first by seed count: beyond `top` reads the in-place kernel has no tail to hide -- except for the reads
+    // whose seeds sit in few chains (low-complexity tracts: every extension runs the full length of the read, 25-40 ms for one read on
+    // its wave, against ~10 ms for a read of a many-copy repeat with one seed per chain); those are taken whatever their rank.
+    if (s >= top && !(ratio > 0 && nc > 0 && (unsigned int)nc * ratio <= cap)) return;
+    slot_cnt[s] = cap;
     unsigned int jobs = 0;
     for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + CAND_PART - 1) / CAND_PART;
     job_cnt[s] = jobs;
