@@ -100,7 +100,7 @@ void slx_aligner_free(slx_aligner *al);
  *   "lut_k" -1|0|2..14 (-1)   width of the k-mer table of the seeding kernels (4^k x 8 or 16 bytes); -1 = by index size, 0 = none
  *   "threads"                 lanes of the persistent seeding kernel (default 1 536 per CU)
  *   "cap_intv"                kept SMEM intervals per read the first attempt allows (overflow -> the chunk is re-run with twice as many)
- *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_ratio", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
+ *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
  *   "wide_index" 1            test hook: run an index below 2^32 symbols through the u64 kernels
  *   "keep_stages" 1           test hook: keep what slx_debug_stage reads

@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
 
 // per heavy read: seed slots (table space) and (chain, part) jobs
 __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds,
-                             unsigned int top, unsigned int ratio)
+                             unsigned int top, unsigned int rep_pct, unsigned int *n_part, unsigned int part_max, int count_only)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= *n_heavy) return;
@@ -629,10 +629,16 @@ __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_h
     const unsigned int cap = (unsigned int)(ck.seed_off[r + 1] - so);
     if (cap < min_seeds) return;                    // (counts are zero-initialised) short enough to be extended in place
     const int nc = ck.n_chain[r];
-    // The list is heaviest-first by seed count: beyond `top` reads the in-place kernel has no tail to hide -- except for the reads
-    // whose seeds sit in few chains (low-complexity tracts: every extension runs the full length of the read, 25-40 ms for one read on
-    // its wave, against ~10 ms for a read of a many-copy repeat with one seed per chain); those are taken whatever their rank.
-    if (s >= top && !(ratio > 0 && nc > 0 && (unsigned int)nc * ratio <= cap)) return;
+    // The list is heaviest-first by seed count: beyond `top` reads the in-place kernel has no tail to hide -- except for the reads that
+    // are only PARTLY repetitive (l_rep, the read length covered by intervals of more than max_occ occurrences, below rep_pct % of the
+    // read): their extensions run on through the unique part, 25-40 ms for one read on its wave against ~3 ms for a read that lies
+    // inside a repeat (measured: SLX_DEBUG_CYC=1); those are taken whatever their rank.
+    // ... when there are few of them (n_part counts them in a first pass): with thousands in a chunk their tails overlap each other and
+    // the other workers' kernels, and the ahead-of-time pass would only add work.
+    const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
+    const bool part = rep_pct > 0 && (unsigned int)ck.l_rep[r] * 100u < (unsigned int)len * rep_pct;
+    if (count_only) { if (part && s >= top) atomicAdd(n_part, 1u); return; }
+    if (s >= top && !(part && *n_part <= part_max)) return;
     slot_cnt[s] = cap;
     unsigned int jobs = 0;
     for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + CAND_PART - 1) / CAND_PART;

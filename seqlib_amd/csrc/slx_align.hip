@@ -137,7 +137,9 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_top = 512;           // ... and only for the first cand_top reads of the heaviest-first list
-    int cand_ratio = 5;           // ... plus, whatever their rank, the reads with at least this many seed occurrences per chain (0 = none)
+    int cand_rep = 0;             // ... plus, whatever their rank, the reads less than this per cent repetitive (l_rep / length; 0 = none:
+                                  // at 75 C2 gains 7 % -- 3.3 M-read chunks, where this tail is 40 % of a chunk's time -- and C3 loses 4 %)
+    int cand_rep_max = 1 << 30;   // ... when the chunk has at most this many of them
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
     int lut_k = -1;               // k-mer table of the seeding kernels (dev_seed4.h, k_kmer_lut): 4^k entries of 8 / 16 bytes; 0 = none,
                                   // -1 = by index size (measured best where a k-mer still has a handful of occurrences: log4(symbols) - 1)
@@ -484,7 +486,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
-    else if (!strcmp(key, "cand_ratio")) { if (value < 0) return SLX_EINVAL; al->cand_ratio = (int)value; }
+    else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
+    else if (!strcmp(key, "cand_rep")) { if (value < 0 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
@@ -804,8 +807,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 const unsigned gb = (unsigned)((n + 255) / 256);
                 unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
                 unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (n + 2);
-                hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
-                                   hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)al->cand_ratio);
+                for (int pass = al->cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
+                    hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
+                                       hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)al->cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, n + 1, st));
                 tb = wk->scan_tmp.cap;
@@ -919,7 +923,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 (double)c6[0], (double)c6[1] / (double)(c6[0] ? c6[0] : 1), (double)c6[2], (double)c6[3] / (double)(c6[2] ? c6[2] : 1), (double)c6[4], (double)c6[5], (double)c6[6], (double)c6[7] / (double)(c6[6] ? c6[6] : 1), n);
     } else if (ck.dbg_cyc) {   // the reads the extension kernel spent longest on
         std::vector<unsigned long long> cyc((size_t)n * 4), sc((size_t)n);
-        std::vector<int> nch((size_t)n), nrg((size_t)n);
+        std::vector<int> nch((size_t)n), nrg((size_t)n), lrep((size_t)n);
+        HIPCHK(hipMemcpy(lrep.data(), wk->l_rep.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(cyc.data(), wk->dbg_cyc.p, (size_t)n * 32, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(sc.data(), wk->seed_cnt.p, (size_t)n * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(nch.data(), wk->n_chain.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -949,11 +954,20 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 fprintf(stderr, "[regions >= %d] reads %ld  ticks %.3g (A %.3g B %.3g C %.3g)\n", lim[b], cnt, (double)cy, (double)a, (double)bb, (double)c);
             }
         }
+        {
+            const int lb[5] = {0, 1, 50, 100, 140};
+            for (int b = 0; b < 5; ++b) {
+                long cnt = 0; unsigned long long cy = 0;
+                for (int i = 0; i < n; ++i)
+                    if (nrg[(size_t)i] >= 256 && lrep[(size_t)i] >= lb[b] && (b == 4 || lrep[(size_t)i] < lb[b + 1])) { ++cnt; cy += cyc[(size_t)i]; }
+                fprintf(stderr, "[>= 256 regions, l_rep >= %d] reads %ld  mean ticks %.3g\n", lb[b], cnt, cnt ? (double)cy / (double)cnt : 0.0);
+            }
+        }
         fprintf(stderr, "[ext cycles] n=%d total=%.3g (100 MHz ticks) heavy share=%.3f\n", n, (double)tot, tot ? (double)tot_heavy / (double)tot : 0.0);
         for (int i = 0; i < top; ++i) {
             const size_t r = (size_t)ord[(size_t)i];
-            fprintf(stderr, "  read %zu: %.3g ticks (A %.3g, B %.3g, C %.3g; stage 1: sort, covered tests, extend+store; stage 2: sort by end, dedup/patch, second sort)  seeds=%llu chains=%d regions=%d\n", r, (double)cyc[r],
-                    (double)cyc[(size_t)n + r], (double)cyc[2 * (size_t)n + r], (double)cyc[3 * (size_t)n + r], sc[r], nch[r], nrg[r]);
+            fprintf(stderr, "  read %zu: %.3g ticks (A %.3g, B %.3g, C %.3g; stage 1: sort, covered tests, extend+store; stage 2: sort by end, dedup/patch, second sort)  seeds=%llu chains=%d regions=%d l_rep=%d\n", r, (double)cyc[r],
+                    (double)cyc[(size_t)n + r], (double)cyc[2 * (size_t)n + r], (double)cyc[3 * (size_t)n + r], sc[r], nch[r], nrg[r], lrep[r]);
         }
     }
     if (getenv("SLX_DEBUG_SUB")) {
