@@ -1,5 +1,5 @@
 #!/bin/bash
-# seeding A/B: alone-run (one worker, one chunk) and whole-pipeline numbers per library variant / seed_mode
+# seeding A/B: alone-run (one worker, one chunk) and whole-pipeline numbers per library variant (scripts/build_variant.sh) and knob set (KN=...)
 mkdir -p gpurun_out
 for spec in "$@"; do
     name=${spec%%|*}; envs=${spec#*|}
