@@ -39,7 +39,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CU x 4 SIMD x 16 lanes/cycle x 2.4 GHz = 39.3 T int32 lane-ops/s
 DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000, "C4h": 25_000_000}
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+ROUND = "r03"
+PMC_SUMMARY = os.environ.get("SLX_PMC_SUMMARY") or os.path.join("profiles", ROUND + "_pmc_summary.json")     # follows the round
 
 _G = {}
 
@@ -76,16 +77,16 @@ def gen_reads(cfg, refs, n_reads, first_block, share=1):
     return out
 
 
-def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=12.0):
-    """The CPU oracle (a port of the reference path: it cannot be built from /root/reference) timed on this box's
-    host cores on a bounded sample of the same reads: one oracle process per core (python -m oracle.cpu_bench, started fresh --
-    nothing of this process is forked), each timing its own slice after loading the index.  Also returns the oracle-counted
-    algorithmic bytes / DP cells per read that the roofline figures are computed from."""
+def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
+    """The CPU oracle (a port of the reference path: it cannot be built from /root/reference) timed on this box's host
+    cores as SURVEY 8d(ii) specifies: ONE process, std::thread over disjoint read ranges sharing one read-only index, on all
+    `nproc` cores, -O2, one read per call; bounded to ~budget_s of work per thread on a sample of the same reads.  Also returns
+    the oracle-counted algorithmic bytes / DP cells per read that the roofline figures are computed from."""
     from oracle import orc
     idx = orc.Index.load(prefix)
     opt = orc.default_opt()
     read_len = reads_ascii.shape[1]
-    cores = min(os.cpu_count() or 1, 64)
+    cores = os.cpu_count() or 1
     cal = min(2000, len(reads_ascii))
     offs = (np.arange(cal + 1, dtype=np.uint64) * np.uint64(read_len))
     orc.lib().orc_counters_reset()
@@ -95,28 +96,21 @@ def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=12.0):
     cnt = orc.counters()
     per_read = {k: v / cal for k, v in cnt.items()}
     rate1 = cal / dt1
+    per_thread = int(max(200, min(rate1 * budget_s, (len(reads_ascii) - cal) // max(cores, 1))))
+    m = per_thread * cores
+    sample = np.ascontiguousarray(reads_ascii[cal:cal + m])
+    m = len(sample)
+    offs = np.arange(m + 1, dtype=np.uint64) * np.uint64(read_len)
+    wall, _, ts = orc.time_batch_mt(opt, idx, sample.tobytes(), offs, cores, first_ordinal=cal)
+    rate = m / wall if wall > 0 else 0.0
+    # thread t spent ts[t] on its m / cores reads: the in-flight slowdown per thread, against the calibrated single thread
+    eff = rate / (rate1 * cores) if rate1 > 0 else None
     del idx
-    per_proc = int(max(500, min(rate1 * budget_s, (len(reads_ascii) - cal) // max(cores, 1))))
-    if per_proc * cores + cal > len(reads_ascii):
-        per_proc = max(1, (len(reads_ascii) - cal) // cores)
-    tmp = tempfile.mkdtemp(prefix="slx_cpu_")
-    sample = os.path.join(tmp, "sample.bin")
-    reads_ascii[cal:cal + per_proc * cores].tofile(sample)
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", prefix, sample, str(read_len), str(t * per_proc), str(per_proc), str(cal + t * per_proc)],
-                           stdout=subprocess.PIPE, env=env, cwd=ROOT) for t in range(cores)]
-    secs, done = [], 0
-    for p in ps:
-        o = p.communicate()[0].decode().strip().splitlines()
-        if p.returncode == 0 and o:
-            r = json.loads(o[-1])
-            secs.append(r["seconds"]); done += r["reads"]
-    os.remove(sample)
-    rate = done / max(secs) if secs else 0.0
-    return dict(value=rate, unit="reads/s", cores=len(secs), kind="port",
-                sample="%d reads x %d oracle processes of the same synthetic %s reads (single thread: %.0f reads/s; the oracle is scalar, "
-                       "malloc-heavy C and scales sub-linearly with the core count)" % (per_proc, len(secs), cfg_name, rate1),
-                single_thread=rate1), per_read
+    return dict(value=rate, unit="reads/s", cores=cores, kind="port",
+                sample="%d reads of the same synthetic %s reads, one oracle process, %d std::threads over disjoint read ranges sharing one index "
+                       "(single thread on %d reads: %.0f reads/s; parallel efficiency %.2f; slowest / fastest thread %.1f / %.1f s)"
+                       % (m, cfg_name, cores, cal, rate1, eff or 0.0, max(ts), min(ts)),
+                single_thread=rate1, parallel_efficiency=eff), per_read
 
 
 def compare(got, exp, m):
@@ -180,7 +174,17 @@ def main():
     t_setup = time.time()
     refs = synth.make_reference(cfg)
     blocks_per_rank = (n + synth.BLOCK - 1) // synth.BLOCK
-    reads = gen_reads(cfg, refs, n, first_block=rank * blocks_per_rank, share=world)
+    # SLX_BENCH_READS_CACHE=<file>: the read set is loaded from it when present (else generated and saved).  The profile scripts
+    # fill it in an un-profiled run first: under rocprofv3 the tool's library has initialised the GPU before main(), and the
+    # block-parallel generator must not fork from such a process.
+    cache = os.environ.get("SLX_BENCH_READS_CACHE")
+    cache = cache and "%s.%s.%d.%d" % (cache, args.config, n, rank)
+    if cache and os.path.exists(cache) and os.path.getsize(cache) == n * read_len:
+        reads = np.fromfile(cache, dtype=np.uint8).reshape(n, read_len)
+    else:
+        reads = gen_reads(cfg, refs, n, first_block=rank * blocks_per_rank, share=world)
+        if cache:
+            np.ascontiguousarray(reads).tofile(cache)
     t_gen = time.time() - t_setup
     first_ordinal = rank * n
 
@@ -228,7 +232,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    stage_acc, probe_acc = {}, {}
+    stage_acc, probe_acc, launches_acc = {}, {}, 0
     fence()
     t0 = time.time()
     step_marks = [t0]
@@ -239,6 +243,7 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
         for k, v in al.probe_ms()[0].items():
             probe_acc[k] = probe_acc.get(k, 0.0) + v
+        launches_acc += al.probe_launches()
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -305,7 +310,7 @@ def main():
             del pin, offs_pin
             tool = os.path.join(ROOT, "seqlib_amd", "bamrec_bench")
             if os.path.exists(tool):
-                m = min(n, 2_000_000)
+                m = min(n, int(os.environ.get("SLX_BAM_SAMPLE", "10000000")))     # >= 10 M reads of the timed batch
                 sample = os.path.join(tmp, "bam_sample.bin")
                 reads[:m].tofile(sample)
                 try:
@@ -316,7 +321,7 @@ def main():
                     bam = dict(error=str(e))
                 os.remove(sample)
         # ---- rooflines
-        launches = al_launches(n)
+        launches = max(1, launches_acc // max(args.steps, 1))     # counted by the library: chunks over all workers, whatever the knobs
         roof, roof_ext = None, None
         pmc = None
         try:
@@ -335,9 +340,17 @@ def main():
             if pmc and pmc.get("config") == args.config:
                 traffic = (pmc["seed_fetch_bytes_per_read"] + pmc["seed_write_bytes_per_read"]) * n / launches
                 src = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % PMC_SUMMARY
+            mean_launch_ms = seed_ms / launches
+            physical = traffic / (mean_launch_ms * 1e-3) / 1e9 if traffic else None
             roof = dict(bound="hbm", kernel="k_seed12m + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src, launches_per_step=launches, reads_per_launch=n / launches,
-                        kernel_ms=seed_ms, kernel_ms_mean_launch=seed_ms / launches, timing="HIP events on each worker's own stream around the two kernels, summed over the step's launches",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src,
+                        achieved_basis="ALGORITHMIC bytes (SURVEY 8d: the oracle's count on bwa's own layout, 64 B per Occ block touched + the read) per launch / "
+                                       "mean launch duration; the kernel itself moves fewer bytes (32-byte occ planes, k-mer table, direct text steps): see physical_gbs",
+                        physical_gbs=physical, physical_frac=physical / HBM_PEAK_GBS if physical else None,
+                        launches_per_step=launches, reads_per_launch=n / launches,
+                        kernel_ms=seed_ms, kernel_ms_mean_launch=mean_launch_ms,
+                        timing="HIP events on each worker's own stream around the three kernels; kernel_ms is the SUM over the step's launches, which run "
+                               "concurrently on the workers' streams (it can exceed the step time); the mean launch duration is what achieved uses",
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,
                         path_achieved=path_bytes * n / (ms_per_step * 1e-3) / 1e9)
             cells = per_read.get("ext_cells", 0.0) + per_read.get("glb_cells", 0.0)
@@ -349,7 +362,7 @@ def main():
                                 kernel_ms=ext_ms + cig_ms, extend_ms=ext_ms, cigar_ms=cig_ms, achieved=ach / 1e12, peak=VALU_PEAK_LANE_OPS / 1e12,
                                 unit="T int32 lane-op/s", frac=ach / VALU_PEAK_LANE_OPS,
                                 valu_busy=(pmc or {}).get("ext_valu_busy") if pmc and pmc.get("config") == args.config else None,
-                                valu_busy_source=("%s: SQ_ACTIVE_INST_VALU x 4 / (n_simd x GRBM_GUI_ACTIVE); formula and units in that file" % PMC_SUMMARY)
+                                valu_busy_source=("%s: %s" % (PMC_SUMMARY, pmc.get("valu_busy_formula", "formula and units in that file")))
                                 if pmc and pmc.get("config") == args.config else None)
         out = {
             "metric": "aligned reads/sec (150 bp) via BWAAligner", "value": value, "unit": "reads/s", "n_gpus": world,
@@ -364,7 +377,7 @@ def main():
             "value_host_to_host": h2h, "value_bamrecords": bam,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
             "gather_equals_single_process": gather_ok,
-            "seed_launches_per_step": launches, "reads_per_seed_launch": n / launches,
+            "seed_launches_per_step": launches if rank == 0 else None, "reads_per_seed_launch": n / launches,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
             "probe_ms_per_step": {k: v / args.steps for k, v in probe_acc.items()},
             "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(step_marks[:-1], step_marks[1:])],
@@ -375,14 +388,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def al_launches(n, workers=3):
-    """seeding launches per step: `workers` workers (batches >= 2^19 reads), each in chunks of at most 2^23 reads"""
-    if n < (1 << 19):
-        return 1
-    per = (n + workers - 1) // workers
-    return workers * max(1, -(-per // (1 << 23)))
 
 
 if __name__ == "__main__":

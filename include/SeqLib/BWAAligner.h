@@ -16,12 +16,17 @@
 // process-wide lock (peek + advance of the libc state is one step), and the C-ABI serves the calls of one handle
 // one after another (the aligner's own lock): concurrent callers get correct results, not concurrent GPU work --
 // use alignSequences for throughput.
-// Limits of the GPU path, both reported by exceptions: reads longer than SLX_MAX_READ_LEN; indexes with ALT contigs.
+// Limit of the GPU path, reported by an exception: reads longer than SLX_MAX_READ_LEN.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cassert>
-#include <exception>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -35,10 +40,80 @@
 
 namespace SeqLib {
 
+namespace detail {
+// Host threads of one alignSequences call: task groups run to completion in submission order within a priority class; packing
+// the next chunk's reads (high) goes before building the previous chunk's records (low), so the GPU never waits for its input.
+class TaskPool {
+public:
+    struct Group {
+        std::function<void(int)> fn;
+        int n = 0;
+        std::atomic<int> next{0};
+        int done = 0;
+        std::exception_ptr err;
+    };
+    explicit TaskPool(unsigned n_threads)
+    {
+        for (unsigned t = 0; t < n_threads; ++t) th_.emplace_back([this]() { loop(); });
+    }
+    ~TaskPool()
+    {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    std::shared_ptr<Group> submit(int n_tasks, std::function<void(int)> fn, bool high)
+    {
+        auto g = std::make_shared<Group>();
+        g->fn = std::move(fn); g->n = n_tasks;
+        if (n_tasks > 0) {
+            { std::lock_guard<std::mutex> l(mu_); (high ? hi_ : lo_).push_back(g); }
+            cv_.notify_all();
+        }
+        return g;
+    }
+    void wait(const std::shared_ptr<Group> &g)
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        done_cv_.wait(l, [&]() { return g->done >= g->n; });
+        if (g->err) std::rethrow_exception(g->err);
+    }
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        for (;;) {
+            cv_.wait(l, [&]() { return stop_ || !hi_.empty() || !lo_.empty(); });
+            if (stop_) return;
+            auto &q = !hi_.empty() ? hi_ : lo_;
+            std::shared_ptr<Group> g = q.front();
+            const int i = g->next.fetch_add(1);
+            if (i >= g->n) { if (!q.empty() && q.front() == g) q.pop_front(); continue; }
+            if (i == g->n - 1 && !q.empty() && q.front() == g) q.pop_front();
+            l.unlock();
+            std::exception_ptr e;
+            try { g->fn(i); } catch (...) { e = std::current_exception(); }
+            l.lock();
+            if (e && !g->err) g->err = e;
+            if (++g->done >= g->n) done_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::shared_ptr<Group>> hi_, lo_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_ = false;
+};
+}  // namespace detail
+
 class BWAAligner {
 public:
     explicit BWAAligner(BWAIndexPtr idx) : index_(std::move(idx)) { slx_opt_init(&memopt_); }   // mem_opt_init + MEM_F_SOFTCLIP
-    ~BWAAligner() { if (al_) slx_aligner_free(al_); }
+    ~BWAAligner()
+    {
+        for (Staging &st : stage_) { slx_host_free(st.bases); slx_host_free(st.offs); }
+        if (al_) slx_aligner_free(al_);
+    }
     BWAAligner(const BWAAligner &) = delete;
     BWAAligner &operator=(const BWAAligner &) = delete;
 
@@ -106,22 +181,21 @@ public:
         if (!copyComment_) return;
         for (auto &rec : out) rec->AddZTag("BC", us.Com);
     }
-    // ---- batch entry (new): one GPU pass for the whole vector ---------------------------------------
+    // ---- batch entry (new): the whole vector in GPU-sized passes -------------------------------------
+    // A large batch is cut into chunks: the GPU aligns chunk k while the host threads build the BamRecords of chunk k-1
+    // and pack the bases of chunk k+1 straight into pinned staging memory (no concatenated copy of the reads).
     void alignSequences(const UnalignedSequenceVector &reads, std::vector<BamRecordPtrVector> &out, bool hardclip, double keepSecFrac,
                         int maxSecondary) const
     {
         out.clear();
         out.resize(reads.size());
         if (index_->IsEmpty() || reads.empty()) return;
-        std::string bases;
-        std::vector<uint64_t> offs(reads.size() + 1, 0);
-        std::vector<const char *> names(reads.size());
-        size_t tot = 0;
-        for (auto &r : reads) tot += r.Seq.size();
-        bases.reserve(tot);
-        for (size_t i = 0; i < reads.size(); ++i) { bases += reads[i].Seq; offs[i + 1] = bases.size(); names[i] = reads[i].Name.c_str(); }
-        run(bases.data(), offs.data(), (int64_t)reads.size(), names.data(), &reads, hardclip, keepSecFrac, maxSecondary, nullptr, &out);
+        run_batch(reads, out, hardclip, keepSecFrac, maxSecondary);
     }
+    // The GPUs this aligner drives (HIP ordinals; before the first alignment).  Default: the current device, or what the
+    // environment variable SEQLIB_AMD_DEVICES names ("all", or a comma-separated list).  With several devices a batch is
+    // sharded over them by contiguous read ranges inside the C-ABI (slx_aligner_create with n_dev > 1); results are identical.
+    void UseDevices(const std::vector<int> &devices) { devices_ = devices; }
     // ---- north-star spellings ---------------------------------------------------------------------
     void AlignSequence(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double keepSecFrac,
                        int maxSecondary) const { alignSequence(seq, name, out, hardclip, keepSecFrac, maxSecondary); }
@@ -139,23 +213,58 @@ private:
     mutable slx_aligner *al_ = nullptr;
     mutable std::once_flag al_once_;
     bool copyComment_ = false;
+    std::vector<int> devices_;
+    struct Staging { char *bases = nullptr; uint64_t *offs = nullptr; size_t cap_bases = 0, cap_reads = 0; };
+    mutable Staging stage_[2];                 // pinned staging of the chunked batch path (kept between calls)
+    mutable std::mutex batch_mu_;              // one chunked batch at a time per aligner (they share the staging)
+
+    static long env_long(const char *name, long dflt)
+    {
+        const char *v = std::getenv(name);
+        return v && *v ? std::atol(v) : dflt;
+    }
 
     slx_aligner *handle() const
     {   // created on first use, once, whichever thread gets here first (a failed creation throws and may be retried)
         std::call_once(al_once_, [this]() {
+            std::vector<int> dev = devices_;
+            if (dev.empty()) {
+                const char *e = std::getenv("SEQLIB_AMD_DEVICES");
+                if (e && *e) {
+                    if (!std::strcmp(e, "all")) { for (int d = 0; d < slx_device_count(); ++d) dev.push_back(d); }
+                    else for (const char *p = e; *p;) {
+                        char *end = nullptr;
+                        const long d = std::strtol(p, &end, 10);
+                        if (end == p) throw std::invalid_argument(std::string("SEQLIB_AMD_DEVICES: cannot parse '") + e + "'");
+                        dev.push_back((int)d);
+                        p = end;
+                        while (*p == ',' || *p == ' ') ++p;
+                    }
+                }
+            }
             slx_aligner *al = nullptr;
-            const int rc = slx_aligner_create(index_->idx_, nullptr, 0, &al);
+            const int rc = slx_aligner_create(index_->idx_, dev.empty() ? nullptr : dev.data(), (int)dev.size(), &al);
             if (rc == SLX_ENOMEM) throw std::bad_alloc();
             if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner: ") + slx_last_error());
             al_ = al;
+            n_dev_ = dev.empty() ? 1 : (int)dev.size();
         });
         return al_;
     }
+    mutable int n_dev_ = 1;
 
     static std::mutex &rng_mutex() { static std::mutex m; return m; }
 
-    // record construction of src/BWAAligner.cpp:151-248 for hit k of `h`
-    static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, bool hardclip)
+    static void throw_rc(int rc)
+    {
+        if (rc == SLX_ENOMEM) throw std::bad_alloc();
+        if (rc == SLX_EINVAL) throw std::invalid_argument(slx_last_error());
+        if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner::alignSequence: ") + slx_last_error());
+    }
+
+    // record construction of src/BWAAligner.cpp:151-248 for hit k of `h`.  Same bytes as the reference builds; one allocation
+    // for the data blob, sized for the three integer tags it ends with (the reference reallocs at each bam_aux_append).
+    static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, size_t l_name, bool hardclip)
     {
         auto b = std::make_shared<BamRecord>();
         bam1_t *r = b->b.get();
@@ -178,32 +287,30 @@ private:
             assert(clen && tstart + clen <= seq.size());
         }
         const std::string_view clipped = seq.substr(tstart, clen);
-        const size_t l_name = std::strlen(name);
         r->core.l_qname = (uint16_t)(l_name + 1);
         r->core.l_qseq = (int32_t)clipped.size();
-        r->l_data = r->core.l_qname + (n_cigar << 2) + ((r->core.l_qseq + 1) >> 1) + r->core.l_qseq;
-        r->data = static_cast<uint8_t *>(std::calloc((size_t)r->l_data ? (size_t)r->l_data : 1, 1));   // reference: malloc; quals past [0] are zero here
+        const int l_core = r->core.l_qname + (n_cigar << 2) + ((r->core.l_qseq + 1) >> 1) + r->core.l_qseq;
+        const int l_tags = 3 * 7;                           // NA:i NM:i AS:i
+        r->data = static_cast<uint8_t *>(std::malloc((size_t)(l_core + l_tags)));
         if (!r->data) throw std::bad_alloc();
-        r->m_data = 0;                                      // as the reference leaves it: the first tag append reallocs
-        std::memcpy(r->data, name, l_name + 1);
+        r->m_data = (uint32_t)(l_core + l_tags);
+        r->l_data = l_core;
+        std::memcpy(r->data, name, l_name);
+        r->data[l_name] = 0;
         std::memcpy(r->data + r->core.l_qname, cig, (size_t)n_cigar << 2);
         uint8_t *seqbuf = r->data + r->core.l_qname + (r->core.n_cigar << 2);
         const int sl = (int)clipped.size();
-        if (h.flag[k] & BAM_FREVERSE) {                     // :208-220 -- A<->T swapped, C and G left as they are (reference behaviour)
-            int j = 0;
-            for (int p = sl - 1; p >= 0; --p, ++j) {
-                uint8_t v = 15;
-                switch (clipped[(size_t)p]) { case 'A': v = 8; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = 1; break; }
-                seqbuf[j >> 1] &= (uint8_t)~(0xF << ((~j & 1) << 2));
-                seqbuf[j >> 1] |= (uint8_t)(v << ((~j & 1) << 2));
-            }
+        std::memset(seqbuf, 0, (size_t)((sl + 1) >> 1) + (size_t)sl);   // (reference: malloc; quals past [0] are zero here)
+        static const struct Nib { uint8_t f[256], r[256]; Nib() {
+            for (int c = 0; c < 256; ++c) { f[c] = 15; r[c] = 15; }
+            f['A'] = 1; f['C'] = 2; f['G'] = 4; f['T'] = 8;
+            r['A'] = 8; r['C'] = 2; r['G'] = 4; r['T'] = 1;  // :208-220 -- A<->T swapped, C and G left as they are (reference behaviour)
+        } } nib;
+        const uint8_t *cp = reinterpret_cast<const uint8_t *>(clipped.data());
+        if (h.flag[k] & BAM_FREVERSE) {
+            for (int j = 0; j < sl; ++j) seqbuf[j >> 1] |= (uint8_t)(nib.r[cp[sl - 1 - j]] << ((~j & 1) << 2));
         } else {
-            for (int p = 0; p < sl; ++p) {
-                uint8_t v = 15;
-                switch (clipped[(size_t)p]) { case 'A': v = 1; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = 8; break; }
-                seqbuf[p >> 1] &= (uint8_t)~(0xF << ((~p & 1) << 2));
-                seqbuf[p >> 1] |= (uint8_t)(v << ((~p & 1) << 2));
-            }
+            for (int p = 0; p < sl; ++p) seqbuf[p >> 1] |= (uint8_t)(nib.f[cp[p]] << ((~p & 1) << 2));
         }
         if (sl > 0) bam_get_qual(r)[0] = 0xff;
         b->AddIntTag("NA", h.na[k]);
@@ -212,6 +319,27 @@ private:
         return b;
     }
 
+    // BamRecords of reads [a, b) of a result whose read 0 is read `base` of the call
+    void materialise(const slx_hits &h, int64_t a, int64_t b, const char *bases, const uint64_t *offs, const char *const *names,
+                     const UnalignedSequenceVector *reads, int64_t base, bool hardclip, BamRecordPtrVector *single_out,
+                     std::vector<BamRecordPtrVector> *batch_out) const
+    {
+        for (int64_t i = a; i < b; ++i) {
+            const std::string_view seq(bases + offs[i], (size_t)(offs[i + 1] - offs[i]));
+            BamRecordPtrVector &dst = single_out ? *single_out : (*batch_out)[(size_t)(base + i)];
+            const int64_t k0 = h.hit_off[i], k1 = h.hit_off[i + 1];
+            if (k1 > k0) dst.reserve(dst.size() + (size_t)(k1 - k0));
+            const char *nm = reads ? (*reads)[(size_t)(base + i)].Name.c_str() : names[i];
+            const size_t l_name = reads ? (*reads)[(size_t)(base + i)].Name.size() : std::strlen(nm);
+            for (int64_t k = k0; k < k1; ++k) {
+                BamRecordPtr rec = make_record(h, k, seq, nm, l_name, hardclip);
+                if (reads && copyComment_) rec->AddZTag("BC", (*reads)[(size_t)(base + i)].Com);
+                dst.push_back(std::move(rec));              // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
+            }
+        }
+    }
+
+    // one read (the reference's calling convention): one GPU round trip, records built on the calling thread
     void run(const char *bases, const uint64_t *offs, int64_t n, const char *const *names, const UnalignedSequenceVector *reads, bool hardclip,
              double keepSecFrac, int maxSecondary, BamRecordPtrVector *single_out, std::vector<BamRecordPtrVector> *batch_out) const
     {
@@ -225,38 +353,121 @@ private:
             slx_lrand48_skip_libc((uint64_t)n);
         }
         slx_hits h;
-        const int rc = slx_align_batch(al, &memopt_, bases, offs, n, state, 0, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &h);
-        if (rc == SLX_ENOMEM) throw std::bad_alloc();
-        if (rc == SLX_EINVAL) throw std::invalid_argument(slx_last_error());
-        if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner::alignSequence: ") + slx_last_error());
-        // record construction (src/BWAAligner.cpp:151-248): reads [a, b) -- every read owns its own output vector, so a large
-        // batch is materialised by several host threads (the step is malloc- and shared_ptr-bound, SURVEY hard part 7)
-        auto materialise = [&](int64_t a, int64_t b) {
-            for (int64_t i = a; i < b; ++i) {
-                const std::string_view seq(bases + offs[i], (size_t)(offs[i + 1] - offs[i]));
-                BamRecordPtrVector &dst = single_out ? *single_out : (*batch_out)[(size_t)i];
-                for (int64_t k = h.hit_off[i]; k < h.hit_off[i + 1]; ++k) {
-                    BamRecordPtr rec = make_record(h, k, seq, names[i], hardclip);
-                    if (reads && copyComment_) rec->AddZTag("BC", (*reads)[(size_t)i].Com);
-                    dst.push_back(rec);                     // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
+        throw_rc(slx_align_batch(al, &memopt_, bases, offs, n, state, 0, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &h));
+        try { materialise(h, 0, n, bases, offs, names, reads, 0, hardclip, single_out, batch_out); } catch (...) { slx_hits_free(&h); throw; }
+        slx_hits_free(&h);
+    }
+
+    // the batch: chunks of the read vector through pack (host threads) -> align (GPU) -> records (host threads), overlapped.
+    // Tunables (environment): SEQLIB_AMD_THREADS host threads (default: all hardware threads), SEQLIB_AMD_CHUNK reads per chunk
+    // and device (default 2 M).
+    void run_batch(const UnalignedSequenceVector &reads, std::vector<BamRecordPtrVector> &out, bool hardclip, double keepSecFrac, int maxSecondary) const
+    {
+        slx_aligner *al = handle();
+        const int64_t n = (int64_t)reads.size();
+        uint64_t state;
+        {
+            std::lock_guard<std::mutex> g(rng_mutex());
+            state = slx_lrand48_peek_libc();
+            slx_lrand48_skip_libc((uint64_t)n);
+        }
+        std::lock_guard<std::mutex> batch(batch_mu_);
+        const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 2000000) * n_dev_);
+        const int64_t n_chunks = (n + chunk - 1) / chunk;
+        unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)std::max(1u, std::thread::hardware_concurrency()));
+        T = std::max(1u, std::min(T, 512u));
+        if (n < 8192) T = 1;
+        detail::TaskPool pool(T);
+        const int parts = (int)std::min<int64_t>((int64_t)T * 4, std::max<int64_t>(1, chunk / 2048));   // tasks per stage of a chunk
+
+        struct ChunkJob { int64_t lo = 0, hi = 0; std::vector<uint64_t> part_bytes; std::shared_ptr<detail::TaskPool::Group> packed, built; slx_hits h; bool have_h = false; };
+        std::vector<ChunkJob> jobs((size_t)n_chunks);
+        for (int64_t c = 0; c < n_chunks; ++c) { jobs[(size_t)c].lo = c * chunk; jobs[(size_t)c].hi = std::min(n, (c + 1) * chunk); }
+
+        // pack chunk c into staging slot c & 1: lengths per part -> exclusive scan -> offsets + bases, all on the pool
+        auto submit_pack = [&](int64_t c) {
+            ChunkJob &J = jobs[(size_t)c];
+            Staging &S = stage_[c & 1];
+            const int64_t m = J.hi - J.lo;
+            if ((size_t)m + 1 > S.cap_reads) {
+                slx_host_free(S.offs);
+                S.cap_reads = 0;
+                S.offs = static_cast<uint64_t *>(slx_host_alloc(((size_t)m + 1) * 8));
+                if (!S.offs) throw std::bad_alloc();
+                S.cap_reads = (size_t)m + 1;
+            }
+            J.part_bytes.assign((size_t)parts + 1, 0);
+            auto sized = pool.submit(parts, [&, c](int t) {
+                const ChunkJob &Jc = jobs[(size_t)c];
+                const int64_t mm = Jc.hi - Jc.lo, a = Jc.lo + mm * t / parts, b = Jc.lo + mm * (t + 1) / parts;
+                uint64_t tot = 0;
+                for (int64_t i = a; i < b; ++i) tot += reads[(size_t)i].Seq.size();
+                jobs[(size_t)c].part_bytes[(size_t)t + 1] = tot;
+            }, true);
+            pool.wait(sized);
+            for (int t = 0; t < parts; ++t) J.part_bytes[(size_t)t + 1] += J.part_bytes[(size_t)t];
+            const uint64_t total = J.part_bytes[(size_t)parts];
+            if (total + 64 > S.cap_bases) {
+                slx_host_free(S.bases);
+                S.cap_bases = 0;
+                const size_t want = (size_t)(total + total / 8 + 4096);
+                S.bases = static_cast<char *>(slx_host_alloc(want));
+                if (!S.bases) throw std::bad_alloc();
+                S.cap_bases = want;
+            }
+            J.packed = pool.submit(parts, [&, c](int t) {
+                const ChunkJob &Jc = jobs[(size_t)c];
+                Staging &Sc = stage_[c & 1];
+                const int64_t mm = Jc.hi - Jc.lo, a = Jc.lo + mm * t / parts, b = Jc.lo + mm * (t + 1) / parts;
+                uint64_t o = Jc.part_bytes[(size_t)t];
+                for (int64_t i = a; i < b; ++i) {
+                    const std::string &sq = reads[(size_t)i].Seq;
+                    Sc.offs[i - Jc.lo] = o;
+                    std::memcpy(Sc.bases + o, sq.data(), sq.size());
+                    o += sq.size();
                 }
+                if (b == Jc.hi) Sc.offs[mm] = o;
+            }, true);
+        };
+
+        auto cleanup = [&]() {
+            for (ChunkJob &J : jobs) {
+                if (J.built) { try { pool.wait(J.built); } catch (...) {} }
+                if (J.packed) { try { pool.wait(J.packed); } catch (...) {} }
+                if (J.have_h) { slx_hits_free(&J.h); J.have_h = false; }
             }
         };
         try {
-            unsigned T = (single_out || n < 8192) ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-            if (T <= 1) materialise(0, n);
-            else {
-                std::vector<std::thread> th;
-                std::vector<std::exception_ptr> err(T);
-                for (unsigned t = 0; t < T; ++t)
-                    th.emplace_back([&, t]() {
-                        try { materialise(n * (int64_t)t / (int64_t)T, n * (int64_t)(t + 1) / (int64_t)T); } catch (...) { err[t] = std::current_exception(); }
-                    });
-                for (auto &x : th) x.join();
-                for (auto &e : err) if (e) std::rethrow_exception(e);
+            submit_pack(0);
+            for (int64_t c = 0; c < n_chunks; ++c) {
+                ChunkJob &J = jobs[(size_t)c];
+                pool.wait(J.packed);
+                // staging slot (c+1)&1 was last read by the alignment of chunk c-1, which has returned (the records of chunk c-1, being
+                // built meanwhile, read the caller's reads and their own result block); at most two result blocks are alive at a time
+                if (c >= 2) { ChunkJob &P = jobs[(size_t)c - 2]; pool.wait(P.built); slx_hits_free(&P.h); P.have_h = false; }
+                if (c + 1 < n_chunks) submit_pack(c + 1);
+                Staging &S = stage_[c & 1];
+                throw_rc(slx_align_batch(al, &memopt_, S.bases, S.offs, J.hi - J.lo, state, (uint64_t)J.lo, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &J.h));
+                J.have_h = true;
+                J.built = pool.submit(parts, [&, c](int t) {
+                    const ChunkJob &Jc = jobs[(size_t)c];
+                    const int64_t mm = Jc.hi - Jc.lo;
+                    // the sequence of a record comes from the caller's reads (the staging slot is reused two chunks later)
+                    for (int64_t i = mm * t / parts; i < mm * (t + 1) / parts; ++i) {
+                        const UnalignedSequence &us = reads[(size_t)(Jc.lo + i)];
+                        BamRecordPtrVector &dst = out[(size_t)(Jc.lo + i)];
+                        const int64_t k0 = Jc.h.hit_off[i], k1 = Jc.h.hit_off[i + 1];
+                        if (k1 > k0) dst.reserve((size_t)(k1 - k0));
+                        for (int64_t k = k0; k < k1; ++k) {
+                            BamRecordPtr rec = make_record(Jc.h, k, us.Seq, us.Name.c_str(), us.Name.size(), hardclip);
+                            if (copyComment_) rec->AddZTag("BC", us.Com);
+                            dst.push_back(std::move(rec));
+                        }
+                    }
+                }, false);
             }
-        } catch (...) { slx_hits_free(&h); throw; }
-        slx_hits_free(&h);
+            for (ChunkJob &J : jobs) if (J.built) { pool.wait(J.built); if (J.have_h) { slx_hits_free(&J.h); J.have_h = false; } }
+        } catch (...) { cleanup(); throw; }
     }
 };
 

@@ -6,6 +6,8 @@
 #pragma once
 #include <cassert>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <regex>
@@ -20,6 +22,20 @@ namespace SeqLib {
 struct Bam1Deleter {            // /root/reference/SeqLib/BamWalker.h:19-24
     void operator()(bam1_t *b) const { if (b) bam_destroy1(b); }
 };
+// A default-constructed BamRecord keeps its bam1_t and the shared_ptr control block in ONE allocation (the reference pays
+// bam_init1's calloc plus the control block): the record's shared_ptr<bam1_t> aliases the member of this box.
+struct Bam1Box {
+    bam1_t b;
+    Bam1Box() { std::memset(&b, 0, sizeof b); }
+    ~Bam1Box() { std::free(b.data); }
+    Bam1Box(const Bam1Box &) = delete;
+    Bam1Box &operator=(const Bam1Box &) = delete;
+};
+inline std::shared_ptr<bam1_t> make_bam1()
+{
+    auto box = std::make_shared<Bam1Box>();
+    return std::shared_ptr<bam1_t>(box, &box->b);
+}
 
 constexpr char BASES[16] = {' ', 'A', 'C', ' ', 'G', ' ', ' ', ' ', 'T', ' ', ' ', ' ', ' ', ' ', ' ', 'N'};
 
@@ -90,7 +106,7 @@ typedef std::vector<BamRecordPtr> BamRecordPtrVector;
 class BamRecord {
     friend class BWAAligner;
 public:
-    BamRecord() : b(bam_init1(), Bam1Deleter()) {}
+    BamRecord() : b(make_bam1()) {}
     explicit BamRecord(bam1_t *raw) : b(raw, Bam1Deleter()) {}
     BamRecord(const BamRecord &) = delete;
     BamRecord &operator=(const BamRecord &) = delete;

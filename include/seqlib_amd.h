@@ -21,6 +21,7 @@
  *                       the hit sort/filter glue                  src/BWAAligner.cpp:89-146
  *                       (record materialisation :151-248 stays in the C++ mirror)
  *   slx_hits_pack       (new) packed image of the hits for the multi-GPU gather; no reference counterpart
+ *   slx_device_count, slx_host_alloc/free/trim   (new) plumbing of the multi-device and pinned-staging paths; no reference counterpart
  *   slx_lrand48_*       the libc lrand48() stream mem_align1 consumes
  */
 #ifndef SEQLIB_AMD_H
@@ -88,9 +89,14 @@ int64_t slx_index_len(const slx_index *idx, int i);
 int64_t slx_index_l_pac(const slx_index *idx);
 int  slx_index_n_holes(const slx_index *idx);
 
-/* ---- aligner (device-resident FM-index + workspaces on one GPU) ---- */
-/* devices/n_dev: HIP device ordinals; this round one aligner drives devices[0] (one process per GPU).
- * NULL/0 = current device. */
+/* ---- aligner (device-resident FM-index + workspaces) ---- */
+/* devices/n_dev: HIP device ordinals; NULL/0 = the current device.  With n_dev > 1 the handle drives every listed device: the
+ * index is replicated on each, slx_align_batch shards a batch over them by contiguous read-ordinal ranges (read i keeps
+ * lrand48 draw first_ordinal + i wherever it runs) with one host thread per device, and the per-device results are merged on
+ * the host -- the records are those of one device (no reference counterpart).  A device may be listed more
+ * than once (independent work sets on it).  slx_align_batch_device, slx_debug_stage and device-resident slx_hits_pack take
+ * single-device handles only. */
+int  slx_device_count(void);   /* visible HIP devices (0 without a GPU) */
 int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
 void slx_aligner_free(slx_aligner *al);
 /* Tuning / test knobs; none of them changes a result (tests/test_gpu_parity.py runs each against the oracle).
@@ -145,6 +151,13 @@ int  slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const void *d_b
                             double keepSecFrac, int maxSecondary, slx_hits *out);
 void slx_hits_free(slx_hits *h);          /* host results only */
 
+/* Pinned host memory, for callers that stage their reads themselves (full PCIe rate for slx_align_batch's uploads).
+ * Large host results come in pinned blocks that slx_hits_free recycles: at most two blocks and 8 GB are retained, and they are
+ * released when the last aligner is freed or by slx_host_trim(). */
+void *slx_host_alloc(uint64_t bytes);
+void  slx_host_free(void *p);
+void  slx_host_trim(void);
+
 /* One contiguous image of a result, for the single RCCL gather of hits to rank 0.
  * Layout (little endian): int64 hdr[4] = {n_reads, n_hits, n_cigar, 0}; int64 hit_off[n_reads+1];
  * int64 pos[n_hits]; int64 cig_off[n_hits+1]; int32 rid, score, nm, na, n_cigar_ops [n_hits] each;
@@ -167,6 +180,8 @@ const char *slx_stage_name(int i);
  * family (k_extend_cand, k_first_prep, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_dp) */
 #define SLX_N_PROBES 3
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
+/* how many launches of each of those groups the sums cover (= chunks of the last batch over all workers and devices) */
+int  slx_aligner_probe_launches(const slx_aligner *al);
 
 /* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work
  * areas as int64 words.  what = 0: SMEM intervals after mem_collect_intv {start, end, x0, x2}; 1: kept chains in extension order

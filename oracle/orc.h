@@ -231,6 +231,10 @@ int  orc_align_batch(const orc_opt *opt, const orc_index *idx, const char *bases
                      int maxSecondary, uint64_t rng_base, uint64_t first_ordinal,
                      orc_batch_out *out);
 void orc_batch_free(orc_batch_out *o);
+/* bench.py's CPU baseline: n_threads std::threads over disjoint read ranges of one batch sharing one index; returns wall seconds */
+double orc_time_batch_mt(const orc_opt *opt, const orc_index *idx, const char *bases, const uint64_t *offs, int64_t n_reads,
+                         int n_threads, int hardclip, double keepSecFrac, int maxSecondary, uint64_t rng_base,
+                         uint64_t first_ordinal, int64_t *n_hits_out, double *thread_secs);
 void orc_free(void *p);
 
 extern const uint8_t orc_nt4_table[256];

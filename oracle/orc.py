@@ -106,6 +106,9 @@ def lib():
         L.orc_align_batch.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_int64,
                                       C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(BatchOut)]
         L.orc_batch_free.argtypes = [C.POINTER(BatchOut)]
+        L.orc_time_batch_mt.restype = C.c_double
+        L.orc_time_batch_mt.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_int64, C.c_int, C.c_int,
+                                        C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.orc_counters_get.argtypes = [C.POINTER(Counters)]
         L.orc_stage_dump.restype = C.c_int64
         L.orc_stage_dump.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int64]
@@ -216,6 +219,18 @@ def align_batch_flat(opt, index, bases, offs, hardclip=False, keep_sec_frac=0.9,
                cigar=arr(o.cigar, int(cig_off[-1]) if nh else 0, np.uint32), hit_off=arr(o.hit_off, n + 1, np.int64))
     lib().orc_batch_free(C.byref(o))
     return res
+
+
+def time_batch_mt(opt, index, bases, offs, n_threads, hardclip=False, keep_sec_frac=0.9, max_secondary=10, rng_base=0, first_ordinal=0):
+    """bench.py's CPU baseline: one process, n_threads std::threads over disjoint read ranges sharing the index.
+    -> (wall seconds, hits, per-thread seconds)"""
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    nh = C.c_int64()
+    ts = (C.c_double * n_threads)()
+    wall = lib().orc_time_batch_mt(C.byref(opt), index.h, bases, offs.ctypes.data_as(C.POINTER(C.c_uint64)), n, n_threads, int(hardclip),
+                                   keep_sec_frac, max_secondary, rng_base, first_ordinal, C.byref(nh), ts)
+    return wall, nh.value, list(ts)
 
 
 def stage_dump(opt, index, seq, what):

@@ -8,8 +8,10 @@
  */
 #include "orc.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 extern "C" orc_counters *orc_counters_ptr(void);
@@ -190,4 +192,42 @@ extern "C" void orc_batch_free(orc_batch_out *o)
     std::free(o->n_cigar); std::free(o->pos); std::free(o->flag); std::free(o->mapq); std::free(o->cig_off);
     std::free(o->cigar); std::free(o->hit_off);
     std::memset(o, 0, sizeof *o);
+}
+
+/* The CPU baseline of bench.py as SURVEY 8d(ii) defines it: ONE process, n_threads std::threads over disjoint contiguous read
+ * ranges sharing one read-only index, each read one orc_align_sequence call (the reference's calling convention).  Returns the
+ * wall time from the start of the first thread to the join of the last; thread_secs[t] (if not null) = thread t's own time. */
+extern "C" double orc_time_batch_mt(const orc_opt *opt, const orc_index *idx, const char *bases, const uint64_t *offs, int64_t n_reads,
+                                    int n_threads, int hardclip, double keepSecFrac, int maxSecondary, uint64_t rng_base,
+                                    uint64_t first_ordinal, int64_t *n_hits_out, double *thread_secs)
+{
+    if (n_threads < 1) n_threads = 1;
+    std::vector<int64_t> hits((size_t)n_threads, 0);
+    std::vector<double> secs((size_t)n_threads, 0.0);
+    auto work = [&](int t) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int64_t a = n_reads * t / n_threads, b = n_reads * (t + 1) / n_threads;
+        int64_t nh = 0;
+        for (int64_t r = a; r < b; ++r) {
+            orc_hit *h = nullptr;
+            const int n = orc_align_sequence(opt, idx, bases + offs[r], (int)(offs[r + 1] - offs[r]), "r", hardclip, keepSecFrac, maxSecondary,
+                                             rng_base, first_ordinal + (uint64_t)r, &h);
+            nh += n;
+            orc_hits_free(h, n);
+        }
+        hits[(size_t)t] = nh;
+        secs[(size_t)t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int64_t tot = 0;
+    for (int t = 0; t < n_threads; ++t) { tot += hits[(size_t)t]; if (thread_secs) thread_secs[t] = secs[(size_t)t]; }
+    if (n_hits_out) *n_hits_out = tot;
+    return wall;
 }

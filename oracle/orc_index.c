@@ -320,6 +320,24 @@ orc_index *orc_index_load(const char *prefix)
         p->offset = ll; p->len = a; p->n_ambs = b; p->is_alt = 0;
     }
     fclose(fp);
+    /* bns_restore: <prefix>.alt, if present -- the first field of every line that does not start with '@' names an ALT contig
+     * (bwa looks the name up in a hash of the contig names in which a later contig of the same name replaces an earlier one) */
+    snprintf(fn, sizeof fn, "%s.alt", prefix);
+    if ((fp = fopen(fn, "r")) != NULL) {
+        char str[1024];
+        int c, k = 0;
+        while ((c = fgetc(fp)) != EOF) {
+            if (c == '\t' || c == '\n' || c == '\r') {
+                str[k] = 0;
+                if (str[0] != '@')
+                    for (i = idx->n_seqs - 1; i >= 0; --i)
+                        if (strcmp(idx->anns[i].name, str) == 0) { idx->anns[i].is_alt = 1; break; }
+                while (c != '\n' && c != EOF) c = fgetc(fp);
+                k = 0;
+            } else if (k < 1022) str[k++] = (char)c;
+        }
+        fclose(fp);
+    }
     /* .amb */
     snprintf(fn, sizeof fn, "%s.amb", prefix);
     if (!(fp = fopen(fn, "r"))) goto fail;

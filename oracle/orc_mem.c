@@ -9,6 +9,7 @@
 #include "orc.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 #include <math.h>
 #include <assert.h>
@@ -143,6 +144,9 @@ ORC_SORT_INIT(ars2, orc_reg, reg_slt2)
 ORC_SORT_INIT(ars, orc_reg, reg_slt)
 #define reg_hlt(a, b) ((a).score > (b).score || ((a).score == (b).score && ((a).is_alt < (b).is_alt || ((a).is_alt == (b).is_alt && (a).hash < (b).hash))))
 ORC_SORT_INIT(ars_hash, orc_reg, reg_hlt)
+/* alnreg_hlt2: primary-assembly hits first, then by score and hash (second round of mem_mark_primary_se on an ALT-aware index) */
+#define reg_hlt2(a, b) ((a).is_alt < (b).is_alt || ((a).is_alt == (b).is_alt && ((a).score > (b).score || ((a).score == (b).score && (a).hash < (b).hash))))
+ORC_SORT_INIT(ars_hash2, orc_reg, reg_hlt2)
 
 /* ------------------------------------------------------------------ A.4 FM-index interval extension (bwt.c) */
 static void set_intv(const orc_index *idx, int c, orc_intv *ik)
@@ -1200,21 +1204,13 @@ static inline uint64_t hash_64(uint64_t key)
     return key;
 }
 
-static void mem_mark_primary_se(const orc_opt *opt, int n, orc_reg *a, int64_t id)
+/* mem_mark_primary_se_core: z is scratch of n ints */
+static void mem_mark_primary_se_core(const orc_opt *opt, int n, orc_reg *a, int *z)
 {
     int i, k, tmp, nz = 0;
-    int *z;
-    if (n == 0) return;
-    for (i = 0; i < n; ++i) {
-        a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1;
-        a[i].hash = hash_64((uint64_t)(id + i));
-    }
-    introsort_ars_hash((size_t)n, a);
-    /* mem_mark_primary_se_core */
     tmp = opt->a + opt->b;
     tmp = opt->o_del + opt->e_del > tmp ? opt->o_del + opt->e_del : tmp;
     tmp = opt->o_ins + opt->e_ins > tmp ? opt->o_ins + opt->e_ins : tmp;
-    z = (int *)malloc((size_t)n * sizeof(int));
     z[nz++] = 0;
     for (i = 1; i < n; ++i) {
         for (k = 0; k < nz; ++k) {
@@ -1233,8 +1229,46 @@ static void mem_mark_primary_se(const orc_opt *opt, int n, orc_reg *a, int64_t i
         if (k == nz) z[nz++] = i;
         else a[i].secondary = z[k];
     }
+}
+
+/* mem_mark_primary_se, including its ALT-aware second round (bwamem.c): with ALT hits present the regions are re-sorted with the
+ * primary-assembly hits first, `secondary_all` keeps the first round's parent (as a rank in the new order), ALT secondaries get
+ * secondary = INT_MAX, and the primary-assembly hits are marked again among themselves (sub_n is not reset between the rounds). */
+static void mem_mark_primary_se(const orc_opt *opt, int n, orc_reg *a, int64_t id)
+{
+    int i, n_pri = 0;
+    int *z;
+    if (n == 0) return;
+    for (i = 0; i < n; ++i) {
+        a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1;
+        a[i].hash = hash_64((uint64_t)(id + i));
+        if (!a[i].is_alt) ++n_pri;
+    }
+    introsort_ars_hash((size_t)n, a);
+    z = (int *)malloc((size_t)n * sizeof(int));
+    mem_mark_primary_se_core(opt, n, a, z);
+    for (i = 0; i < n; ++i) {
+        orc_reg *p = &a[i];
+        p->secondary_all = i; /* the rank in the first round */
+        if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
+    }
+    if (n_pri >= 0 && n_pri < n) {
+        if (n_pri > 0) introsort_ars_hash2((size_t)n, a);
+        for (i = 0; i < n; ++i) z[a[i].secondary_all] = i;
+        for (i = 0; i < n; ++i) {
+            if (a[i].secondary >= 0) {
+                a[i].secondary_all = z[a[i].secondary];
+                if (a[i].is_alt) a[i].secondary = INT_MAX;
+            } else a[i].secondary_all = -1;
+        }
+        if (n_pri > 0) { /* mark primaries among the hits to the primary assembly only */
+            for (i = 0; i < n_pri; ++i) { a[i].sub = 0; a[i].secondary = -1; }
+            mem_mark_primary_se_core(opt, n_pri, a, z);
+        }
+    } else {
+        for (i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary;
+    }
     free(z);
-    for (i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary; /* no ALT contigs on this path */
 }
 
 /* ------------------------------------------------------------------ A.2 mem_align1 */

@@ -72,6 +72,7 @@ res = {
     "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --config %s --no-cpu-baseline --no-extras --verify 0 --steps 2 --warmup 1 "
                "(one pass per counter set; scripts/profile_round.sh)" % config,
     "note": "per-launch means over the full-size launches; see the module docstring of scripts/pmc_summary.py for units and formulas",
+    "valu_busy_formula": "SQ_ACTIVE_INST_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
     "reads_per_launch": reads,
     "seed_fetch_bytes_per_read": fetch, "seed_write_bytes_per_read": write,
     "seed_l2_hit_rate": (g(seed12, "TCC_HIT_sum") / g(seed12, "TCC_REQ_sum")) if g(seed12, "TCC_REQ_sum") else None,

@@ -7,6 +7,10 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --config $CFG --no-cpu-baseline --no-extras --verify 0 --steps 2 --warmup 1 $*"
+# the read set is generated once, un-profiled (forked generator workers), and the profiled runs only load it: under rocprofv3 the
+# tool has initialised the GPU before main(), and a process in that state must not fork
+export SLX_BENCH_READS_CACHE=/tmp/slx_reads_cache
+timeout -s KILL 600 $BENCH > $OUT/bench_unprofiled.log 2>&1
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv

@@ -153,9 +153,10 @@ class BWAAligner:
             al = C.c_void_p()
             if self._device is None:
                 rc = _ffi.lib().slx_aligner_create(self.index_._h, None, 0, C.byref(al))
-            else:
-                dev = (C.c_int * 1)(self._device)
-                rc = _ffi.lib().slx_aligner_create(self.index_._h, dev, 1, C.byref(al))
+            else:                      # one device ordinal, or a list of them (a group handle: the batch is sharded inside the C-ABI)
+                devs = list(self._device) if isinstance(self._device, (list, tuple)) else [self._device]
+                dev = (C.c_int * len(devs))(*devs)
+                rc = _ffi.lib().slx_aligner_create(self.index_._h, dev, len(devs), C.byref(al))
             _ffi.check(rc)
             self._al = al
         return self._al
@@ -245,6 +246,10 @@ class BWAAligner:
         ms, n = (C.c_float * _ffi.SLX_N_PROBES)(), C.c_int64()
         _ffi.check(_ffi.lib().slx_aligner_probe_ms(self._handle(), ms, C.byref(n)))
         return dict(seed=ms[0], extend=ms[1], cigar=ms[2]), n.value
+
+    def probe_launches(self):
+        """launches of each probed kernel group in the last batch (chunks over all workers and devices)"""
+        return int(_ffi.lib().slx_aligner_probe_launches(self._handle()))
 
     def stage_ms(self):
         ms = (C.c_float * _ffi.SLX_N_STAGES)()

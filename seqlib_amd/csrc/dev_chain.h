@@ -221,7 +221,8 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                     const int j = kept[k], cj = a[j];
                     const int b_max = cbeg(cj) > cbeg(ci) ? cbeg(cj) : cbeg(ci);
                     const int e_min = cend(cj) < cend(ci) ? cend(cj) : cend(ci);
-                    if (e_min > b_max) {         // overlap on the query (no ALT contigs on this path)
+                    // overlap on the query; not counted when the kept chain is on an ALT contig and this one is not (mem_chain_flt)
+                    if (e_min > b_max && (!ref_is_alt(R, w.c_rid[cj]) || ref_is_alt(R, w.c_rid[ci]))) {
                         const int li = cend(ci) - cbeg(ci), lj = cend(cj) - cbeg(cj);
                         const int min_l = li < lj ? li : lj;
                         if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {

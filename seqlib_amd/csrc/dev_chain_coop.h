@@ -184,6 +184,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
             for (int i = 1; i < n_chn; ++i) {
                 const int ci = a[i];
                 const int bi = s_cb[ci], ei = s_ce[ci], wi = s_w[ci], li = ei - bi;
+                const bool i_alt = ref_is_alt(R, w.c_rid[ci]) != 0;
                 int large_ovlp = 0;
                 bool broke = false;
                 for (int kb = 0; kb < n_kept && !broke; kb += 64) {
@@ -194,7 +195,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                         cj = a[s_kept[k]];
                         const int bj = s_cb[cj], ej = s_ce[cj];
                         const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
-                        if (e_min > b_max) {
+                        if (e_min > b_max && (!ref_is_alt(R, w.c_rid[cj]) || i_alt)) {   // (an ALT kept chain does not shadow a primary-assembly one)
                             const int lj = ej - bj;
                             const int min_l = li < lj ? li : lj;
                             if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {

@@ -230,6 +230,80 @@ __device__ inline int dev_approx_mapq_se(const slx_opt &o, const DReg &a, const 
     return mapq;
 }
 
+// mem_mark_primary_se on an index with ALT contigs (bwamem.c, both rounds), one lane, regions by handle in global memory:
+// round one over all regions in (score desc, is_alt, hash) order; when ALT hits are present the list is re-sorted with the
+// primary-assembly hits first (alnreg_hlt2), an ALT hit that had a parent becomes secondary = INT_MAX, and the primary-assembly
+// hits are marked again among themselves (sub and secondary reset, sub_n carried over, as bwa does).  `secondary_all` (the
+// first round's parent as a rank in the final order) is left by handle in the read's srt[] scratch for callers that want it.
+__device__ inline void dev_mark_primary_alt(const DevRef &R, const slx_opt &opt, const ReadWS &w, int n, uint64_t id)
+{
+    int *a = w.ia, *z = w.ib;
+    int *par = (int *)w.srt;                       // by handle: first-round parent (handle), then secondary_all
+    DReg *G = w.regs;
+    auto alt = [&](int h) { return ref_is_alt(R, G[h].rid); };
+    int tmp = opt.a + opt.b;
+    tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
+    tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
+    auto core = [&](int m) {                       // mem_mark_primary_se_core over a[0..m)
+        int nz = 0;
+        z[nz++] = 0;
+        for (int i = 1; i < m; ++i) {
+            int k;
+            DReg &ai = G[a[i]];
+            for (k = 0; k < nz; ++k) {
+                DReg &aj = G[a[z[k]]];
+                const int b_max = aj.qb > ai.qb ? aj.qb : ai.qb;
+                const int e_min = aj.qe < ai.qe ? aj.qe : ai.qe;
+                if (e_min > b_max) {
+                    const int min_l = ai.qe - ai.qb < aj.qe - aj.qb ? ai.qe - ai.qb : aj.qe - aj.qb;
+                    if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) {
+                        if (aj.sub == 0) aj.sub = ai.score;
+                        if (aj.score - ai.score <= tmp && (alt(a[z[k]]) || !alt(a[i]))) ++aj.sub_n;
+                        break;
+                    }
+                }
+            }
+            if (k == nz) z[nz++] = i;
+            else ai.secondary = z[k];
+        }
+    };
+    int n_pri = 0;
+    for (int i = 0; i < n; ++i) {
+        DReg &p = G[a[i]];
+        p.sub = 0; p.secondary = -1;
+        p.hash = dev_hash_64(id + (uint64_t)i);
+        if (!alt(a[i])) ++n_pri;
+    }
+    ks_introsort_idx(n, a, [&](int x, int y) {
+        const DReg &X = G[x], &Y = G[y];
+        if (X.score != Y.score) return X.score > Y.score;
+        const int ax = alt(x), ay = alt(y);
+        return ax < ay || (ax == ay && X.hash < Y.hash);
+    });
+    core(n);
+    if (n_pri < n) {
+        for (int i = 0; i < n; ++i) { const int sidx = G[a[i]].secondary; par[a[i]] = sidx >= 0 ? a[sidx] : -1; }
+        if (n_pri > 0)
+            ks_introsort_idx(n, a, [&](int x, int y) {
+                const DReg &X = G[x], &Y = G[y];
+                const int ax = alt(x), ay = alt(y);
+                if (ax != ay) return ax < ay;
+                return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);
+            });
+        for (int i = 0; i < n; ++i) z[a[i]] = i;                      // handle -> rank in the final order
+        for (int i = 0; i < n; ++i) {
+            const int h = a[i], ph = par[h];
+            if (ph >= 0) { par[h] = z[ph]; if (alt(h)) G[h].secondary = 0x7fffffff; }
+            else par[h] = -1;
+        }
+        if (n_pri > 0) {
+            for (int i = 0; i < n_pri; ++i) { DReg &p = G[a[i]]; p.sub = 0; p.secondary = -1; }
+            core(n_pri);
+        }
+    } else
+        for (int i = 0; i < n; ++i) par[a[i]] = G[a[i]].secondary;
+}
+
 // mem_sort_dedup_patch + mem_mark_primary_se for one read; returns the number of regions left (their handles are
 // w.ia[0..n) in mem_mark_primary_se order).  Shared by the fused and the split finalize kernels.
 // LDS staging for the three ks_introsort passes of a read with MANY regions (wave-per-read kernel only).  klib's introsort is
@@ -459,6 +533,15 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
         // ---------------- mem_mark_primary_se (salt = this read's lrand48() draw)
         if (n > 0) {
             const uint64_t id = dev_lrand48_nth(ck.rng_state, ck.first_ordinal + (uint64_t)r + 1);
+            if (R.ann_alt) {
+                // ALT-aware index: the two-round marking of bwa, serial (one lane of the wave when the lists are staged -- the handles and
+                // regions it reads were last written by other lanes)
+                if (staged) {
+                    __threadfence_block(); __syncthreads();
+                    if (ss->lane == 0) dev_mark_primary_alt(R, opt, w, n, id);
+                    __threadfence_block(); __syncthreads();
+                } else dev_mark_primary_alt(R, opt, w, n, id);
+            } else {
             if (staged) {
                 for (int i = ss->lane; i < n; i += 64) { DReg &p = G[a[i]]; p.sub = 0; p.secondary = -1; p.hash = dev_hash_64(id + (uint64_t)i); }
                 __threadfence_block();
@@ -474,7 +557,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                          },
                          [&](int x, int y) {
                              const DReg &X = G[x], &Y = G[y];
-                             return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // is_alt is 0 for every region
+                             return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // (no ALT contig in this index: is_alt is 0 for every region)
                          });
             int tmp = opt.a + opt.b;
             tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
@@ -546,6 +629,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 }
                 if (k == nz) z[nz++] = i;
                 else ai.secondary = z[k];
+            }
             }
             }
         }

@@ -22,7 +22,10 @@ struct DevRef {               // packed reference + contig table (bntseq_t)
     int n_seqs;
     const int64_t *ann_off;   // n_seqs
     const int32_t *ann_len;
+    const uint8_t *ann_alt;   // bntann1_t::is_alt per contig (from <prefix>.alt); null when the index has no ALT contig
 };
+
+__device__ __forceinline__ int ref_is_alt(const DevRef &R, int rid) { return R.ann_alt && rid >= 0 ? (int)R.ann_alt[rid] : 0; }
 
 struct DevOpt {               // mem_opt_t as the kernels see it (plain copy of slx_opt)
     slx_opt o;

@@ -97,6 +97,7 @@ struct Worker {
     hipEvent_t ev_probe[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around the seeding kernels / the extension family / the CIGAR kernels
     float stage_ms[SLX_N_STAGES];
     float probe_ms[SLX_N_PROBES] = {0, 0, 0};
+    int n_chunks = 0;                    // chunks this worker ran in the current batch
     int64_t n_hits = 0, n_cig = 0;
     int rc = SLX_OK;
     std::string err;
@@ -114,10 +115,14 @@ struct Worker {
 };
 
 struct slx_aligner {
+    // n_dev > 1 at slx_aligner_create: this handle is a GROUP -- one full single-device aligner per entry of `devices` (the index
+    // replicated on each), a batch sharded over them by contiguous read-ordinal ranges; nothing below is used then
+    std::vector<slx_aligner *> subs;
+    bool is_group = false;
     int device = 0;
     hipStream_t stream = nullptr;
     // index in HBM
-    DevBuf d_bwt, d_occ, d_sup, d_lut, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_loglut;
+    DevBuf d_bwt, d_occ, d_sup, d_lut, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_loglut;
     bool wide = false;            // u64 index (>= 2^32 - 1 BWT symbols, or forced with the "wide_index" knob)
     DevFM<uint32_t> fm32;
     DevFM<uint64_t> fm64;
@@ -168,6 +173,8 @@ struct slx_aligner {
     float stage_ms[SLX_N_STAGES];
     float probe_ms[SLX_N_PROBES] = {0, 0, 0};   // kernel groups of the last batch, summed over the workers' launches (HIP events on the workers' streams)
     int64_t probe_reads = 0;
+    int probe_launches = 0;                     // chunks (= launches of each kernel group) of the last batch, over all workers
+    uint64_t h_first = 0, h_last = 0;           // host-buffer entry: offs[0] and offs[n] of the call in flight (bounds of every part's upload)
 };
 
 template <typename I> static DevFM<I> &fm_of(slx_aligner *al);
@@ -402,6 +409,17 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     al->ref.n_seqs = (int)idx->anns.size();
     al->ref.ann_off = al->d_ann_off.as<int64_t>();
     al->ref.ann_len = al->d_ann_len.as<int32_t>();
+    {   // ALT contigs (<prefix>.alt, bns_restore): mem_chain_flt and mem_mark_primary_se treat their hits differently
+        std::vector<uint8_t> alt;
+        bool any = false;
+        for (const slx_ann &a : idx->anns) { alt.push_back(a.is_alt ? 1 : 0); any = any || a.is_alt; }
+        al->ref.ann_alt = nullptr;
+        if (any) {
+            if ((rc = al->d_ann_alt.ensure(alt.size() + 8)) != SLX_OK) return rc;
+            HIPCHK(hipMemcpy(al->d_ann_alt.p, alt.data(), alt.size(), hipMemcpyHostToDevice));
+            al->ref.ann_alt = al->d_ann_alt.as<uint8_t>();
+        }
+    }
     // log() table from the host's libm
     const int LUT_N = 1 << 16;
     std::vector<double> lut((size_t)LUT_N);
@@ -412,33 +430,76 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     return SLX_OK;
 }
 
+static std::mutex g_live_mu;
+static int g_live_aligners = 0;                 // single-device aligners alive: the pinned-block pool is released with the last one
+static void pin_pool_release_all();
+
+static int create_one(const slx_index *idx, int device, bool current, slx_aligner **out)
+{
+    slx_aligner *al = new slx_aligner();
+    { std::lock_guard<std::mutex> g(g_live_mu); ++g_live_aligners; }
+    const int rc = aligner_init(al, idx, current ? nullptr : &device, current ? 0 : 1);
+    if (rc != SLX_OK) { slx_aligner_free(al); return rc; }   // every partially built resource is owned by *al
+    *out = al;
+    return SLX_OK;
+}
+
+extern "C" int slx_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ndev;
+}
+
 extern "C" int slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out)
 {
     if (!out) return SLX_EINVAL;
     *out = nullptr;
     if (!idx) { slx_set_error("slx_aligner_create: index is null"); return SLX_EINVAL; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    const int ndev = slx_device_count();
+    if (ndev == 0) {
         slx_set_error("no HIP device: the BWAAligner hot path runs on MI355X only (no CPU fallback)");
         return SLX_ENODEVICE;
     }
-    for (const slx_ann &a : idx->anns)
-        if (a.is_alt) {
-            slx_set_error("index has ALT contigs (.alt file): the ALT-aware primary marking of bwa is not implemented on the GPU path");
-            return SLX_EUNSUPPORTED;
+    if (n_dev < 0 || (n_dev > 0 && !devices)) { slx_set_error("slx_aligner_create: bad device list"); return SLX_EINVAL; }
+    for (int i = 0; i < n_dev; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) { slx_set_error("slx_aligner_create: device %d is not one of the %d visible", devices[i], ndev); return SLX_EINVAL; }
+    if (n_dev <= 1) return create_one(idx, n_dev ? devices[0] : 0, n_dev == 0, out);
+    // several devices: one sub-aligner each (a device may be listed twice: two independent work sets on it), built side by side
+    slx_aligner *grp = new slx_aligner();
+    grp->is_group = true;
+    grp->subs.assign((size_t)n_dev, nullptr);
+    grp->host_idx = idx;
+    std::vector<int> rcs((size_t)n_dev, SLX_OK);
+    std::vector<std::string> errs((size_t)n_dev);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_dev; ++i)
+        th.emplace_back([&, i]() {
+            rcs[(size_t)i] = create_one(idx, devices[i], false, &grp->subs[(size_t)i]);
+            if (rcs[(size_t)i] != SLX_OK) errs[(size_t)i] = slx_last_error();
+        });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n_dev; ++i)
+        if (rcs[(size_t)i] != SLX_OK) {
+            slx_set_error("device %d: %s", devices[i], errs[(size_t)i].c_str());
+            const int rc = rcs[(size_t)i];
+            slx_aligner_free(grp);
+            return rc;
         }
-    slx_aligner *al = new slx_aligner();
-    const int rc = aligner_init(al, idx, devices, n_dev);
-    if (rc != SLX_OK) { slx_aligner_free(al); return rc; }   // every partially built resource is owned by *al
-    *out = al;
+    *out = grp;
     return SLX_OK;
 }
 
 extern "C" void slx_aligner_free(slx_aligner *al)
 {
     if (!al) return;
+    if (al->is_group) {                          // the devices' aligners own everything
+        for (slx_aligner *sub : al->subs) slx_aligner_free(sub);
+        delete al;
+        return;
+    }
     (void)hipSetDevice(al->device);
-    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_loglut, &al->o_hit_off,
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_ann_alt, &al->d_loglut, &al->o_hit_off,
                       &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar,
                       &al->st_bases, &al->st_offs, &al->st_pack};
     for (DevBuf *b : bufs) b->release();
@@ -452,11 +513,19 @@ extern "C" void slx_aligner_free(slx_aligner *al)
     }
     if (al->stream) (void)hipStreamDestroy(al->stream);
     delete al;
+    bool last;
+    { std::lock_guard<std::mutex> g(g_live_mu); last = --g_live_aligners == 0; }
+    if (last) pin_pool_release_all();          // recycled pinned result blocks are not kept beyond the last aligner
 }
 
 extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
 {
     if (!al || !key) return SLX_EINVAL;
+    if (al->is_group) {                          // a knob of a group goes to every device's aligner
+        std::lock_guard<std::mutex> call(al->call_mu);
+        for (slx_aligner *sub : al->subs) { const int rc = slx_aligner_set(sub, key, value); if (rc != SLX_OK) return rc; }
+        return SLX_OK;
+    }
     std::lock_guard<std::mutex> call(al->call_mu);
     if (!strcmp(key, "chunk_reads")) { if (value < 1) return SLX_EINVAL; al->chunk_reads = value; }
     else if (!strcmp(key, "cap_intv")) { if (value < 1) return SLX_EINVAL; al->cap_intv = (int)value; }
@@ -506,7 +575,11 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
 
 extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES])
 {
-    if (!al) return SLX_EINVAL;
+    if (!al || !ms) return SLX_EINVAL;
+    if (al->is_group) {                          // devices run side by side: per stage the slowest device
+        for (int i = 0; i < SLX_N_STAGES; ++i) { ms[i] = 0; for (const slx_aligner *sub : al->subs) ms[i] = std::max(ms[i], sub->stage_ms[i]); }
+        return SLX_OK;
+    }
     for (int i = 0; i < SLX_N_STAGES; ++i) ms[i] = al->stage_ms[i];
     return SLX_OK;
 }
@@ -514,9 +587,23 @@ extern "C" int slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES
 extern "C" int slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads)
 {
     if (!al || !ms) return SLX_EINVAL;
+    if (al->is_group) {
+        int64_t n = 0;
+        for (int i = 0; i < SLX_N_PROBES; ++i) ms[i] = 0;
+        for (const slx_aligner *sub : al->subs) { for (int i = 0; i < SLX_N_PROBES; ++i) ms[i] += sub->probe_ms[i]; n += sub->probe_reads; }
+        if (n_reads) *n_reads = n;
+        return SLX_OK;
+    }
     for (int i = 0; i < SLX_N_PROBES; ++i) ms[i] = al->probe_ms[i];
     if (n_reads) *n_reads = al->probe_reads;
     return SLX_OK;
+}
+
+extern "C" int slx_aligner_probe_launches(const slx_aligner *al)
+{   // launches of each probed kernel group in the last batch (= chunks over all workers, and over all devices of a group)
+    if (!al) return 0;
+    if (al->is_group) { int n = 0; for (const slx_aligner *sub : al->subs) n += sub->probe_launches; return n; }
+    return al->probe_launches;
 }
 
 // ---------------------------------------------------------------- one chunk
@@ -1002,11 +1089,15 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
         // host-buffer entry: this worker's part of the reads goes up on its own stream, so the first part's kernels run while the
         // later parts are still on the PCIe link (full rate needs pinned caller memory; pageable memory is staged by the runtime)
         const uint64_t b0 = h_offs[r_lo], b1 = h_offs[r_hi];
+        // the part boundaries come from the caller's offsets, which nothing has validated yet (k_len_stats checks monotonicity on the
+        // device, after the upload): a part must lie inside [offs[0], offs[n]] or the copy would leave the staging buffer
+        if (b0 < al->h_first || b1 < b0 || b1 > al->h_last) { slx_set_error("read offsets are not monotonic (part [%lld, %lld))", (long long)r_lo, (long long)r_hi); return SLX_EINVAL; }
         if (b1 > b0) HIPCHK(hipMemcpyAsync((void *)(d_bases + b0), h_bases + b0, b1 - b0, hipMemcpyHostToDevice, wk->stream));
         HIPCHK(hipMemcpyAsync((void *)(d_offs + r_lo), h_offs + r_lo, ((size_t)(r_hi - r_lo) + 1) * 8, hipMemcpyHostToDevice, wk->stream));
     }
     for (int i = 0; i < SLX_N_STAGES; ++i) wk->stage_ms[i] = 0;
     for (int i = 0; i < SLX_N_PROBES; ++i) wk->probe_ms[i] = 0;
+    wk->n_chunks = 0;
     int rc;
     const int64_t n_part = r_hi - r_lo;
     if ((rc = wk->o_hit_off.ensure(((size_t)n_part + 1) * 8)) != SLX_OK) return rc;
@@ -1047,6 +1138,7 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
             if (rc != SLX_OK) return rc;
             if (!fl) {
                 hit_base = hb; cig_base = cb;
+                ++wk->n_chunks;
                 std::lock_guard<std::mutex> g(al->mu);   // remember what this workload needed: the next batch does not pay for the retry again
                 al->cap_intv = std::max(al->cap_intv, caps.cap_intv);
                 if (attempt > 0) {   // only what an overflow taught -- per read from a large chunk, as a floor from a small one (a batch
@@ -1133,6 +1225,8 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
         for (int k = 0; k < K; ++k) al->stage_ms[i] += al->workers[(size_t)k]->stage_ms[i];
     }
     al->probe_reads = n_reads;
+    al->probe_launches = 0;
+    for (int k = 0; k < K; ++k) al->probe_launches += al->workers[(size_t)k]->n_chunks;
     for (int i = 0; i < SLX_N_PROBES; ++i) {
         al->probe_ms[i] = 0;
         for (int k = 0; k < K; ++k) al->probe_ms[i] += al->workers[(size_t)k]->probe_ms[i];
@@ -1193,6 +1287,7 @@ extern "C" int slx_align_batch_device(slx_aligner *al, const slx_opt *opt, const
                                       slx_hits *out)
 {
     if (!al || !opt || !out || n_reads < 0) { slx_set_error("slx_align_batch_device: bad argument"); return SLX_EINVAL; }
+    if (al->is_group) { slx_set_error("slx_align_batch_device: reads resident on one GPU cannot be sharded -- use one aligner per device, or slx_align_batch"); return SLX_EINVAL; }
     std::lock_guard<std::mutex> call(al->call_mu);
     return align_device_locked(al, opt, d_bases, d_offs, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, out);
 }
@@ -1203,13 +1298,16 @@ namespace {
 struct PinBlock { void *p; uint64_t cap; };
 std::mutex g_pin_mu;
 std::vector<PinBlock> g_pin_pool;
-const size_t PIN_KEEP = 2;
+const size_t PIN_KEEP = 2;                      // blocks kept ...
+const uint64_t PIN_KEEP_BYTES = 8ull << 30;     // ... and bytes kept, at most (a 50 M-read result is ~2.7 GB); dropped when the last aligner is freed
 void *pin_acquire(uint64_t bytes, uint64_t *cap)
 {
-    {
+    {   // best fit: a small result must not take the multi-gigabyte block the next large one wants
         std::lock_guard<std::mutex> g(g_pin_mu);
+        size_t best = g_pin_pool.size();
         for (size_t i = 0; i < g_pin_pool.size(); ++i)
-            if (g_pin_pool[i].cap >= bytes) { void *p = g_pin_pool[i].p; *cap = g_pin_pool[i].cap; g_pin_pool.erase(g_pin_pool.begin() + (long)i); return p; }
+            if (g_pin_pool[i].cap >= bytes && (best == g_pin_pool.size() || g_pin_pool[i].cap < g_pin_pool[best].cap)) best = i;
+        if (best < g_pin_pool.size()) { void *p = g_pin_pool[best].p; *cap = g_pin_pool[best].cap; g_pin_pool.erase(g_pin_pool.begin() + (long)best); return p; }
     }
     void *p = nullptr;
     const uint64_t want = bytes + bytes / 16;
@@ -1221,11 +1319,31 @@ void pin_release(void *p, uint64_t cap)
 {
     {
         std::lock_guard<std::mutex> g(g_pin_mu);
-        if (g_pin_pool.size() < PIN_KEEP) { g_pin_pool.push_back({p, cap}); return; }
+        uint64_t held = cap;
+        for (const PinBlock &b : g_pin_pool) held += b.cap;
+        bool alive;
+        { std::lock_guard<std::mutex> g2(g_live_mu); alive = g_live_aligners > 0; }
+        if (alive && g_pin_pool.size() < PIN_KEEP && held <= PIN_KEEP_BYTES) { g_pin_pool.push_back({p, cap}); return; }
     }
     (void)hipHostFree(p);
 }
 }  // namespace
+static void pin_pool_release_all()
+{
+    std::vector<PinBlock> drop;
+    { std::lock_guard<std::mutex> g(g_pin_mu); drop.swap(g_pin_pool); }
+    for (const PinBlock &b : drop) (void)hipHostFree(b.p);
+}
+
+// pinned host memory for callers that stage reads themselves (the C++ mirror packs a batch straight into it)
+extern "C" void *slx_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slx_set_error("cannot pin %llu bytes of host memory", (unsigned long long)bytes); return nullptr; }
+    return p;
+}
+extern "C" void slx_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" void slx_host_trim(void) { pin_pool_release_all(); }
 
 static uint64_t packed_size(uint64_t N, uint64_t H, uint64_t Cg) { return 32 + 8 * (N + 1) + 8 * H + 8 * (H + 1) + 5 * 4 * H + 4 * Cg + 2 * H + H; }
 
@@ -1248,14 +1366,85 @@ static void view_packed(slx_hits *out, uint8_t *blk, int64_t N, int64_t H, int64
     out->mapq = (uint8_t *)d;
 }
 
+// A group handle (n_dev > 1): the batch is cut into contiguous read-ordinal ranges, one per device (read i keeps lrand48
+// draw first_ordinal + i wherever it runs), every device's aligner takes its range through the ordinary host entry on its own host
+// thread, and the per-device results are merged on the host into one packed block -- no data-path traffic between the GPUs.
+static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads, uint64_t rng_state,
+                             uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
+{
+    std::lock_guard<std::mutex> call(grp->call_mu);
+    const int G = (int)grp->subs.size();
+    std::vector<int64_t> lo((size_t)G + 1);
+    for (int g = 0; g <= G; ++g) lo[(size_t)g] = n_reads * g / G;
+    std::vector<slx_hits> part((size_t)G);
+    std::vector<int> rcs((size_t)G, SLX_OK);
+    std::vector<std::string> errs((size_t)G);
+    for (auto &h : part) memset(&h, 0, sizeof h);
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g)
+            th.emplace_back([&, g]() {
+                const int64_t a = lo[(size_t)g], b = lo[(size_t)g + 1];
+                if (b == a) return;
+                rcs[(size_t)g] = slx_align_batch(grp->subs[(size_t)g], opt, bases, offs + a, b - a, rng_state, first_ordinal + (uint64_t)a, hardclip, keepSecFrac,
+                                                 maxSecondary, &part[(size_t)g]);
+                if (rcs[(size_t)g] != SLX_OK) errs[(size_t)g] = slx_last_error();
+            });
+        for (auto &t : th) t.join();
+    }
+    auto drop_parts = [&]() { for (auto &h : part) slx_hits_free(&h); };
+    for (int g = 0; g < G; ++g)
+        if (rcs[(size_t)g] != SLX_OK) { slx_set_error("device %d: %s", grp->subs[(size_t)g]->device, errs[(size_t)g].c_str()); drop_parts(); return rcs[(size_t)g]; }
+    int64_t H = 0, C = 0;
+    for (const auto &h : part) { H += h.n_hits; C += h.n_cigar; }
+    const uint64_t bytes = packed_size((uint64_t)n_reads, (uint64_t)H, (uint64_t)C);
+    void *blk = nullptr;
+    uint64_t blk_cap = 0;
+    if (bytes >= (1u << 20)) blk = pin_acquire(bytes, &blk_cap);
+    const bool is_pinned = blk != nullptr;
+    if (!blk) blk = malloc(bytes);
+    if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); drop_parts(); return SLX_ENOMEM; }
+    int64_t hdr[4] = {n_reads, H, C, 0};
+    memcpy(blk, hdr, 32);
+    out->n_reads = n_reads; out->n_hits = H; out->n_cigar = C; out->on_device = 0;
+    out->block = blk; out->block_pinned = is_pinned ? 1 : 0; out->block_bytes = is_pinned ? blk_cap : bytes;
+    view_packed(out, (uint8_t *)blk, n_reads, H, C);
+    {   // every device's slice lands at its hit / cigar base (one host thread per slice)
+        std::vector<int64_t> hb((size_t)G + 1, 0), cb((size_t)G + 1, 0);
+        for (int g = 0; g < G; ++g) { hb[(size_t)g + 1] = hb[(size_t)g] + part[(size_t)g].n_hits; cb[(size_t)g + 1] = cb[(size_t)g] + part[(size_t)g].n_cigar; }
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g)
+            th.emplace_back([&, g]() {
+                const slx_hits &p = part[(size_t)g];
+                const int64_t np = lo[(size_t)g + 1] - lo[(size_t)g], h = p.n_hits, c = p.n_cigar, h0 = hb[(size_t)g], c0 = cb[(size_t)g];
+                for (int64_t i = 0; i < np; ++i) out->hit_off[lo[(size_t)g] + i] = p.hit_off[i] + h0;
+                for (int64_t i = 0; i < h; ++i) out->cig_off[h0 + i] = p.cig_off[i] + c0;
+                if (h) {
+                    memcpy(out->rid + h0, p.rid, (size_t)h * 4); memcpy(out->pos + h0, p.pos, (size_t)h * 8); memcpy(out->flag + h0, p.flag, (size_t)h * 2);
+                    memcpy(out->mapq + h0, p.mapq, (size_t)h); memcpy(out->score + h0, p.score, (size_t)h * 4); memcpy(out->nm + h0, p.nm, (size_t)h * 4);
+                    memcpy(out->na + h0, p.na, (size_t)h * 4); memcpy(out->n_cigar_ops + h0, p.n_cigar_ops, (size_t)h * 4);
+                }
+                if (c) memcpy(out->cigar + c0, p.cigar, (size_t)c * 4);
+            });
+        for (auto &t : th) t.join();
+        out->hit_off[n_reads] = H;
+        out->cig_off[H] = C;
+    }
+    drop_parts();
+    return SLX_OK;
+}
+
 extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
                                uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
 {
     if (!al || !opt || !out || n_reads < 0 || (n_reads > 0 && (!bases || !offs))) { slx_set_error("slx_align_batch: bad argument"); return SLX_EINVAL; }
     memset(out, 0, sizeof *out);
+    if (al->is_group) return group_align_batch(al, opt, bases, offs, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, out);
     std::lock_guard<std::mutex> call(al->call_mu);
     HIPCHK(hipSetDevice(al->device));
+    if (n_reads && offs[n_reads] < offs[0]) { slx_set_error("read offsets are not monotonic"); return SLX_EINVAL; }
     const uint64_t first = n_reads ? offs[0] : 0, total = n_reads ? offs[n_reads] - first : 0;
+    al->h_first = first; al->h_last = first + total;
     int rc;
     if ((rc = al->st_bases.ensure(total + 16)) != SLX_OK) return rc;
     if ((rc = al->st_offs.ensure(((size_t)n_reads + 1) * 8)) != SLX_OK) return rc;
@@ -1333,7 +1522,7 @@ extern "C" int slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint
     if (!h || !dst) return SLX_EINVAL;
     if (dst_bytes < slx_hits_packed_size(h)) { slx_set_error("slx_hits_pack: destination too small"); return SLX_EINVAL; }
     if (h->on_device) {
-        if (!al) return SLX_EINVAL;
+        if (!al || al->is_group) return SLX_EINVAL;
         std::lock_guard<std::mutex> call(al->call_mu);
         return pack_locked(al, h, dst);
     }
@@ -1348,6 +1537,7 @@ extern "C" int slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint
 extern "C" int slx_debug_stage(slx_aligner *al, int64_t read, int what, int64_t *buf, uint64_t cap_words, uint64_t *n_out)
 {
     if (!al || !buf || !n_out) return SLX_EINVAL;
+    if (al->is_group) { slx_set_error("slx_debug_stage: single-device aligners only"); return SLX_EINVAL; }
     std::lock_guard<std::mutex> call(al->call_mu);
     Worker *wk = al->workers[0];
     if (!al->keep_stages || !wk->last_valid || al->active_k != 1) { slx_set_error("slx_debug_stage: set keep_stages = 1 and run a single-worker batch first"); return SLX_EINVAL; }

@@ -269,8 +269,8 @@ extern "C" int slx_index_load(const char *prefix_, slx_index **out)
         int c;
         while ((c = fgetc(fp)) != EOF) {
             if (c == '\t' || c == '\n' || c == '\r') {
-                if (!tok.empty() && tok[0] != '@')
-                    for (slx_ann &an : idx->anns) if (an.name == tok) { an.is_alt = 1; break; }
+                if (tok.empty() || tok[0] != '@')   // (bwa's name hash keeps the LAST contig of a given name)
+                    for (size_t k = idx->anns.size(); k-- > 0;) if (idx->anns[k].name == tok) { idx->anns[k].is_alt = 1; break; }
                 while (c != '\n' && c != EOF) c = fgetc(fp);
                 tok.clear();
             } else tok.push_back((char)c);
