@@ -278,8 +278,70 @@ static int thread_checks(const std::string &prefix, const std::string &fastq, lo
     return 0;
 }
 
+// every byte a record carries: core fields + the data blob
+static std::string rec_bytes(const BamRecordPtrVector &v)
+{
+    std::string o;
+    for (auto &r : v) {
+        const bam1_t *b = r->raw();
+        o.append(reinterpret_cast<const char *>(&b->core.pos), sizeof b->core.pos);
+        o.append(reinterpret_cast<const char *>(&b->core.tid), sizeof b->core.tid);
+        const uint32_t misc[6] = {b->core.qual, b->core.flag, b->core.l_qname, b->core.n_cigar, (uint32_t)b->core.l_qseq, (uint32_t)b->l_data};
+        o.append(reinterpret_cast<const char *>(misc), sizeof misc);
+        o.append(reinterpret_cast<const char *>(b->data), (size_t)b->l_data);
+        o.push_back('|');
+    }
+    return o;
+}
+
+// multidev <prefix> <fastq> <n> <copies>: the batch through (a) one device in one chunk, (b) every visible device listed `copies`
+// times (a group handle: the C-ABI shards the batch) with the batch cut into small chunks (SEQLIB_AMD_CHUNK) so that the
+// pack / align / build pipeline of alignSequences runs several rounds.  Every record must be byte-identical.
+static int multidev_checks(const std::string &prefix, const std::string &fastq, long n, int copies)
+{
+    auto idx = std::make_shared<BWAIndex>();
+    idx->LoadIndex(prefix);
+    std::ifstream fq(fastq);
+    std::string h, s, p, q;
+    UnalignedSequenceVector reads;
+    while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q) && (long)reads.size() < n)
+        reads.emplace_back(h.substr(1), s, q);
+    reads.emplace_back("empty", "");                  // ragged input: an empty read, a short one, a low-complexity one
+    reads.emplace_back("short", "ACGTACGTAC");
+    reads.emplace_back("lowcx", std::string(150, 'A'));
+    const uint64_t st = slx_lrand48_peek_libc();
+    auto rewind = [&]() { unsigned short x[3] = {(unsigned short)(st & 0xffff), (unsigned short)((st >> 16) & 0xffff), (unsigned short)((st >> 32) & 0xffff)}; seed48(x); };
+    std::vector<BamRecordPtrVector> one, many;
+    {
+        BWAAligner bwa(idx);
+        bwa.alignSequences(reads, one, false, 0.9, 10);
+    }
+    rewind();
+    const int ndev = slx_device_count();
+    CHECK(ndev >= 1);
+    std::vector<int> devs;
+    for (int c = 0; c < copies; ++c) for (int d = 0; d < ndev; ++d) devs.push_back(d);
+    setenv("SEQLIB_AMD_CHUNK", "257", 1);
+    setenv("SEQLIB_AMD_THREADS", "5", 1);
+    {
+        BWAAligner bwa(idx);
+        bwa.UseDevices(devs);
+        bwa.alignSequences(reads, many, false, 0.9, 10);
+    }
+    CHECK(one.size() == reads.size() && many.size() == reads.size());
+    long bad = 0, recs = 0;
+    for (size_t i = 0; i < reads.size(); ++i) {
+        recs += (long)one[i].size();
+        if (rec_bytes(one[i]) != rec_bytes(many[i])) { if (!bad) std::fprintf(stderr, "read %zu differs\n", i); ++bad; }
+    }
+    std::printf("devices=%zu (visible %d) reads=%zu records=%ld mismatches=%ld\n", devs.size(), ndev, reads.size(), recs, bad);
+    CHECK(bad == 0 && recs > n * 9 / 10);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 6 && std::string(argv[1]) == "multidev") return multidev_checks(argv[2], argv[3], std::atol(argv[4]), std::atoi(argv[5]));
     if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);
     if (argc >= 3 && std::string(argv[1]) == "fastq") return fastq_dump(argv[2]);
     if (argc >= 4 && std::string(argv[1]) == "writer") return writer_checks(argv[2], std::atol(argv[3]));

@@ -60,6 +60,17 @@ def test_cpp_one_aligner_shared_by_threads(exe, golden_dir):
     assert "mismatches=0" in r.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_multi_device_handle_and_chunked_pipeline(exe, golden_dir):
+    """SeqLib::BWAAligner over a group handle (every visible GPU, each listed twice: slx_aligner_create with n_dev > 1 shards the
+    batch by contiguous read ranges) with the batch cut into 257-read chunks, so that the pack / align / build pipeline of
+    alignSequences runs many rounds: every BamRecord byte-identical to the one-device, one-chunk pass"""
+    r = subprocess.run([exe, "multidev", os.path.join(golden_dir, "tiny.fa"), os.path.join(golden_dir, "sim1_bcr.head3000.fq"), "3000", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches=0" in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------- FastqReader / BamWriter
 def _kseq_like(text):
     """Independent statement of the record grammar FastqReader follows (bwa kseq.h, see include/SeqLib/FastqReader.h),

@@ -484,6 +484,127 @@ def test_config_C4_wide_index(sl, orc, tmp_path):
     assert (np.diff(got["hit_off"]) >= 1).mean() > 0.999
 
 
+def _alt_fixture(sl, orc, tmp_path):
+    """a small ALT-aware index: two primary contigs, and ALT contigs that are diverged / identical copies of stretches of them
+    (the shape of hs38DH's chr*_alt), written by the product, marked by a hand-written <prefix>.alt in bwa's format"""
+    from seqlib_amd import synth
+    rng = np.random.default_rng(77)
+    P = synth.make_genome(300000, seed=701)
+    Q = synth.make_genome(120000, seed=702)
+
+    def diverged(seg, rate, indels):
+        seg = seg.copy()
+        mut = rng.random(len(seg)) < rate
+        seg[mut] = (seg[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        out = list(seg)
+        for _ in range(indels):
+            p = int(rng.integers(100, len(out) - 100))
+            if rng.random() < 0.5:
+                del out[p:p + int(rng.integers(1, 8))]
+            else:
+                out[p:p] = list(rng.integers(0, 4, size=int(rng.integers(1, 8)), dtype=np.uint8))
+        return np.array(out, dtype=np.uint8)
+
+    alts = [("alt_div1", diverged(P[50000:62000], 0.015, 6)), ("alt_same", P[100000:103000].copy()),
+            ("alt_div3", diverged(Q[20000:35000], 0.03, 10)), ("alt_lowcx", np.concatenate([P[200000:200400], np.resize(np.array([0, 1], dtype=np.uint8), 300), P[200400:201000]]))]
+    refs = [("chrP", P), ("chrQ", Q)] + alts
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(nm, synth.genome_ascii(g)) for nm, g in refs])
+    prefix = str(tmp_path / "alt")
+    idx.WriteIndex(prefix)
+    # bwa's .alt is SAM-like: header lines start with '@', the first field of every other line names an ALT contig
+    open(prefix + ".alt", "w").write("@SQ\tSN:ignored\nalt_div1\t0\tchrP\t50001\t60\t12000M\nalt_same\nnot_a_contig\t1\nalt_div3\t16\tchrQ\r\nalt_lowcx\tx\n")
+    # reads: everywhere on the primaries (incl. the stretches the ALTs copy), from the ALT contigs themselves, low complexity
+    reads = []
+    genomes = [g for _, g in refs]
+    for gi, g in enumerate(genomes):
+        nb = 6000 if gi < 2 else 1500
+        blk, _, _ = synth.make_reads_block(g, gi, nb, 150, 4242)
+        reads += [bytes(r).decode() for r in blk]
+    for lo in range(49000, 63000, 97):
+        reads.append(synth.genome_ascii(P[lo:lo + 150]))
+    for lo in range(99900, 103100, 41):
+        reads.append(synth.genome_ascii(P[lo:lo + 150]))
+    reads += ["AC" * 75, "A" * 150, synth.genome_ascii(P[200350:200400]) + "AC" * 50, "ACAC" * 30 + synth.genome_ascii(P[200400:200430])]
+    return prefix, reads
+
+
+def test_alt_contigs_match_oracle(sl, orc, tmp_path):
+    """ALT-aware index (<prefix>.alt, the usual hs38DH shape): bwa's mem_chain_flt lets an ALT chain not shadow a primary-assembly
+    one, and mem_mark_primary_se runs its second round (primary-assembly hits re-marked among themselves, ALT secondaries ->
+    INT_MAX).  Bit-exact vs the oracle on every schedule; and the .alt file must change the answer."""
+    prefix, reads = _alt_fixture(sl, orc, tmp_path)
+    oidx = orc.Index.load(prefix)
+    exp = orc.align_batch(orc.default_opt(), oidx, reads)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+    for knobs in ((), (("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1)), (("regs_big", 2),), (("regs_big", 2), ("split_min", 16), ("heavy_seeds", 3)),
+                  (("wide_index", 1),), (("chain_mode", 0),)):
+        al = sl.BWAAligner(idx)
+        for k, v in knobs:
+            al.set(k, v)
+        assert_same(al.alignSequences(reads), exp, "ALT index %s" % (knobs,))
+    for hc, ksf, ms in ((True, 0.5, 3), (False, 1.5, 10)):
+        al = sl.BWAAligner(idx)
+        assert_same(al.alignSequences(reads, hardclip=hc, keepSecFrac=ksf, maxSecondary=ms),
+                    orc.align_batch(orc.default_opt(), oidx, reads, hardclip=hc, keep_sec_frac=ksf, max_secondary=ms), "ALT index, glue args")
+    # the same index files without the .alt: other records for the reads that touch the ALT contigs (the test would be vacuous otherwise)
+    os.remove(prefix + ".alt")
+    plain = orc.align_batch(orc.default_opt(), orc.Index.load(prefix), reads)
+    assert not all(np.array_equal(plain[k], exp[k]) for k in ("flag", "mapq", "rid", "pos"))
+    idx2 = sl.BWAIndex()
+    idx2.LoadIndex(prefix)
+    assert_same(sl.BWAAligner(idx2).alignSequences(reads), plain, "same files, no .alt")
+
+
+def test_multi_device_handle_equals_single(sl, orc, tiny_gpu, tiny_index, sim_reads):
+    """slx_aligner_create with n_dev > 1 (every visible GPU, each listed up to three times -- also the stand-in for several GPUs on a
+    1-GPU box): slx_align_batch shards the batch by contiguous read-ordinal ranges, one host thread per device, results merged on
+    the host; records, ordinals (a second batch continues the stream) and error paths as with one device"""
+    import torch
+    from seqlib_amd import _ffi
+    (_, s1), (_, s2) = sim_reads
+    seqs = s1[:2500] + ["", "ACGT", "A" * 150] + s2[:2500]
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    nd = torch.cuda.device_count()
+    for copies in (2, 3):
+        al = sl.BWAAligner(tiny_gpu, device=list(range(nd)) * copies)
+        assert_same(al.alignSequences(seqs), exp, "group of %d" % (nd * copies))
+        again = al.alignSequences(s1[:300])
+        assert_same(again, orc.align_batch(orc.default_opt(), tiny_index, s1[:300], first_ordinal=len(seqs)), "second batch on the group")
+        assert_same(al.alignSequences(["ACGT"]), orc.align_batch(orc.default_opt(), tiny_index, ["ACGT"], first_ordinal=len(seqs) + 300), "fewer reads than devices")
+        al.set("heavy_seeds", 8)                       # a knob reaches every device's aligner
+        with pytest.raises(_ffi.SlxError):
+            al.set("no_such_knob", 1)
+        with pytest.raises(_ffi.SlxError) as e:        # a failure on one device fails the call
+            al.alignSequences(s1[:10] + ["ACGT" * (_ffi.SLX_MAX_READ_LEN // 4 + 1)])
+        assert e.value.code == _ffi.SLX_EUNSUPPORTED
+    with pytest.raises(_ffi.SlxError):
+        sl.BWAAligner(tiny_gpu, device=[0, nd + 5])._handle()
+
+
+def test_host_entry_rejects_bad_offsets(sl, tiny_gpu, sim_reads):
+    """non-monotonic offsets are refused before any upload that their part boundaries would size (large batch: several workers)"""
+    from seqlib_amd import _ffi
+    (_, s1), _ = sim_reads
+    n = 1 << 19
+    bases = ("".join(s1[:64]) * (n // 64)).encode()
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("min_split", 1 << 17)
+    bad = offs.copy()
+    bad[n // 3] = offs[-1] + np.uint64(1 << 30)        # a part boundary far outside the buffer
+    with pytest.raises(_ffi.SlxError) as e:
+        al.align_flat(bases, bad)
+    assert e.value.code == _ffi.SLX_EINVAL
+    bad = offs.copy()
+    bad[-1] = 0                                        # offs[n] < offs[0 + 1]
+    with pytest.raises(_ffi.SlxError):
+        al.align_flat(bases, bad)
+    ok = al.align_flat(bases, offs)                    # the handle is still usable
+    assert len(ok["hit_off"]) == n + 1
+
+
 def test_full_size_properties(sl):
     """BASELINE-size batch (2 M reads of C2 here; bench.py runs the 10 M) checked through size-independent
     properties: query-consuming CIGAR length == read length, positions inside the contig, idempotence of a
