@@ -45,6 +45,29 @@ PMC_SUMMARY = os.environ.get("SLX_PMC_SUMMARY") or os.path.join("profiles", ROUN
 _G = {}
 
 
+def effective_cpus():
+    """CPUs this process may use: os.cpu_count() cut down to the affinity mask and the cgroup CPU quota (the GPU boxes show 256
+    hardware threads under a quota of 16 CPUs: 256 busy threads would each run at a sixteenth of their speed)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def _gen_block(job):
     from seqlib_amd import synth
     b, lo, m = job
@@ -64,7 +87,7 @@ def gen_reads(cfg, refs, n_reads, first_block, share=1):
     out = np.frombuffer(buf, dtype=np.uint8).reshape(n_reads, read_len)
     nb = (n_reads + synth.BLOCK - 1) // synth.BLOCK
     jobs = [(first_block + b, b * synth.BLOCK, min(synth.BLOCK, n_reads - b * synth.BLOCK)) for b in range(nb)]
-    procs = max(1, min(nb, (os.cpu_count() or 8) // max(1, share), 48))
+    procs = max(1, min(nb, effective_cpus() // max(1, share), 48))
     _G.update(cfg=cfg, refs=refs, out=out)
     if procs > 1:
         with mp.get_context("fork").Pool(procs) as pool:
@@ -86,7 +109,7 @@ def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
     idx = orc.Index.load(prefix)
     opt = orc.default_opt()
     read_len = reads_ascii.shape[1]
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()                     # hardware threads cut down to the cgroup CPU quota
     cal = min(2000, len(reads_ascii))
     offs = (np.arange(cal + 1, dtype=np.uint64) * np.uint64(read_len))
     orc.lib().orc_counters_reset()
@@ -108,8 +131,9 @@ def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
     del idx
     return dict(value=rate, unit="reads/s", cores=cores, kind="port",
                 sample="%d reads of the same synthetic %s reads, one oracle process, %d std::threads over disjoint read ranges sharing one index "
-                       "(single thread on %d reads: %.0f reads/s; parallel efficiency %.2f; slowest / fastest thread %.1f / %.1f s)"
-                       % (m, cfg_name, cores, cal, rate1, eff or 0.0, max(ts), min(ts)),
+                       "(= the CPUs this process may use: %d hardware threads under the container's CPU quota; single thread on %d reads: %.0f reads/s; "
+                       "parallel efficiency %.2f; slowest / fastest thread %.1f / %.1f s)"
+                       % (m, cfg_name, cores, os.cpu_count() or 1, cal, rate1, eff or 0.0, max(ts), min(ts)),
                 single_thread=rate1, parallel_efficiency=eff), per_read
 
 

@@ -21,7 +21,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cassert>
+#include <chrono>
+#include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -41,6 +44,31 @@
 namespace SeqLib {
 
 namespace detail {
+// CPUs this process may actually use: hardware threads, cut down to the CPU affinity mask and to the cgroup's CPU quota (a container
+// that shows 256 hardware threads with a quota of 16 CPUs runs 256 busy threads at a sixteenth of their speed each).
+inline unsigned effective_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    auto quota = [](const char *path, const char *path_period) -> double {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return 0.0;
+        char a[64] = {0}, b[64] = {0};
+        double q = 0.0;
+        const int got = std::fscanf(f, "%63s %63s", a, b);
+        std::fclose(f);
+        if (got >= 1 && std::strcmp(a, "max") != 0 && std::atof(a) > 0) {
+            double period = got >= 2 ? std::atof(b) : 0.0;
+            if (period <= 0 && path_period) { FILE *g = std::fopen(path_period, "r"); if (g) { if (std::fscanf(g, "%63s", b) == 1) period = std::atof(b); std::fclose(g); } }
+            if (period > 0) q = std::atof(a) / period;
+        }
+        return q;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                         // cgroup v2: "<quota> <period>" or "max <period>"
+    if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // cgroup v1
+    if (q > 0) n = std::min(n, (unsigned)std::max(1.0, std::ceil(q)));
+    return n;
+}
+
 // Host threads of one alignSequences call: task groups run to completion in submission order within a priority class; packing
 // the next chunk's reads (high) goes before building the previous chunk's records (low), so the GPU never waits for its input.
 class TaskPool {
@@ -359,8 +387,8 @@ private:
     }
 
     // the batch: chunks of the read vector through pack (host threads) -> align (GPU) -> records (host threads), overlapped.
-    // Tunables (environment): SEQLIB_AMD_THREADS host threads (default: all hardware threads), SEQLIB_AMD_CHUNK reads per chunk
-    // and device (default 2 M).
+    // Tunables (environment): SEQLIB_AMD_THREADS host threads (default: the CPUs the process may use -- hardware threads cut down to the
+    // cgroup CPU quota), SEQLIB_AMD_CHUNK reads per chunk and device (default 2 M), SEQLIB_AMD_TRACE=1 per-chunk timings on stderr.
     void run_batch(const UnalignedSequenceVector &reads, std::vector<BamRecordPtrVector> &out, bool hardclip, double keepSecFrac, int maxSecondary) const
     {
         slx_aligner *al = handle();
@@ -374,7 +402,7 @@ private:
         std::lock_guard<std::mutex> batch(batch_mu_);
         const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 2000000) * n_dev_);
         const int64_t n_chunks = (n + chunk - 1) / chunk;
-        unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)std::max(1u, std::thread::hardware_concurrency()));
+        unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)detail::effective_cpus());
         T = std::max(1u, std::min(T, 512u));
         if (n < 8192) T = 1;
         detail::TaskPool pool(T);
@@ -437,18 +465,26 @@ private:
                 if (J.have_h) { slx_hits_free(&J.h); J.have_h = false; }
             }
         };
+        const bool trace = env_long("SEQLIB_AMD_TRACE", 0) != 0;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         try {
             submit_pack(0);
             for (int64_t c = 0; c < n_chunks; ++c) {
                 ChunkJob &J = jobs[(size_t)c];
+                const auto t_c = std::chrono::steady_clock::now();
                 pool.wait(J.packed);
+                const double ms_packwait = ms_since(t_c);
                 // staging slot (c+1)&1 was last read by the alignment of chunk c-1, which has returned (the records of chunk c-1, being
                 // built meanwhile, read the caller's reads and their own result block); at most two result blocks are alive at a time
                 if (c >= 2) { ChunkJob &P = jobs[(size_t)c - 2]; pool.wait(P.built); slx_hits_free(&P.h); P.have_h = false; }
                 if (c + 1 < n_chunks) submit_pack(c + 1);
                 Staging &S = stage_[c & 1];
+                const double ms_pre = ms_since(t_c);
                 throw_rc(slx_align_batch(al, &memopt_, S.bases, S.offs, J.hi - J.lo, state, (uint64_t)J.lo, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &J.h));
                 J.have_h = true;
+                if (trace) std::fprintf(stderr, "[alignSequences] chunk %lld (%lld reads): waited %.1f ms for its pack, %.1f ms until the GPU call, GPU call %.1f ms, t = %.1f ms, %u host threads\n",
+                                        (long long)c, (long long)(J.hi - J.lo), ms_packwait, ms_pre, ms_since(t_c) - ms_pre, ms_since(t_begin), T);
                 J.built = pool.submit(parts, [&, c](int t) {
                     const ChunkJob &Jc = jobs[(size_t)c];
                     const int64_t mm = Jc.hi - Jc.lo;
@@ -466,7 +502,9 @@ private:
                     }
                 }, false);
             }
+            const auto t_tail = std::chrono::steady_clock::now();
             for (ChunkJob &J : jobs) if (J.built) { pool.wait(J.built); if (J.have_h) { slx_hits_free(&J.h); J.have_h = false; } }
+            if (trace) std::fprintf(stderr, "[alignSequences] records of the last chunks: %.1f ms after the last GPU call; total %.1f ms\n", ms_since(t_tail), ms_since(t_begin));
         } catch (...) { cleanup(); throw; }
     }
 };

@@ -68,6 +68,9 @@ typedef struct {
     float mapQ_coef_len;
     int mapQ_coef_fac;
     int8_t mat[25];
+    /* read only by the opt-in mem_reg2sam semantics (SLX_F_REG2SAM in flag): bwa's XA_drop_ratio, max_XA_hits, max_XA_hits_alt */
+    float XA_drop_ratio;
+    int max_XA_hits, max_XA_hits_alt;
 } slx_opt;
 
 typedef struct slx_index slx_index;

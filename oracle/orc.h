@@ -54,6 +54,9 @@ typedef struct {
     float mapQ_coef_len;
     int mapQ_coef_fac;
     int8_t mat[25];
+    /* read only by the opt-in mem_reg2sam semantics (orc_align_sequence_sam): bwa's XA_drop_ratio, max_XA_hits, max_XA_hits_alt */
+    float XA_drop_ratio;
+    int max_XA_hits, max_XA_hits_alt;
 } orc_opt;
 
 void orc_opt_init(orc_opt *o);                    /* mem_opt_init + flag|=0x200 (SeqLib/BWAAligner.h:14-18) */
@@ -231,6 +234,30 @@ int  orc_align_batch(const orc_opt *opt, const orc_index *idx, const char *bases
                      int maxSecondary, uint64_t rng_base, uint64_t first_ordinal,
                      orc_batch_out *out);
 void orc_batch_free(orc_batch_out *o);
+/* ---------------------------------------------------------------- bwa's own record selection (mem_reg2sam + mem_gen_alt + the SA tag of
+ * mem_aln2sam, bwamem.c / bwamem_extra.c) -- what `bwa mem` prints for a single-end read and what SeqLib's glue bypasses
+ * (/root/reference/src/BWAAligner.cpp:136-146 have no opt->T, no 0x800, and h.XA is always NULL at :240).  SURVEY.md 8f-3.
+ * Entries of one read: first the RECORDS in bwa's order (primaries with score >= opt->T; the first is the representative, the
+ * others carry 0x800 and a mapq capped at the first's), then the XA ALTERNATIVES (secondaries within XA_drop_ratio of their
+ * first-round primary, when that primary is a record and has at most max_XA_hits of them -- max_XA_hits_alt when one is on an ALT
+ * contig).  A read without records gets no entry (bwa prints an unmapped record; callers synthesise it).  keepSecFrac and
+ * maxSecondary of the SeqLib glue do not apply. */
+typedef struct {
+    int32_t  rid;
+    int64_t  pos;
+    uint16_t flag;        /* 0x10, 0x800 */
+    uint8_t  mapq;
+    int32_t  score, nm, na, sub;   /* sub = XS (max(sub, csub)) */
+    int32_t  n_cigar;
+    uint32_t *cigar;      /* BAM op codes; clips of a record are S (4) or H (5, hardclip), of an XA alternative always S */
+    int32_t  xa_parent;   /* -1 = a record; else the index (among this read's records) of the record it is an alternative of */
+    char    *xa;          /* records: the XA:Z value as bwa builds it (NULL if none) */
+    char    *sa;          /* records: the SA:Z value (NULL if none) */
+} orc_samhit;
+int  orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, const char *seq, int len, int hardclip,
+                            uint64_t rng_base, uint64_t ordinal, orc_samhit **out);
+void orc_samhits_free(orc_samhit *h, int n);
+
 /* bench.py's CPU baseline: n_threads std::threads over disjoint read ranges of one batch sharing one index; returns wall seconds */
 double orc_time_batch_mt(const orc_opt *opt, const orc_index *idx, const char *bases, const uint64_t *offs, int64_t n_reads,
                          int n_threads, int hardclip, double keepSecFrac, int maxSecondary, uint64_t rng_base,

@@ -29,7 +29,7 @@ class Opt(C.Structure):
                [("split_factor", C.c_float), ("split_width", C.c_int), ("max_occ", C.c_int), ("max_chain_gap", C.c_int),
                 ("max_mem_intv", C.c_int), ("mask_level", C.c_float), ("drop_ratio", C.c_float),
                 ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
-                ("mat", C.c_int8 * 25)]
+                ("mat", C.c_int8 * 25), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int), ("max_XA_hits_alt", C.c_int)]
 
 
 class Intv(C.Structure):
@@ -57,6 +57,12 @@ class Hit(C.Structure):
     _fields_ = [("rid", C.c_int32), ("pos", C.c_int64), ("flag", C.c_uint16), ("mapq", C.c_uint8), ("score", C.c_int32),
                 ("nm", C.c_int32), ("na", C.c_int32), ("n_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint32)),
                 ("l_data", C.c_int32), ("data", C.POINTER(C.c_uint8)), ("l_qname", C.c_int32), ("l_qseq", C.c_int32)]
+
+
+class SamHit(C.Structure):
+    _fields_ = [("rid", C.c_int32), ("pos", C.c_int64), ("flag", C.c_uint16), ("mapq", C.c_uint8), ("score", C.c_int32), ("nm", C.c_int32),
+                ("na", C.c_int32), ("sub", C.c_int32), ("n_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint32)), ("xa_parent", C.c_int32),
+                ("xa", C.c_char_p), ("sa", C.c_char_p)]
 
 
 class BatchOut(C.Structure):
@@ -106,6 +112,9 @@ def lib():
         L.orc_align_batch.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_int64,
                                       C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(BatchOut)]
         L.orc_batch_free.argtypes = [C.POINTER(BatchOut)]
+        L.orc_align_sequence_sam.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                             C.POINTER(C.POINTER(SamHit))]
+        L.orc_samhits_free.argtypes = [C.POINTER(SamHit), C.c_int]
         L.orc_time_batch_mt.restype = C.c_double
         L.orc_time_batch_mt.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_int64, C.c_int, C.c_int,
                                         C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -219,6 +228,23 @@ def align_batch_flat(opt, index, bases, offs, hardclip=False, keep_sec_frac=0.9,
                cigar=arr(o.cigar, int(cig_off[-1]) if nh else 0, np.uint32), hit_off=arr(o.hit_off, n + 1, np.int64))
     lib().orc_batch_free(C.byref(o))
     return res
+
+
+def align_sequence_sam(opt, index, seq, hardclip=False, rng_base=0, ordinal=0):
+    """bwa's own record selection for one read (mem_reg2sam / mem_gen_alt / SA tag; orc.h): list of dict entries, records first
+    (xa_parent == -1, with their XA / SA strings), then the XA alternatives"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = C.POINTER(SamHit)()
+    n = lib().orc_align_sequence_sam(C.byref(opt), index.h, seq, len(seq), int(hardclip), rng_base, ordinal, C.byref(out))
+    recs = []
+    for i in range(n):
+        h = out[i]
+        recs.append(dict(rid=h.rid, pos=h.pos, flag=h.flag, mapq=h.mapq, AS=h.score, NM=h.nm, NA=h.na, XS=h.sub,
+                         cigar=[h.cigar[k] for k in range(h.n_cigar)], xa_parent=h.xa_parent,
+                         XA=h.xa.decode() if h.xa else None, SA=h.sa.decode() if h.sa else None))
+    lib().orc_samhits_free(out, n)
+    return recs
 
 
 def time_batch_mt(opt, index, bases, offs, n_threads, hardclip=False, keep_sec_frac=0.9, max_secondary=10, rng_base=0, first_ordinal=0):

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -230,4 +232,129 @@ extern "C" double orc_time_batch_mt(const orc_opt *opt, const orc_index *idx, co
     for (int t = 0; t < n_threads; ++t) { tot += hits[(size_t)t]; if (thread_secs) thread_secs[t] = secs[(size_t)t]; }
     if (n_hits_out) *n_hits_out = tot;
     return wall;
+}
+
+/* ---------------------------------------------------------------------------------------------- mem_reg2sam semantics
+ * Restates bwamem.c:mem_reg2sam (without MEM_F_ALL / MEM_F_NO_MULTI, which SeqLib's API cannot set), bwamem_extra.c:mem_gen_alt
+ * and the SA tag of bwamem.c:mem_aln2sam. */
+static int get_pri_idx(double XA_drop_ratio, const orc_reg *a, int i)
+{
+    int k = a[i].secondary_all;
+    if (k >= 0 && a[i].score >= a[k].score * XA_drop_ratio) return k;
+    return -1;
+}
+
+static void put_cigar(std::string &s, const uint32_t *cig, int n, const char *ops)
+{
+    for (int k = 0; k < n; ++k) { s += std::to_string(cig[k] >> 4); s.push_back(ops[cig[k] & 0xf]); }
+}
+
+extern "C" int orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, const char *seq, int len, int hardclip,
+                                      uint64_t rng_base, uint64_t ordinal, orc_samhit **out)
+{
+    *out = nullptr;
+    if (!idx) return 0;
+    const uint64_t salt = orc_lrand48_nth(rng_base, ordinal + 1);
+    orc_reg *a = nullptr;
+    const int n = orc_align1(opt, idx, len, seq, salt, &a);
+    /* mem_gen_alt: which secondaries become XA alternatives of which primary */
+    std::vector<int> cnt((size_t)n, 0), pri((size_t)n, -1);
+    std::vector<char> has_alt((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        const int r = get_pri_idx(opt->XA_drop_ratio, a, i);
+        pri[(size_t)i] = r;
+        if (r >= 0) { ++cnt[(size_t)r]; if (a[i].is_alt) has_alt[(size_t)r] = 1; }
+    }
+    /* mem_reg2sam: the records */
+    struct Rec { int k; orc_aln aln; int flag; int mapq; int sub; };
+    std::vector<Rec> recs;
+    std::vector<int> rec_of((size_t)n, -1);
+    for (int k = 0; k < n; ++k) {
+        const orc_reg *p = &a[k];
+        if (p->score < opt->T) continue;
+        if (p->secondary >= 0) continue;                     /* (p->is_alt || !(opt->flag & MEM_F_ALL)) holds: MEM_F_ALL is never set */
+        Rec q;
+        q.k = k;
+        q.aln = orc_reg2aln(opt, idx, len, seq, p);
+        q.flag = q.aln.flag | (q.aln.is_rev ? 0x10 : 0);
+        q.mapq = (int)q.aln.mapq;
+        q.sub = q.aln.sub;
+        if (!recs.empty()) q.flag |= 0x800;                  /* supplementary */
+        if (!recs.empty() && !p->is_alt && q.mapq > recs[0].mapq) q.mapq = recs[0].mapq;
+        rec_of[(size_t)k] = (int)recs.size();
+        recs.push_back(q);
+    }
+    std::vector<orc_samhit> o;
+    std::vector<std::string> xa(recs.size());
+    /* XA alternatives, in region order, with the string bwa would append to XA[r] */
+    struct Alt { int parent; orc_aln aln; };
+    std::vector<Alt> alts;
+    for (int i = 0; i < n; ++i) {
+        const int r = pri[(size_t)i];
+        if (r < 0) continue;
+        if (cnt[(size_t)r] > opt->max_XA_hits_alt || (!has_alt[(size_t)r] && cnt[(size_t)r] > opt->max_XA_hits)) continue;
+        if (rec_of[(size_t)r] < 0) continue;                 /* its primary is not printed: neither is its XA */
+        Alt t;
+        t.parent = rec_of[(size_t)r];
+        t.aln = orc_reg2aln(opt, idx, len, seq, &a[i]);
+        std::string &x = xa[(size_t)t.parent];
+        x += idx->anns[t.aln.rid].name;
+        x.push_back(',');
+        x.push_back("+-"[t.aln.is_rev]);
+        x += std::to_string((long long)t.aln.pos + 1);
+        x.push_back(',');
+        put_cigar(x, t.aln.cigar, t.aln.n_cigar, "MIDSHN");
+        x.push_back(',');
+        x += std::to_string((int)t.aln.NM);
+        x.push_back(';');
+        alts.push_back(t);
+    }
+    auto emit = [&](const orc_aln &al, int flag, int mapq, int sub, int parent, bool clip_hard) {
+        orc_samhit h;
+        std::memset(&h, 0, sizeof h);
+        h.rid = al.rid; h.pos = al.pos; h.flag = (uint16_t)flag; h.mapq = (uint8_t)mapq; h.score = al.score; h.nm = (int32_t)al.NM; h.na = n;
+        h.sub = sub; h.n_cigar = al.n_cigar; h.xa_parent = parent;
+        h.cigar = (uint32_t *)std::malloc(4 * (size_t)(al.n_cigar ? al.n_cigar : 1));
+        for (int c = 0; c < al.n_cigar; ++c) {
+            uint32_t w = al.cigar[c];
+            if ((w & 0xf) == 3) w = (w & ~0xfu) | (clip_hard ? 5u : 4u);
+            h.cigar[c] = w;
+        }
+        o.push_back(h);
+    };
+    for (size_t j = 0; j < recs.size(); ++j) {
+        emit(recs[j].aln, recs[j].flag, recs[j].mapq, recs[j].sub, -1, hardclip != 0);
+        if (!xa[j].empty()) o.back().xa = strdup(xa[j].c_str());
+        if (recs.size() > 1) {                               /* mem_aln2sam: the other non-secondary hits of the list */
+            std::string sa;
+            for (size_t i = 0; i < recs.size(); ++i) {
+                if (i == j) continue;
+                const orc_aln &r = recs[i].aln;
+                sa += idx->anns[r.rid].name; sa.push_back(',');
+                sa += std::to_string((long long)r.pos + 1); sa.push_back(',');
+                sa.push_back("+-"[r.is_rev]); sa.push_back(',');
+                put_cigar(sa, r.cigar, r.n_cigar, "MIDSH");
+                sa.push_back(','); sa += std::to_string(recs[i].mapq);
+                sa.push_back(','); sa += std::to_string((int)r.NM);
+                sa.push_back(';');
+            }
+            o.back().sa = strdup(sa.c_str());
+        }
+    }
+    for (const Alt &t : alts) emit(t.aln, (t.aln.flag | (t.aln.is_rev ? 0x10 : 0)), 0, -1, t.parent, false);
+    for (Rec &q : recs) std::free(q.aln.cigar);
+    for (Alt &t : alts) std::free(t.aln.cigar);
+    std::free(a);
+    if (!o.empty()) {
+        *out = (orc_samhit *)std::malloc(o.size() * sizeof(orc_samhit));
+        std::memcpy(*out, o.data(), o.size() * sizeof(orc_samhit));
+    }
+    return (int)o.size();
+}
+
+extern "C" void orc_samhits_free(orc_samhit *h, int n)
+{
+    if (!h) return;
+    for (int i = 0; i < n; ++i) { std::free(h[i].cigar); std::free(h[i].xa); std::free(h[i].sa); }
+    std::free(h);
 }

@@ -55,6 +55,7 @@ void orc_opt_init(orc_opt *o)
     o->mask_level_redun = 0.95f;
     o->min_chain_weight = 0;
     o->max_chain_extend = 1 << 30;
+    o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5; o->max_XA_hits_alt = 200;
     o->mapQ_coef_len = 50;
     o->mapQ_coef_fac = (int)log(o->mapQ_coef_len); /* stored into an int field => 3 */
     o->flag = 0x200;                                /* MEM_F_SOFTCLIP, SeqLib/BWAAligner.h:17 (no effect on this path) */

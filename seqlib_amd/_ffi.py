@@ -32,7 +32,7 @@ class Opt(C.Structure):
                [("split_factor", C.c_float), ("split_width", C.c_int), ("max_occ", C.c_int), ("max_chain_gap", C.c_int),
                 ("max_mem_intv", C.c_int), ("mask_level", C.c_float), ("drop_ratio", C.c_float),
                 ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int),
-                ("mat", C.c_int8 * 25)]
+                ("mat", C.c_int8 * 25), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int), ("max_XA_hits_alt", C.c_int)]
 
 
 class Hits(C.Structure):

@@ -80,6 +80,9 @@ struct slx_aligner;
 // of the chain / extend / finalize kernels of one part overlap with the bulk of the others.
 struct Worker {
     hipStream_t stream = nullptr;
+    hipStream_t seed_stream = nullptr;   // optional: the persistent seeding kernels on a stream of their own, confined to a CU mask that leaves some CUs
+                                         // of the chip to the latency-bound kernels of the other workers ("seed_free_cus" knob)
+    hipEvent_t ev_seed_in = nullptr, ev_seed_out = nullptr;
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
@@ -152,6 +155,8 @@ struct slx_aligner {
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
+    int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
+    int stream_prio = 0;
     int n_workers = 3;            // concurrent parts of a large batch
     int active_k = 1;             // workers running in the current call
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
@@ -362,13 +367,39 @@ static int upload_fm(slx_aligner *al)
 
 #define SLX_MAX_WORKERS 8
 
+static int make_worker_stream(slx_aligner *al, Worker *wk)
+{
+    if (al->stream_prio) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&wk->stream, hipStreamNonBlocking, greatest));
+    } else HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
+    return SLX_OK;
+}
+
+// (re)creates the worker's seeding stream for the current "seed_free_cus" setting
+static int set_seed_stream(slx_aligner *al, Worker *wk)
+{
+    if (wk->seed_stream) { HIPCHK(hipStreamSynchronize(wk->seed_stream)); HIPCHK(hipStreamDestroy(wk->seed_stream)); wk->seed_stream = nullptr; }
+    if (al->seed_free_cus <= 0) return SLX_OK;
+    const int words = (al->n_cu + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int cu = 0; cu < al->n_cu; ++cu)
+        if ((cu & 31) < 32 - al->seed_free_cus) mask[(size_t)(cu >> 5)] |= 1u << (cu & 31);
+    HIPCHK(hipExtStreamCreateWithCUMask(&wk->seed_stream, (uint32_t)words, mask.data()));
+    if (!wk->ev_seed_in) HIPCHK(hipEventCreateWithFlags(&wk->ev_seed_in, hipEventDisableTiming));
+    if (!wk->ev_seed_out) HIPCHK(hipEventCreateWithFlags(&wk->ev_seed_out, hipEventDisableTiming));
+    return SLX_OK;
+}
+
 static int add_worker(slx_aligner *al)
 {
     Worker *wk = new Worker();
     wk->id = (int)al->workers.size();
     wk->collect();
     al->workers.push_back(wk);
-    HIPCHK(hipStreamCreateWithFlags(&wk->stream, hipStreamNonBlocking));
+    { const int rc = make_worker_stream(al, wk); if (rc != SLX_OK) return rc; }
+    { const int rc = set_seed_stream(al, wk); if (rc != SLX_OK) return rc; }
     for (int b = 0; b < 6; ++b) HIPCHK(hipEventCreate(&wk->dbg_ev[b]));
     for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
     for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&wk->ev_probe[i]));
@@ -509,6 +540,9 @@ extern "C" void slx_aligner_free(slx_aligner *al)
         for (int i = 0; i < 6; ++i) if (wk->dbg_ev[i]) (void)hipEventDestroy(wk->dbg_ev[i]);
         for (int i = 0; i < 6; ++i) if (wk->ev_probe[i]) (void)hipEventDestroy(wk->ev_probe[i]);
         if (wk->stream) (void)hipStreamDestroy(wk->stream);
+        if (wk->seed_stream) (void)hipStreamDestroy(wk->seed_stream);
+        if (wk->ev_seed_in) (void)hipEventDestroy(wk->ev_seed_in);
+        if (wk->ev_seed_out) (void)hipEventDestroy(wk->ev_seed_out);
         delete wk;
     }
     if (al->stream) (void)hipStreamDestroy(al->stream);
@@ -567,6 +601,24 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         al->n_workers = (int)value;
     }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
+    else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
+        if (value < 0 || value > 24) return SLX_EINVAL;
+        HIPCHK(hipSetDevice(al->device));
+        al->seed_free_cus = (int)value;
+        for (Worker *wk : al->workers) { const int rc = set_seed_stream(al, wk); if (rc != SLX_OK) return rc; }
+    }
+    else if (!strcmp(key, "stream_prio")) {     // 1 = the workers' streams are re-created at the highest priority the device offers
+        if (value < 0 || value > 1) return SLX_EINVAL;
+        HIPCHK(hipSetDevice(al->device));
+        al->stream_prio = (int)value;
+        for (Worker *wk : al->workers) {
+            HIPCHK(hipStreamSynchronize(wk->stream));
+            HIPCHK(hipStreamDestroy(wk->stream));
+            wk->stream = nullptr;
+            const int rc = make_worker_stream(al, wk);
+            if (rc != SLX_OK) return rc;
+        }
+    }
     else if (!strcmp(key, "threads")) { if (value < 64) return SLX_EINVAL; al->max_threads = (int)value; }
     else if (!strcmp(key, "zarena_bytes")) { if (value < 1024) return SLX_EINVAL; al->zcap = (unsigned long long)value; }
     else { slx_set_error("slx_aligner_set: unknown key %s", key); return SLX_EINVAL; }
@@ -721,6 +773,9 @@ static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
 
 struct ChunkCaps { int cap_intv; unsigned long long zcap, cigcap; };
 
+// chunks of the production schedule (large, short reads) are the ones whose seeding launch fills the chip
+static bool production_seed(const slx_aligner *al, int n, bool has_long) { return n >= al->split_min && !has_long; }
+
 // runs the pipeline on reads [r0, r0+n) whose ASCII bases are d_ascii + d_offs[r0]...; appends to the outputs.
 template <typename I>
 static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint8_t *d_ascii, const uint64_t *d_offs, const uint64_t *h_offs_pair,
@@ -798,9 +853,21 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     }
     (void)hipEventRecord(wk->ev[1], st);
     (void)hipEventRecord(wk->ev_probe[0], st);
-    hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29);
-    hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, fm, al->ref, ck, dopt);
-    hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, ck, dopt, wk->queues.as<unsigned int>() + 31);
+    {
+        hipStream_t ss = st;
+        if (wk->seed_stream && production_seed(al, n, has_long)) {   // the CU-masked seeding stream: encode -> [seeding] -> scan
+            ss = wk->seed_stream;
+            HIPCHK(hipEventRecord(wk->ev_seed_in, st));
+            HIPCHK(hipStreamWaitEvent(ss, wk->ev_seed_in, 0));
+        }
+        hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29);
+        hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
+        hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31);
+        if (ss != st) {
+            HIPCHK(hipEventRecord(wk->ev_seed_out, ss));
+            HIPCHK(hipStreamWaitEvent(st, wk->ev_seed_out, 0));
+        }
+    }
     (void)hipEventRecord(wk->ev_probe[1], st);
     (void)hipEventRecord(wk->ev[2], st);
     {   // exclusive scan of the per-read seed counts -> seed-slot regions

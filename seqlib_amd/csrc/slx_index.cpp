@@ -79,6 +79,7 @@ extern "C" void slx_opt_init(slx_opt *o)
     o->min_chain_weight = 0; o->max_chain_extend = 1 << 30;
     o->mapQ_coef_len = 50; o->mapQ_coef_fac = 3;   // (int)log(50)
     o->flag = 0x200;                               // MEM_F_SOFTCLIP
+    o->XA_drop_ratio = 0.80f; o->max_XA_hits = 5; o->max_XA_hits_alt = 200;
     slx_fill_scmat(o->a, o->b, o->mat);
 }
 

@@ -605,6 +605,50 @@ def test_host_entry_rejects_bad_offsets(sl, tiny_gpu, sim_reads):
     assert len(ok["hit_off"]) == n + 1
 
 
+def test_config_C4_full(sl, orc, tmp_path):
+    """BASELINE config 4 at full size: grch38_syn, 24 contigs with GRCh38's primary-assembly lengths (3.09 Gbp, 6.2 G BWT symbols), built by
+    the 64-bit GPU suffix sorter, written in bwa's format (the reference's only route to such an index is LoadIndex of `bwa index`
+    files, /root/reference/src/BWAIndex.cpp:28-33), re-loaded through slx_index_load, read by the oracle; 65 536 synthetic 150 bp
+    reads over all contigs through the u64 kernels, bit-exact.  Host memory is kept low on purpose (reads are drawn before the
+    index is built, every large array is dropped as soon as it has been handed on); SLX_C4_CONTIGS shrinks it for a quick run."""
+    import gc
+    from seqlib_amd import synth
+    cfg = dict(synth.CONFIGS["C4"])
+    k = int(os.environ.get("SLX_C4_CONTIGS", "24"))
+    cfg["contigs"] = cfg["contigs"][:k]
+    refs = synth.make_reference(cfg)
+    total = sum(len(g) for _, g in refs)
+    reads = synth.make_config_reads(cfg, refs, 1 << 16)
+    offs = synth.offsets_for(len(reads), cfg["read_len"])
+    asc = []
+    while refs:                                       # ASCII contig by contig, the codes dropped as we go
+        nm, g = refs.pop(0)
+        asc.append((nm, synth.genome_ascii_bytes(g)))
+        del g
+    gc.collect()
+    idx = sl.BWAIndex()
+    idx.ConstructIndex(asc)
+    del asc
+    gc.collect()
+    if k >= 24:
+        assert idx.NumSequences() == 24 and 2 * total + 1 >= 6_000_000_000
+    prefix = str(tmp_path / "c4full")
+    idx.WriteIndex(prefix)
+    del idx
+    gc.collect()
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)                             # the route the reference takes for GRCh38
+    al = sl.BWAAligner(idx)
+    got = al.align_flat(reads.tobytes(), offs)
+    del al, idx
+    gc.collect()
+    oidx = orc.Index.load(prefix)
+    exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
+    assert_same(got, exp, "grch38_syn full")
+    assert (np.diff(got["hit_off"]) >= 1).mean() > 0.999
+    assert len(np.unique(got["rid"])) == k            # hits on every contig
+
+
 def test_full_size_properties(sl):
     """BASELINE-size batch (2 M reads of C2 here; bench.py runs the 10 M) checked through size-independent
     properties: query-consuming CIGAR length == read length, positions inside the contig, idempotence of a

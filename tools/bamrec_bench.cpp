@@ -48,8 +48,8 @@ int main(int argc, char **argv)
             for (auto &v : out) records += v.size();
         }
         std::printf("{\"value\": %.1f, \"unit\": \"reads/s\", \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, \"host_threads\": %u, "
-                    "\"path\": \"C++ SeqLib::BWAAligner::alignSequences: UnalignedSequenceVector -> GPU -> std::vector<BamRecordPtrVector> (sample of the bench reads)\"}\n",
-                    (double)n / best, n, records, best, std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u));
+                    "\"path\": \"C++ SeqLib::BWAAligner::alignSequences: UnalignedSequenceVector -> chunks: pack into pinned staging (host threads) | GPU | BamRecords (host threads), overlapped -> std::vector<BamRecordPtrVector> (sample of the bench reads)\"}\n",
+                    (double)n / best, n, records, best, std::getenv("SEQLIB_AMD_THREADS") ? (unsigned)std::atoi(std::getenv("SEQLIB_AMD_THREADS")) : detail::effective_cpus());
     } catch (const std::exception &e) {
         std::fprintf(stderr, "bamrec_bench: %s\n", e.what());
         return 1;
