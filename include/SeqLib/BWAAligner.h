@@ -193,6 +193,19 @@ public:
         if (trigger < 0.0f) throw std::invalid_argument{"SetReseedTrigger: trigger must be >= 0"};
         memopt_.split_factor = trigger;
     }
+    // ---- not in the reference: bwa's own output rules ---------------------------------
+    // The reference's glue emits every region bwa finds, sorted by mapq, with its own secondary filters and without the score
+    // threshold, the supplementary flag and the XA / SA tags `bwa mem` would give (src/BWAAligner.cpp:136-146, :240: h.XA is
+    // always NULL).  With UseBwaMemRecords(true) a read yields what bwa's mem_reg2sam prints for it instead: its primaries
+    // scoring >= T in bwa's order (0x800 on all but the first, mapq capped at the first's), XA:Z from mem_gen_alt through the
+    // branch of :240, XS:i and SA:Z; a read without such a record yields one unmapped record (flag 4).  keepSecFrac and
+    // maxSecondary are not used then.
+    void UseBwaMemRecords(bool on = true) { if (on) memopt_.flag |= SLX_F_REG2SAM; else memopt_.flag &= ~SLX_F_REG2SAM; }
+    void SetOutputScoreThreshold(int T)
+    {
+        if (T < 0) throw std::invalid_argument{"SetOutputScoreThreshold: T must be >= 0"};
+        memopt_.T = T;
+    }
 
     // ---- the reference's entry points -------------------------------------------------------------
     void alignSequence(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double keepSecFrac,
@@ -242,6 +255,8 @@ private:
     mutable std::once_flag al_once_;
     bool copyComment_ = false;
     std::vector<int> devices_;
+    mutable std::vector<std::string> names_;   // contig names, for the XA / SA strings
+    mutable std::once_flag names_once_;
     struct Staging { char *bases = nullptr; uint64_t *offs = nullptr; size_t cap_bases = 0, cap_reads = 0; };
     mutable Staging stage_[2];                 // pinned staging of the chunked batch path (kept between calls)
     mutable std::mutex batch_mu_;              // one chunked batch at a time per aligner (they share the staging)
@@ -291,8 +306,10 @@ private:
     }
 
     // record construction of src/BWAAligner.cpp:151-248 for hit k of `h`.  Same bytes as the reference builds; one allocation
-    // for the data blob, sized for the three integer tags it ends with (the reference reallocs at each bam_aux_append).
-    static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, size_t l_name, bool hardclip)
+    // for the data blob, sized for the tags it ends with (the reference reallocs at each bam_aux_append).  xa / sa / xs: the
+    // extra tags of a UseBwaMemRecords record (XA:Z where :240 puts it, XS:i and SA:Z after AS:i).
+    static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, size_t l_name, bool hardclip,
+                                    const std::string *xa = nullptr, const std::string *sa = nullptr, const int32_t *xs = nullptr)
     {
         auto b = std::make_shared<BamRecord>();
         bam1_t *r = b->b.get();
@@ -318,7 +335,7 @@ private:
         r->core.l_qname = (uint16_t)(l_name + 1);
         r->core.l_qseq = (int32_t)clipped.size();
         const int l_core = r->core.l_qname + (n_cigar << 2) + ((r->core.l_qseq + 1) >> 1) + r->core.l_qseq;
-        const int l_tags = 3 * 7;                           // NA:i NM:i AS:i
+        const int l_tags = 3 * 7 + (xa && !xa->empty() ? 4 + (int)xa->size() : 0) + (sa && !sa->empty() ? 4 + (int)sa->size() : 0) + (xs ? 7 : 0);
         r->data = static_cast<uint8_t *>(std::malloc((size_t)(l_core + l_tags)));
         if (!r->data) throw std::bad_alloc();
         r->m_data = (uint32_t)(l_core + l_tags);
@@ -343,8 +360,104 @@ private:
         if (sl > 0) bam_get_qual(r)[0] = 0xff;
         b->AddIntTag("NA", h.na[k]);
         b->AddIntTag("NM", h.nm[k]);
+        if (xa && !xa->empty()) b->AddZTag("XA", *xa);       // `if (h.XA) b->AddZTag("XA", ...)` (:240)
         b->AddIntTag("AS", h.score[k]);
+        if (xs && *xs >= 0) b->AddIntTag("XS", *xs);
+        if (sa && !sa->empty()) b->AddZTag("SA", *sa);
         return b;
+    }
+
+    // what `bwa mem` prints for a read nothing of which scores >= T: flag 4, no position, the read as it came (mem_aln2sam on mem_reg2aln(0))
+    static BamRecordPtr make_unmapped(const std::string_view seq, const char *name, size_t l_name)
+    {
+        auto b = std::make_shared<BamRecord>();
+        bam1_t *r = b->b.get();
+        r->core.tid = -1; r->core.pos = -1; r->core.qual = 0; r->core.flag = BAM_FUNMAP; r->core.n_cigar = 0;
+        r->core.mtid = -1; r->core.mpos = -1; r->core.isize = 0;
+        r->core.l_qname = (uint16_t)(l_name + 1);
+        r->core.l_qseq = (int32_t)seq.size();
+        const int sl = (int)seq.size();
+        const int l_core = r->core.l_qname + ((sl + 1) >> 1) + sl;
+        r->data = static_cast<uint8_t *>(std::calloc((size_t)(l_core + 3 * 7), 1));
+        if (!r->data) throw std::bad_alloc();
+        r->m_data = (uint32_t)(l_core + 3 * 7);
+        r->l_data = l_core;
+        std::memcpy(r->data, name, l_name);
+        uint8_t *seqbuf = r->data + r->core.l_qname;
+        for (int p = 0; p < sl; ++p) {
+            uint8_t v = 15;
+            switch (seq[(size_t)p]) { case 'A': v = 1; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = 8; break; }
+            seqbuf[p >> 1] |= (uint8_t)(v << ((~p & 1) << 2));
+        }
+        if (sl > 0) bam_get_qual(r)[0] = 0xff;
+        b->AddIntTag("NA", 0);
+        b->AddIntTag("AS", 0);
+        b->AddIntTag("XS", 0);
+        return b;
+    }
+
+    const std::string &contig_name(int rid) const
+    {
+        std::call_once(names_once_, [this]() { for (int i = 0; i < index_->NumSequences(); ++i) names_.push_back(index_->ChrIDToName(i)); });
+        return names_[(size_t)rid];
+    }
+
+    // all records of read i of a result: the glue's (src/BWAAligner.cpp:136-248), or -- UseBwaMemRecords -- bwa's own: records first,
+    // then the alternatives that make up the records' XA:Z, as the C-ABI hands them over (SLX_F_REG2SAM)
+    void build_read(const slx_hits &h, int64_t i, const std::string_view seq, const char *name, size_t l_name, bool hardclip, const std::string *com,
+                    BamRecordPtrVector &dst) const
+    {
+        const int64_t k0 = h.hit_off[i], k1 = h.hit_off[i + 1];
+        if (!h.xa_parent) {
+            if (k1 > k0) dst.reserve(dst.size() + (size_t)(k1 - k0));
+            for (int64_t k = k0; k < k1; ++k) {
+                BamRecordPtr rec = make_record(h, k, seq, name, l_name, hardclip);
+                if (com) rec->AddZTag("BC", *com);
+                dst.push_back(std::move(rec));              // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
+            }
+            return;
+        }
+        int64_t n_rec = 0;
+        while (k0 + n_rec < k1 && h.xa_parent[k0 + n_rec] < 0) ++n_rec;
+        if (n_rec == 0) {
+            BamRecordPtr rec = make_unmapped(seq, name, l_name);
+            if (com) rec->AddZTag("BC", *com);
+            dst.push_back(std::move(rec));
+            return;
+        }
+        auto put_cigar = [&](std::string &o, int64_t k, bool soft_only) {
+            const uint32_t *cig = h.cigar + h.cig_off[k];
+            for (int c = 0; c < h.n_cigar_ops[k]; ++c) {
+                o += std::to_string(bam_cigar_oplen(cig[c]));
+                const uint32_t op = bam_cigar_op(cig[c]);
+                o.push_back(soft_only && op == BAM_CHARD_CLIP ? 'S' : BAM_CIGAR_STR[op]);      // bwa's SA:Z keeps the S of its own cigar
+            }
+        };
+        std::vector<std::string> xa((size_t)n_rec), sa((size_t)n_rec);
+        for (int64_t k = k0 + n_rec; k < k1; ++k) {          // mem_gen_alt: "chr,<strand><pos>,<CIGAR>,<NM>;"
+            std::string &o = xa[(size_t)h.xa_parent[k]];
+            o += contig_name(h.rid[k]); o.push_back(',');
+            o.push_back((h.flag[k] & BAM_FREVERSE) ? '-' : '+'); o += std::to_string((long long)h.pos[k] + 1); o.push_back(',');
+            put_cigar(o, k, false);
+            o.push_back(','); o += std::to_string(h.nm[k]); o.push_back(';');
+        }
+        if (n_rec > 1)                                        // mem_aln2sam: "chr,<pos>,<strand>,<CIGAR>,<mapq>,<NM>;" of every other record
+            for (int64_t j = 0; j < n_rec; ++j)
+                for (int64_t q = 0; q < n_rec; ++q) {
+                    if (q == j) continue;
+                    const int64_t k = k0 + q;
+                    std::string &o = sa[(size_t)j];
+                    o += contig_name(h.rid[k]); o.push_back(','); o += std::to_string((long long)h.pos[k] + 1); o.push_back(',');
+                    o.push_back((h.flag[k] & BAM_FREVERSE) ? '-' : '+'); o.push_back(',');
+                    put_cigar(o, k, true);
+                    o.push_back(','); o += std::to_string((int)h.mapq[k]); o.push_back(','); o += std::to_string(h.nm[k]); o.push_back(';');
+                }
+        dst.reserve(dst.size() + (size_t)n_rec);
+        for (int64_t j = 0; j < n_rec; ++j) {
+            BamRecordPtr rec = make_record(h, k0 + j, seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[k0 + j]);
+            if (com) rec->AddZTag("BC", *com);
+            dst.push_back(std::move(rec));
+        }
     }
 
     // BamRecords of reads [a, b) of a result whose read 0 is read `base` of the call
@@ -355,15 +468,9 @@ private:
         for (int64_t i = a; i < b; ++i) {
             const std::string_view seq(bases + offs[i], (size_t)(offs[i + 1] - offs[i]));
             BamRecordPtrVector &dst = single_out ? *single_out : (*batch_out)[(size_t)(base + i)];
-            const int64_t k0 = h.hit_off[i], k1 = h.hit_off[i + 1];
-            if (k1 > k0) dst.reserve(dst.size() + (size_t)(k1 - k0));
             const char *nm = reads ? (*reads)[(size_t)(base + i)].Name.c_str() : names[i];
             const size_t l_name = reads ? (*reads)[(size_t)(base + i)].Name.size() : std::strlen(nm);
-            for (int64_t k = k0; k < k1; ++k) {
-                BamRecordPtr rec = make_record(h, k, seq, nm, l_name, hardclip);
-                if (reads && copyComment_) rec->AddZTag("BC", (*reads)[(size_t)(base + i)].Com);
-                dst.push_back(std::move(rec));              // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
-            }
+            build_read(h, i, seq, nm, l_name, hardclip, (reads && copyComment_) ? &(*reads)[(size_t)(base + i)].Com : nullptr, dst);
         }
     }
 
@@ -491,14 +598,7 @@ private:
                     // the sequence of a record comes from the caller's reads (the staging slot is reused two chunks later)
                     for (int64_t i = mm * t / parts; i < mm * (t + 1) / parts; ++i) {
                         const UnalignedSequence &us = reads[(size_t)(Jc.lo + i)];
-                        BamRecordPtrVector &dst = out[(size_t)(Jc.lo + i)];
-                        const int64_t k0 = Jc.h.hit_off[i], k1 = Jc.h.hit_off[i + 1];
-                        if (k1 > k0) dst.reserve((size_t)(k1 - k0));
-                        for (int64_t k = k0; k < k1; ++k) {
-                            BamRecordPtr rec = make_record(Jc.h, k, us.Seq, us.Name.c_str(), us.Name.size(), hardclip);
-                            if (copyComment_) rec->AddZTag("BC", us.Com);
-                            dst.push_back(std::move(rec));
-                        }
+                        build_read(Jc.h, i, us.Seq, us.Name.c_str(), us.Name.size(), hardclip, copyComment_ ? &us.Com : nullptr, out[(size_t)(Jc.lo + i)]);
                     }
                 }, false);
             }

@@ -73,6 +73,15 @@ typedef struct {
     int max_XA_hits, max_XA_hits_alt;
 } slx_opt;
 
+/* Opt-in bit of slx_opt.flag (no bwa counterpart; bwa's own MEM_F_* bits sit below 0x1000): apply bwa's OWN record selection to
+ * every read -- mem_reg2sam + mem_gen_alt (bwamem.c, bwamem_extra.c), which SeqLib's glue bypasses (src/BWAAligner.cpp:136-146
+ * have no opt->T threshold and no 0x800, and h.XA is always NULL at :240) -- instead of the glue's sort and secondary filters
+ * (keepSecFrac / maxSecondary are then not used).  The entries of a read are then: first its RECORDS in bwa's order (primaries
+ * scoring >= opt->T; the first is the representative, the others carry 0x800 and a mapq capped at the first's), then its XA
+ * ALTERNATIVES (xa_parent[k] = index among the read's records of the record they belong to; soft clips whatever `hardclip`).
+ * slx_hits.sub carries XS.  A read without a record has no entry (bwa prints an unmapped record: the caller's to synthesise). */
+#define SLX_F_REG2SAM 0x40000000
+
 typedef struct slx_index slx_index;
 typedef struct slx_aligner slx_aligner;
 
@@ -111,6 +120,8 @@ void slx_aligner_free(slx_aligner *al);
  *   "cap_intv"                kept SMEM intervals per read the first attempt allows (overflow -> the chunk is re-run with twice as many)
  *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
+ *   "seed_free_cus" 0..24 (0) CUs of every 32 the persistent seeding kernels leave to the other kernels (a CU-masked stream of their own)
+ *   "stream_prio" 0|1 (0)     workers' streams at the device's highest priority
  *   "wide_index" 1            test hook: run an index below 2^32 symbols through the u64 kernels
  *   "keep_stages" 1           test hook: keep what slx_debug_stage reads
  * Returns SLX_EINVAL for an unknown key or a value out of range. */
@@ -138,6 +149,8 @@ typedef struct {
     void     *block;        /* host results: the one allocation every array above points into (layout of slx_hits_pack) */
     int       block_pinned; /* 1: block is pinned host memory (recycled by slx_hits_free); 0: malloc */
     uint64_t  block_bytes;
+    int32_t  *xa_parent;    /* SLX_F_REG2SAM results only (else NULL): -1 = a record, k >= 0 = XA alternative of the read's record k */
+    int32_t  *sub;          /* SLX_F_REG2SAM results only: XS of a record (-1 for an alternative) */
 } slx_hits;
 
 /* bases/offs on the HOST: read i is bases[offs[i] .. offs[i+1]) in ASCII.  Read i behaves as the
@@ -164,7 +177,8 @@ void  slx_host_trim(void);
 /* One contiguous image of a result, for the single RCCL gather of hits to rank 0.
  * Layout (little endian): int64 hdr[4] = {n_reads, n_hits, n_cigar, 0}; int64 hit_off[n_reads+1];
  * int64 pos[n_hits]; int64 cig_off[n_hits+1]; int32 rid, score, nm, na, n_cigar_ops [n_hits] each;
- * uint32 cigar[n_cigar]; uint16 flag[n_hits]; uint8 mapq[n_hits].  Works for device-resident results
+ * uint32 cigar[n_cigar]; uint16 flag[n_hits]; uint8 mapq[n_hits]; and for SLX_F_REG2SAM results (hdr[3] = 1), after padding
+ * to a multiple of 4 bytes: int32 xa_parent[n_hits], sub[n_hits].  Works for device-resident results
  * (d_dst is a device buffer) and host results (dst is host memory). */
 uint64_t slx_hits_packed_size(const slx_hits *h);
 int  slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_bytes);

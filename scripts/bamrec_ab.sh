@@ -7,8 +7,7 @@ cd $R
 python3 - $N <<'PY'
 import sys, os, numpy as np
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import importlib.util
-spec = importlib.util.spec_from_file_location("bench", os.path.join(os.environ["GRAFT_REPO_ROOT"], "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+import bench as b
 from seqlib_amd import synth
 import seqlib_amd
 n = int(sys.argv[1])

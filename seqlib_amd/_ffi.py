@@ -14,6 +14,7 @@ SLX_OK, SLX_EINVAL, SLX_EIO, SLX_ENOMEM, SLX_ENODEVICE, SLX_EUNSUPPORTED, SLX_EI
 SLX_N_STAGES = 8
 SLX_N_PROBES = 3
 SLX_MAX_READ_LEN = 8000
+SLX_F_REG2SAM = 0x40000000
 
 # every symbol include/seqlib_amd.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
@@ -40,7 +41,7 @@ class Hits(C.Structure):
                 ("rid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
                 ("score", C.c_void_p), ("nm", C.c_void_p), ("na", C.c_void_p), ("n_cigar_ops", C.c_void_p),
                 ("cig_off", C.c_void_p), ("cigar", C.c_void_p), ("on_device", C.c_int), ("block", C.c_void_p),
-                ("block_pinned", C.c_int), ("block_bytes", C.c_uint64)]
+                ("block_pinned", C.c_int), ("block_bytes", C.c_uint64), ("xa_parent", C.c_void_p), ("sub", C.c_void_p)]
 
 
 _LIB = None

@@ -270,7 +270,8 @@ def hits_to_numpy(h):
     return dict(n_hits=nh, hit_off=_arr(h.hit_off, n + 1, np.int64), rid=_arr(h.rid, nh, np.int32), pos=_arr(h.pos, nh, np.int64),
                 flag=_arr(h.flag, nh, np.uint16), mapq=_arr(h.mapq, nh, np.uint8), score=_arr(h.score, nh, np.int32),
                 nm=_arr(h.nm, nh, np.int32), na=_arr(h.na, nh, np.int32), n_cigar=_arr(h.n_cigar_ops, nh, np.int32),
-                cig_off=_arr(h.cig_off, nh + 1, np.int64), cigar=_arr(h.cigar, h.n_cigar, np.uint32))
+                cig_off=_arr(h.cig_off, nh + 1, np.int64), cigar=_arr(h.cigar, h.n_cigar, np.uint32),
+                **(dict(xa_parent=_arr(h.xa_parent, nh, np.int32), sub=_arr(h.sub, nh, np.int32)) if h.xa_parent else {}))
 
 
 def records_of(res, i):

@@ -353,8 +353,13 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
 #endif
 template <int MAXQ>
 __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int hi_prio,
-                                                                   const int *first = nullptr, const unsigned int *n_first = nullptr)
+                                                                   const int *first = nullptr, const unsigned int *n_first = nullptr,
+                                                                   const unsigned int *top_off = nullptr, unsigned int top_cap = 0, const DReg *top_tab = nullptr)
 {
+    // top_tab (optional): the region of the top (longest) seed of every kept chain, extended ahead of time one wave per chain by
+    // k_ext_first -- top_tab[top_off[r] + chain index] for the reads whose slots lie below top_cap.  What the extension of a seed
+    // yields depends on its chain only, so the walk below takes the stored region where it would extend that seed.  For a read from
+    // a repeat (hundreds of one-seed chains, each extended) this leaves the covered tests as the only serial work.
     // `first` (optional): reads to take before the ones in `order` -- the heavy reads, heaviest first, so that a read that
     // keeps one wave busy for tens of milliseconds starts at once instead of wherever it sits in the batch
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -387,6 +392,12 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         const float frac_rep = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ck.frac_rep[r])));
         const int64_t l_pac = R.l_pac;
         const int cand_at = ck.cand_base ? __builtin_amdgcn_readfirstlane(ck.cand_base[r]) : -1;
+        int top_at = -1;
+        if (top_tab && cand_at < 0) {
+            const unsigned int o = (unsigned int)__builtin_amdgcn_readfirstlane((int)top_off[r]);
+            const unsigned int c = (unsigned int)__builtin_amdgcn_readfirstlane((int)top_off[r + 1]) - o;
+            if (c == (unsigned int)n_chn && o + c <= top_cap) top_at = (int)o;
+        }
         int n_av = 0;
         unsigned long long t_sort = 0, t_test = 0, t_dp = 0, t_mark;
 #define DBG_T0() do { if (dbg) t_mark = __builtin_readcyclecounter(); } while (0)
@@ -579,7 +590,8 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 const bool have_cand = cand_at >= 0;                         // heavy read: every seed was extended ahead of time (k_extend_cand)
                 if (have_cand) a = ck.cand[cand_at + s];
                 else {
-                    a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
+                    if (top_at >= 0 && k == n - 1) a = top_tab[top_at + ci];    // this chain's top seed: extended ahead of time (seedcov not filled in)
+                    else a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
                     int cov = 0;
                     for (int i = lane; i < n; i += WAVE) {
                         const uint32_t tq = w.s_ql[cs[i]];
@@ -767,12 +779,15 @@ __global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_extend_cand(DevRef R, Chu
 // that is the only extension such a read normally needs -- and k_ext_replay runs the decision sequence one read per LANE,
 // taking those regions from the table.  A read that turns out to need any other extension is put on a list and redone by
 // k_extend_reg together with the heavy reads.
-__global__ void k_first_count(Chunk ck, int n, unsigned int heavy_seeds, unsigned int *cnt)
-{
+__global__ void k_first_count(Chunk ck, int n, unsigned int heavy_seeds, unsigned int *cnt, int heavy_too)
+{   // jobs of k_ext_first per read: one per kept chain -- of the light reads, and (heavy_too) of the heavy reads that the ahead-of-time pass
+    // over ALL seeds (k_extend_cand) does not hold
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int nc = ck.n_chain[r];
-    cnt[r] = (ck.seed_cnt[r] < heavy_seeds && nc > 0) ? (unsigned int)nc : 0u;
+    const bool light = ck.seed_cnt[r] < heavy_seeds;
+    const bool take = nc > 0 && (light || (heavy_too && !(ck.cand_base && ck.cand_base[r] >= 0)));
+    cnt[r] = take ? (unsigned int)nc : 0u;
 }
 
 __global__ void k_add_u32(const unsigned int *a, const unsigned int *b, unsigned int *out) { *out = *a + *b; }

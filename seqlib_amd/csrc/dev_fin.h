@@ -646,6 +646,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
 struct HitsSoA {
     int64_t *hit_off; int32_t *rid; int64_t *pos; uint16_t *flag; uint8_t *mapq; int32_t *score, *nm, *na, *n_cigar_ops;
     int64_t *cig_off; uint32_t *cigar;
+    int32_t *xa_parent, *sub;     // SLX_F_REG2SAM only (null otherwise)
 };
 
 __global__ void k_hit_counts(Chunk ck, unsigned long long *n_cig_words)
@@ -670,6 +671,12 @@ __global__ void k_compact(Chunk ck, const unsigned long long *hit_off, const uns
     for (int i = 0; i < ck.n_hit[r]; ++i, ++ho) {
         const DHit &h = ck.hits[o + ck.ic[o + i]];
         out.rid[ho] = h.rid; out.pos[ho] = h.pos; out.flag[ho] = (uint16_t)h.flag; out.mapq[ho] = (uint8_t)h.mapq;
+        if (out.xa_parent) {                           // the record an XA alternative belongs to rides in the upper half of the flag (k_hits_sam)
+            const int par = (h.flag >> 16) - 1;
+            out.xa_parent[ho] = par;
+            const DReg &g = ck.regs[o + ck.ia[o + ck.ic[o + i]]];
+            out.sub[ho] = par >= 0 ? -1 : (g.sub > g.csub ? g.sub : g.csub);      // XS
+        }
         out.score[ho] = h.score; out.nm[ho] = h.nm; out.na[ho] = ck.na[r]; out.n_cigar_ops[ho] = h.n_cigar;
         out.cig_off[ho] = co;
         for (int k = 0; k < h.n_cigar; ++k) out.cigar[co++] = ck.cigpool[h.cig_start + k];

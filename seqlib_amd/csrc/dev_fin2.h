@@ -244,7 +244,7 @@ struct WaveScorer {
 // choice); returns false when the glue's `r.secondary && (...)` filter drops it.
 __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt, const FinLists &fl, int r, uint64_t slot, const DReg &ar, bool leader)
 {
-    const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+    const bool drop_sec = !ck.sam_mode && (ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0);
     if (ar.secondary != 0 && drop_sec) return false;   // `r.secondary && (...)`: -1 (primary) is true, 0 is false
     DHit h;
     h.flag = ar.secondary >= 0 ? 0x100 : 0;
@@ -284,7 +284,7 @@ __device__ void dev_regs_read(const DevRef &R, const Chunk &ck, const slx_opt &o
     const uint64_t so = ck.seed_off[r];
     int nh = 0;
     if (ss) {                                         // wave per read: one region per lane, slots by a ballot prefix
-        const bool drop_sec = ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0;
+        const bool drop_sec = !ck.sam_mode && (ck.keepSecFrac < 0.0 || ck.keepSecFrac > 1.0);
         for (int base = 0; base < n; base += 64) {
             const int i = base + ss->lane;
             DReg ar;
@@ -317,7 +317,11 @@ __global__ void __launch_bounds__(256) k_regs1(Chunk ck, DevOpt dopt, FinLists f
             const uint64_t so = ck.seed_off[r];
             DReg ar = ck.regs[so];
             ar.sub = 0; ar.secondary = -1;          // mem_mark_primary_se on a single region
-            if (dev_reg_emit(ck, opt, fl, r, so, ar, true)) nh = 1;
+            if (ck.sam_mode) {                      // mem_reg2sam: the one region is a record unless it scores below opt->T
+                ck.regs[so].sub = 0; ck.regs[so].secondary = -1;
+                ck.ia[so] = 0;                      // (k_compact reads XS from the region behind the hit)
+                if (ar.score >= opt.T && dev_reg_emit(ck, opt, fl, r, so, ar, true)) nh = 1;
+            } else if (dev_reg_emit(ck, opt, fl, r, so, ar, true)) nh = 1;
             ck.ic[so] = 0;                          // the glue's std::sort order of one hit
         }
         ck.na[r] = nr > 0 ? 1 : 0;
@@ -404,7 +408,8 @@ __device__ __forceinline__ void dev_finish_hit(const DevRef &R, const Chunk &ck,
     }
     if (j.qb != 0 || j.qe != l_query) {           // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
         const int clip5 = is_rev ? l_query - j.qe : j.qb, clip3 = is_rev ? j.qb : l_query - j.qe;
-        const uint32_t cop = ck.hardclip ? 5u : 4u;
+        // (an XA alternative -- every secondary under SLX_F_REG2SAM -- is printed by bwa with soft clips whatever the record's clipping)
+        const uint32_t cop = ck.hardclip && !(ck.sam_mode && (h.flag & 0x100)) ? 5u : 4u;
         if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
         if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
     }
@@ -671,6 +676,65 @@ __global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsign
             if (tooLow || tooMany) continue;
             if (!isSec) primaryScore = (double)h.score;
             hh[n_out++] = hh[i];
+        }
+        ck.n_hit[r] = n_out;
+    }
+}
+
+// SLX_F_REG2SAM: bwa's own record selection for the reads with two or more regions, in place of k_hits --
+// bwamem.c:mem_reg2sam without MEM_F_ALL (records = primaries scoring >= opt->T in region order; the first is the representative,
+// the others get 0x800 and a mapq capped at the first's unless on an ALT contig) and bwamem_extra.c:mem_gen_alt (a secondary within
+// XA_drop_ratio of its first-round primary is an XA alternative of it when that primary has at most max_XA_hits of them, or
+// max_XA_hits_alt when one sits on an ALT contig, and is itself a record).  Output order: the records, then the alternatives in
+// region order; an alternative carries its record's index (+1) in the upper half of DHit::flag (k_compact splits it off).
+__global__ void __launch_bounds__(128) k_hits_sam(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots)
+{
+    const slx_opt &opt = dopt.o;
+    const int n_todo = (int)*n_slots;
+    while (true) {
+        const int slot = next_slot(queue, 0);
+        if (__all(slot >= n_todo)) break;
+        if (slot >= n_todo) continue;
+        const int r = order ? order[slot] : slot;
+        ReadWS w = make_ws(ck, r);
+        const int n = ck.n_hit[r];                 // = regions of the read: nothing was dropped on the way here
+        const int *a = w.ia;
+        const DReg *G = w.regs;
+        int *hh = w.ic, *cnt = w.ib;               // output order; per region: XA alternatives it is the primary of (bit 30: one of them is ALT)
+        int *rec_of = (int *)w.srt + w.cap;        // per region: its index among the records, or -1 (the lower half of srt holds secondary_all on an ALT index)
+        const int *sec_all = (const int *)w.srt;
+        auto pri_of = [&](int i) {                 // get_pri_idx: the region this one would be an XA alternative of
+            const int k = R.ann_alt ? sec_all[a[i]] : G[a[i]].secondary;
+            if (k >= 0 && (double)G[a[i]].score >= (double)G[a[k]].score * (double)opt.XA_drop_ratio) return k;
+            return -1;
+        };
+        for (int i = 0; i < n; ++i) cnt[i] = 0;
+        for (int i = 0; i < n; ++i) {
+            const int p = pri_of(i);
+            if (p >= 0) cnt[p] = (cnt[p] + 1) | (ref_is_alt(R, G[a[i]].rid) ? 1 << 30 : 0);
+        }
+        int n_rec = 0, first_mapq = 0;
+        for (int k = 0; k < n; ++k) {
+            const DReg &p = G[a[k]];
+            rec_of[k] = -1;
+            if (p.score < opt.T || p.secondary >= 0) continue;
+            DHit &h = w.hits[k];
+            if (n_rec) {
+                h.flag |= 0x800;
+                if (!ref_is_alt(R, p.rid) && h.mapq > first_mapq) h.mapq = first_mapq;
+            } else first_mapq = h.mapq;
+            rec_of[k] = n_rec;
+            hh[n_rec++] = k;
+        }
+        int n_out = n_rec;
+        for (int i = 0; i < n; ++i) {
+            const int p = pri_of(i);
+            if (p < 0) continue;
+            const int c = cnt[p] & 0x3fffffff;
+            if (c > opt.max_XA_hits_alt || (!(cnt[p] >> 30) && c > opt.max_XA_hits)) continue;
+            if (rec_of[p] < 0) continue;           // its primary is not printed: neither is its XA
+            w.hits[i].flag = (w.hits[i].flag & 0xffff) | (rec_of[p] + 1) << 16;
+            hh[n_out++] = i;
         }
         ck.n_hit[r] = n_out;
     }

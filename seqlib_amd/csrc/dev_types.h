@@ -112,6 +112,8 @@ struct Chunk {
     int *long_scratch; int long_stride; int long_threads;
     // glue parameters (src/BWAAligner.cpp:89-95)
     int hardclip; double keepSecFrac; int maxSecondary;
+    // SLX_F_REG2SAM: bwa's own record selection (mem_reg2sam / mem_gen_alt) instead of the SeqLib glue's sort + filters
+    int sam_mode;
 };
 
 __device__ __forceinline__ int ref_base(const DevRef &R, int64_t p)

@@ -95,7 +95,7 @@ struct Worker {
     int id = 0;
     unsigned int max_seed_cnt = 0;       // of the chunk in flight (k_seed_epi)
     hipEvent_t dbg_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
+    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar, o_xa, o_sub;
     hipEvent_t ev[SLX_N_STAGES + 1];
     hipEvent_t ev_probe[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around the seeding kernels / the extension family / the CIGAR kernels
     float stage_ms[SLX_N_STAGES];
@@ -112,7 +112,7 @@ struct Worker {
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
                &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &snap_ia, &snap_regs, &snap_nreg,
-               &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar};
+               &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
 };
@@ -155,6 +155,8 @@ struct slx_aligner {
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
+    int top_heavy = 1;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain)
+    int top_reuse = 1;            // 1 = k_extend_reg takes top-seed regions from that table (heavy reads, and light reads it redoes) instead of extending in place
     int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
     int stream_prio = 0;
     int n_workers = 3;            // concurrent parts of a large batch
@@ -172,7 +174,7 @@ struct slx_aligner {
     std::mutex call_mu;           // one batch at a time per aligner: the C++ mirror's alignSequence is const and may be called from many threads
     std::vector<Worker *> workers;
     // concatenated outputs of a multi-worker batch
-    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar;
+    DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar, o_xa, o_sub;
     // staging of the host-buffer entry (cached between calls: the per-read alignSequence pays no hipMalloc)
     DevBuf st_bases, st_offs, st_pack;
     float stage_ms[SLX_N_STAGES];
@@ -531,7 +533,7 @@ extern "C" void slx_aligner_free(slx_aligner *al)
     }
     (void)hipSetDevice(al->device);
     DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_ann_alt, &al->d_loglut, &al->o_hit_off,
-                      &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar,
+                      &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar, &al->o_xa, &al->o_sub,
                       &al->st_bases, &al->st_offs, &al->st_pack};
     for (DevBuf *b : bufs) b->release();
     for (Worker *wk : al->workers) {
@@ -601,6 +603,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         al->n_workers = (int)value;
     }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
+    else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
+    else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
         if (value < 0 || value > 24) return SLX_EINVAL;
         HIPCHK(hipSetDevice(al->device));
@@ -696,7 +700,8 @@ static void with_maxq(int max_len, F f)
 // extension -> regions -> CIGAR jobs -> hit sort/filter, over all reads of the chunk on the worker's stream
 template <int MAXQ>
 static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, unsigned int *q, const unsigned int *n_slots, int grid, int bs, int n,
-                        const int *ext_light, const int *ext_heavy, const unsigned int *n_heavy, const unsigned int *ext_slots)
+                        const int *ext_light, const int *ext_heavy, const unsigned int *n_heavy, const unsigned int *ext_slots,
+                        const unsigned int *top_off = nullptr, unsigned int top_cap = 0, const DReg *top_tab = nullptr)
 {
     hipStream_t st = wk->stream;
     hipEvent_t *dbg = wk->dbg_ev;
@@ -704,7 +709,7 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     if (dbg_on) (void)hipEventRecord(dbg[1], st);
     const int g = std::max(1, std::min(n, al->n_cu * 32));
     if (ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, ext_light, q + 1, ext_slots ? ext_slots : n_slots, 0,
-                                      ext_heavy, n_heavy);
+                                      ext_heavy, n_heavy, top_off, top_cap, top_tab);
     else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
                             (const unsigned int *)nullptr);
     if (al->keep_stages && wk->last_S1) {      // the region stage reuses ia[] and rewrites regs[] in place
@@ -751,7 +756,9 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     else hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl);
     (void)hipEventRecord(wk->ev_probe[5], st);
     if (dbg_on) (void)hipEventRecord(dbg[4], st);
-    hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, wk->order_out.as<int>(), q + 3, q + 33, 0);   // single-region reads are final already
+    // single-region reads are final already; the others: the glue's std::sort + secondary filters, or (SLX_F_REG2SAM) bwa's own selection
+    if (ck.sam_mode) hipLaunchKernelGGL(k_hits_sam, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), q + 3, q + 33);
+    else hipLaunchKernelGGL(k_hits, dim3(grid), dim3(bs), 0, st, ck, wk->order_out.as<int>(), q + 3, q + 33, 0);
     if (dbg_on) (void)hipEventRecord(dbg[5], st);
 }
 
@@ -826,6 +833,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.log_lut = al->d_loglut.as<double>(); ck.log_lut_n = 1 << 16;
     ck.lists = wk->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
     ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
+    ck.sam_mode = (opt->flag & SLX_F_REG2SAM) ? 1 : 0;
     ck.seed_cnt = wk->seed_cnt.as<unsigned long long>();
     const bool production = al->chain_mode == 1 && n >= al->split_min && !has_long;
     const bool use_cand = al->cand_mode == 1 && production;
@@ -979,27 +987,31 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             if (hsort && al->ext_split) {
                 // light reads: top seed of every chain extended one wave per chain, decision sequence one read per lane; what is left
                 // (reads needing another extension) joins the heavy reads in the wave-per-read kernel
-                ENS(first_tab, (size_t)n * sizeof(DReg)); ENS(first_cnt, ((size_t)n + 2) * 4); ENS(first_off, ((size_t)n + 2) * 4); ENS(fb_list, (size_t)n * 4);
+                // the table takes one entry per kept chain: ~1.2 per light read, and the chains of the heavy reads (kept chains <= seed slots)
+                const unsigned int top_cap = (unsigned int)std::min<uint64_t>((uint64_t)n + std::min<uint64_t>((uint64_t)S1, (uint64_t)n), 0x7fffffffu);
+                ENS(first_tab, (size_t)top_cap * sizeof(DReg)); ENS(first_cnt, ((size_t)n + 2) * 4); ENS(first_off, ((size_t)n + 2) * 4); ENS(fb_list, (size_t)n * 4);
                 unsigned int *n_fb = q + 20, *ext_tot = q + 21;
                 HIPCHK(hipMemsetAsync(wk->first_cnt.p, 0, ((size_t)n + 2) * 4, st));
-                hipLaunchKernelGGL(k_first_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, n, (unsigned int)al->heavy_seeds, wk->first_cnt.as<unsigned int>());
+                hipLaunchKernelGGL(k_first_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, n, (unsigned int)al->heavy_seeds, wk->first_cnt.as<unsigned int>(),
+                                   al->top_heavy);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->first_cnt.as<unsigned int>(), wk->first_off.as<unsigned int>(), n + 1, st));
                 const int gf = al->n_cu * 32;
-                ENS(first_jobs, (size_t)n * sizeof(FirstJob));
+                ENS(first_jobs, (size_t)top_cap * sizeof(FirstJob));
                 hipLaunchKernelGGL(k_first_prep, dim3(std::max(1, std::min(n / 128 + 1, al->n_cu * 12))), dim3(128), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(),
-                                   (unsigned int)n, wk->first_jobs.as<FirstJob>());
+                                   top_cap, wk->first_jobs.as<FirstJob>());
                 with_maxq(max_len, [&](auto mq) {
                     constexpr int MAXQ = decltype(mq)::value;
-                    hipLaunchKernelGGL(k_ext_first<MAXQ>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), (unsigned int)n, q + 22,
+                    hipLaunchKernelGGL(k_ext_first<MAXQ>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), top_cap, q + 22,
                                        wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
                     hipLaunchKernelGGL(k_ext_replay<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
-                                       (unsigned int)n, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
+                                       top_cap, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
                 });
                 hipLaunchKernelGGL(k_add_u32, dim3(1), dim3(1), 0, st, counts + 1, n_fb, ext_tot);
                 (void)hipEventRecord(wk->ev[4], st);
                 with_maxq(max_len, [&](auto mq) {
-                    launch_tail<decltype(mq)::value>(al, wk, ck, dopt, q, counts + 2, grid, bs, n, wk->fb_list.as<int>(), wk->order_out.as<int>(), counts + 1, ext_tot);
+                    launch_tail<decltype(mq)::value>(al, wk, ck, dopt, q, counts + 2, grid, bs, n, wk->fb_list.as<int>(), wk->order_out.as<int>(), counts + 1, ext_tot,
+                                                     al->top_reuse ? wk->first_off.as<unsigned int>() : nullptr, top_cap, wk->first_tab.as<DReg>());
                 });
             } else {
                 (void)hipEventRecord(wk->ev[4], st);
@@ -1038,11 +1050,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     GROW(o_mapq, (H + 1), *hit_base); GROW(o_score, (H + 1) * 4, *hit_base * 4); GROW(o_nm, (H + 1) * 4, *hit_base * 4);
     GROW(o_na, (H + 1) * 4, *hit_base * 4); GROW(o_ncig, (H + 1) * 4, *hit_base * 4); GROW(o_cig_off, (H + 2) * 8, *hit_base * 8);
     GROW(o_cigar, (C + 1) * 4, *cig_base * 4);
+    if (ck.sam_mode) { GROW(o_xa, (H + 1) * 4, *hit_base * 4); GROW(o_sub, (H + 1) * 4, *hit_base * 4); }
     HitsSoA so;
     so.hit_off = wk->o_hit_off.as<int64_t>(); so.rid = wk->o_rid.as<int32_t>(); so.pos = wk->o_pos.as<int64_t>();
     so.flag = wk->o_flag.as<uint16_t>(); so.mapq = wk->o_mapq.as<uint8_t>(); so.score = wk->o_score.as<int32_t>();
     so.nm = wk->o_nm.as<int32_t>(); so.na = wk->o_na.as<int32_t>(); so.n_cigar_ops = wk->o_ncig.as<int32_t>();
     so.cig_off = wk->o_cig_off.as<int64_t>(); so.cigar = wk->o_cigar.as<uint32_t>();
+    so.xa_parent = ck.sam_mode ? wk->o_xa.as<int32_t>() : nullptr; so.sub = ck.sam_mode ? wk->o_sub.as<int32_t>() : nullptr;
     hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, wk->hit_off_c.as<unsigned long long>(),
                        wk->cig_off_c.as<unsigned long long>(), so, r0 - part_lo, *hit_base, *cig_base);
     (void)hipEventRecord(wk->ev[7], st);
@@ -1265,6 +1279,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
     std::vector<int64_t> lo((size_t)K + 1);
     for (int k = 0; k <= K; ++k) lo[(size_t)k] = n_reads * k / K;
     const bool wide = al->wide;
+    const bool sam = (opt->flag & SLX_F_REG2SAM) != 0;
     auto run_worker = [=](Worker *wk, int64_t a, int64_t b) {
         return wide ? worker_run<uint64_t>(al, wk, opt, (const uint8_t *)d_bases, d_offs, a, b, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, h_bases, h_offs)
                     : worker_run<uint32_t>(al, wk, opt, (const uint8_t *)d_bases, d_offs, a, b, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, h_bases, h_offs);
@@ -1308,6 +1323,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
         r.flag = wk->o_flag.as<uint16_t>(); r.mapq = wk->o_mapq.as<uint8_t>(); r.score = wk->o_score.as<int32_t>();
         r.nm = wk->o_nm.as<int32_t>(); r.na = wk->o_na.as<int32_t>(); r.n_cigar_ops = wk->o_ncig.as<int32_t>();
         r.cig_off = wk->o_cig_off.as<int64_t>(); r.cigar = wk->o_cigar.as<uint32_t>();
+        if (sam) { r.xa_parent = wk->o_xa.as<int32_t>(); r.sub = wk->o_sub.as<int32_t>(); }
     } else {   // concatenate the workers' results (read order = worker order)
         int64_t H = 0, C = 0;
         for (int k = 0; k < K; ++k) { H += al->workers[(size_t)k]->n_hits; C += al->workers[(size_t)k]->n_cig; }
@@ -1316,6 +1332,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
         ENSO(o_hit_off, ((size_t)n_reads + 1) * 8); ENSO(o_rid, ((size_t)H + 1) * 4); ENSO(o_pos, ((size_t)H + 1) * 8); ENSO(o_flag, ((size_t)H + 1) * 2);
         ENSO(o_mapq, (size_t)H + 1); ENSO(o_score, ((size_t)H + 1) * 4); ENSO(o_nm, ((size_t)H + 1) * 4); ENSO(o_na, ((size_t)H + 1) * 4);
         ENSO(o_ncig, ((size_t)H + 1) * 4); ENSO(o_cig_off, ((size_t)H + 2) * 8); ENSO(o_cigar, ((size_t)C + 1) * 4);
+        if (sam) { ENSO(o_xa, ((size_t)H + 1) * 4); ENSO(o_sub, ((size_t)H + 1) * 4); }
 #undef ENSO
         int64_t hb = 0, cb = 0;
         hipStream_t st = al->stream;
@@ -1330,6 +1347,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
 #define CAT(buf, type, cnt, base) if ((cnt) > 0) HIPCHK(hipMemcpyAsync(al->buf.as<type>() + (base), wk->buf.as<type>(), (size_t)(cnt) * sizeof(type), hipMemcpyDeviceToDevice, st))
             CAT(o_rid, int32_t, h, hb); CAT(o_pos, int64_t, h, hb); CAT(o_flag, uint16_t, h, hb); CAT(o_mapq, uint8_t, h, hb); CAT(o_score, int32_t, h, hb);
             CAT(o_nm, int32_t, h, hb); CAT(o_na, int32_t, h, hb); CAT(o_ncig, int32_t, h, hb); CAT(o_cigar, uint32_t, c, cb);
+            if (sam) { CAT(o_xa, int32_t, h, hb); CAT(o_sub, int32_t, h, hb); }
 #undef CAT
             hb += h; cb += c;
         }
@@ -1339,6 +1357,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
         r.flag = al->o_flag.as<uint16_t>(); r.mapq = al->o_mapq.as<uint8_t>(); r.score = al->o_score.as<int32_t>();
         r.nm = al->o_nm.as<int32_t>(); r.na = al->o_na.as<int32_t>(); r.n_cigar_ops = al->o_ncig.as<int32_t>();
         r.cig_off = al->o_cig_off.as<int64_t>(); r.cigar = al->o_cigar.as<uint32_t>();
+        if (sam) { r.xa_parent = al->o_xa.as<int32_t>(); r.sub = al->o_sub.as<int32_t>(); }
     }
     HIPCHK(hipEventRecord(tp.t1, al->stream));
     HIPCHK(hipStreamSynchronize(al->stream));
@@ -1412,12 +1431,14 @@ extern "C" void *slx_host_alloc(uint64_t bytes)
 extern "C" void slx_host_free(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" void slx_host_trim(void) { pin_pool_release_all(); }
 
-static uint64_t packed_size(uint64_t N, uint64_t H, uint64_t Cg) { return 32 + 8 * (N + 1) + 8 * H + 8 * (H + 1) + 5 * 4 * H + 4 * Cg + 2 * H + H; }
+// packed image: the base layout of slx_hits_pack, then -- for SLX_F_REG2SAM results (hdr[3] = 1) -- padding to 4 bytes and int32 xa_parent[H], sub[H]
+static uint64_t packed_base(uint64_t N, uint64_t H, uint64_t Cg) { return 32 + 8 * (N + 1) + 8 * H + 8 * (H + 1) + 5 * 4 * H + 4 * Cg + 2 * H + H; }
+static uint64_t packed_size(uint64_t N, uint64_t H, uint64_t Cg, bool sam = false) { const uint64_t b = packed_base(N, H, Cg); return sam ? ((b + 3) & ~3ull) + 8 * H : b; }
 
 static int pack_locked(slx_aligner *al, const slx_hits *h, void *dst);
 
 // point the fields of a host result into one packed image (layout of slx_hits_pack)
-static void view_packed(slx_hits *out, uint8_t *blk, int64_t N, int64_t H, int64_t C)
+static void view_packed(slx_hits *out, uint8_t *blk, int64_t N, int64_t H, int64_t C, bool sam = false)
 {
     uint8_t *d = blk + 32;
     out->hit_off = (int64_t *)d; d += 8 * ((size_t)N + 1);
@@ -1431,6 +1452,11 @@ static void view_packed(slx_hits *out, uint8_t *blk, int64_t N, int64_t H, int64
     out->cigar = (uint32_t *)d; d += 4 * (size_t)C;
     out->flag = (uint16_t *)d; d += 2 * (size_t)H;
     out->mapq = (uint8_t *)d;
+    out->xa_parent = out->sub = nullptr;
+    if (sam) {
+        uint8_t *e = blk + ((packed_base((uint64_t)N, (uint64_t)H, (uint64_t)C) + 3) & ~3ull);
+        out->xa_parent = (int32_t *)e; out->sub = (int32_t *)(e + 4 * (size_t)H);
+    }
 }
 
 // A group handle (n_dev > 1): the batch is cut into contiguous read-ordinal ranges, one per device (read i keeps lrand48
@@ -1464,18 +1490,19 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
         if (rcs[(size_t)g] != SLX_OK) { slx_set_error("device %d: %s", grp->subs[(size_t)g]->device, errs[(size_t)g].c_str()); drop_parts(); return rcs[(size_t)g]; }
     int64_t H = 0, C = 0;
     for (const auto &h : part) { H += h.n_hits; C += h.n_cigar; }
-    const uint64_t bytes = packed_size((uint64_t)n_reads, (uint64_t)H, (uint64_t)C);
+    const bool sam = (opt->flag & SLX_F_REG2SAM) != 0;
+    const uint64_t bytes = packed_size((uint64_t)n_reads, (uint64_t)H, (uint64_t)C, sam);
     void *blk = nullptr;
     uint64_t blk_cap = 0;
     if (bytes >= (1u << 20)) blk = pin_acquire(bytes, &blk_cap);
     const bool is_pinned = blk != nullptr;
     if (!blk) blk = malloc(bytes);
     if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); drop_parts(); return SLX_ENOMEM; }
-    int64_t hdr[4] = {n_reads, H, C, 0};
+    int64_t hdr[4] = {n_reads, H, C, sam ? 1 : 0};
     memcpy(blk, hdr, 32);
     out->n_reads = n_reads; out->n_hits = H; out->n_cigar = C; out->on_device = 0;
     out->block = blk; out->block_pinned = is_pinned ? 1 : 0; out->block_bytes = is_pinned ? blk_cap : bytes;
-    view_packed(out, (uint8_t *)blk, n_reads, H, C);
+    view_packed(out, (uint8_t *)blk, n_reads, H, C, sam);
     {   // every device's slice lands at its hit / cigar base (one host thread per slice)
         std::vector<int64_t> hb((size_t)G + 1, 0), cb((size_t)G + 1, 0);
         for (int g = 0; g < G; ++g) { hb[(size_t)g + 1] = hb[(size_t)g] + part[(size_t)g].n_hits; cb[(size_t)g + 1] = cb[(size_t)g] + part[(size_t)g].n_cigar; }
@@ -1490,6 +1517,7 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
                     memcpy(out->rid + h0, p.rid, (size_t)h * 4); memcpy(out->pos + h0, p.pos, (size_t)h * 8); memcpy(out->flag + h0, p.flag, (size_t)h * 2);
                     memcpy(out->mapq + h0, p.mapq, (size_t)h); memcpy(out->score + h0, p.score, (size_t)h * 4); memcpy(out->nm + h0, p.nm, (size_t)h * 4);
                     memcpy(out->na + h0, p.na, (size_t)h * 4); memcpy(out->n_cigar_ops + h0, p.n_cigar_ops, (size_t)h * 4);
+                    if (sam && p.xa_parent) { memcpy(out->xa_parent + h0, p.xa_parent, (size_t)h * 4); memcpy(out->sub + h0, p.sub, (size_t)h * 4); }
                 }
                 if (c) memcpy(out->cigar + c0, p.cigar, (size_t)c * 4);
             });
@@ -1524,7 +1552,8 @@ extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *
                              bases, offs);
     if (rc != SLX_OK) return rc;
     // one packed image on the device, ONE device-to-host copy, and the result's arrays are views into it
-    const uint64_t bytes = packed_size((uint64_t)dv.n_reads, (uint64_t)dv.n_hits, (uint64_t)dv.n_cigar);
+    const bool sam = dv.xa_parent != nullptr;
+    const uint64_t bytes = packed_size((uint64_t)dv.n_reads, (uint64_t)dv.n_hits, (uint64_t)dv.n_cigar, sam);
     if ((rc = al->st_pack.ensure(bytes)) != SLX_OK) return rc;
     if ((rc = pack_locked(al, &dv, al->st_pack.p)) != SLX_OK) return rc;
     void *blk = nullptr;
@@ -1541,7 +1570,7 @@ extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *
     }
     out->n_reads = dv.n_reads; out->n_hits = dv.n_hits; out->n_cigar = dv.n_cigar; out->on_device = 0;
     out->block = blk; out->block_pinned = is_pinned ? 1 : 0; out->block_bytes = is_pinned ? blk_cap : bytes;
-    view_packed(out, (uint8_t *)blk, dv.n_reads, dv.n_hits, dv.n_cigar);
+    view_packed(out, (uint8_t *)blk, dv.n_reads, dv.n_hits, dv.n_cigar, sam);
     return SLX_OK;
 }
 
@@ -1556,30 +1585,32 @@ extern "C" void slx_hits_free(slx_hits *h)
 extern "C" uint64_t slx_hits_packed_size(const slx_hits *h)
 {
     if (!h) return 0;
-    return packed_size((uint64_t)h->n_reads, (uint64_t)h->n_hits, (uint64_t)h->n_cigar);
+    return packed_size((uint64_t)h->n_reads, (uint64_t)h->n_hits, (uint64_t)h->n_cigar, h->xa_parent != nullptr);
 }
 
 static int pack_locked(slx_aligner *al, const slx_hits *h, void *dst)
 {
     const size_t N = (size_t)h->n_reads, H = (size_t)h->n_hits, Cg = (size_t)h->n_cigar;
-    int64_t hdr[4] = {h->n_reads, h->n_hits, h->n_cigar, 0};
+    const bool sam = h->xa_parent != nullptr;
+    int64_t hdr[4] = {h->n_reads, h->n_hits, h->n_cigar, sam ? 1 : 0};
     uint8_t *d = (uint8_t *)dst;
-    struct Part { const void *src; size_t bytes; };
-    const Part parts[] = {{h->hit_off, 8 * (N + 1)}, {h->pos, 8 * H}, {h->cig_off, 8 * (H + 1)}, {h->rid, 4 * H}, {h->score, 4 * H},
-                          {h->nm, 4 * H}, {h->na, 4 * H}, {h->n_cigar_ops, 4 * H}, {h->cigar, 4 * Cg}, {h->flag, 2 * H}, {h->mapq, H}};
+    struct Part { const void *src; size_t bytes; size_t at; };
+    std::vector<Part> parts;
+    size_t at = 32;
+    auto add = [&](const void *src, size_t bytes) { parts.push_back({src, bytes, at}); at += bytes; };
+    add(h->hit_off, 8 * (N + 1)); add(h->pos, 8 * H); add(h->cig_off, 8 * (H + 1)); add(h->rid, 4 * H); add(h->score, 4 * H);
+    add(h->nm, 4 * H); add(h->na, 4 * H); add(h->n_cigar_ops, 4 * H); add(h->cigar, 4 * Cg); add(h->flag, 2 * H); add(h->mapq, H);
+    if (sam) { at = (at + 3) & ~(size_t)3; add(h->xa_parent, 4 * H); add(h->sub, 4 * H); }
     if (h->on_device) {
         if (!al) return SLX_EINVAL;
         HIPCHK(hipSetDevice(al->device));
         HIPCHK(hipMemcpyAsync(d, hdr, 32, hipMemcpyHostToDevice, al->stream));
-        d += 32;
-        for (const Part &p : parts) {
-            if (p.bytes) HIPCHK(hipMemcpyAsync(d, p.src, p.bytes, hipMemcpyDeviceToDevice, al->stream));
-            d += p.bytes;
-        }
+        for (const Part &p : parts)
+            if (p.bytes) HIPCHK(hipMemcpyAsync(d + p.at, p.src, p.bytes, hipMemcpyDeviceToDevice, al->stream));
         HIPCHK(hipStreamSynchronize(al->stream));
     } else {
-        memcpy(d, hdr, 32); d += 32;
-        for (const Part &p : parts) { if (p.bytes) memcpy(d, p.src, p.bytes); d += p.bytes; }
+        memcpy(d, hdr, 32);
+        for (const Part &p : parts) if (p.bytes) memcpy(d + p.at, p.src, p.bytes);
     }
     return SLX_OK;
 }
