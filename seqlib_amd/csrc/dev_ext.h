@@ -1,88 +1,17 @@
-// dev_ext.h -- seed extension: bwa's mem_chain2aln and ksw_extend2 (banded affine-gap extension
-// with z-drop, band shrinking on zero cells and the local-vs-to-end choice), as reached from
-// /root/reference/src/BWAAligner.cpp:104 (mem_align1 -> mem_align1_core).  SURVEY.md A.7/A.8.
-// v0 mapping: one lane per read, the H/E row pair in lane-private scratch; the reference window is
-// never materialised -- target bases are read straight from the 2-bit pac in HBM.
+// dev_ext.h -- the decision sequence of bwa's mem_chain2aln for one read on one LANE, replaying regions that k_ext_first
+// extended ahead of time (one wave per chain): which seed of which chain is extended, which is dropped as covered by an
+// earlier region.  Reached from /root/reference/src/BWAAligner.cpp:104 (mem_align1 -> mem_align1_core); SURVEY.md A.7.
+// The extensions themselves (ksw_extend2) live in dev_ext_reg.h / dev_ext_wave.h.
 #pragma once
 #include "dev_chain.h"
 
 struct ExtResult { int score, qle, tle, gtle, gscore, max_off; };
 
-// ksw_extend2.  QF(j) = j-th query base of the extension, TF(i) = i-th target base.
-template <int MAXQ, typename QF, typename TF>
-__device__ ExtResult dev_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, int end_bonus, int h0,
-                                     int *eh_h, int *eh_e)
-{
-    const int8_t *mat = o.mat;
-    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    int i, j, beg, end, max, max_i, max_j, max_ins, max_del, max_ie, gscore, max_off;
-    for (j = 0; j <= qlen; ++j) { eh_h[j] = 0; eh_e[j] = 0; }
-    eh_h[0] = h0; eh_h[1] = h0 > oe_ins ? h0 - oe_ins : 0;
-    for (j = 2; j <= qlen && eh_h[j - 1] > e_ins; ++j) eh_h[j] = eh_h[j - 1] - e_ins;
-    max = 0;
-    for (i = 0; i < 25; ++i) max = max > mat[i] ? max : mat[i];
-    max_ins = (int)((double)(qlen * max + end_bonus - o_ins) / e_ins + 1.);
-    max_ins = max_ins > 1 ? max_ins : 1;
-    w = w < max_ins ? w : max_ins;
-    max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
-    max_del = max_del > 1 ? max_del : 1;
-    w = w < max_del ? w : max_del;
-    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
-    beg = 0; end = qlen;
-    for (i = 0; i < tlen; ++i) {
-        int t, f = 0, h1, m = 0, mj = -1;
-        const int8_t *qrow = mat + tf(i) * 5;
-        if (beg < i - w) beg = i - w;
-        if (end > i + w + 1) end = i + w + 1;
-        if (end > qlen) end = qlen;
-        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
-        else h1 = 0;
-        for (j = beg; j < end; ++j) {
-            int h, M = eh_h[j], e = eh_e[j];
-            eh_h[j] = h1;
-            M = M ? M + qrow[qf(j)] : 0;
-            h = M > e ? M : e;
-            h = h > f ? h : f;
-            h1 = h;
-            mj = m > h ? mj : j;
-            m = m > h ? m : h;
-            t = M - oe_del; t = t > 0 ? t : 0;
-            e -= e_del; e = e > t ? e : t;
-            eh_e[j] = e;
-            t = M - oe_ins; t = t > 0 ? t : 0;
-            f -= e_ins; f = f > t ? f : t;
-        }
-        eh_h[end] = h1; eh_e[end] = 0;
-        if (j == qlen) {
-            max_ie = gscore > h1 ? max_ie : i;
-            gscore = gscore > h1 ? gscore : h1;
-        }
-        if (m == 0) break;
-        if (m > max) {
-            max = m; max_i = i; max_j = mj;
-            const int off = mj - i < 0 ? i - mj : mj - i;
-            max_off = max_off > off ? max_off : off;
-        } else if (zdrop > 0) {
-            if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
-            else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
-        }
-        for (j = beg; j < end && eh_h[j] == 0 && eh_e[j] == 0; ++j);
-        beg = j;
-        for (j = end; j >= beg && eh_h[j] == 0 && eh_e[j] == 0; --j);
-        end = j + 2 < qlen ? j + 2 : qlen;
-    }
-    ExtResult r;
-    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-    return r;
-}
-
-// mem_chain2aln for one read on one lane.  REPLAY = false: the reference kernel of ext_mode 0 (extensions run on the lane, H/E rows
-// in lane-private scratch).  REPLAY = true: the decision sequence only -- the region of each chain's top (longest) seed was
-// computed ahead of time by k_ext_first (one wave per chain) and is taken from `first`; if any OTHER seed turns out to need an
+// mem_chain2aln for one read on one lane, the decision sequence only: the region of each chain's top (longest) seed was computed
+// ahead of time by k_ext_first (one wave per chain) and is taken from `first`; if any OTHER seed turns out to need an
 // extension the read is given up (returns false, nothing stored) and the wave-per-read kernel redoes it.
-template <int MAXQ, bool REPLAY>
-__device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt &opt, int r, int *eh_h, int *eh_e, const DReg *first)
+template <int MAXQ>
+__device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt &opt, int r, const DReg *first)
 {
         ReadWS w = make_ws(ck, r);
         const uint8_t *query = ck.codes + ck.offs[r];
@@ -159,62 +88,14 @@ __device__ bool dev_extend_lane(const DevRef &R, const Chunk &ck, const slx_opt 
                     }
                     if (i == n) { srt_h[k] = -1; continue; }
                 }
-                DReg a;
-                if (REPLAY) {
-                    if (k != n - 1) return false;            // a seed other than the chain's top seed needs extending: not precomputed
-                    a = first[ci];                           // (k_ext_first leaves seedcov to this kernel, which has the chain's seeds at hand)
-                    a.seedcov = 0;
-                    for (i = 0; i < n; ++i) {
-                        const int t = cs[i];
-                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                        const int64_t t_rbeg = w.s_rbeg[t];
-                        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
-                    }
-                } else {
-                    a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
-                    a.n_comp = 0; a.hash = 0;
-                    int aw0 = opt.w, aw1 = opt.w;
-                    a.w = opt.w; a.score = a.truesc = -1; a.rid = w.c_rid[c];
-                    if (s_qbeg) {                    // left extension: both sequences reversed
-                        const int64_t tmp = s_rbeg - rmax0;
-                        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                        for (i = 0; i < 2; ++i) {    // MAX_BAND_TRY
-                            const int prev = a.score;
-                            aw0 = opt.w << i;
-                            er = dev_ksw_extend2<MAXQ>(s_qbeg, [&](int j) { return (int)query[s_qbeg - 1 - j]; }, (int)tmp,
-                                                       [&](int t) { return ref_base(R, s_rbeg - 1 - t); }, opt, aw0, opt.pen_clip5,
-                                                       s_len * opt.a, eh_h, eh_e);
-                            a.score = er.score;
-                            if (a.score == prev || er.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-                        }
-                        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
-                        else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
-                    } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
-                    if (s_qbeg + s_len != l_query) { // right extension
-                        const int sc0 = a.score, qe = s_qbeg + s_len;
-                        const int64_t re0 = s_rbeg + s_len;      // = rmax0 + re in bwa's local coordinates
-                        ExtResult er; er.score = -1; er.qle = er.tle = er.gtle = er.gscore = er.max_off = 0;
-                        for (i = 0; i < 2; ++i) {
-                            const int prev = a.score;
-                            aw1 = opt.w << i;
-                            er = dev_ksw_extend2<MAXQ>(l_query - qe, [&](int j) { return (int)query[qe + j]; }, (int)(rmax1 - re0),
-                                                       [&](int t) { return ref_base(R, re0 + t); }, opt, aw1, opt.pen_clip3, sc0, eh_h, eh_e);
-                            a.score = er.score;
-                            if (a.score == prev || er.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-                        }
-                        if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
-                        else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
-                    } else { a.qe = l_query; a.re = s_rbeg + s_len; }
-                    a.seedcov = 0;
-                    for (i = 0; i < n; ++i) {
-                        const int t = cs[i];
-                        const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
-                        const int64_t t_rbeg = w.s_rbeg[t];
-                        if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
-                    }
-                    a.w = aw0 > aw1 ? aw0 : aw1;
-                    a.seedlen0 = s_len;
-                    a.frac_rep = frac_rep;
+                if (k != n - 1) return false;                // a seed other than the chain's top seed needs extending: not precomputed
+                DReg a = first[ci];                          // (k_ext_first leaves seedcov to this kernel, which has the chain's seeds at hand)
+                a.seedcov = 0;
+                for (i = 0; i < n; ++i) {
+                    const int t = cs[i];
+                    const int t_qbeg = w.s_qbeg(t), t_len = w.s_len(t);
+                    const int64_t t_rbeg = w.s_rbeg[t];
+                    if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) a.seedcov += t_len;
                 }
                 w.regs[n_av++] = a;
             }

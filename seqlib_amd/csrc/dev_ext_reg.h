@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(128) k_ext_replay(DevRef R, Chunk ck, DevOpt d
         if (nc == 0) { ck.n_reg[r] = 0; done = true; }
         else {
             const unsigned int off = first_off[r];
-            done = off + (unsigned int)nc <= cap && dev_extend_lane<MAXQ, true>(R, ck, opt, r, nullptr, nullptr, first + off);
+            done = off + (unsigned int)nc <= cap && dev_extend_lane<MAXQ>(R, ck, opt, r, first + off);
         }
         if (!done) fb_list[wave_fetch_inc(n_fb)] = r;
     }

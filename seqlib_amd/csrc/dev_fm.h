@@ -32,6 +32,16 @@ struct alignas(16) IntvE {    // one bidirectional interval on a SMEM work list
     uint32_t info;            // end position in the query (start is attached when a MEM is emitted)
 };
 
+// the two SMEM work lists of a lane (bwt_smem1a's prev / curr): lane-interleaved in HBM scratch, so that lanes walking their lists
+// in step touch neighbouring 16-byte slots
+template <typename I>
+struct WorkLists {
+    IntvE<I> *base;           // already offset by the lane's slot
+    size_t stride;            // n_threads
+    int cap;
+    __device__ __forceinline__ IntvE<I> &at(int list, int e) { return base[((size_t)list * cap + e) * stride]; }
+};
+
 __device__ __forceinline__ void count_word(uint32_t w, int nb, uint32_t &c, uint32_t &g, uint32_t &t)
 {
     // keep the top nb (0..16) symbols of the word

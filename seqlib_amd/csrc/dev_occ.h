@@ -5,7 +5,8 @@
 //                 A rank query is one 32-byte read, one 64-bit mask and two to four popcounts, instead of a 64-byte line and
 //                 eight masked 16-symbol words.  Templated users: u32 for indexes below 2^32 BWT symbols, u64 above (GRCh38).
 #pragma once
-#include "dev_seed.h"
+#include "dev_fm.h"
+#include "dev_types.h"
 
 // Indexes with >= 2^32 symbols (GRCh38: 6.2 G) keep the same 32-byte blocks: the u32 counts are then relative to the
 // block's SUPER-BLOCK (2^32 symbols), whose four u64 base counts sit in a table of a few entries (`sup`, filled by

@@ -339,8 +339,39 @@ static int multidev_checks(const std::string &prefix, const std::string &fastq, 
     return 0;
 }
 
+// bwamem <prefix> <fastq> <n>: UseBwaMemRecords -- "read# rec# flag rid pos mapq CIGAR AS NM NA XS XA SA" per record ('*' = tag absent)
+static int bwamem_dump(const std::string &prefix, const std::string &fastq, long n)
+{
+    auto idx = std::make_shared<BWAIndex>();
+    idx->LoadIndex(prefix);
+    BWAAligner bwa(idx);
+    bwa.UseBwaMemRecords();
+    CHECK_THROWS(bwa.SetOutputScoreThreshold(-1), std::invalid_argument);
+    std::ifstream fq(fastq);
+    std::string h, s, p, q;
+    UnalignedSequenceVector reads;
+    while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q) && (long)reads.size() < n)
+        reads.emplace_back(h.substr(1), s, q);
+    reads.emplace_back("nohit", "ACGTACGTACGTTGCATGCATGCAAACCGGTT");
+    std::vector<BamRecordPtrVector> outs;
+    bwa.alignSequences(reads, outs, false, 0.9, 10);
+    for (size_t i = 0; i < outs.size(); ++i)
+        for (size_t j = 0; j < outs[i].size(); ++j) {
+            const BamRecord &r = *outs[i][j];
+            int32_t as = 0, nm = -1, na = 0, xs = -1;
+            std::string xa = "*", sa = "*";
+            r.GetIntTag("AS", as); r.GetIntTag("NM", nm); r.GetIntTag("NA", na);
+            if (!r.GetIntTag("XS", xs)) xs = -1;
+            r.GetZTag("XA", xa); r.GetZTag("SA", sa);
+            std::printf("%zu\t%zu\t%u\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%d\t%s\t%s\n", i, j, r.AlignmentFlag(), r.ChrID(), r.Position(), r.MapQuality(),
+                        r.CigarString().empty() ? "*" : r.CigarString().c_str(), as, nm, na, xs, xa.c_str(), sa.c_str());
+        }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 5 && std::string(argv[1]) == "bwamem") return bwamem_dump(argv[2], argv[3], std::atol(argv[4]));
     if (argc >= 6 && std::string(argv[1]) == "multidev") return multidev_checks(argv[2], argv[3], std::atol(argv[4]), std::atoi(argv[5]));
     if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);
     if (argc >= 3 && std::string(argv[1]) == "fastq") return fastq_dump(argv[2]);

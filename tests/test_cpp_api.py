@@ -71,6 +71,37 @@ def test_cpp_multi_device_handle_and_chunked_pipeline(exe, golden_dir):
     assert "mismatches=0" in r.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_bwa_mem_records(exe, golden_dir):
+    """BWAAligner::UseBwaMemRecords: the records `bwa mem` would print (opt->T, 0x800, mapq cap, XS:i, XA:Z through the reference's
+    own branch at src/BWAAligner.cpp:240, SA:Z; an unmapped record for a read without one) -- tag strings as the oracle's
+    restatement of mem_gen_alt / mem_aln2sam builds them"""
+    from oracle import orc
+    n = 3000
+    fq = os.path.join(golden_dir, "sim2_bcr.head3000.fq")
+    r = subprocess.run([exe, "bwamem", os.path.join(golden_dir, "tiny.fa"), fq, str(n)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = {}
+    for l in r.stdout.strip().split("\n"):
+        f = l.split("\t")
+        got.setdefault(int(f[0]), []).append(f[2:])
+    oidx = orc.Index.load(os.path.join(golden_dir, "tiny.fa"))
+    _, seqs = orc.read_fastq(fq, n)
+    seqs.append("ACGTACGTACGTTGCATGCATGCAAACCGGTT")
+    n_sa = n_xa = 0
+    for i, sq in enumerate(seqs):
+        recs = [e for e in orc.align_sequence_sam(orc.default_opt(), oidx, sq, ordinal=i) if e["xa_parent"] < 0]
+        if not recs:                                   # bwa prints an unmapped record
+            assert got[i] == [["4", "-1", "-1", "0", "*", "0", "-1", "0", "0", "*", "*"]], (i, got[i])
+            continue
+        exp = [[str(e["flag"]), str(e["rid"]), str(e["pos"]), str(e["mapq"]), orc.cigar_str(e["cigar"]), str(e["AS"]), str(e["NM"]), str(e["NA"]),
+                str(e["XS"]), e["XA"] or "*", e["SA"] or "*"] for e in recs]
+        assert got[i] == exp, (i, got[i], exp)
+        n_sa += any(e["SA"] for e in recs)
+        n_xa += any(e["XA"] for e in recs)
+    assert n_sa >= 1 and len(got) == len(seqs)
+
+
 # ---------------------------------------------------------------------------------------------- FastqReader / BamWriter
 def _kseq_like(text):
     """Independent statement of the record grammar FastqReader follows (bwa kseq.h, see include/SeqLib/FastqReader.h),

@@ -557,6 +557,104 @@ def test_alt_contigs_match_oracle(sl, orc, tmp_path):
     assert_same(sl.BWAAligner(idx2).alignSequences(reads), plain, "same files, no .alt")
 
 
+def _sam_entries(res, i):
+    out = []
+    for k in range(int(res["hit_off"][i]), int(res["hit_off"][i + 1])):
+        c0, c1 = int(res["cig_off"][k]), int(res["cig_off"][k + 1])
+        out.append((int(res["rid"][k]), int(res["pos"][k]), int(res["flag"][k]), int(res["mapq"][k]), int(res["score"][k]), int(res["nm"][k]),
+                    int(res["na"][k]), tuple(int(w) for w in res["cigar"][c0:c1]), int(res["xa_parent"][k]), int(res["sub"][k])))
+    return out
+
+
+def _check_sam_mode(sl, orc, idx, oidx, reads, what, knobs=(), hardclip=False, tweak=None):
+    from seqlib_amd import _ffi
+    al = sl.BWAAligner(idx)
+    opt = orc.default_opt()
+    for k, v in knobs:
+        al.set(k, v)
+    if tweak:
+        tweak(al.opt); tweak(opt)
+    al.opt.flag |= _ffi.SLX_F_REG2SAM
+    got = al.alignSequences(reads, hardclip=hardclip, keepSecFrac=-1.0, maxSecondary=0)     # (the glue's filters must play no part)
+    assert "xa_parent" in got
+    n_multi = n_xa = 0
+    for i, sq in enumerate(reads):
+        exp = [(r["rid"], r["pos"], r["flag"], r["mapq"], r["AS"], r["NM"], r["NA"], tuple(r["cigar"]), r["xa_parent"], r["XS"])
+               for r in orc.align_sequence_sam(opt, oidx, sq, hardclip=hardclip, ordinal=i)]
+        g = _sam_entries(got, i)
+        assert g == exp, "%s: read %d differs\n gpu=%s\n cpu=%s" % (what, i, g, exp)
+        n_multi += sum(1 for e in exp if e[8] < 0) > 1
+        n_xa += any(e[8] >= 0 for e in exp)
+    return n_multi, n_xa
+
+
+def test_bwa_mem_record_mode(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir, tmp_path):
+    """SLX_F_REG2SAM: what bwa's mem_reg2sam / mem_gen_alt give for every read -- opt->T, 0x800 + mapq cap on the
+    supplementary records, the XA alternatives with their parent record, XS -- entry for entry against the oracle's restatement:
+    the reference's fixture (chimeric bcr/abl reads -> supplementary records), repeats and low complexity (XA lists, and lists too
+    long to be kept), both region kernels, hard clipping, other thresholds, and an ALT-aware index (max_XA_hits_alt)"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    (_, s1), (_, s2) = sim_reads
+    rep = refs[0][7000:7060]
+    extra = ["", "ACGT", "A" * 150, "AC" * 75, refs[0][1000:1080] + refs[2][500:570], refs[1][300:420] + refs[3][100:130], rep + rep[:40] + rep,
+             refs[0][5000:5040] + "ACGTTGCA" * 8 + refs[0][5040:5086]]
+    reads = s1[:2500] + extra + s2[:2500]
+    n_multi, n_xa = _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads, "fixture")
+    assert n_multi >= 1
+    _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "fixture, wave region kernel", knobs=(("regs_big", 2), ("split_min", 16), ("heavy_seeds", 8)))
+    _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "fixture, hard clips", hardclip=True)
+
+    def other(o):
+        o.T = 60; o.XA_drop_ratio = 0.5; o.max_XA_hits = 2
+    _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "T = 60, XA_drop_ratio 0.5, max_XA_hits 2", tweak=other)
+    prefix, areads = _alt_fixture(sl, orc, tmp_path)
+    aidx = sl.BWAIndex()
+    aidx.LoadIndex(prefix)
+    n_multi, n_xa = _check_sam_mode(sl, orc, aidx, orc.Index.load(prefix), areads[::3], "ALT index")
+    assert n_xa >= 10                                  # reads on the stretches the ALT contigs copy carry XA alternatives
+
+
+def test_option_fuzz_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
+    """option space, not one KAT set: band width, z-drop, seed length, occurrence cap, re-seeding, gap / mismatch / clipping
+    penalties, chain filter ratios drawn at random over their useful ranges (fixed seed) -- every set bit-exact vs the oracle on
+    fixture reads plus low-complexity and chimeric ones, on the production schedule"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    (_, s1), (_, s2) = sim_reads
+    rng = np.random.default_rng(20261002)
+    base = s1[:450] + s2[:450] + ["A" * 150, "AC" * 75, "ACG" * 50, refs[0][1000:1080] + refs[2][500:570], refs[1][300:420] + refs[3][100:130],
+                                  refs[0][2000:2070] + "ACGTAC" + refs[0][2070:2140], refs[0][3000:3060] + refs[0][3075:3160]]
+    for trial in range(14):
+        o = orc.default_opt()
+        al = sl.BWAAligner(tiny_gpu)
+
+        def put(name, v):
+            setattr(o, name, v); setattr(al.opt, name, v)
+        put("w", int(rng.choice([3, 10, 25, 50, 100, 150, 300])))
+        put("zdrop", int(rng.choice([0, 10, 40, 100, 200])))
+        put("min_seed_len", int(rng.integers(10, 28)))
+        put("max_occ", int(rng.choice([2, 10, 50, 500, 2000])))
+        put("max_mem_intv", int(rng.choice([0, 5, 20, 50])))
+        put("split_width", int(rng.choice([1, 10, 40])))
+        put("split_factor", float(rng.choice([1.0, 1.5, 2.5])))
+        put("b", int(rng.integers(1, 9)))
+        for f in ("o_del", "o_ins"):
+            put(f, int(rng.integers(1, 13)))
+        for f in ("e_del", "e_ins"):
+            put(f, int(rng.integers(1, 4)))
+        put("pen_clip5", int(rng.integers(0, 11))); put("pen_clip3", int(rng.integers(0, 11)))
+        put("max_chain_gap", int(rng.choice([50, 1000, 10000])))
+        put("mask_level", float(rng.choice([0.3, 0.5, 0.8]))); put("drop_ratio", float(rng.choice([0.3, 0.5, 0.7])))
+        put("mask_level_redun", float(rng.choice([0.8, 0.95]))); put("min_chain_weight", int(rng.choice([0, 0, 25])))
+        orc.lib().orc_fill_scmat(o.a, o.b, o.mat)
+        for i in range(25):
+            al.opt.mat[i] = o.mat[i]
+        if trial % 2:
+            al.set("split_min", 16); al.set("heavy_seeds", int(rng.choice([3, 16])))
+        what = "fuzz %d: " % trial + " ".join("%s=%s" % (f, getattr(o, f)) for f in ("w", "zdrop", "min_seed_len", "max_occ", "max_mem_intv", "split_width",
+                                                                                     "b", "o_del", "o_ins", "e_del", "e_ins", "pen_clip5", "pen_clip3", "max_chain_gap", "min_chain_weight"))
+        assert_same(al.alignSequences(base), orc.align_batch(o, tiny_index, base), what)
+
+
 def test_multi_device_handle_equals_single(sl, orc, tiny_gpu, tiny_index, sim_reads):
     """slx_aligner_create with n_dev > 1 (every visible GPU, each listed up to three times -- also the stand-in for several GPUs on a
     1-GPU box): slx_align_batch shards the batch by contiguous read-ordinal ranges, one host thread per device, results merged on
