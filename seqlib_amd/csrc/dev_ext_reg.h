@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         const int64_t l_pac = R.l_pac;
         const int cand_at = ck.cand_base ? __builtin_amdgcn_readfirstlane(ck.cand_base[r]) : -1;
         int top_at = -1;
-        if (top_tab && cand_at < 0) {
+        if (top_tab && top_off && cand_at < 0) {
             const unsigned int o = (unsigned int)__builtin_amdgcn_readfirstlane((int)top_off[r]);
             const unsigned int c = (unsigned int)__builtin_amdgcn_readfirstlane((int)top_off[r + 1]) - o;
             if (c == (unsigned int)n_chn && o + c <= top_cap) top_at = (int)o;

@@ -1,7 +1,7 @@
 """Multi-GPU result gather: reads are sharded by contiguous ordinal range, the index is
 replicated, and the only collective is ONE gather of each rank's packed hits to rank 0 -- RCCL over xGMI
 when the process group is "nccl", gloo in the CPU tests.  RCCL has no gatherv, so ranks first all_gather
-their byte counts and then gather buffers padded to the largest."""
+their byte counts and then send their images at their exact sizes (grouped point-to-point)."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -24,6 +24,9 @@ def unpack(buf):
     for k in ("rid", "score", "nm", "na", "n_cigar"):
         take(k, H, np.int32)
     take("cigar", Cg, np.uint32); take("flag", H, np.uint16); take("mapq", H, np.uint8)
+    if int(hdr[3]) & 1:                              # SLX_F_REG2SAM results carry two more arrays, 4-byte aligned
+        o = (o + 3) & ~3
+        take("xa_parent", H, np.int32); take("sub", H, np.int32)
     return out
 
 
@@ -38,7 +41,9 @@ def pack_numpy(res):
 
 
 def gather_packed(buf, dst=0):
-    """buf: 1-D uint8 tensor (CPU for gloo, GPU for nccl=RCCL).  Returns the list of per-rank tensors on dst, else None."""
+    """buf: 1-D uint8 tensor (CPU for gloo, GPU for nccl=RCCL).  Returns the list of per-rank tensors on dst, else None.
+    SURVEY 8e: all_gather of the byte counts, then every rank's image travels at its exact size -- one send per rank, the receives
+    posted together on dst (grouped point-to-point: over RCCL they run as one fused exchange on the xGMI links)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [buf]
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -46,13 +51,16 @@ def gather_packed(buf, dst=0):
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    padded = buf if buf.numel() == mx else torch.cat([buf, torch.zeros(mx - buf.numel(), dtype=torch.uint8, device=buf.device)])
     if rank == dst:
-        recv = [torch.empty(mx, dtype=torch.uint8, device=buf.device) for _ in range(world)]
-        dist.gather(padded, recv, dst=dst)
-        return [recv[i][:sizes[i]] for i in range(world)]
-    dist.gather(padded, None, dst=dst)
+        recv = [buf if r == dst else torch.empty(sizes[r], dtype=torch.uint8, device=buf.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, recv[r], r) for r in range(world) if r != dst and sizes[r] > 0]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return recv
+    if buf.numel() > 0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst)]):
+            w.wait()
     return None
 
 
