@@ -507,7 +507,7 @@ private:
             slx_lrand48_skip_libc((uint64_t)n);
         }
         std::lock_guard<std::mutex> batch(batch_mu_);
-        const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 2000000) * n_dev_);
+        const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 4000000) * n_dev_);
         const int64_t n_chunks = (n + chunk - 1) / chunk;
         unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)detail::effective_cpus());
         T = std::max(1u, std::min(T, 512u));

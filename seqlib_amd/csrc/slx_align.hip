@@ -155,7 +155,9 @@ struct slx_aligner {
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
-    int top_heavy = 1;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain)
+    int top_heavy = 0;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain):
+                                  // measured on C3: 46.2 M reads/s against 48.4 M without -- the repeat reads' extensions are real DP work (hundreds per read),
+                                  // and in the pipeline their serial walk hides behind the other workers while the extra k_ext_first jobs do not
     int top_reuse = 1;            // 1 = k_extend_reg takes top-seed regions from that table (heavy reads, and light reads it redoes) instead of extending in place
     int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
     int stream_prio = 0;

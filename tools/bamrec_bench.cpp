@@ -4,6 +4,7 @@
 // (one shared_ptr<BamRecord> + bam1_t blob + three tag appends per hit), on a sample of the bench's reads.
 //   bamrec_bench <index prefix> <reads.bin (fixed-length ASCII)> <read_len> <n_reads>
 // Prints one JSON line.  Built by seqlib_amd/build.py with g++ against libseqlib_amd.so.
+#include <malloc.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,9 @@ int main(int argc, char **argv)
     FILE *fp = std::fopen(argv[2], "rb");
     if (!fp || std::fread(raw.data(), 1, raw.size(), fp) != raw.size()) { std::fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
     std::fclose(fp);
+    // glibc: let the per-thread arenas grow in large steps and never shrink (10 M records are 30 M allocations from 16 threads; with the
+    // default 128 KB steps every step is an mprotect call that serialises the threads on the process's memory map).  SLX_NO_MALLOPT=1 keeps glibc's defaults.
+    if (!std::getenv("SLX_NO_MALLOPT")) { mallopt(M_TOP_PAD, 256 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); }
     try {
         BWAIndexPtr idx = std::make_shared<BWAIndex>();
         idx->LoadIndex(prefix);
