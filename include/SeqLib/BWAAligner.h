@@ -402,8 +402,8 @@ private:
         return names_[(size_t)rid];
     }
 
-    // all records of read i of a result: the glue's (src/BWAAligner.cpp:136-248), or -- UseBwaMemRecords -- bwa's own: records first,
-    // then the alternatives that make up the records' XA:Z, as the C-ABI hands them over (SLX_F_REG2SAM)
+    // all records of read i of a result: the glue's (src/BWAAligner.cpp:136-248), or -- UseBwaMemRecords -- bwa's own, from the entries
+    // the C-ABI hands over (SLX_F_REG2SAM): records (sub >= 0) and the alternatives (xa_parent) that make up their XA:Z
     void build_read(const slx_hits &h, int64_t i, const std::string_view seq, const char *name, size_t l_name, bool hardclip, const std::string *com,
                     BamRecordPtrVector &dst) const
     {
@@ -417,46 +417,48 @@ private:
             }
             return;
         }
-        int64_t n_rec = 0;
-        while (k0 + n_rec < k1 && h.xa_parent[k0 + n_rec] < 0) ++n_rec;
+        std::vector<int64_t> rec;                               // entries that are records (sub >= 0), in bwa's order
+        for (int64_t k = k0; k < k1; ++k) if (h.sub[k] >= 0) rec.push_back(k);
+        const int64_t n_rec = (int64_t)rec.size();
         if (n_rec == 0) {
-            BamRecordPtr rec = make_unmapped(seq, name, l_name);
-            if (com) rec->AddZTag("BC", *com);
-            dst.push_back(std::move(rec));
+            BamRecordPtr r = make_unmapped(seq, name, l_name);
+            if (com) r->AddZTag("BC", *com);
+            dst.push_back(std::move(r));
             return;
         }
-        auto put_cigar = [&](std::string &o, int64_t k, bool soft_only) {
+        auto put_cigar = [&](std::string &o, int64_t k) {       // XA:Z and SA:Z show bwa's own cigar: clips are S whatever the record's clipping
             const uint32_t *cig = h.cigar + h.cig_off[k];
             for (int c = 0; c < h.n_cigar_ops[k]; ++c) {
                 o += std::to_string(bam_cigar_oplen(cig[c]));
                 const uint32_t op = bam_cigar_op(cig[c]);
-                o.push_back(soft_only && op == BAM_CHARD_CLIP ? 'S' : BAM_CIGAR_STR[op]);      // bwa's SA:Z keeps the S of its own cigar
+                o.push_back(op == BAM_CHARD_CLIP ? 'S' : BAM_CIGAR_STR[op]);
             }
         };
         std::vector<std::string> xa((size_t)n_rec), sa((size_t)n_rec);
-        for (int64_t k = k0 + n_rec; k < k1; ++k) {          // mem_gen_alt: "chr,<strand><pos>,<CIGAR>,<NM>;"
+        for (int64_t k = k0; k < k1; ++k) {                      // mem_gen_alt: "chr,<strand><pos>,<CIGAR>,<NM>;" in region order
+            if (h.xa_parent[k] < 0) continue;
             std::string &o = xa[(size_t)h.xa_parent[k]];
             o += contig_name(h.rid[k]); o.push_back(',');
             o.push_back((h.flag[k] & BAM_FREVERSE) ? '-' : '+'); o += std::to_string((long long)h.pos[k] + 1); o.push_back(',');
-            put_cigar(o, k, false);
+            put_cigar(o, k);
             o.push_back(','); o += std::to_string(h.nm[k]); o.push_back(';');
         }
         if (n_rec > 1)                                        // mem_aln2sam: "chr,<pos>,<strand>,<CIGAR>,<mapq>,<NM>;" of every other record
             for (int64_t j = 0; j < n_rec; ++j)
                 for (int64_t q = 0; q < n_rec; ++q) {
                     if (q == j) continue;
-                    const int64_t k = k0 + q;
+                    const int64_t k = rec[(size_t)q];
                     std::string &o = sa[(size_t)j];
                     o += contig_name(h.rid[k]); o.push_back(','); o += std::to_string((long long)h.pos[k] + 1); o.push_back(',');
                     o.push_back((h.flag[k] & BAM_FREVERSE) ? '-' : '+'); o.push_back(',');
-                    put_cigar(o, k, true);
+                    put_cigar(o, k);
                     o.push_back(','); o += std::to_string((int)h.mapq[k]); o.push_back(','); o += std::to_string(h.nm[k]); o.push_back(';');
                 }
         dst.reserve(dst.size() + (size_t)n_rec);
         for (int64_t j = 0; j < n_rec; ++j) {
-            BamRecordPtr rec = make_record(h, k0 + j, seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[k0 + j]);
-            if (com) rec->AddZTag("BC", *com);
-            dst.push_back(std::move(rec));
+            BamRecordPtr r = make_record(h, rec[(size_t)j], seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[rec[(size_t)j]]);
+            if (com) r->AddZTag("BC", *com);
+            dst.push_back(std::move(r));
         }
     }
 
@@ -495,7 +497,7 @@ private:
 
     // the batch: chunks of the read vector through pack (host threads) -> align (GPU) -> records (host threads), overlapped.
     // Tunables (environment): SEQLIB_AMD_THREADS host threads (default: the CPUs the process may use -- hardware threads cut down to the
-    // cgroup CPU quota), SEQLIB_AMD_CHUNK reads per chunk and device (default 2 M), SEQLIB_AMD_TRACE=1 per-chunk timings on stderr.
+    // cgroup CPU quota), SEQLIB_AMD_CHUNK reads per chunk and device (default 4 M), SEQLIB_AMD_TRACE=1 per-chunk timings on stderr.
     void run_batch(const UnalignedSequenceVector &reads, std::vector<BamRecordPtrVector> &out, bool hardclip, double keepSecFrac, int maxSecondary) const
     {
         slx_aligner *al = handle();

@@ -76,10 +76,11 @@ typedef struct {
 /* Opt-in bit of slx_opt.flag (no bwa counterpart; bwa's own MEM_F_* bits sit below 0x1000): apply bwa's OWN record selection to
  * every read -- mem_reg2sam + mem_gen_alt (bwamem.c, bwamem_extra.c), which SeqLib's glue bypasses (src/BWAAligner.cpp:136-146
  * have no opt->T threshold and no 0x800, and h.XA is always NULL at :240) -- instead of the glue's sort and secondary filters
- * (keepSecFrac / maxSecondary are then not used).  The entries of a read are then: first its RECORDS in bwa's order (primaries
- * scoring >= opt->T; the first is the representative, the others carry 0x800 and a mapq capped at the first's), then its XA
- * ALTERNATIVES (xa_parent[k] = index among the read's records of the record they belong to; soft clips whatever `hardclip`).
- * slx_hits.sub carries XS.  A read without a record has no entry (bwa prints an unmapped record: the caller's to synthesise). */
+ * (keepSecFrac / maxSecondary are then not used).  The entries of a read are then its regions in bwa's order, each one a RECORD
+ * (sub[k] >= 0: a primary scoring >= opt->T; the first is the representative, the others carry 0x800 and a mapq capped at the
+ * first's), an XA ALTERNATIVE (xa_parent[k] = ordinal, among the read's records, of the record whose XA:Z lists it) or -- on an
+ * ALT-aware index -- both; regions that are neither are dropped.  sub carries XS.  A read without a record has no entry (bwa
+ * prints an unmapped record: the caller's to synthesise). */
 #define SLX_F_REG2SAM 0x40000000
 
 typedef struct slx_index slx_index;
@@ -149,8 +150,8 @@ typedef struct {
     void     *block;        /* host results: the one allocation every array above points into (layout of slx_hits_pack) */
     int       block_pinned; /* 1: block is pinned host memory (recycled by slx_hits_free); 0: malloc */
     uint64_t  block_bytes;
-    int32_t  *xa_parent;    /* SLX_F_REG2SAM results only (else NULL): -1 = a record, k >= 0 = XA alternative of the read's record k */
-    int32_t  *sub;          /* SLX_F_REG2SAM results only: XS of a record (-1 for an alternative) */
+    int32_t  *xa_parent;    /* SLX_F_REG2SAM results only (else NULL): k >= 0 = XA alternative of the read's k-th record; -1 = of none */
+    int32_t  *sub;          /* SLX_F_REG2SAM results only: XS of a record; -1 = the entry is not a record (an alternative only) */
 } slx_hits;
 
 /* bases/offs on the HOST: read i is bases[offs[i] .. offs[i+1]) in ASCII.  Read i behaves as the

@@ -237,20 +237,21 @@ void orc_batch_free(orc_batch_out *o);
 /* ---------------------------------------------------------------- bwa's own record selection (mem_reg2sam + mem_gen_alt + the SA tag of
  * mem_aln2sam, bwamem.c / bwamem_extra.c) -- what `bwa mem` prints for a single-end read and what SeqLib's glue bypasses
  * (/root/reference/src/BWAAligner.cpp:136-146 have no opt->T, no 0x800, and h.XA is always NULL at :240).  SURVEY.md 8f-3.
- * Entries of one read: first the RECORDS in bwa's order (primaries with score >= opt->T; the first is the representative, the
- * others carry 0x800 and a mapq capped at the first's), then the XA ALTERNATIVES (secondaries within XA_drop_ratio of their
- * first-round primary, when that primary is a record and has at most max_XA_hits of them -- max_XA_hits_alt when one is on an ALT
- * contig).  A read without records gets no entry (bwa prints an unmapped record; callers synthesise it).  keepSecFrac and
+ * Entries of one read, in region order (the order mem_mark_primary_se leaves): every region that is a RECORD (a primary with score
+ * >= opt->T; the first is the representative, the others carry 0x800 and a mapq capped at the first's), an XA ALTERNATIVE (a region
+ * within XA_drop_ratio of its first-round primary, when that primary is a record and has at most max_XA_hits of them --
+ * max_XA_hits_alt when one is on an ALT contig), or both (ALT-aware index: a primary-assembly hit beaten by an ALT hit in the first
+ * round).  A read without records gets no entry (bwa prints an unmapped record; callers synthesise it).  keepSecFrac and
  * maxSecondary of the SeqLib glue do not apply. */
 typedef struct {
     int32_t  rid;
     int64_t  pos;
     uint16_t flag;        /* 0x10, 0x800 */
     uint8_t  mapq;
-    int32_t  score, nm, na, sub;   /* sub = XS (max(sub, csub)) */
+    int32_t  score, nm, na, sub;   /* sub: XS (max(sub, csub)) of a record; -1 = not a record */
     int32_t  n_cigar;
-    uint32_t *cigar;      /* BAM op codes; clips of a record are S (4) or H (5, hardclip), of an XA alternative always S */
-    int32_t  xa_parent;   /* -1 = a record; else the index (among this read's records) of the record it is an alternative of */
+    uint32_t *cigar;      /* BAM op codes; clips are S (4) or H (5, hardclip) -- XA:Z / SA:Z print S either way */
+    int32_t  xa_parent;   /* the ordinal (among this read's records, in entry order) of the record it is an XA alternative of; -1 = of none */
     char    *xa;          /* records: the XA:Z value as bwa builds it (NULL if none) */
     char    *sa;          /* records: the SA:Z value (NULL if none) */
 } orc_samhit;

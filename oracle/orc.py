@@ -231,8 +231,8 @@ def align_batch_flat(opt, index, bases, offs, hardclip=False, keep_sec_frac=0.9,
 
 
 def align_sequence_sam(opt, index, seq, hardclip=False, rng_base=0, ordinal=0):
-    """bwa's own record selection for one read (mem_reg2sam / mem_gen_alt / SA tag; orc.h): list of dict entries, records first
-    (xa_parent == -1, with their XA / SA strings), then the XA alternatives"""
+    """bwa's own record selection for one read (mem_reg2sam / mem_gen_alt / SA tag; orc.h): list of dict entries in region order;
+    XS >= 0 marks a record (with its XA / SA strings), xa_parent >= 0 an XA alternative of that record ordinal"""
     if isinstance(seq, str):
         seq = seq.encode()
     out = C.POINTER(SamHit)()

@@ -284,66 +284,68 @@ extern "C" int orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, 
         rec_of[(size_t)k] = (int)recs.size();
         recs.push_back(q);
     }
-    std::vector<orc_samhit> o;
+    /* which regions are XA alternatives, of which record, and the string bwa appends to XA[r] for them (region order) */
     std::vector<std::string> xa(recs.size());
-    /* XA alternatives, in region order, with the string bwa would append to XA[r] */
-    struct Alt { int parent; orc_aln aln; };
-    std::vector<Alt> alts;
+    std::vector<int> alt_parent((size_t)n, -1);
     for (int i = 0; i < n; ++i) {
         const int r = pri[(size_t)i];
         if (r < 0) continue;
         if (cnt[(size_t)r] > opt->max_XA_hits_alt || (!has_alt[(size_t)r] && cnt[(size_t)r] > opt->max_XA_hits)) continue;
         if (rec_of[(size_t)r] < 0) continue;                 /* its primary is not printed: neither is its XA */
-        Alt t;
-        t.parent = rec_of[(size_t)r];
-        t.aln = orc_reg2aln(opt, idx, len, seq, &a[i]);
-        std::string &x = xa[(size_t)t.parent];
-        x += idx->anns[t.aln.rid].name;
+        alt_parent[(size_t)i] = rec_of[(size_t)r];
+        orc_aln t = orc_reg2aln(opt, idx, len, seq, &a[i]);
+        std::string &x = xa[(size_t)rec_of[(size_t)r]];
+        x += idx->anns[t.rid].name;
         x.push_back(',');
-        x.push_back("+-"[t.aln.is_rev]);
-        x += std::to_string((long long)t.aln.pos + 1);
+        x.push_back("+-"[t.is_rev]);
+        x += std::to_string((long long)t.pos + 1);
         x.push_back(',');
-        put_cigar(x, t.aln.cigar, t.aln.n_cigar, "MIDSHN");
+        put_cigar(x, t.cigar, t.n_cigar, "MIDSHN");
         x.push_back(',');
-        x += std::to_string((int)t.aln.NM);
+        x += std::to_string((int)t.NM);
         x.push_back(';');
-        alts.push_back(t);
+        std::free(t.cigar);
     }
-    auto emit = [&](const orc_aln &al, int flag, int mapq, int sub, int parent, bool clip_hard) {
+    /* entries in region order: a region that is a record, an alternative, or (ALT-aware index) both */
+    std::vector<orc_samhit> o;
+    for (int k = 0; k < n; ++k) {
+        const int j = rec_of[(size_t)k];
+        if (j < 0 && alt_parent[(size_t)k] < 0) continue;
+        orc_aln al = j >= 0 ? recs[(size_t)j].aln : orc_reg2aln(opt, idx, len, seq, &a[k]);
         orc_samhit h;
         std::memset(&h, 0, sizeof h);
-        h.rid = al.rid; h.pos = al.pos; h.flag = (uint16_t)flag; h.mapq = (uint8_t)mapq; h.score = al.score; h.nm = (int32_t)al.NM; h.na = n;
-        h.sub = sub; h.n_cigar = al.n_cigar; h.xa_parent = parent;
+        h.rid = al.rid; h.pos = al.pos; h.score = al.score; h.nm = (int32_t)al.NM; h.na = n; h.n_cigar = al.n_cigar;
+        h.flag = (uint16_t)(j >= 0 ? recs[(size_t)j].flag : (al.flag | (al.is_rev ? 0x10 : 0)));
+        h.mapq = (uint8_t)(j >= 0 ? recs[(size_t)j].mapq : (int)al.mapq);
+        h.sub = j >= 0 ? recs[(size_t)j].sub : -1;
+        h.xa_parent = alt_parent[(size_t)k];
         h.cigar = (uint32_t *)std::malloc(4 * (size_t)(al.n_cigar ? al.n_cigar : 1));
         for (int c = 0; c < al.n_cigar; ++c) {
             uint32_t w = al.cigar[c];
-            if ((w & 0xf) == 3) w = (w & ~0xfu) | (clip_hard ? 5u : 4u);
+            if ((w & 0xf) == 3) w = (w & ~0xfu) | (hardclip ? 5u : 4u);
             h.cigar[c] = w;
         }
-        o.push_back(h);
-    };
-    for (size_t j = 0; j < recs.size(); ++j) {
-        emit(recs[j].aln, recs[j].flag, recs[j].mapq, recs[j].sub, -1, hardclip != 0);
-        if (!xa[j].empty()) o.back().xa = strdup(xa[j].c_str());
-        if (recs.size() > 1) {                               /* mem_aln2sam: the other non-secondary hits of the list */
-            std::string sa;
-            for (size_t i = 0; i < recs.size(); ++i) {
-                if (i == j) continue;
-                const orc_aln &r = recs[i].aln;
-                sa += idx->anns[r.rid].name; sa.push_back(',');
-                sa += std::to_string((long long)r.pos + 1); sa.push_back(',');
-                sa.push_back("+-"[r.is_rev]); sa.push_back(',');
-                put_cigar(sa, r.cigar, r.n_cigar, "MIDSH");
-                sa.push_back(','); sa += std::to_string(recs[i].mapq);
-                sa.push_back(','); sa += std::to_string((int)r.NM);
-                sa.push_back(';');
+        if (j >= 0) {
+            if (!xa[(size_t)j].empty()) h.xa = strdup(xa[(size_t)j].c_str());
+            if (recs.size() > 1) {                           /* mem_aln2sam: the other non-secondary hits of the list */
+                std::string sa;
+                for (size_t i = 0; i < recs.size(); ++i) {
+                    if ((int)i == j) continue;
+                    const orc_aln &r = recs[i].aln;
+                    sa += idx->anns[r.rid].name; sa.push_back(',');
+                    sa += std::to_string((long long)r.pos + 1); sa.push_back(',');
+                    sa.push_back("+-"[r.is_rev]); sa.push_back(',');
+                    put_cigar(sa, r.cigar, r.n_cigar, "MIDSH");
+                    sa.push_back(','); sa += std::to_string(recs[i].mapq);
+                    sa.push_back(','); sa += std::to_string((int)r.NM);
+                    sa.push_back(';');
+                }
+                h.sa = strdup(sa.c_str());
             }
-            o.back().sa = strdup(sa.c_str());
-        }
+        } else std::free(al.cigar);
+        o.push_back(h);
     }
-    for (const Alt &t : alts) emit(t.aln, (t.aln.flag | (t.aln.is_rev ? 0x10 : 0)), 0, -1, t.parent, false);
     for (Rec &q : recs) std::free(q.aln.cigar);
-    for (Alt &t : alts) std::free(t.aln.cigar);
     std::free(a);
     if (!o.empty()) {
         *out = (orc_samhit *)std::malloc(o.size() * sizeof(orc_samhit));

@@ -671,11 +671,10 @@ __global__ void k_compact(Chunk ck, const unsigned long long *hit_off, const uns
     for (int i = 0; i < ck.n_hit[r]; ++i, ++ho) {
         const DHit &h = ck.hits[o + ck.ic[o + i]];
         out.rid[ho] = h.rid; out.pos[ho] = h.pos; out.flag[ho] = (uint16_t)h.flag; out.mapq[ho] = (uint8_t)h.mapq;
-        if (out.xa_parent) {                           // the record an XA alternative belongs to rides in the upper half of the flag (k_hits_sam)
-            const int par = (h.flag >> 16) - 1;
-            out.xa_parent[ho] = par;
+        if (out.xa_parent) {                           // SLX_F_REG2SAM: record / alternative marks ride in the upper half of the flag (k_hits_sam)
+            out.xa_parent[ho] = ((h.flag >> 16) & 0x7fff) - 1;
             const DReg &g = ck.regs[o + ck.ia[o + ck.ic[o + i]]];
-            out.sub[ho] = par >= 0 ? -1 : (g.sub > g.csub ? g.sub : g.csub);      // XS
+            out.sub[ho] = h.flag < 0 ? (g.sub > g.csub ? g.sub : g.csub) : -1;      // XS of a record; -1 = not a record
         }
         out.score[ho] = h.score; out.nm[ho] = h.nm; out.na[ho] = ck.na[r]; out.n_cigar_ops[ho] = h.n_cigar;
         out.cig_off[ho] = co;

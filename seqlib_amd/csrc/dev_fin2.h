@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_regs1(Chunk ck, DevOpt dopt, FinLists f
             if (ck.sam_mode) {                      // mem_reg2sam: the one region is a record unless it scores below opt->T
                 ck.regs[so].sub = 0; ck.regs[so].secondary = -1;
                 ck.ia[so] = 0;                      // (k_compact reads XS from the region behind the hit)
-                if (ar.score >= opt.T && dev_reg_emit(ck, opt, fl, r, so, ar, true)) nh = 1;
+                if (ar.score >= opt.T && dev_reg_emit(ck, opt, fl, r, so, ar, true)) { nh = 1; ck.hits[so].flag |= (int)0x80000000; }
             } else if (dev_reg_emit(ck, opt, fl, r, so, ar, true)) nh = 1;
             ck.ic[so] = 0;                          // the glue's std::sort order of one hit
         }
@@ -408,8 +408,7 @@ __device__ __forceinline__ void dev_finish_hit(const DevRef &R, const Chunk &ck,
     }
     if (j.qb != 0 || j.qe != l_query) {           // clipping; bwa's op 3 becomes BAM S (4) or H (5) as the glue rewrites it (:193-202)
         const int clip5 = is_rev ? l_query - j.qe : j.qb, clip3 = is_rev ? j.qb : l_query - j.qe;
-        // (an XA alternative -- every secondary under SLX_F_REG2SAM -- is printed by bwa with soft clips whatever the record's clipping)
-        const uint32_t cop = ck.hardclip && !(ck.sam_mode && (h.flag & 0x100)) ? 5u : 4u;
+        const uint32_t cop = ck.hardclip ? 5u : 4u;
         if (clip5) { --cs; ck.cigpool[cs] = (uint32_t)clip5 << 4 | cop; ++nc; }
         if (clip3) { ck.cigpool[cs + nc] = (uint32_t)clip3 << 4 | cop; ++nc; }
     }
@@ -683,10 +682,12 @@ __global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsign
 
 // SLX_F_REG2SAM: bwa's own record selection for the reads with two or more regions, in place of k_hits --
 // bwamem.c:mem_reg2sam without MEM_F_ALL (records = primaries scoring >= opt->T in region order; the first is the representative,
-// the others get 0x800 and a mapq capped at the first's unless on an ALT contig) and bwamem_extra.c:mem_gen_alt (a secondary within
+// the others get 0x800 and a mapq capped at the first's unless on an ALT contig) and bwamem_extra.c:mem_gen_alt (a region within
 // XA_drop_ratio of its first-round primary is an XA alternative of it when that primary has at most max_XA_hits of them, or
-// max_XA_hits_alt when one sits on an ALT contig, and is itself a record).  Output order: the records, then the alternatives in
-// region order; an alternative carries its record's index (+1) in the upper half of DHit::flag (k_compact splits it off).
+// max_XA_hits_alt when one sits on an ALT contig, and is itself a record).  Entries stay in region order, a region that is neither is
+// dropped; on an ALT-aware index a primary-assembly hit can be both (a record, and an alternative of the ALT hit that beat it in the
+// first round).  DHit::flag carries the result to k_compact: bit 31 = record, bits 16..30 = 1 + ordinal of the record it is an
+// alternative of (0 = none).
 __global__ void __launch_bounds__(128) k_hits_sam(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots)
 {
     const slx_opt &opt = dopt.o;
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(128) k_hits_sam(DevRef R, Chunk ck, DevOpt dop
         const int *a = w.ia;
         const DReg *G = w.regs;
         int *hh = w.ic, *cnt = w.ib;               // output order; per region: XA alternatives it is the primary of (bit 30: one of them is ALT)
-        int *rec_of = (int *)w.srt + w.cap;        // per region: its index among the records, or -1 (the lower half of srt holds secondary_all on an ALT index)
+        int *rec_of = (int *)w.srt + w.cap;        // per region: its ordinal among the records, or -1 (the lower half of srt holds secondary_all on an ALT index)
         const int *sec_all = (const int *)w.srt;
         auto pri_of = [&](int i) {                 // get_pri_idx: the region this one would be an XA alternative of
             const int k = R.ann_alt ? sec_all[a[i]] : G[a[i]].secondary;
@@ -723,17 +724,20 @@ __global__ void __launch_bounds__(128) k_hits_sam(DevRef R, Chunk ck, DevOpt dop
                 h.flag |= 0x800;
                 if (!ref_is_alt(R, p.rid) && h.mapq > first_mapq) h.mapq = first_mapq;
             } else first_mapq = h.mapq;
-            rec_of[k] = n_rec;
-            hh[n_rec++] = k;
+            rec_of[k] = n_rec++;
         }
-        int n_out = n_rec;
+        if (n_rec > 0x7ffe) atomicOr(ck.flags, ERR_INTERNAL);
+        int n_out = 0;
         for (int i = 0; i < n; ++i) {
+            int par = -1;
             const int p = pri_of(i);
-            if (p < 0) continue;
-            const int c = cnt[p] & 0x3fffffff;
-            if (c > opt.max_XA_hits_alt || (!(cnt[p] >> 30) && c > opt.max_XA_hits)) continue;
-            if (rec_of[p] < 0) continue;           // its primary is not printed: neither is its XA
-            w.hits[i].flag = (w.hits[i].flag & 0xffff) | (rec_of[p] + 1) << 16;
+            if (p >= 0) {
+                const int c = cnt[p] & 0x3fffffff;
+                const bool listed = !(c > opt.max_XA_hits_alt || (!(cnt[p] >> 30) && c > opt.max_XA_hits));
+                if (listed && rec_of[p] >= 0) par = rec_of[p];         // (its primary is not printed: neither is its XA)
+            }
+            if (rec_of[i] < 0 && par < 0) continue;
+            w.hits[i].flag = (w.hits[i].flag & 0xffff) | ((par + 1) & 0x7fff) << 16 | (rec_of[i] >= 0 ? (int)0x80000000 : 0);
             hh[n_out++] = i;
         }
         ck.n_hit[r] = n_out;

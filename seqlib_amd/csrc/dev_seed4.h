@@ -205,8 +205,11 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW, S4_BWD, S4_DONE };
 
 template <typename I>
-__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue)
+__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota)
 {
+    // wave_quota: reads a wave takes from the queue before it stops fetching and drains (0 = until the queue is empty: persistent waves).
+    // With a quota the launch has many more blocks than fit the chip and slots keep coming free, so the other workers' kernels -- the
+    // dozens of small launches of a chunk above all -- get onto the CUs while a seeding launch is in flight instead of behind it.
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x & 63;
     WorkLists<I> wl;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     const uint32_t n_reads = (uint32_t)ck.n_reads;
     // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
     uint32_t pool_next = 0, pool_end = 0, res_next = 0, res_end = 0;
-    uint32_t pend_base = 0;
+    uint32_t pend_base = 0, taken = 0;
     bool pending = false, exhausted = false;
     // ---- per-lane state
     int phase = S4_FETCH;
@@ -302,7 +305,11 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend_base);
                 pending = false;
                 if (base >= n_reads) exhausted = true;
-                else { res_next = base; res_end = base + SEED_POOL < n_reads ? base + SEED_POOL : n_reads; }
+                else {
+                    res_next = base; res_end = base + SEED_POOL < n_reads ? base + SEED_POOL : n_reads;
+                    taken += SEED_POOL;
+                    if (wave_quota && taken >= wave_quota) exhausted = true;      // this wave's share: what is in hand is finished, nothing more is fetched
+                }
             }
             if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
             if (res_next == res_end && !exhausted) {

@@ -155,6 +155,7 @@ struct slx_aligner {
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
+    int seed_quota = 0;           // reads a wave of the seeding kernel takes before it leaves (0 = persistent waves); see k_seed12m
     int top_heavy = 0;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain):
                                   // measured on C3: 46.2 M reads/s against 48.4 M without -- the repeat reads' extensions are real DP work (hundreds per read),
                                   // and in the pipeline their serial walk hides behind the other workers while the extra k_ext_first jobs do not
@@ -605,6 +606,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         al->n_workers = (int)value;
     }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
+    else if (!strcmp(key, "seed_quota")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->seed_quota = (int)value; }
     else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
     else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
@@ -799,6 +801,14 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     const bool has_long = max_len > 704 || flt_live(*opt, max_len, log((double)std::max(max_len, 1)), nullptr);
     int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)(has_long ? std::min(al->max_threads, 16384) : al->max_threads));
     const int grid = n_threads / bs;
+    // seeding launch: persistent waves fed from the queue, or ("seed_quota" > 0) waves that take a fixed share of the reads and leave
+    int seed_grid = grid;
+    uint32_t seed_quota = 0;
+    if (al->seed_quota > 0 && !has_long && n >= al->split_min) {
+        seed_quota = (uint32_t)((al->seed_quota + SEED_POOL - 1) / SEED_POOL * SEED_POOL);
+        seed_grid = (int)(((int64_t)n + 2 * (int64_t)seed_quota - 1) / (2 * (int64_t)seed_quota));     // 128 lanes = two waves per block
+        n_threads = std::max(n_threads, seed_grid * bs);                                              // (the work-list scratch is per launched thread)
+    }
     const int cap_list = max_len + 1;
 #define ENS(buf, bytes) if ((rc = wk->buf.ensure((size_t)(bytes))) != SLX_OK) return rc
     ENS(codes, n_bases + 16); ENS(offs_rel, ((size_t)n + 1) * 8);
@@ -870,7 +880,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             HIPCHK(hipEventRecord(wk->ev_seed_in, st));
             HIPCHK(hipStreamWaitEvent(ss, wk->ev_seed_in, 0));
         }
-        hipLaunchKernelGGL(k_seed12m<I>, dim3(grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29);
+        hipLaunchKernelGGL(k_seed12m<I>, dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29, seed_quota);
         hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
         hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31);
         if (ss != st) {

@@ -583,7 +583,7 @@ def _check_sam_mode(sl, orc, idx, oidx, reads, what, knobs=(), hardclip=False, t
                for r in orc.align_sequence_sam(opt, oidx, sq, hardclip=hardclip, ordinal=i)]
         g = _sam_entries(got, i)
         assert g == exp, "%s: read %d differs\n gpu=%s\n cpu=%s" % (what, i, g, exp)
-        n_multi += sum(1 for e in exp if e[8] < 0) > 1
+        n_multi += sum(1 for e in exp if e[9] >= 0) > 1
         n_xa += any(e[8] >= 0 for e in exp)
     return n_multi, n_xa
 
