@@ -7,7 +7,11 @@ mkdir -p $OUT
 export SLX_BENCH_READS_CACHE=/tmp/slx_reads_cache
 for spec in "$@"; do
   name=${spec%%=*}; knobs=${spec#*=}
-  SLX_KNOBS="$knobs" timeout 400 python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --no-cpu-baseline --no-extras --verify 0 --steps ${STEPS:-4} --warmup 1 > $OUT/$name.json 2> $OUT/$name.err
+  # a "lib=<variant>" token selects seqlib_amd/variants/libseqlib_amd_<variant>.so (scripts/build_variant.sh) instead of the default library
+  lib=""; rest=""
+  for kv in ${knobs//,/ }; do if [ "${kv%%=*}" = lib ]; then lib=${kv#lib=}; else rest="${rest:+$rest,}$kv"; fi; done
+  if [ -n "$lib" ]; then export SLX_LIB=$GRAFT_REPO_ROOT/seqlib_amd/variants/libseqlib_amd_$lib.so; else unset SLX_LIB; fi
+  SLX_KNOBS="$rest" timeout 400 python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --no-cpu-baseline --no-extras --verify 0 --steps ${STEPS:-4} --warmup 1 > $OUT/$name.json 2> $OUT/$name.err
   python3 - "$name" "$knobs" $OUT/$name.json <<'PY'
 import json, sys
 name, knobs, fn = sys.argv[1:4]
