@@ -317,7 +317,7 @@ def main():
             match = compare(got, exp, m)
             del oidx
         # ---- the metric as SURVEY 8d words it: host reads -> host hits, and the C++ class with BamRecord materialisation
-        h2h, bam = None, None
+        h2h = None
         if not args.no_extras:
             pin = torch.from_numpy(reads.reshape(-1)).pin_memory()
             offs_pin = (torch.arange(0, n + 1, dtype=torch.int64) * read_len).pin_memory()
@@ -332,18 +332,6 @@ def main():
             h2h = dict(value=n / best, unit="reads/s", ms=best * 1e3, hits=int(nh),
                        path="slx_align_batch: pinned host reads -> three per-worker H2D copies on the workers' streams -> pipeline -> one packed D2H into a recycled pinned block")
             del pin, offs_pin
-            tool = os.path.join(ROOT, "seqlib_amd", "bamrec_bench")
-            if os.path.exists(tool):
-                m = min(n, int(os.environ.get("SLX_BAM_SAMPLE", "10000000")))     # >= 10 M reads of the timed batch (VERDICT r2 item 2)
-                sample = os.path.join(tmp, "bam_sample.bin")
-                reads[:m].tofile(sample)
-                try:
-                    o = subprocess.run([tool, prefix, sample, str(read_len), str(m)], stdout=subprocess.PIPE, timeout=600, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank)))
-                    if o.returncode == 0:
-                        bam = json.loads(o.stdout.decode().strip().splitlines()[-1])
-                except Exception as e:          # the extra must not take the bench line down
-                    bam = dict(error=str(e))
-                os.remove(sample)
         # ---- rooflines
         launches = max(1, launches_acc // max(args.steps, 1))     # counted by the library: chunks over all workers, whatever the knobs
         roof, roof_ext = None, None
@@ -388,6 +376,25 @@ def main():
                                 valu_busy=(pmc or {}).get("ext_valu_busy") if pmc and pmc.get("config") == args.config else None,
                                 valu_busy_source=("%s: %s" % (PMC_SUMMARY, pmc.get("valu_busy_formula", "formula and units in that file")))
                                 if pmc and pmc.get("config") == args.config else None)
+        # ---- the C++ class end to end with BamRecord materialisation (tools/bamrec_bench.cpp), last: it is a process of its own with
+        # its own copy of the index in HBM, so this process lets go of its aligner and reads first
+        bam = None
+        if not args.no_extras:
+            tool = os.path.join(ROOT, "seqlib_amd", "bamrec_bench")
+            if os.path.exists(tool):
+                m = min(n, int(os.environ.get("SLX_BAM_SAMPLE", "10000000")))     # >= 10 M reads of the timed batch (VERDICT r2 item 2)
+                sample = os.path.join(tmp, "bam_sample.bin")
+                reads[:m].tofile(sample)
+                del al, d_bases, d_offs
+                idx = None
+                torch.cuda.empty_cache()
+                try:
+                    o = subprocess.run([tool, prefix, sample, str(read_len), str(m)], stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank)))
+                    if o.returncode == 0:
+                        bam = json.loads(o.stdout.decode().strip().splitlines()[-1])
+                except Exception as e:          # the extra must not take the bench line down
+                    bam = dict(error=str(e))
+                os.remove(sample)
         out = {
             "metric": "aligned reads/sec (150 bp) via BWAAligner", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -396,7 +403,10 @@ def main():
                                    "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], sum(len(g) for _, g in refs), len(refs),
                                                                                       "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
                                                                                       " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
-                       "reads_per_gpu": n, "read_len": read_len, "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world},
+                       "reads_per_gpu": n, "read_len": read_len, "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
+                       "headline": "value = reads resident in HBM -> hits resident in HBM (the contract's timed region); value_host_to_host = host reads -> host "
+                                   "SoA hits through slx_align_batch (the metric as SURVEY 8d words it); value_bamrecords = SeqLib::BWAAligner::alignSequences "
+                                   "with BamRecord output (the north-star sentence read literally)"},
             "roofline": roof, "roofline_ext": roof_ext, "cpu_baseline": cpu,
             "value_host_to_host": h2h, "value_bamrecords": bam,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
