@@ -371,6 +371,9 @@ static int upload_fm(slx_aligner *al)
 }
 
 #define SLX_MAX_WORKERS 8
+#ifndef COOP_N1
+#define COOP_N1 1536     // chains the first LDS table of k_chain_coop holds (tuning builds: 512 / 768 / 1024)
+#endif
 
 static int make_worker_stream(slx_aligner *al, Worker *wk)
 {
@@ -773,12 +776,16 @@ template <typename I>
 static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<I> &fm, hipStream_t st, unsigned int *q,
                         unsigned int *counts, int n)
 {
-    hipLaunchKernelGGL((k_chain_coop<I, 1536, false>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * 4))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+    // first table: COOP_N1 chains per wave in LDS (33 bytes each).  The kernel is bound by the serial merge steps of single reads, so what
+    // counts is how many reads are in flight: the table size sets the waves per CU (1 536 chains = 50 KB: three; 512 = 17 KB: nine)
+    constexpr int N1 = COOP_N1;
+    constexpr int WAVES_PER_CU = N1 <= 512 ? 8 : N1 <= 768 ? 6 : N1 <= 1024 ? 4 : 3;
+    hipLaunchKernelGGL((k_chain_coop<I, N1, false>), dim3(std::max(1, std::min(n / 8 + 1, al->n_cu * WAVES_PER_CU))), dim3(64), 0, st, fm, al->ref, ck, dopt,
                        wk->order_out.as<int>(), q + 8, counts + 1, al->coop_lim1);
     // the 4 096-chain table only when a read can have more chains than the first table takes (chains <= seed occurrences): in the
     // pipeline an empty launch of it still waited ~20 ms for a CU with that much free LDS
-    if (std::min(1536, al->coop_lim1) < 512 || wk->max_seed_cnt > (unsigned int)std::min(1536, al->coop_lim1))     // (counts up to 512 are not tracked)
-        hipLaunchKernelGGL((k_chain_coop<I, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
+    if (std::min(N1, al->coop_lim1) < 512 || wk->max_seed_cnt > (unsigned int)std::min(N1, al->coop_lim1))     // (counts up to 512 are not tracked)
+        hipLaunchKernelGGL((k_chain_coop<I, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, N1 < 1536 ? al->n_cu : 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
                            wk->order_out.as<int>(), q + 10, counts + 1, al->coop_lim2);
 }
 
