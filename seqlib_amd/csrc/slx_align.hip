@@ -145,9 +145,11 @@ struct slx_aligner {
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_top = 512;           // ... and only for the first cand_top reads of the heaviest-first list
-    int cand_rep = 0;             // ... plus, whatever their rank, the reads less than this per cent repetitive (l_rep / length; 0 = none:
-                                  // at 75 C2 gains 7 % -- 3.3 M-read chunks, where this tail is 40 % of a chunk's time -- and C3 loses 4 %)
-    int cand_rep_max = 1 << 30;   // ... when the chunk has at most this many of them
+    int cand_rep = -1;            // ... plus, whatever their rank, the reads less than this per cent repetitive (l_rep / length; 0 = none).  At 75
+                                  // a chunk of 3.3 M reads (C2) gains 6 % -- the serial walk of those reads is 40 % of such a chunk's time -- and a
+                                  // chunk of 8.3 M (C3) loses 5 %: there the walk hides behind the other workers and the extra extensions do not.
+                                  // -1 = by chunk size: 75 for chunks of at most CAND_REP_AUTO_READS reads, else 0
+    int cand_rep_max = 4096;      // ... when the chunk has at most this many of them
     int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
     int lut_k = -1;               // k-mer table of the seeding kernels (dev_seed4.h, k_kmer_lut): 4^k entries of 8 / 16 bytes; 0 = none,
                                   // -1 = by index size (measured best where a k-mer still has a handful of occurrences: log4(symbols) - 1)
@@ -371,8 +373,10 @@ static int upload_fm(slx_aligner *al)
 }
 
 #define SLX_MAX_WORKERS 8
+#define CAND_REP_AUTO_READS (5 << 20)
 #ifndef COOP_N1
-#define COOP_N1 1536     // chains the first LDS table of k_chain_coop holds (tuning builds: 512 / 768 / 1024)
+#define COOP_N1 768      // chains the first LDS table of k_chain_coop holds: 25 KB per wave, six waves per CU (measured on C3: 1536 -> 47.8,
+                         // 1024 -> 48.9, 768 -> 49.3, 512 -> 49.0 M reads/s; reads beyond it take the 4 096-chain launch)
 #endif
 
 static int make_worker_stream(slx_aligner *al, Worker *wk)
@@ -598,7 +602,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
-    else if (!strcmp(key, "cand_rep")) { if (value < 0 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
+    else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
@@ -988,9 +992,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 const unsigned gb = (unsigned)((n + 255) / 256);
                 unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
                 unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (n + 2);
-                for (int pass = al->cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
+                const int cand_rep = al->cand_rep >= 0 ? al->cand_rep : (n <= CAND_REP_AUTO_READS ? 75 : 0);
+                for (int pass = cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
                     hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
-                                       hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)al->cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass);
+                                       hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, n + 1, st));
                 tb = wk->scan_tmp.cap;
