@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
 #define SEED_EPI_N 20
 #endif
 template <typename I>
-__global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned int *max_cnt)
+__global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned int *max_cnt, unsigned int heavy_thr, unsigned int *n_heavy)
 {
     const slx_opt &opt = dopt.o;
     __shared__ uint32_t s_info[SEED_EPI_N * 64];
@@ -667,4 +667,6 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned
     ck.l_rep[r] = l_rep;
     ck.seed_cnt[r] = (unsigned long long)cnt;
     if (cnt > 512u) atomicMax(max_cnt, cnt);      // the host skips the big-table launches of later stages when no read can need them
+    // how many reads the heavy list will hold: the host sizes the sort of that list (and the scans over it) by it instead of by the chunk
+    if (cnt >= heavy_thr) wave_fetch_inc(n_heavy);
 }

@@ -116,6 +116,27 @@ struct Chunk {
     int sam_mode;
 };
 
+// One atomic per wave instead of one per lane: the lanes that reach this call together (whatever subset of the wave that
+// is) share a single fetch-add on the wave-uniform counter and take consecutive values.  3 M same-address atomics in a
+// kernel otherwise serialise in one L2 channel (measured: 35 ms for a 3.3 M-read launch).
+__device__ __forceinline__ uint32_t wave_fetch_inc(uint32_t *ctr)
+{
+    const unsigned long long m = __ballot(1);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + rank;
+}
+__device__ __forceinline__ unsigned long long wave_fetch_add_u64(unsigned long long *ctr, unsigned long long each)
+{
+    const unsigned long long m = __ballot(1);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    unsigned long long base = 0;
+    if (rank == 0) base = atomicAdd(ctr, each * (unsigned long long)__popcll(m));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    return (((unsigned long long)hi << 32) | lo) + each * rank;
+}
+
 __device__ __forceinline__ int ref_base(const DevRef &R, int64_t p)
 {   // base at coordinate p of forward ++ reverse-complement (bns_get_seq)
     if (p >= R.l_pac) { int64_t f = (R.l_pac << 1) - 1 - p; return 3 - ((R.pac[f >> 2] >> ((~f & 3) << 1)) & 3); }

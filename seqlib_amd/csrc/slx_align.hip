@@ -241,6 +241,15 @@ __global__ void k_order_keys(const unsigned long long *seed_cnt, int n, unsigned
     val[i] = i;
 }
 
+// sort keys of the heavy list (heaviest first): the seed count of every read on it
+__global__ void k_heavy_keys(const unsigned long long *seed_cnt, const int *heavy, unsigned int n_heavy, unsigned int *key)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_heavy) return;
+    const unsigned long long c = seed_cnt[heavy[i]];
+    key[i] = c > 0xfffffu ? 0xfffffu : (unsigned int)c;   // 20-bit keys are plenty
+}
+
 __global__ void k_rel_offsets(const uint64_t *offs, uint64_t *rel, int n_reads, uint64_t base)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -834,7 +843,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
     ENS(queues, 256);
     HIPCHK(hipMemsetAsync(wk->queues.p, 0, 256, st));
-    HIPCHK(hipMemsetAsync(wk->seed_cnt.p, 0, ((size_t)n + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(wk->seed_cnt.as<unsigned long long>() + n, 0, 8, st));      // (k_seed_epi writes the count of every read; the scan takes n + 1 entries)
 
     Chunk ck;
     memset(&ck, 0, sizeof ck);
@@ -863,7 +872,6 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     if (use_cand) {
         ENS(cand, (size_t)al->cand_cap * sizeof(DReg)); ENS(cand_base, (size_t)n * 4); ENS(cand_cnt, ((size_t)n + 2) * 8); ENS(cand_off, ((size_t)n + 2) * 8);
         HIPCHK(hipMemsetAsync(wk->cand_base.p, 0xff, (size_t)n * 4, st));
-        HIPCHK(hipMemsetAsync(wk->cand_cnt.p, 0, ((size_t)n + 2) * 8, st));
         ck.cand = wk->cand.as<DReg>(); ck.cand_base = wk->cand_base.as<int32_t>();
     }
     if (getenv("SLX_DEBUG_CYC")) {
@@ -893,7 +901,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         }
         hipLaunchKernelGGL(k_seed12m<I>, dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29, seed_quota);
         hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
-        hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31);
+        hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31,
+                           (unsigned int)al->heavy_seeds, wk->queues.as<unsigned int>() + 34);
         if (ss != st) {
             HIPCHK(hipEventRecord(wk->ev_seed_out, ss));
             HIPCHK(hipStreamWaitEvent(st, wk->ev_seed_out, 0));
@@ -913,6 +922,8 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     HIPCHK(hipMemcpyAsync(&fl0, ck.flags, 4, hipMemcpyDeviceToHost, st));
     unsigned int max_cnt = 0;                     // largest seed-occurrence count of a read (0: none above 512): bounds its chains and regions
     HIPCHK(hipMemcpyAsync(&max_cnt, wk->queues.as<unsigned int>() + 31, 4, hipMemcpyDeviceToHost, st));
+    unsigned int n_heavy_h = 0;                   // reads with at least heavy_seeds seed occurrences (the heavy list of the production schedule)
+    HIPCHK(hipMemcpyAsync(&n_heavy_h, wk->queues.as<unsigned int>() + 34, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (fl0) { *flags_out = fl0; return SLX_OK; }
     wk->max_seed_cnt = max_cnt;
@@ -972,34 +983,39 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
             hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
                                wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), counts);
-            if (hsort) {
-                // heavy list heaviest-first: all read ids sorted by seed count, descending -- its first counts[1] entries are exactly the heavy reads
-                ENS(order_key_in, (size_t)n * 4); ENS(order_key_out, (size_t)n * 4); ENS(order_tmp, (size_t)n * 4);
-                hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
-                                   wk->order_key_in.as<unsigned int>(), wk->order_tmp.as<int>());
+            if (hsort && n_heavy_h > 1) {
+                // heavy list heaviest-first.  Only that list is sorted (its size is known since the seeding sync): a few thousand to a few
+                // ten thousand reads, not the chunk -- the radix sort of all 8 M read ids cost five launches of 1-7 ms each in the pipeline
+                const unsigned int nh = n_heavy_h;
+                ENS(order_key_in, (size_t)nh * 4); ENS(order_key_out, (size_t)nh * 4); ENS(order_tmp, (size_t)nh * 4);
+                hipLaunchKernelGGL(k_heavy_keys, dim3((nh + 255) / 256), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), wk->order_out.as<int>(), nh,
+                                   wk->order_key_in.as<unsigned int>());
                 size_t tb2 = 0;
                 HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb2, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
-                                                                    wk->order_tmp.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
+                                                                    wk->order_out.as<int>(), wk->order_tmp.as<int>(), (int)nh, 0, 20, st));
                 ENS(sort_tmp, tb2 + 256);
                 HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(wk->sort_tmp.p, tb2, wk->order_key_in.as<unsigned int>(), wk->order_key_out.as<unsigned int>(),
-                                                                    wk->order_tmp.as<int>(), wk->order_out.as<int>(), n, 0, 20, st));
+                                                                    wk->order_out.as<int>(), wk->order_tmp.as<int>(), (int)nh, 0, 20, st));
+                HIPCHK(hipMemcpyAsync(wk->order_out.p, wk->order_tmp.p, (size_t)nh * 4, hipMemcpyDeviceToDevice, st));
             }
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + 2, (unsigned int)n);
             hipLaunchKernelGGL(k_chain<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
             launch_coop<I>(al, wk, ck, dopt, fm, st, q, counts, n);
             (void)hipEventRecord(wk->ev_probe[2], st);
             if (use_cand) {
-                const unsigned gb = (unsigned)((n + 255) / 256);
-                unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (n + 2);
-                unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (n + 2);
+                const int nh = (int)n_heavy_h;                 // slots of these arrays are positions on the heavy list
+                const unsigned gb = (unsigned)((nh + 255) / 256) + 1;
+                HIPCHK(hipMemsetAsync(wk->cand_cnt.p, 0, ((size_t)nh + 2) * 8, st));
+                unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (nh + 2);
+                unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (nh + 2);
                 const int cand_rep = al->cand_rep >= 0 ? al->cand_rep : (n <= CAND_REP_AUTO_READS ? 75 : 0);
                 for (int pass = cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
                     hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
                                        hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass);
                 tb = wk->scan_tmp.cap;
-                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, n + 1, st));
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, nh + 1, st));
                 tb = wk->scan_tmp.cap;
-                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, job_cnt, job_off, n + 1, st));
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, job_cnt, job_off, nh + 1, st));
                 hipLaunchKernelGGL(k_cand_base, dim3(gb), dim3(256), 0, st, wk->order_out.as<int>(), counts + 1, slot_off, (unsigned int)al->cand_cap,
                                    wk->cand_base.as<int32_t>());
                 const int gc = al->n_cu * 32;
