@@ -346,7 +346,8 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
 }
 
 #ifndef EXT_JOB_WAVES
-#define EXT_JOB_WAVES 6       // waves/SIMD of the job kernels (k_ext_first, k_extend_cand): DP only, no per-read bookkeeping
+#define EXT_JOB_WAVES 5       // waves/SIMD of the job kernels (k_ext_first, k_extend_cand): DP only, no per-read bookkeeping.  At 6 the DP loop spills
+                              // (80 VGPRs + 580 B of scratch): k_ext_first 25.4 ms alone; at 5: 23.6 ms; at 4: 24.0; at 8: 34.1
 #endif
 #ifndef EXT_MIN_WAVES
 #define EXT_MIN_WAVES 4

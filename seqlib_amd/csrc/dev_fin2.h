@@ -366,8 +366,10 @@ __device__ __noinline__ void dev_regs_read_wave(const DevRef &R, const Chunk &ck
 }
 
 #define REGS_BIG_N 2048      // handles the LDS stage of the big-table launch of k_regs_wave holds (80 KB: sort keys + the fields the de-duplication loop reads)
+#ifndef REGS_MID_N
 #define REGS_MID_N 640       // ... and of the first launch: 25 KB per wave, so six waves share a CU instead of two -- with max_occ = 500 nearly every
                              // many-region read has at most ~510 regions and fits here; the ~1 000-region reads take the big table
+#endif
 // one wave per read, for reads with at least min_regs regions (0: every read of the list): mem_patch_reg's global alignment runs
 // wave-parallel and the region sorts run against keys staged in LDS
 template <int MAXQ, int NB>
