@@ -110,12 +110,11 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         int64_t cc_frb = 0, cc_lrb = 0;
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
-            const bool at_pos = ix2[i] == 0;         // x2 == 0: one occurrence, stored by its text position (S4_BDIR of k_seed12m)
-            const I x2 = at_pos ? (I)1 : ix2[i];
+            const I x2 = ix2[i];
             const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
             I k = 0;
             for (int count = 0; k < x2 && count < opt.max_occ; k += step, ++count) {
-                const int64_t rbeg = at_pos ? (int64_t)ix0[i] : fm_sa<I>(fm, ix0[i] + k);
+                const int64_t rbeg = fm_sa<I>(fm, ix0[i] + k);
                 const int rid = dev_intv2rid(R, rbeg, rbeg + slen);
                 if (rid < 0) continue;           // bridges two contigs or the forward/reverse boundary
                 // lower = first chain with pos == rbeg, else the chain with the largest pos < rbeg

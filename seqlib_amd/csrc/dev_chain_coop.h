@@ -59,8 +59,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         // ---------------- mem_chain: seeds in interval order, occurrences in rank order
         for (int i = 0; i < n_intv; ++i) {
             const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
-            const bool at_pos = ix2[i] == 0;      // x2 == 0: one occurrence, stored by its text position (S4_BDIR of k_seed12m)
-            const I x0 = ix0[i], x2 = at_pos ? (I)1 : ix2[i];
+            const I x0 = ix0[i], x2 = ix2[i];
             const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
             I cm = (x2 + step - 1) / step;        // trips of `for (k = count = 0; k < x2 && count < max_occ; k += step, ++count)`
             if (cm > (I)opt.max_occ) cm = (I)opt.max_occ;
@@ -70,7 +69,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                 const bool valid = t < count_max;
                 int64_t rb_l = 0; int rid_l = -1;
                 if (valid) {
-                    rb_l = at_pos ? (int64_t)x0 : fm_sa<I>(fm, x0 + (I)t * step);
+                    rb_l = fm_sa<I>(fm, x0 + (I)t * step);
                     rid_l = dev_intv2rid(R, rb_l, rb_l + slen);
                 }
                 const int nb = count_max - base < 64 ? count_max - base : 64;

@@ -202,16 +202,7 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #ifndef SEED4_DIRECT_AFTER
 #define SEED4_DIRECT_AFTER 2
 #endif
-// Direct BACKWARD steps (S4_BDIR).  When a backward row holds a single entry with a single occurrence (and no entry of the k-mer table
-// is still to join), nothing can be added to the list any more: each further row keeps that one occurrence while the base before it in
-// the text equals the base before it in the read (BWT[k] = text[SA[k] - 1]; at text position 0 the BWT holds the sentinel and the
-// extension is empty), and the MEM ends where they differ, at the start of the read or at an ambiguous base.  That is the tail of
-// nearly every bwt_smem1a call on a read from unique sequence -- a third and more of all backward steps, two rank reads each -- and it
-// needs one suffix-array read and the 2-bit text.  The price: the SA INDEX of the finished MEM is not known, only its text position.
-// Such an interval is stored as (x0 = text position, x2 = 0); every consumer of the interval list takes x2 == 0 as "one occurrence at
-// text position x0" (k_seed12m's pass 2, k_seed_epi, dev_chain_read, dev_chain_read_coop), which is all mem_chain wants of it anyway.
-// Off when the sampled-SA walk is in use, and under "keep_stages" (the stage dump shows bwa's own numbers).
-enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW, S4_BWD, S4_DONE, S4_BDIR };
+enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW, S4_BWD, S4_DONE };
 
 template <typename I>
 __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota)
@@ -263,7 +254,6 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     I v0 = 0, v2 = 0;                              // ... and its interval, loaded at the start of the row
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
     const bool direct_ok = fm.sa_dense != nullptr;  // (the sampled-SA walk would cost more than it saves)
-    const bool bdir_ok = direct_ok && ck.seed_bdir != 0;
     int ones = 0;                                  // consecutive forward steps that ended at one occurrence
     int64_t dpos = 0;                              // S4_DIR: text position of that occurrence of q[sx, i)
     RWin rwin; rwin.bits = 0; rwin.chunk = -1;
@@ -360,8 +350,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     while (k2 < old_n) {
                         const size_t o = (size_t)r * ck.cap_intv + k2;
                         const uint32_t inf = ck.intv_info[o];
-                        I s = ((const I *)ck.intv_x2)[o];
-                        if (s == 0) s = 1;              // (x2 == 0: one occurrence, kept by text position -- S4_BDIR)
+                        const I s = ((const I *)ck.intv_x2)[o];
                         ++k2;
                         const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
                         if (end - start < split_len || s > (I)opt.split_width) continue;
@@ -393,7 +382,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         for (int ph = 0; ph < 8; ++ph) d_ph[ph] += (unsigned long long)__popcll(__ballot(phase == ph));
 #endif
         const int nF = __popcll(__ballot(phase == S4_FWD)), nB = __popcll(__ballot(phase == S4_ROW || phase == S4_BWD));
-        const int nD = __popcll(__ballot(phase == S4_DIR || phase == S4_BDIR));
+        const int nD = __popcll(__ballot(phase == S4_DIR));
         if (nF == 0 && nB == 0 && nD == 0) continue;
 #if SEED4_SCHED == 1
         // batches: the short loops (forward, direct) are entered when SEED4_BATCH lanes wait for them (or nothing else can run) and run until
@@ -409,9 +398,9 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
             // ------------------------------------------------ D loop: up to 32 bases against the reference text per step
             const int floor_ = nD >> SEED4_SHORT_FLOOR_SHIFT;
             for (int it = 0; it < SEED4_ITERS; ++it) {
-                if (__popcll(__ballot(phase == S4_DIR || phase == S4_BDIR)) <= floor_ && it) break;
+                if (__popcll(__ballot(phase == S4_DIR)) <= floor_ && it) break;
 #if SEED4_DEBUG
-                ++d_dsteps; d_dlanes += (unsigned long long)__popcll(__ballot(phase == S4_DIR || phase == S4_BDIR));
+                ++d_dsteps; d_dlanes += (unsigned long long)__popcll(__ballot(phase == S4_DIR));
 #endif
                 if (phase == S4_DIR) {
                     for (int t = 0; t < 32; ++t) {
@@ -421,16 +410,6 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         // end of the read, an ambiguous base, or the occurrence ends here (mismatch / end of the text): bwt_smem1a pushes the
                         // interval and stops -- in the last two cases because the extended interval is empty
                         push_fwd(); begin_bwd();
-                        break;
-                    }
-                } else if (phase == S4_BDIR) {          // the single occurrence of q[bi + 1, hinf) starts at text position dpos: walk to the left
-                    for (int t = 0; t < 32; ++t) {
-                        int c = -1;
-                        if (bi >= 0) { c = qb(bi); if (c > 3) c = -1; }
-                        if (c >= 0 && dpos > 0 && text_at(R, dpos - 1, rwin) == c) { --dpos; --bi; continue; }
-                        emit_mem((I)dpos, (I)0, hinf);  // x2 = 0: "one occurrence at text position x0"
-                        if (pass == 1) x = ret;
-                        phase = S4_START;
                         break;
                     }
                 }
@@ -485,15 +464,13 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                             v0 = e.lo; v2 = e.sz;
                         }
                         phase = S4_BWD;
-                        // one entry, one occurrence, no table entry to come: the rest of the call is the text to the left of it (S4_BDIR)
-                        if (bdir_ok && np == 1 && h2 == (I)1 && sx - bi > nv) { dpos = fm_sa<I>(fm, h0); phase = S4_BDIR; }
                     }
                 }
                 const bool act = phase == S4_BWD;
 #if SEED4_SCHED == 1
                 {
                     const int n_fwd = __popcll(__ballot(phase == S4_START || phase == S4_INIT || phase == S4_FWD || (phase == S4_FETCH && pool_next != pool_end)));
-                    const int n_dir = __popcll(__ballot(phase == S4_DIR || phase == S4_BDIR));
+                    const int n_dir = __popcll(__ballot(phase == S4_DIR));
                     if (it && (!__any(act) || n_fwd >= SEED4_BATCH || n_dir >= SEED4_BATCH)) break;
                 }
 #else
@@ -645,7 +622,6 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned
     int b = 0, e = 0, l_rep = 0;
     uint32_t cnt = 0;
     auto account = [&](uint32_t inf, I s) {          // mem_chain prologue, entries in sorted order
-        if (s == 0) s = 1;                           // (x2 == 0: one occurrence, kept by text position -- S4_BDIR of k_seed12m)
         if (s > (I)opt.max_occ) {
             const int sb = (int)(inf >> 16), se = (int)(inf & 0xffff);
             if (sb > e) { l_rep += e - b; b = sb; e = se; }

@@ -114,7 +114,6 @@ struct Chunk {
     int hardclip; double keepSecFrac; int maxSecondary;
     // SLX_F_REG2SAM: bwa's own record selection (mem_reg2sam / mem_gen_alt) instead of the SeqLib glue's sort + filters
     int sam_mode;
-    int seed_bdir;            // 1 = k_seed12m may finish single-occurrence MEMs by walking the text (intervals stored as x2 = 0, x0 = text position)
 };
 
 // One atomic per wave instead of one per lane: the lanes that reach this call together (whatever subset of the wave that

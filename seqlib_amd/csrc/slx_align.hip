@@ -157,7 +157,6 @@ struct slx_aligner {
     int chain_mode = 1;           // 1 = heavy reads (>= heavy_seeds seed occurrences) are chained by the wave-cooperative kernel
     int heavy_seeds = 64;
     int split_min = 4096;         // chunks smaller than this take the simple path (every read on the lane-per-read chaining kernel)
-    int seed_bdir = 1;            // 1 = single-occurrence MEMs are finished by walking the text (dev_seed4.h, S4_BDIR)
     int seed_quota = 0;           // reads a wave of the seeding kernel takes before it leaves (0 = persistent waves); see k_seed12m
     int top_heavy = 0;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain):
                                   // measured on C3: 46.2 M reads/s against 48.4 M without -- the repeat reads' extensions are real DP work (hundreds per read),
@@ -624,7 +623,6 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "seed_quota")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->seed_quota = (int)value; }
-    else if (!strcmp(key, "seed_bdir")) al->seed_bdir = value != 0;
     else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
     else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
@@ -868,7 +866,6 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ck.lists = wk->lists.p; ck.cap_list = cap_list; ck.n_threads = n_threads;
     ck.hardclip = hardclip; ck.keepSecFrac = ksf; ck.maxSecondary = maxsec;
     ck.sam_mode = (opt->flag & SLX_F_REG2SAM) ? 1 : 0;
-    ck.seed_bdir = al->seed_bdir && !al->keep_stages ? 1 : 0;
     ck.seed_cnt = wk->seed_cnt.as<unsigned long long>();
     const bool production = al->chain_mode == 1 && n >= al->split_min && !has_long;
     const bool use_cand = al->cand_mode == 1 && production;
