@@ -121,6 +121,8 @@ void slx_aligner_free(slx_aligner *al);
  *   "cap_intv"                kept SMEM intervals per read the first attempt allows (overflow -> the chunk is re-run with twice as many)
  *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
+ *   "rep_k" 0..31 (19)        k of the repeat filter of seeding pass 2 (one bit per hashed k-mer that occurs twice in the text; 0 = none)
+ *   "seed_quota" (0)          reads a wave of the seeding kernel takes before it leaves (0 = persistent waves)
  *   "seed_free_cus" 0..24 (0) CUs of every 32 the persistent seeding kernels leave to the other kernels (a CU-masked stream of their own)
  *   "stream_prio" 0|1 (0)     workers' streams at the device's highest priority
  *   "wide_index" 1            test hook: run an index below 2^32 symbols through the u64 kernels

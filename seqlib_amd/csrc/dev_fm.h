@@ -21,7 +21,17 @@ struct DevFM {
     int sa_intv;
     const void *lut;          // k-mer table (dev_seed4.h): LutE<I> per lut_k-mer, first base most significant; nullptr = none
     int lut_k;
+    const uint32_t *rep;      // repeat filter (dev_seed4.h, k_rep_filter): one bit per hashed rep_k-mer, set for every rep_k-mer that occurs
+    uint64_t rep_mask;        //   at least twice in the indexed text; rep_mask = bits - 1 (a power of two); nullptr = none
+    int rep_k;
 };
+
+// hash of a k-mer (2 bits per base, first base most significant) for the repeat filter: a 64-bit finaliser, every input bit reaches every output bit
+__host__ __device__ __forceinline__ uint64_t rep_hash(uint64_t kmer)
+{
+    kmer ^= kmer >> 33; kmer *= 0xff51afd7ed558ccdull; kmer ^= kmer >> 33; kmer *= 0xc4ceb9fe1a85ec53ull; kmer ^= kmer >> 33;
+    return kmer;
+}
 
 template <typename I>
 struct alignas(2 * sizeof(I)) LutE { I lo, sz; };   // SA interval [lo, lo + sz) of a k-mer (bwa's x[0], x[2]); lo = 1 where sz = 0

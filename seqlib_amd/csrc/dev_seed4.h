@@ -143,6 +143,95 @@ __global__ void k_kmer_lut(DevFM<I> fm, int K, LutE<I> *out)
     out[w] = e;
 }
 
+// ---------------------------------------------------------------- repeat filter
+// Pass 2 of mem_collect_intv re-seeds from the middle of every long SMEM with few occurrences: bwt_smem1a(mid, min_intv = occ + 1), of whose
+// results only the intervals of >= min_seed_len bases are kept.  For a read from unique sequence (occ = 1) that is HALF of the steps of
+// passes 1 + 2 (k_seed12m without it: 21.9 ms for 8.3 M reads, with it 44.3) -- ~14 backward rows of 3-4 entries -- and it nearly always
+// ends with nothing to keep (3.7 % of the reads of the C3 workload keep anything): sequence that occurs twice AND is >= 19 bases long is
+// what repeats are made of.  A kept interval [s, e) covers mid, is >= min_seed_len long and occurs >= 2 times, so it contains a window of
+// rep_k <= min_seed_len bases that covers mid and occurs >= 2 times.  The filter holds one bit per hashed rep_k-mer of the indexed text
+// that occurs at least twice (two suffixes adjacent in the suffix array share their first rep_k bases): when none of the <= rep_k windows
+// covering mid is in it, the call cannot keep anything, and it has no other effect -- it is not made (k_seed2_select).  A false positive
+// only means the call is made as before.  Exact for occ = 1 (min_intv = 2) calls; the others (parent SMEMs with 2..split_width
+// occurrences) are always made.
+template <typename I>
+__global__ void k_rep_filter(DevFM<I> fm, DevRef R, int kf, uint32_t *bits, uint64_t mask)
+{
+    const uint64_t n = (uint64_t)fm.seq_len;           // ranks 0..n (rank 0 is the sentinel's suffix)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t p = (uint64_t)fm.sa_dense[i], q = (uint64_t)fm.sa_dense[i + 1];
+        if (p + (uint64_t)kf > n || q + (uint64_t)kf > n) continue;
+        RWin wp, wq; wp.bits = wq.bits = 0; wp.chunk = wq.chunk = -1;
+        uint64_t kmer = 0;
+        bool same = true;
+        for (int t = 0; t < kf; ++t) {
+            const int a = text_at(R, (int64_t)(p + t), wp), b = text_at(R, (int64_t)(q + t), wq);
+            if (a != b) { same = false; break; }
+            kmer = (kmer << 2) | (uint64_t)a;
+        }
+        if (!same) continue;
+        const uint64_t h = rep_hash(kmer) & mask;
+        atomicOr(bits + (h >> 5), 1u << (h & 31));
+    }
+}
+
+// Which pass-2 calls of a read are made: one lane per read, after pass 1 (k_seed12m, mode 1).  For every interval pass 1 kept -- in the order
+// pass 2 walks them -- bwa's own conditions (>= split_len bases, <= split_width occurrences, a base at the middle position) and, for a
+// parent with one occurrence, the repeat filter above.  p2mask[r]: bit k < 63 = the call for interval k is made; bit 63 = intervals from
+// the 63rd on are left to the kernel's own tests (a read with that many intervals is rare).  Reads with any call go on `list`.
+template <typename I>
+__global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned long long *p2mask, int *list, unsigned int *n_list)
+{
+    const slx_opt &opt = dopt.o;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ck.n_reads) return;
+    const int n = (int)ck.intv_n[r];
+    unsigned long long mask = 0;
+    if (n > 0) {
+        const uint64_t qoff = ck.offs[r];
+        const int len = (int)(ck.offs[r + 1] - qoff);
+        const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+        QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+        auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+        const bool use_rep = fm.rep != nullptr && fm.rep_k <= opt.min_seed_len && fm.rep_k > 0;
+        const int kf = fm.rep_k;
+        const uint64_t kmask = kf < 32 ? (1ull << (2 * kf)) - 1 : ~0ull;
+        for (int k = 0; k < n; ++k) {
+            const size_t o = (size_t)r * ck.cap_intv + k;
+            const uint32_t inf = ck.intv_info[o];
+            const I s = ((const I *)ck.intv_x2)[o];
+            const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+            if (end - start < split_len || s > (I)opt.split_width) continue;
+            if (k >= 63) { mask |= 1ull << 63; break; }
+            const int mid = (start + end) >> 1;
+            if (qb(mid) > 3) continue;                  // bwt_smem1a returns at once on an ambiguous start
+            bool take = true;
+            if (s == (I)1 && use_rep) {                 // does any window of rep_k bases that covers mid occur twice in the text?
+                const int a_lo = mid - kf + 1 > 0 ? mid - kf + 1 : 0, a_hi = mid < len - kf ? mid : len - kf;
+                uint64_t kmer = 0;
+                int good = 0;                           // valid bases at the end of the current window
+                for (int p = a_lo; p < a_lo + kf - 1; ++p) {
+                    const int c = qb(p);
+                    if (c > 3) { good = 0; kmer = 0; } else { kmer = ((kmer << 2) | (uint64_t)c) & kmask; ++good; }
+                }
+                take = false;
+                for (int a = a_lo; a <= a_hi; ++a) {
+                    const int c = qb(a + kf - 1);
+                    if (c > 3) { good = 0; kmer = 0; continue; }
+                    kmer = ((kmer << 2) | (uint64_t)c) & kmask; ++good;
+                    if (good < kf) continue;
+                    const uint64_t h = rep_hash(kmer) & fm.rep_mask;
+                    if ((fm.rep[h >> 5] >> (h & 31)) & 1u) { take = true; break; }
+                }
+            }
+            if (take) mask |= 1ull << k;
+        }
+    }
+    p2mask[r] = mask;
+    if (mask) list[wave_fetch_inc(n_list)] = r;
+}
+
 // the K-mer at q[p, p + K) as a table index and its reverse complement's; returns the offset of the first ambiguous base, or -1
 template <typename QB>
 __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, uint32_t &rc)
@@ -204,8 +293,11 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #endif
 enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW, S4_BWD, S4_DONE };
 
-template <typename I>
-__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota)
+// MODE 1: pass 1 of every read of the chunk (all SMEMs).  MODE 2: pass 2 (re-seeding) of the reads on `list`, for the intervals
+// k_seed2_select marked in p2mask -- the two passes are separate launches so that the selection between them runs one lane per read.
+template <typename I, int MODE>
+__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota,
+                                                                                                              const int *list, const unsigned int *n_list, const unsigned long long *p2mask)
 {
     // wave_quota: reads a wave takes from the queue before it stops fetching and drains (0 = until the queue is empty: persistent waves).
     // With a quota the launch has many more blocks than fit the chip and slots keep coming free, so the other workers' kernels -- the
@@ -229,7 +321,8 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         else { const IntvE<I> v = wl.at(list, e); a = v.x0; sz = v.x2; inf = v.info; }
     };
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-    const uint32_t n_reads = (uint32_t)ck.n_reads;
+    const uint32_t n_reads = MODE == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_list) : (uint32_t)ck.n_reads;   // (MODE 2: entries of `list`)
+    unsigned long long p2m = 0;                    // MODE 2: this read's pass-2 calls (k_seed2_select)
     // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
     uint32_t pool_next = 0, pool_end = 0, res_next = 0, res_end = 0;
     uint32_t pend_base = 0, taken = 0;
@@ -318,9 +411,15 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
             }
             if (phase == S4_INIT) {                     // offsets requested one round ago
                 qoff = o0; len = (int)(o1 - o0);
-                n_out = 0; out_ovf = false; list_ovf = false;
-                if (len < opt.min_seed_len) finish_read();
-                else { pass = 1; x = 0; phase = S4_START; }
+                out_ovf = false; list_ovf = false;
+                if (MODE == 2) {                        // pass 2 appends to what pass 1 left
+                    n_out = (int)ck.intv_n[r]; p2m = p2mask[r];
+                    pass = 2; k2 = 0; old_n = n_out; phase = S4_START;
+                } else {
+                    n_out = 0;
+                    if (len < opt.min_seed_len) finish_read();
+                    else { pass = 1; x = 0; phase = S4_START; }
+                }
             }
             {
                 const unsigned long long want = __ballot(phase == S4_FETCH);
@@ -329,7 +428,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                     if (phase == S4_FETCH) {
                         if (rank < avail) {
-                            r = pool_next + rank;
+                            r = MODE == 2 ? (uint32_t)list[pool_next + rank] : pool_next + rank;
                             o0 = ck.offs[r]; o1 = ck.offs[r + 1];
                             phase = S4_INIT;
                         } else if (exhausted && !pending && res_next == res_end) phase = S4_DONE;
@@ -341,21 +440,25 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
             if (phase == S4_START) {
                 int xs = -1;
                 I mi = 1;
-                if (pass == 1) {
+                if (MODE == 1) {
                     while (x < len && qb(x) > 3) ++x;
                     if (x < len) xs = x;
-                    else { pass = 2; k2 = 0; old_n = n_out; }
+                    else finish_read();                 // pass 1 is done; pass 2 is another launch (MODE 2)
                 }
-                if (pass == 2) {                        // re-seed from the middle of long SMEMs with few occurrences
+                if (MODE == 2 && pass == 2) {           // re-seed from the middle of long SMEMs with few occurrences
                     while (k2 < old_n) {
-                        const size_t o = (size_t)r * ck.cap_intv + k2;
+                        const int k = k2++;
+                        if (k < 63 && !((p2m >> k) & 1ull)) continue;           // k_seed2_select: not a candidate, or the repeat filter rules a result out
+                        if (k >= 63 && !(p2m >> 63)) { k2 = old_n; break; }
+                        const size_t o = (size_t)r * ck.cap_intv + k;
                         const uint32_t inf = ck.intv_info[o];
                         const I s = ((const I *)ck.intv_x2)[o];
-                        ++k2;
                         const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
-                        if (end - start < split_len || s > (I)opt.split_width) continue;
                         const int mid = (start + end) >> 1;
-                        if (qb(mid) > 3) continue;      // bwt_smem1a returns at once on an ambiguous start
+                        if (k >= 63) {                  // beyond the mask: bwa's own conditions here
+                            if (end - start < split_len || s > (I)opt.split_width) continue;
+                            if (qb(mid) > 3) continue;  // bwt_smem1a returns at once on an ambiguous start
+                        }
                         xs = mid; mi = s + 1;
                         break;
                     }
@@ -455,7 +558,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     p0 = h0; p2 = h2; pinf = hinf;
                     if (cb < 0) {                       // beginning of the read or an ambiguous base: every entry ends here, only the first can be new
                         if (np > 0) emit_mem(p0, p2, pinf);   // (np == 0: only virtual entries are left, too short to report)
-                        if (pass == 1) x = ret;
+                        if (MODE == 1) x = ret;
                         phase = S4_START;
                     } else {
                         if (sx - bi <= nv) {            // this row's virtual entry: the K-mer starting at bi
@@ -506,7 +609,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                             } else list_ovf = true;
                         }
                         if (list_ovf) finish_read();
-                        else if (nc == 0 && t >= nv) { if (pass == 1) x = ret; phase = S4_START; }
+                        else if (nc == 0 && t >= nv) { if (MODE == 1) x = ret; phase = S4_START; }
                         else { cur = 1 - cur; np = nc; rev = 0; --bi; h0 = nh0; h2 = nh2; hinf = nhinf; phase = S4_ROW; }
                     } else { p0 = nx0; p2 = nx2; pinf = nxinf; }
                 }

@@ -88,6 +88,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
+    DevBuf p2mask, p2list;                 // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -111,7 +112,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -125,7 +126,9 @@ struct slx_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     // index in HBM
-    DevBuf d_bwt, d_occ, d_sup, d_lut, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_loglut;
+    DevBuf d_bwt, d_occ, d_sup, d_lut, d_rep, d_sa_samp, d_sa_dense, d_pac, d_ann_off, d_ann_len, d_ann_alt, d_loglut;
+    uint64_t rep_mask = 0;        // repeat filter of the seeding kernels (dev_seed4.h, k_rep_filter): bits - 1; 0 = none
+    int rep_k = 19;               // its k (<= min_seed_len for it to be used); knob "rep_k", 0 = no filter
     bool wide = false;            // u64 index (>= 2^32 - 1 BWT symbols, or forced with the "wide_index" knob)
     DevFM<uint32_t> fm32;
     DevFM<uint64_t> fm64;
@@ -381,6 +384,27 @@ static int upload_fm(slx_aligner *al)
     return SLX_OK;
 }
 
+// the repeat filter of pass 2 of the seeding kernels: one bit per hashed rep_k-mer that occurs at least twice (8-16 bits per text symbol:
+// 128 MB for a 129 M-symbol index, 8 GB for GRCh38's 6.2 G)
+template <typename I>
+static int build_rep_filter(slx_aligner *al)
+{
+    al->rep_mask = 0;
+    if (al->rep_k <= 0 || al->rep_k > 31 || !al->have_dense || al->host_idx->seq_len < 1024) return SLX_OK;
+    uint64_t bits = 1ull << 20;
+    while (bits < al->host_idx->seq_len * 8ull) bits <<= 1;
+    int rc;
+    if ((rc = al->d_rep.ensure(bits / 8)) != SLX_OK) return rc;
+    HIPCHK(hipMemsetAsync(al->d_rep.p, 0, bits / 8, al->stream));
+    DevFM<I> fm = fm_of<I>(al);
+    fm.sa_dense = al->d_sa_dense.as<I>();
+    hipLaunchKernelGGL(k_rep_filter<I>, dim3(al->n_cu * 64), dim3(256), 0, al->stream, fm, al->ref, al->rep_k, al->d_rep.as<uint32_t>(), bits - 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(al->stream));
+    al->rep_mask = bits - 1;
+    return SLX_OK;
+}
+
 #define SLX_MAX_WORKERS 8
 #define CAND_REP_AUTO_READS (5 << 20)
 #ifndef COOP_N1
@@ -472,6 +496,7 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
             al->ref.ann_alt = al->d_ann_alt.as<uint8_t>();
         }
     }
+    if ((rc = al->wide ? build_rep_filter<uint64_t>(al) : build_rep_filter<uint32_t>(al)) != SLX_OK) return rc;
     // log() table from the host's libm
     const int LUT_N = 1 << 16;
     std::vector<double> lut((size_t)LUT_N);
@@ -551,7 +576,7 @@ extern "C" void slx_aligner_free(slx_aligner *al)
         return;
     }
     (void)hipSetDevice(al->device);
-    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_ann_alt, &al->d_loglut, &al->o_hit_off,
+    DevBuf *bufs[] = {&al->d_bwt, &al->d_occ, &al->d_sup, &al->d_lut, &al->d_rep, &al->d_sa_samp, &al->d_sa_dense, &al->d_pac, &al->d_ann_off, &al->d_ann_len, &al->d_ann_alt, &al->d_loglut, &al->o_hit_off,
                       &al->o_rid, &al->o_pos, &al->o_flag, &al->o_mapq, &al->o_score, &al->o_nm, &al->o_na, &al->o_ncig, &al->o_cig_off, &al->o_cigar, &al->o_xa, &al->o_sub,
                       &al->st_bases, &al->st_offs, &al->st_pack};
     for (DevBuf *b : bufs) b->release();
@@ -590,8 +615,9 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         if (want != al->wide) {
             HIPCHK(hipSetDevice(al->device));
             al->wide = want;
-            const int rc = want ? upload_fm<uint64_t>(al) : upload_fm<uint32_t>(al);
+            int rc = want ? upload_fm<uint64_t>(al) : upload_fm<uint32_t>(al);
             if (rc != SLX_OK) return rc;
+            if ((rc = want ? build_rep_filter<uint64_t>(al) : build_rep_filter<uint32_t>(al)) != SLX_OK) return rc;
         }
     }
     else if (!strcmp(key, "chain_mode")) al->chain_mode = (int)value;
@@ -623,6 +649,12 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     }
     else if (!strcmp(key, "min_split")) { if (value < 1) return SLX_EINVAL; al->min_split = value; }
     else if (!strcmp(key, "seed_quota")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->seed_quota = (int)value; }
+    else if (!strcmp(key, "rep_k")) {           // k of the repeat filter of seeding pass 2 (0 = none)
+        if (value < 0 || value > 31) return SLX_EINVAL;
+        al->rep_k = (int)value;
+        HIPCHK(hipSetDevice(al->device));
+        return al->wide ? build_rep_filter<uint64_t>(al) : build_rep_filter<uint32_t>(al);
+    }
     else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
     else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
@@ -838,7 +870,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
-    ENS(counters, 64);
+    ENS(counters, 64); ENS(p2mask, (size_t)n * 8); ENS(p2list, (size_t)n * 4);
     // counters: [0] zused, [1] cigused, [2] flags(u32)
     HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
     ENS(queues, 256);
@@ -883,6 +915,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     DevOpt dopt; dopt.o = *opt;
     DevFM<I> fm = fm_of<I>(al);
     fm.sa_dense = (al->dense_sa && al->have_dense) ? al->d_sa_dense.as<I>() : nullptr;
+    fm.rep = al->rep_mask ? al->d_rep.as<uint32_t>() : nullptr; fm.rep_mask = al->rep_mask; fm.rep_k = al->rep_k;
 
     (void)hipEventRecord(wk->ev[0], st);
     {   // encode + relative offsets
@@ -899,7 +932,14 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             HIPCHK(hipEventRecord(wk->ev_seed_in, st));
             HIPCHK(hipStreamWaitEvent(ss, wk->ev_seed_in, 0));
         }
-        hipLaunchKernelGGL(k_seed12m<I>, dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, wk->queues.as<unsigned int>() + 29, seed_quota);
+        // passes 1 + 2 of mem_collect_intv: all SMEMs; then, one lane per read, which re-seeding calls can keep anything (repeat filter);
+        // then those calls -- a few per cent of the reads
+        unsigned int *qq = wk->queues.as<unsigned int>();
+        hipLaunchKernelGGL((k_seed12m<I, 1>), dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 29, seed_quota,
+                           (const int *)nullptr, (const unsigned int *)nullptr, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_seed2_select<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, ck, dopt, wk->p2mask.as<unsigned long long>(), wk->p2list.as<int>(), qq + 35);
+        hipLaunchKernelGGL((k_seed12m<I, 2>), dim3(grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 36, 0u, wk->p2list.as<int>(), qq + 35,
+                           wk->p2mask.as<unsigned long long>());
         hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
         hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31,
                            (unsigned int)al->heavy_seeds, wk->queues.as<unsigned int>() + 34);
@@ -924,7 +964,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     HIPCHK(hipMemcpyAsync(&max_cnt, wk->queues.as<unsigned int>() + 31, 4, hipMemcpyDeviceToHost, st));
     unsigned int n_heavy_h = 0;                   // reads with at least heavy_seeds seed occurrences (the heavy list of the production schedule)
     HIPCHK(hipMemcpyAsync(&n_heavy_h, wk->queues.as<unsigned int>() + 34, 4, hipMemcpyDeviceToHost, st));
+    unsigned int n_p2_h = 0;                      // reads whose pass 2 was run (SLX_DEBUG_SEED)
+    if (getenv("SLX_DEBUG_SEED")) HIPCHK(hipMemcpyAsync(&n_p2_h, wk->queues.as<unsigned int>() + 35, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (getenv("SLX_DEBUG_SEED")) fprintf(stderr, "[seed] worker %d: %d reads, pass 2 run for %u of them (repeat filter k = %d), %u heavy\n", wk->id, n, n_p2_h, fm.rep ? fm.rep_k : 0, n_heavy_h);
     if (fl0) { *flags_out = fl0; return SLX_OK; }
     wk->max_seed_cnt = max_cnt;
     const size_t S1 = (size_t)S + 1;
