@@ -354,7 +354,7 @@ def main():
                 src = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % PMC_SUMMARY
             mean_launch_ms = seed_ms / launches
             physical = traffic / (mean_launch_ms * 1e-3) / 1e9 if traffic else None
-            roof = dict(bound="hbm", kernel="k_seed12m + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            roof = dict(bound="hbm", kernel="seeding: k_seed12m<1> + k_seed2_select + k_seed12m<2> + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src,
                         achieved_basis="ALGORITHMIC bytes (SURVEY 8d: the oracle's count on bwa's own layout, 64 B per Occ block touched + the read) per launch / "
                                        "mean launch duration; the kernel itself moves fewer bytes (32-byte occ planes, k-mer table, direct text steps): see physical_gbs",

@@ -196,7 +196,7 @@ int  slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_b
 int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
 const char *slx_stage_name(int i);
 /* kernel groups of the last batch: duration summed over the workers' launches, from HIP events recorded on the worker's own
- * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m + k_seed3m + k_seed_epi), [1] the extension
+ * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m<1>, k_seed2_select, k_seed12m<2>, k_seed3m, k_seed_epi), [1] the extension
  * family (k_extend_cand, k_first_prep, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_dp) */
 #define SLX_N_PROBES 3
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);

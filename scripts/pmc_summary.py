@@ -60,7 +60,8 @@ try:
     reads = bench["reads_per_seed_launch"]
 except Exception:
     bench, reads = None, {"C2": 10e6 / 3, "C3": 50e6 / 6}.get(config, 1.0)
-seed12 = (pick("k_seed12") or ["k_seed12m"])[0]
+seed12 = ([k for k in pick("k_seed12") if ", 1>" in k] or pick("k_seed12") or ["k_seed12m"])[0]      # pass 1 (the bulk); pass 2 is k_seed12m<.., 2>
+seed12_p2 = ([k for k in pick("k_seed12") if ", 2>" in k] or [None])[0]
 seed_all = pick("k_seed")                     # k_seed12m, k_seed3m, k_seed_epi
 fetch = sum(g(k, "FETCH_SIZE") for k in seed_all) * 1024.0 / reads
 write = sum(g(k, "WRITE_SIZE") for k in seed_all) * 1024.0 / reads
@@ -78,6 +79,7 @@ res = {
     "seed_l2_hit_rate": (g(seed12, "TCC_HIT_sum") / g(seed12, "TCC_REQ_sum")) if g(seed12, "TCC_REQ_sum") else None,
     "seed_wait_frac_of_wave_cycles": (g(seed12, "SQ_WAIT_ANY") / g(seed12, "SQ_WAVE_CYCLES")) if g(seed12, "SQ_WAVE_CYCLES") else None,
     "seed_valu_lane_utilisation": lane_util(seed12), "seed_valu_busy": valu_busy(seed12), "seed_lds_instructions": g(seed12, "SQ_INSTS_LDS"),
+    "seed_pass2_valu_lane_utilisation": lane_util(seed12_p2) if seed12_p2 else None,
     # extension family: instruction-weighted over its kernels' full-size launches
     "ext_valu_busy": (ext_inst * 2.0 / (N_SIMD * ext_gui / N_XCD)) if ext_gui else None,
     "ext_valu_busy_by_kernel": {k: valu_busy(k) for k in ext},
