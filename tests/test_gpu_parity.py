@@ -566,9 +566,9 @@ def _sam_entries(res, i):
     return out
 
 
-def _check_sam_mode(sl, orc, idx, oidx, reads, what, knobs=(), hardclip=False, tweak=None):
+def _check_sam_mode(sl, orc, idx, oidx, reads, what, knobs=(), hardclip=False, tweak=None, device=None):
     from seqlib_amd import _ffi
-    al = sl.BWAAligner(idx)
+    al = sl.BWAAligner(idx, device=device)
     opt = orc.default_opt()
     for k, v in knobs:
         al.set(k, v)
@@ -603,6 +603,7 @@ def test_bwa_mem_record_mode(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_di
     assert n_multi >= 1
     _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "fixture, wave region kernel", knobs=(("regs_big", 2), ("split_min", 16), ("heavy_seeds", 8)))
     _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "fixture, hard clips", hardclip=True)
+    _check_sam_mode(sl, orc, tiny_gpu, tiny_index, reads[2300:2700], "fixture, group handle (device 0 twice)", device=[0, 0])
 
     def other(o):
         o.T = 60; o.XA_drop_ratio = 0.5; o.max_XA_hits = 2
