@@ -122,6 +122,8 @@ void slx_aligner_free(slx_aligner *al);
  *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
  *   "rep_k" 0..31 (19)        k of the repeat filter of seeding pass 2 (one bit per hashed k-mer that occurs twice in the text; 0 = none)
+ *   "p2_items" 0|1 (1)        seeding pass 2: 1 = one lane per re-seeding call, 0 = one lane per read;  "p2_items_cap" (0 = one per read): test hook,
+ *                             capacity of the call list (reads whose calls do not fit are walked whole)
  *   "seed_quota" (0)          reads a wave of the seeding kernel takes before it leaves (0 = persistent waves)
  *   "seed_free_cus" 0..24 (0) CUs of every 32 the persistent seeding kernels leave to the other kernels (a CU-masked stream of their own)
  *   "stream_prio" 0|1 (0)     workers' streams at the device's highest priority

@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t dpp_incl_umax_scan(uint32_t v)
 }
 __device__ __forceinline__ int dpp_shr1_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane 0 receives 0
 
+#ifdef EXT_STATS
+__device__ unsigned long long g_ext_stats[8];     // tuning build: [0] extensions, [1] answered by the diagonal, [2] / [3] query / target columns of the others, [4] DP rows, [5] DPs ended by the tail bound, [6] band columns over all rows
+#endif
 struct MatCols { uint32_t c[5]; };   // score matrix by query base: byte t of c[q] = mat[t*5+q], t = 0..3 (the reference has no N)
 __device__ __forceinline__ MatCols make_matcols(const int8_t *mat)
 {
@@ -111,12 +114,22 @@ __device__ ExtResult reg_ksw_extend2(int qlen_, QF qf, int tlen_, TF tf, const s
     max_del = max_del > 1 ? max_del : 1;
     w = w < max_del ? w : max_del;
     w = __builtin_amdgcn_readfirstlane(w);                       // the f64 divisions above run on the vector unit
+    const int tail_top = ext_tail_bound0(o, qlen, h0, max);
     max = h0;
     int max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     // target bases are fetched 64 rows at a time (lane t holds row i0+t) one block ahead, then read with v_readlane
     int tb_cur = lane < tlen ? tf(lane) : 0;
     int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
     for (int i = 0; i < tlen; ++i) {
+        if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) {           // dev_ext_wave.h: rows that cannot matter
+#ifdef EXT_STATS
+            if (lane == 0) atomicAdd(&g_ext_stats[5], 1ull);
+#endif
+            break;
+        }
+#ifdef EXT_STATS
+        if (lane == 0) { atomicAdd(&g_ext_stats[4], 1ull); atomicAdd(&g_ext_stats[6], (unsigned long long)(end > beg ? end - beg : 0)); }
+#endif
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
         const uint32_t sh = (uint32_t)t << 3;
@@ -291,7 +304,11 @@ __device__ __forceinline__ ExtResult reg_ksw_extend2_auto(int qlen, QF qf, int t
 {
     {
         ExtResult d;
-        if (diag_extend(qlen, qf, tlen, tf, o, mr, h0, lane, d)) return d;
+        const bool dg = diag_extend(qlen, qf, tlen, tf, o, mr, h0, lane, d);
+#ifdef EXT_STATS
+        if (lane == 0) { atomicAdd(&g_ext_stats[0], 1ull); if (dg) atomicAdd(&g_ext_stats[1], 1ull); else { atomicAdd(&g_ext_stats[2], (unsigned long long)qlen); atomicAdd(&g_ext_stats[3], (unsigned long long)tlen); } }
+#endif
+        if (dg) return d;
     }
     if (qlen + 1 <= WAVE) return reg_ksw_extend2<1>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);
     if (qlen + 1 <= 2 * WAVE) return reg_ksw_extend2<2>(qlen, qf, tlen, tf, o, mr, w, end_bonus, h0, lane);

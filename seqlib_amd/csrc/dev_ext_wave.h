@@ -54,6 +54,24 @@ __device__ __forceinline__ MatRows make_matrows(const int8_t *mat)
     return m;
 }
 
+// Rows below the query (i >= qlen) that cannot matter.  A cell (i, j) with i > j ends an alignment of i + 1 target and j + 1 query bases:
+// at least i - j target bases sit in deletions (>= o_del + (i - j) * e_del) and at most j + 1 steps are diagonal, so
+//     H(i, j) <= max(0, h0 + (j + 1) * amax - o_del - (i - j) * e_del) <= max(0, B_i),   B_i = h0 + qlen * amax - o_del - (i - qlen + 1) * e_del
+// for every column of row i >= qlen, and B_i does not grow with i.  (Cells that re-enter the band were zero when they left it, and the
+// insertion ramp of row -1 beyond the band lies above the diagonal, where using it late only adds deletions: neither can beat B_i.)
+// ksw_extend2 changes max / max_i / max_j / max_off only when a row maximum EXCEEDS max, and gscore / max_ie only when the cell of the
+// last query column is >= gscore; so once B_i <= max and max(B_i, 0) < gscore every remaining row -- until z-drop, an all-zero row or
+// tlen ends the loop -- leaves all six reported values as they are, and the loop can stop.  With h0 = 90 and a 57-column extension
+// through two mismatches that is row 61 instead of row ~110 (the first column alone stays alive for h0 - o_del rows).
+// Needs non-negative gap penalties (else: never).  The scalar restatement in oracle/ has no such exit: the parity tests compare the two.
+__device__ __forceinline__ int ext_tail_bound0(const slx_opt &o, int qlen, int h0, int amax)
+{   // B_qlen (the value at row i = qlen); INT_MAX when the bound does not hold
+    if (o.o_del < 0 || o.e_del < 0 || o.o_ins < 0 || o.e_ins < 0) return 0x7fffffff;
+    const long long b = (long long)h0 + (long long)qlen * (amax > 0 ? amax : 0) - o.o_del - o.e_del;
+    return b > 0x3fffffff ? 0x7fffffff : (int)b;
+}
+__device__ __forceinline__ bool ext_tail_done(int b, int max, int gscore) { return b <= max && (b > 0 ? b : 0) < gscore; }
+
 // wave-cooperative ksw_extend2; every lane returns the same result.  eh_h / eh_e are LDS rows of qlen+2 ints.
 template <int NCH, typename QF, typename TF>
 __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0,
@@ -80,9 +98,11 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     int max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
     max_del = max_del > 1 ? max_del : 1;
     w = w < max_del ? w : max_del;
+    const int tail_top = ext_tail_bound0(o, qlen, h0, max);
     max = h0;
     int max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     for (int i = 0; i < tlen; ++i) {
+        if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) break;      // rows that cannot matter (above)
         const int t = tf(i);
         const uint32_t rowp = mr.packed[t];
         const int row4 = mr.q4[t];

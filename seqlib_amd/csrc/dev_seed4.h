@@ -181,12 +181,13 @@ __global__ void k_rep_filter(DevFM<I> fm, DevRef R, int kf, uint32_t *bits, uint
 // parent with one occurrence, the repeat filter above.  p2mask[r]: bit k < 63 = the call for interval k is made; bit 63 = intervals from
 // the 63rd on are left to the kernel's own tests (a read with that many intervals is rare).  Reads with any call go on `list`.
 template <typename I>
-__global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned long long *p2mask, int *list, unsigned int *n_list)
+__global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, DevOpt dopt, unsigned long long *p2mask, int *list, unsigned int *n_list,
+                                                      uint32_t *items, unsigned int *n_items, uint32_t cap_items)
 {
     const slx_opt &opt = dopt.o;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ck.n_reads) return;
-    const int n = (int)ck.intv_n[r];
+    const bool live = r < ck.n_reads;
+    const int n = live ? (int)ck.intv_n[r] : 0;
     unsigned long long mask = 0;
     if (n > 0) {
         const uint64_t qoff = ck.offs[r];
@@ -228,8 +229,34 @@ __global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, Dev
             if (take) mask |= 1ull << k;
         }
     }
-    p2mask[r] = mask;
-    if (mask) list[wave_fetch_inc(n_list)] = r;
+    if (live) p2mask[r] = mask;
+    // The calls of a read are independent of each other (each reads pass 1's intervals and appends its own), so they go out as single ITEMS
+    // (read << 6 | interval), one lane each in k_seed12m<2>: the reads in multi-copy repeats make a dozen calls of ~175 backward steps, and
+    // taken one read per lane they were a tail of 4 busy lanes per wave.  A read with calls beyond the mask, or whose items do not fit,
+    // goes on `list` and is walked by one lane as before.
+    const uint32_t cnt = (uint32_t)__popcll(mask & ~(1ull << 63));
+    const bool whole = (mask >> 63) != 0;
+    uint32_t base = 0xffffffffu;
+    {   // wave-aggregated reservation of cnt item slots per lane
+        const uint32_t want = (live && !whole) ? cnt : 0u;
+        uint32_t incl = want;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += u; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t wbase = 0;
+        if (total) {
+            if ((threadIdx.x & 63) == 0) wbase = atomicAdd(n_items, total);
+            wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+            base = wbase + incl - want;
+        }
+    }
+    if (!live || !mask) return;
+    if (!whole && cnt && base + cnt <= cap_items) {
+        unsigned long long m = mask;
+        for (uint32_t t = 0; t < cnt; ++t) { const int k = __ffsll((long long)m) - 1; m &= m - 1; items[base + t] = (uint32_t)r << 6 | (uint32_t)k; }
+    } else {
+        if (!whole) for (uint32_t t = 0; t < cnt && base + t < cap_items; ++t) items[base + t] = 0xffffffffu;   // reserved but not used: k_seed12m skips them
+        list[wave_fetch_inc(n_list)] = r;
+    }
 }
 
 // the K-mer at q[p, p + K) as a table index and its reverse complement's; returns the offset of the first ambiguous base, or -1
@@ -297,7 +324,8 @@ enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW,
 // k_seed2_select marked in p2mask -- the two passes are separate launches so that the selection between them runs one lane per read.
 template <typename I, int MODE>
 __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota,
-                                                                                                              const int *list, const unsigned int *n_list, const unsigned long long *p2mask)
+                                                                                                              const int *list, const unsigned int *n_list, const unsigned long long *p2mask,
+                                                                                                              const uint32_t *items, const unsigned int *n_items, uint32_t cap_items)
 {
     // wave_quota: reads a wave takes from the queue before it stops fetching and drains (0 = until the queue is empty: persistent waves).
     // With a quota the launch has many more blocks than fit the chip and slots keep coming free, so the other workers' kernels -- the
@@ -321,8 +349,12 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         else { const IntvE<I> v = wl.at(list, e); a = v.x0; sz = v.x2; inf = v.info; }
     };
     const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-    const uint32_t n_reads = MODE == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_list) : (uint32_t)ck.n_reads;   // (MODE 2: entries of `list`)
-    unsigned long long p2m = 0;                    // MODE 2: this read's pass-2 calls (k_seed2_select)
+    // MODE 2: the work units are the single-call items first, then the whole reads of `list` (k_seed2_select)
+    uint32_t n_it = 0;
+    if (MODE == 2) { n_it = (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_items); n_it = n_it < cap_items ? n_it : cap_items; }   // (reads whose items did not fit are on `list`)
+    const uint32_t n_reads = MODE == 2 ? n_it + (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_list) : (uint32_t)ck.n_reads;
+    unsigned long long p2m = 0;                    // MODE 2: this unit's pass-2 calls
+    bool single = false;                           // MODE 2: one call of a read whose other calls run on other lanes: results are appended atomically
     // ---- wave-level pool of read indices: [pool_next, pool_end) in use, [res_next, res_end) in reserve
     uint32_t pool_next = 0, pool_end = 0, res_next = 0, res_end = 0;
     uint32_t pend_base = 0, taken = 0;
@@ -361,7 +393,13 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         ++n;
     };
     auto out_push = [&](int start, int end, I a, I s) {
-        if (n_out < ck.cap_intv) {
+        if (MODE == 2 && single) {                  // a slot of the read's interval array, shared with the lanes that run its other calls
+            const uint32_t slot = atomicAdd(ck.intv_n + r, 1u);
+            if (slot < (uint32_t)ck.cap_intv) {
+                const size_t o = (size_t)r * ck.cap_intv + slot;
+                ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
+            } else { atomicSub(ck.intv_n + r, 1u); out_ovf = true; }   // (the count never stays above the capacity: later kernels index with it)
+        } else if (n_out < ck.cap_intv) {
             const size_t o = (size_t)r * ck.cap_intv + n_out;
             ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
             ++n_out;
@@ -374,7 +412,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         }
     };
     auto finish_read = [&]() {                     // passes 1 + 2 done (or abandoned on a work-list overflow)
-        ck.intv_n[r] = (uint32_t)n_out;
+        if (!(MODE == 2 && single)) ck.intv_n[r] = (uint32_t)n_out;
         if (out_ovf) atomicOr(ck.flags, OVF_INTV);
         if (list_ovf) atomicOr(ck.flags, OVF_LIST);
         phase = S4_FETCH;
@@ -413,8 +451,9 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                 qoff = o0; len = (int)(o1 - o0);
                 out_ovf = false; list_ovf = false;
                 if (MODE == 2) {                        // pass 2 appends to what pass 1 left
-                    n_out = (int)ck.intv_n[r]; p2m = p2mask[r];
-                    pass = 2; k2 = 0; old_n = n_out; phase = S4_START;
+                    if (single) { k2 = (int)p2m; old_n = k2 + 1; p2m = 1ull << k2; n_out = 0; }      // (p2m held the interval number since the fetch)
+                    else { n_out = (int)ck.intv_n[r]; p2m = p2mask[r]; k2 = 0; old_n = n_out; }
+                    pass = 2; phase = S4_START;
                 } else {
                     n_out = 0;
                     if (len < opt.min_seed_len) finish_read();
@@ -428,9 +467,14 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                     if (phase == S4_FETCH) {
                         if (rank < avail) {
-                            r = MODE == 2 ? (uint32_t)list[pool_next + rank] : pool_next + rank;
-                            o0 = ck.offs[r]; o1 = ck.offs[r + 1];
-                            phase = S4_INIT;
+                            if (MODE == 2) {
+                                const uint32_t u = pool_next + rank;
+                                single = u < n_it;
+                                uint32_t it = 0;
+                                if (single) { it = items[u]; r = it >> 6; p2m = it & 63u; }
+                                else r = (uint32_t)list[u - n_it];
+                                if (it != 0xffffffffu) { o0 = ck.offs[r]; o1 = ck.offs[r + 1]; phase = S4_INIT; }     // (else: a slot left empty by k_seed2_select)
+                            } else { r = pool_next + rank; o0 = ck.offs[r]; o1 = ck.offs[r + 1]; phase = S4_INIT; }
                         } else if (exhausted && !pending && res_next == res_end) phase = S4_DONE;
                     }
                     const uint32_t cnt = (uint32_t)__popcll(want);

@@ -88,7 +88,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
-    DevBuf p2mask, p2list;                 // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf p2mask, p2list, p2items;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -112,7 +112,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -164,6 +164,8 @@ struct slx_aligner {
     int top_heavy = 0;            // 1 = the top seed of every kept chain of the HEAVY reads is extended ahead of time too (k_ext_first, one wave per chain):
                                   // measured on C3: 46.2 M reads/s against 48.4 M without -- the repeat reads' extensions are real DP work (hundreds per read),
                                   // and in the pipeline their serial walk hides behind the other workers while the extra k_ext_first jobs do not
+    int p2_items = 1;             // seeding pass 2: 1 = one lane per re-seeding CALL (k_seed2_select's items), 0 = one lane per read
+    int p2_items_cap = 0;         // test hook: capacity of the item list (0 = one per read of the chunk); reads whose items do not fit are walked whole
     int top_reuse = 1;            // 1 = k_extend_reg takes top-seed regions from that table (heavy reads, and light reads it redoes) instead of extending in place
     int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
     int stream_prio = 0;
@@ -657,6 +659,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     }
     else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
     else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
+    else if (!strcmp(key, "p2_items")) al->p2_items = value != 0;
+    else if (!strcmp(key, "p2_items_cap")) al->p2_items_cap = (int)value;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
         if (value < 0 || value > 24) return SLX_EINVAL;
         HIPCHK(hipSetDevice(al->device));
@@ -749,6 +753,21 @@ static void with_maxq(int max_len, F f)
 }
 #define MAXQ_LONG (SLX_MAX_READ_LEN + 4)
 
+#ifdef EXT_STATS
+static void ext_stats_print(hipStream_t st, const char *what, int n, const unsigned int *d_jobs)
+{   // tuning build (-DEXT_STATS=1): what the extension kernels did since the last print
+    unsigned long long a[8], b[8]; unsigned int nj = 0;
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(a, HIP_SYMBOL(g_ext_stats), sizeof a);
+    if (d_jobs) (void)hipMemcpy(&nj, d_jobs, 4, hipMemcpyDeviceToHost);
+    static unsigned long long prev[8];
+    for (int i = 0; i < 8; ++i) { b[i] = a[i] - prev[i]; prev[i] = a[i]; }
+    const double nd = (double)(b[0] - b[1] ? b[0] - b[1] : 1);
+    fprintf(stderr, "[ext %s] %d reads, %u jobs: %llu extensions, %llu diagonal, DP mean qlen %.1f tlen %.1f rows %.1f band %.1f, %llu ended by the tail bound\n", what, n, nj,
+            b[0], b[1], (double)b[2] / nd, (double)b[3] / nd, (double)b[4] / nd, b[4] ? (double)b[6] / (double)b[4] : 0., b[5]);
+}
+#endif
+
 // extension -> regions -> CIGAR jobs -> hit sort/filter, over all reads of the chunk on the worker's stream
 template <int MAXQ>
 static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, unsigned int *q, const unsigned int *n_slots, int grid, int bs, int n,
@@ -764,6 +783,9 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
                                       ext_heavy, n_heavy, top_off, top_cap, top_tab);
     else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
                             (const unsigned int *)nullptr);
+#ifdef EXT_STATS
+    ext_stats_print(st, "extend_reg", n, nullptr);
+#endif
     if (al->keep_stages && wk->last_S1) {      // the region stage reuses ia[] and rewrites regs[] in place
         if (wk->snap_ia.ensure(wk->last_S1 * 4) == SLX_OK && wk->snap_regs.ensure(wk->last_S1 * sizeof(DReg)) == SLX_OK && wk->snap_nreg.ensure((size_t)n * 4) == SLX_OK) {
             (void)hipMemcpyAsync(wk->snap_ia.p, ck.ia, wk->last_S1 * 4, hipMemcpyDeviceToDevice, st);
@@ -870,7 +892,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
-    ENS(counters, 64); ENS(p2mask, (size_t)n * 8); ENS(p2list, (size_t)n * 4);
+    ENS(counters, 64); ENS(p2mask, (size_t)n * 8); ENS(p2list, (size_t)n * 4); ENS(p2items, (size_t)n * 4);
     // counters: [0] zused, [1] cigused, [2] flags(u32)
     HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
     ENS(queues, 256);
@@ -936,10 +958,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         // then those calls -- a few per cent of the reads
         unsigned int *qq = wk->queues.as<unsigned int>();
         hipLaunchKernelGGL((k_seed12m<I, 1>), dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 29, seed_quota,
-                           (const int *)nullptr, (const unsigned int *)nullptr, (const unsigned long long *)nullptr);
-        hipLaunchKernelGGL(k_seed2_select<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, ck, dopt, wk->p2mask.as<unsigned long long>(), wk->p2list.as<int>(), qq + 35);
+                           (const int *)nullptr, (const unsigned int *)nullptr, (const unsigned long long *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr, 0u);
+        // pass-2 calls as single items (read << 6 | interval): at most one per read on average, else whole reads (k_seed2_select)
+        const uint32_t cap_items = (al->p2_items && n < (1 << 26)) ? (uint32_t)(al->p2_items_cap > 0 ? std::min(al->p2_items_cap, n) : n) : 0u;
+        hipLaunchKernelGGL(k_seed2_select<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, ck, dopt, wk->p2mask.as<unsigned long long>(), wk->p2list.as<int>(), qq + 35,
+                           wk->p2items.as<uint32_t>(), qq + 37, cap_items);
         hipLaunchKernelGGL((k_seed12m<I, 2>), dim3(grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 36, 0u, wk->p2list.as<int>(), qq + 35,
-                           wk->p2mask.as<unsigned long long>());
+                           wk->p2mask.as<unsigned long long>(), wk->p2items.as<uint32_t>(), qq + 37, cap_items);
         hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
         hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31,
                            (unsigned int)al->heavy_seeds, wk->queues.as<unsigned int>() + 34);
@@ -965,9 +990,13 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     unsigned int n_heavy_h = 0;                   // reads with at least heavy_seeds seed occurrences (the heavy list of the production schedule)
     HIPCHK(hipMemcpyAsync(&n_heavy_h, wk->queues.as<unsigned int>() + 34, 4, hipMemcpyDeviceToHost, st));
     unsigned int n_p2_h = 0;                      // reads whose pass 2 was run (SLX_DEBUG_SEED)
-    if (getenv("SLX_DEBUG_SEED")) HIPCHK(hipMemcpyAsync(&n_p2_h, wk->queues.as<unsigned int>() + 35, 4, hipMemcpyDeviceToHost, st));
+    unsigned int n_it_h = 0;                      // ... and single calls on the item list
+    if (getenv("SLX_DEBUG_SEED")) {
+        HIPCHK(hipMemcpyAsync(&n_p2_h, wk->queues.as<unsigned int>() + 35, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&n_it_h, wk->queues.as<unsigned int>() + 37, 4, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
-    if (getenv("SLX_DEBUG_SEED")) fprintf(stderr, "[seed] worker %d: %d reads, pass 2 run for %u of them (repeat filter k = %d), %u heavy\n", wk->id, n, n_p2_h, fm.rep ? fm.rep_k : 0, n_heavy_h);
+    if (getenv("SLX_DEBUG_SEED")) fprintf(stderr, "[seed] worker %d: %d reads, pass 2: %u single calls + %u whole reads (repeat filter k = %d), %u heavy\n", wk->id, n, n_it_h, n_p2_h, fm.rep ? fm.rep_k : 0, n_heavy_h);
     if (fl0) { *flags_out = fl0; return SLX_OK; }
     wk->max_seed_cnt = max_cnt;
     const size_t S1 = (size_t)S + 1;
@@ -1087,6 +1116,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                     constexpr int MAXQ = decltype(mq)::value;
                     hipLaunchKernelGGL(k_ext_first<MAXQ>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), top_cap, q + 22,
                                        wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
+#ifdef EXT_STATS
+                    ext_stats_print(st, "cand + ext_first", n, wk->first_off.as<unsigned int>() + n);
+#endif
                     hipLaunchKernelGGL(k_ext_replay<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, n, (unsigned int)al->heavy_seeds, wk->first_off.as<unsigned int>(),
                                        top_cap, wk->first_tab.as<DReg>(), q + 23, wk->fb_list.as<int>(), n_fb);
                 });
