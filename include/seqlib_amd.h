@@ -122,6 +122,7 @@ void slx_aligner_free(slx_aligner *al);
  *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
  *   "rep_k" 0..31 (19)        k of the repeat filter of seeding pass 2 (one bit per hashed k-mer that occurs twice in the text; 0 = none)
+ *   "p2_coop" 0|1 (1)         seeding pass 2: re-seeding calls inside repeats one wave per call (k_seed2_coop); needs p2_items
  *   "p2_items" 0|1 (1)        seeding pass 2: 1 = one lane per re-seeding call, 0 = one lane per read;  "p2_items_cap" (0 = one per read): test hook,
  *                             capacity of the call list (reads whose calls do not fit are walked whole)
  *   "seed_quota" (0)          reads a wave of the seeding kernel takes before it leaves (0 = persistent waves)
@@ -204,6 +205,9 @@ const char *slx_stage_name(int i);
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
 /* how many launches of each of those groups the sums cover (= chunks of the last batch over all workers and devices) */
 int  slx_aligner_probe_launches(const slx_aligner *al);
+/* what the last batch held, by name (diagnostics and tests; -1 = unknown name): "heavy_reads" (reads on the wave-per-read schedule),
+ * "p2_calls" (re-seeding calls of pass 2 run one per lane), "p2_coop_calls" (those of them run one per wave), "p2_whole_reads" */
+int64_t slx_aligner_counter(const slx_aligner *al, const char *key);
 
 /* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work
  * areas as int64 words.  what = 0: SMEM intervals after mem_collect_intv {start, end, x0, x2}; 1: kept chains in extension order

@@ -22,7 +22,7 @@ EXPORTS = [
     "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_aligner_create",
     "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free", "slx_hits_packed_size", "slx_hits_pack",
     "slx_aligner_stage_ms", "slx_stage_name", "slx_aligner_probe_ms", "slx_debug_stage", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
-    "slx_last_error", "slx_version", "slx_device_count", "slx_aligner_probe_launches", "slx_host_alloc", "slx_host_free", "slx_host_trim",
+    "slx_last_error", "slx_version", "slx_device_count", "slx_aligner_probe_launches", "slx_aligner_counter", "slx_host_alloc", "slx_host_free", "slx_host_trim",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
     L.slx_version.restype = C.c_char_p
     L.slx_device_count.restype = C.c_int
     L.slx_aligner_probe_launches.argtypes = [C.c_void_p]
+    L.slx_aligner_counter.argtypes = [C.c_void_p, C.c_char_p]
+    L.slx_aligner_counter.restype = C.c_int64
     L.slx_host_alloc.argtypes = [C.c_uint64]
     L.slx_host_alloc.restype = C.c_void_p
     L.slx_host_free.argtypes = [C.c_void_p]

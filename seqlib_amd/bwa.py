@@ -251,6 +251,10 @@ class BWAAligner:
         """launches of each probed kernel group in the last batch (chunks over all workers and devices)"""
         return int(_ffi.lib().slx_aligner_probe_launches(self._handle()))
 
+    def counter(self, key):
+        """what the last batch held: "heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads" (-1: unknown name)"""
+        return int(_ffi.lib().slx_aligner_counter(self._handle(), key.encode()))
+
     def stage_ms(self):
         ms = (C.c_float * _ffi.SLX_N_STAGES)()
         _ffi.check(_ffi.lib().slx_aligner_stage_ms(self._handle(), ms))

@@ -63,7 +63,7 @@ __device__ __forceinline__ MatRows make_matrows(const int8_t *mat)
 // last query column is >= gscore; so once B_i <= max and max(B_i, 0) < gscore every remaining row -- until z-drop, an all-zero row or
 // tlen ends the loop -- leaves all six reported values as they are, and the loop can stop.  With h0 = 90 and a 57-column extension
 // through two mismatches that is row 61 instead of row ~110 (the first column alone stays alive for h0 - o_del rows).
-// Needs non-negative gap penalties (else: never).  The scalar restatement in oracle/ has no such exit: the parity tests compare the two.
+// Needs non-negative gap penalties (else: never).  The scalar CPU restatement the parity tests compare with has no such exit.
 __device__ __forceinline__ int ext_tail_bound0(const slx_opt &o, int qlen, int h0, int amax)
 {   // B_qlen (the value at row i = qlen); INT_MAX when the bound does not hold
     if (o.o_del < 0 || o.e_del < 0 || o.o_ins < 0 || o.e_ins < 0) return 0x7fffffff;

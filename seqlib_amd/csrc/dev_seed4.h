@@ -305,6 +305,13 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #define SEED4_ITERS 24        // steps a mode loop runs at most before the wave looks at events and modes again
 #endif
 
+#ifndef SEED2C_MIN
+#define SEED2C_MIN 12         // pass-2 calls with at least this many entries after their forward phase go to k_seed2_coop (one wave per call)
+#endif
+#define SEED2C_CAP 256        // ... entries per list in its LDS (a call whose forward list + K does not fit stays on its lane)
+#ifndef SEED4_DEBUG_MODE
+#define SEED4_DEBUG_MODE 0    // 1 / 2: the statistics of that launch only (pass 1 / pass 2)
+#endif
 #ifndef SEED4_DEBUG
 #define SEED4_DEBUG 0         // 1 + SLX_DEBUG_CYC=3: loop statistics (steps and active lanes per mode) on stderr
 #endif
@@ -325,7 +332,8 @@ enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW,
 template <typename I, int MODE>
 __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota,
                                                                                                               const int *list, const unsigned int *n_list, const unsigned long long *p2mask,
-                                                                                                              const uint32_t *items, const unsigned int *n_items, uint32_t cap_items)
+                                                                                                              const uint32_t *items, const unsigned int *n_items, uint32_t cap_items,
+                                                                                                              uint32_t *long_items, unsigned int *n_long, uint32_t cap_long)
 {
     // wave_quota: reads a wave takes from the queue before it stops fetching and drains (0 = until the queue is empty: persistent waves).
     // With a quota the launch has many more blocks than fit the chip and slots keep coming free, so the other workers' kernels -- the
@@ -384,6 +392,16 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     RWin rwin; rwin.bits = 0; rwin.chunk = -1;
 #if SEED4_DEBUG
     const unsigned long long d_t0 = __builtin_readcyclecounter();
+    unsigned int d_call = 0;                      // backward steps of the call in hand
+    auto dbg_call_end = [&]() {                    // [16 + 2b] calls, [17 + 2b] steps by bucket b: min_intv == 2 ? 0 : 1;  [20 + 2h], [21 + 2h] by length class h
+        if (!(ck.dbg_cyc && ck.dbg_stage == 3) || !(SEED4_DEBUG_MODE == 0 || SEED4_DEBUG_MODE == MODE)) return;
+        const int b = min_intv <= (I)2 ? 0 : 1;
+        atomicAdd(ck.dbg_cyc + 16 + 2 * b, 1ull); atomicAdd(ck.dbg_cyc + 17 + 2 * b, (unsigned long long)d_call);
+        const int h = d_call < 64 ? 0 : d_call < 256 ? 1 : d_call < 1024 ? 2 : 3;
+        atomicAdd(ck.dbg_cyc + 20 + 2 * h, 1ull); atomicAdd(ck.dbg_cyc + 21 + 2 * h, (unsigned long long)d_call);
+        atomicMax(ck.dbg_cyc + 30, (unsigned long long)d_call);
+        d_call = 0;
+    };
     unsigned long long d_fsteps = 0, d_flanes = 0, d_bsteps = 0, d_blanes = 0, d_rounds = 0, d_ev = 0, d_dsteps = 0, d_dlanes = 0, d_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
@@ -419,6 +437,12 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
     };
     auto begin_bwd = [&]() {                       // the forward phase is over: its last push is the longest extension
         if (list_ovf) { finish_read(); return; }
+        if (MODE == 2 && single && cap_long && n >= SEED2C_MIN && n + K <= SEED2C_CAP) {
+            // a re-seeding call inside a repeat: rows of dozens of entries (rows x entries = thousands of steps on this lane).  Its rows are
+            // data-parallel: the call goes to k_seed2_coop, one wave per call, and this lane takes its next unit
+            const uint32_t idx = wave_fetch_inc(n_long);
+            if (idx < cap_long) { long_items[idx] = r << 6 | (uint32_t)(k2 - 1); phase = S4_START; return; }
+        }
         ret = i;                                    // = info of the entry pushed last = next start of pass 1
         h0 = ik0; h2 = ik2; hinf = (uint32_t)i;
         cur = 1; np = n; rev = 1; last_start = 0x7fffffff; bi = sx - 1;
@@ -604,6 +628,9 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                         if (np > 0) emit_mem(p0, p2, pinf);   // (np == 0: only virtual entries are left, too short to report)
                         if (MODE == 1) x = ret;
                         phase = S4_START;
+#if SEED4_DEBUG
+                        dbg_call_end();
+#endif
                     } else {
                         if (sx - bi <= nv) {            // this row's virtual entry: the K-mer starting at bi
                             vcode = (vcode >> 2) | ((uint32_t)cb << (2 * (K - 1)));
@@ -625,6 +652,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
 #endif
 #if SEED4_DEBUG
                 ++d_bsteps; d_blanes += (unsigned long long)__popcll(__ballot(act));
+                if (act) ++d_call;
 #endif
                 if (act) {
                     I nx0 = 0, nx2 = 0; uint32_t nxinf = 0;
@@ -653,7 +681,13 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
                             } else list_ovf = true;
                         }
                         if (list_ovf) finish_read();
-                        else if (nc == 0 && t >= nv) { if (MODE == 1) x = ret; phase = S4_START; }
+                        else if (nc == 0 && t >= nv) {
+                            if (MODE == 1) x = ret;
+                            phase = S4_START;
+#if SEED4_DEBUG
+                            dbg_call_end();
+#endif
+                        }
                         else { cur = 1 - cur; np = nc; rev = 0; --bi; h0 = nh0; h2 = nh2; hinf = nhinf; phase = S4_ROW; }
                     } else { p0 = nx0; p2 = nx2; pinf = nxinf; }
                 }
@@ -661,7 +695,7 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         }
         }
 #if SEED4_DEBUG
-    if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0) {
+    if (ck.dbg_cyc && ck.dbg_stage == 3 && lane == 0 && (SEED4_DEBUG_MODE == 0 || SEED4_DEBUG_MODE == MODE)) {
         const unsigned long long t_end = __builtin_readcyclecounter();
         ck.dbg_cyc[64 + (size_t)blockIdx.x * 2 + (threadIdx.x >> 6)] = t_end - d_t0;   // this wave's lifetime
         atomicMax(ck.dbg_cyc + 31, t_end - d_t0);
@@ -670,6 +704,150 @@ __global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : S
         atomicAdd(ck.dbg_cyc + 4, d_rounds); atomicAdd(ck.dbg_cyc + 5, d_ev); atomicAdd(ck.dbg_cyc + 6, d_dsteps); atomicAdd(ck.dbg_cyc + 7, d_dlanes);
     }
 #endif
+}
+
+// Pass-2 calls inside repeats, one WAVE per call (the items k_seed12m<2> put aside: >= SEED2C_MIN entries after the forward phase).  The
+// forward phase is run again, every lane the same steps (a chain of dependent rank reads either way); then a backward row is one wave
+// step per 64 entries: every lane extends its entry by the row's base, and what bwt_smem1a does with the results in list order is
+//     entry 0 below min_intv             -> its match ends here: the call's next MEM (later failing entries start at the same position)
+//     entry j kept                       <=> size >= min_intv and (entry j-1 failed or has a different size)
+// because the entries of a row are nested intervals in order of growing size: failing entries are a prefix of the list, equal sizes are
+// neighbours, and the size of the last KEPT entry is the size of entry j-1 whenever entry j-1 did not fail.  Kept entries are compacted
+// into the next row's list in LDS by a ballot prefix count.  The k-mer table's virtual entries join as in k_seed12m.
+template <typename I>
+__global__ void __launch_bounds__(64) k_seed2_coop(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, const uint32_t *items, const unsigned int *n_items, uint32_t cap_items)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    __shared__ I s_x0[2][SEED2C_CAP], s_x2[2][SEED2C_CAP];
+    __shared__ uint32_t s_inf[2][SEED2C_CAP];
+    uint32_t n_it = (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_items);
+    n_it = n_it < cap_items ? n_it : cap_items;
+    const int K = (fm.lut && fm.lut_k <= opt.min_seed_len) ? fm.lut_k : 0;
+    const LutE<I> *lut = (const LutE<I> *)fm.lut;
+    for (;;) {
+        uint32_t u = 0;
+        if (lane == 0) u = atomicAdd(queue, 1u);
+        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= n_it) break;
+        const uint32_t it = items[u];
+        const uint32_t r = it >> 6;
+        const uint64_t qoff = ck.offs[r];
+        const int len = (int)(ck.offs[r + 1] - qoff);
+        const size_t po = (size_t)r * ck.cap_intv + (it & 63u);
+        const uint32_t pinf0 = ck.intv_info[po];
+        const int sx = ((int)(pinf0 >> 16) + (int)(pinf0 & 0xffff)) >> 1;
+        const I min_intv = ((const I *)ck.intv_x2)[po] + 1;
+        QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+        auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
+        // ---- forward phase (bwt_smem1a's first loop), the same on every lane; lane 0 keeps the list
+        I ik0, ik1, ik2;
+        int i, nv = 0, n = 0;
+        uint32_t vcode = 0;
+        bool list_ovf = false;
+        if (K && sx + K <= len) {
+            uint32_t fw, rc;
+            if (kmer_codes(qb, sx, K, fw, rc) < 0) {
+                const LutE<I> e = lut[fw];
+                if (e.sz >= min_intv) { ik0 = e.lo; ik2 = e.sz; ik1 = lut[rc].lo; i = sx + K; nv = K - 1; vcode = fw; }
+            }
+        }
+        if (!nv) { set_intv4<I>(fm, qb(sx), ik0, ik1, ik2); i = sx + 1; }
+        auto push_fwd = [&]() {
+            if (n < ck.cap_list && n < SEED2C_CAP) { if (lane == 0) { s_x0[1][n] = ik0; s_x2[1][n] = ik2; s_inf[1][n] = (uint32_t)i; } }
+            else list_ovf = true;
+            ++n;
+        };
+        for (;;) {
+            int cq = 4;
+            if (i >= len || (cq = qb(i)) > 3) { push_fwd(); break; }
+            I o0_, o1, o2;
+            fwd_step<I>(fm, ik0, ik1, ik2, cq, o0_, o1, o2);
+            if (o2 != ik2) { push_fwd(); if (o2 < min_intv) break; }
+            ik0 = o0_; ik1 = o1; ik2 = o2; ++i;          // (min_intv >= 2 here: an interval never stays at one occurrence, no direct steps)
+        }
+        __syncthreads();
+        if (list_ovf) { if (lane == 0) atomicOr(ck.flags, OVF_LIST); continue; }
+        // ---- backward rows
+        int cur = 1, np = n, rev = 1, last_start = 0x7fffffff, bi = sx - 1;
+        bool out_ovf = false;
+        auto emit_mem = [&](I a, I sz, uint32_t end) {      // lane 0
+            if (bi + 1 < last_start) {
+                last_start = bi + 1;
+                if ((int)end - (bi + 1) >= opt.min_seed_len) {
+                    const uint32_t slot = atomicAdd(ck.intv_n + r, 1u);
+                    if (slot < (uint32_t)ck.cap_intv) {
+                        const size_t o = (size_t)r * ck.cap_intv + slot;
+                        ck.intv_info[o] = ((uint32_t)(bi + 1) << 16) | end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = sz;
+                    } else { atomicSub(ck.intv_n + r, 1u); out_ovf = true; }
+                }
+            }
+        };
+        for (;;) {
+            int cb = -1;
+            if (bi >= 0) { cb = qb(bi); if (cb > 3) cb = -1; }
+            if (cb < 0) {                                   // beginning of the read or an ambiguous base: every entry ends here, only the first can be new
+                if (np > 0 && lane == 0) { const int h = rev ? np - 1 : 0; emit_mem(s_x0[cur][h], s_x2[cur][h], s_inf[cur][h]); }
+                break;
+            }
+            const int t = sx - bi;                          // rows done with this one
+            I v0 = 0, v2 = 0;
+            if (t <= nv) {
+                vcode = (vcode >> 2) | ((uint32_t)cb << (2 * (K - 1)));
+                const LutE<I> e = lut[vcode];
+                v0 = e.lo; v2 = e.sz;
+            }
+            int nc = 0;
+            I last_sz = 0;                                  // size of the last entry that did not fail
+            bool prev_ok = false;                           // ... and whether the entry before this chunk did not fail
+            for (int c0 = 0; c0 < np; c0 += 64) {
+                const int j = c0 + lane;
+                const bool live = j < np;
+                I p0 = 0, p2 = 0, o2 = 0, o0_ = 0; uint32_t pinf = 0;
+                if (live) {
+                    const int idx = rev ? np - 1 - j : j;
+                    p0 = s_x0[cur][idx]; p2 = s_x2[cur][idx]; pinf = s_inf[cur][idx];
+                    RankLd<I> rk, rl;
+                    rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
+                    I ckc, clc, dummy;
+                    rank_finish<I, false>(rk, cb, ckc, dummy); rank_finish<I, false>(rl, cb, clc, dummy);
+                    o2 = clc - ckc;
+                    o0_ = l2_of<I>(fm, cb) + 1 + ckc;
+                }
+                const bool ok = live && o2 >= min_intv;
+                if (c0 == 0 && lane == 0 && !ok) emit_mem(p0, p2, pinf);      // (np > 0 here, so lane 0 is live)
+                // the entry before mine: lane - 1, or the last entry of the previous chunk
+                I left_o2 = (I)__shfl_up((long long)o2, 1, 64);
+                int left_ok = __shfl_up((int)ok, 1, 64);
+                if (lane == 0) { left_o2 = last_sz; left_ok = prev_ok; }
+                const bool kept = ok && (!left_ok || o2 != left_o2);
+                const unsigned long long mk = __ballot(kept), mo = __ballot(ok);
+                if (kept) {
+                    const int pos = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    s_x0[1 - cur][pos] = o0_; s_x2[1 - cur][pos] = o2; s_inf[1 - cur][pos] = pinf;
+                }
+                nc += __popcll(mk);
+                const int last_lane = np - c0 < 64 ? np - c0 - 1 : 63;
+                last_sz = (I)__shfl((long long)o2, last_lane, 64);
+                prev_ok = ((mo >> last_lane) & 1ull) != 0;
+            }
+            // the row's virtual entry [bi, bi + K) joins as its last (k_seed12m); last_sz only matters when an entry was kept, and then the
+            // list's last entry did not fail
+            if (t <= nv && v2 >= min_intv && (nc == 0 || v2 != last_sz)) {
+                if (nc < ck.cap_list) { if (lane == 0) { s_x0[1 - cur][nc] = v0; s_x2[1 - cur][nc] = v2; s_inf[1 - cur][nc] = (uint32_t)(bi + K); } ++nc; }
+                else list_ovf = true;
+            }
+            __syncthreads();
+            if (list_ovf) break;
+            if (nc == 0 && t >= nv) break;
+            cur = 1 - cur; np = nc; rev = 0; --bi;
+        }
+        if (lane == 0) {
+            if (list_ovf) atomicOr(ck.flags, OVF_LIST);
+            if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+        }
+        __syncthreads();
+    }
 }
 
 // pass 3 (bwt_seed_strategy1: forward-only LAST-like seeds); the per-read epilogue follows in k_seed_epi.  One lane per read, one forward extend per base: lanes of a wave run

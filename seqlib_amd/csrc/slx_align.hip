@@ -88,7 +88,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
-    DevBuf p2mask, p2list, p2items;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf p2mask, p2list, p2items, p2long;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -102,6 +102,7 @@ struct Worker {
     float stage_ms[SLX_N_STAGES];
     float probe_ms[SLX_N_PROBES] = {0, 0, 0};
     int n_chunks = 0;                    // chunks this worker ran in the current batch
+    long long cnt[4] = {0, 0, 0, 0};     // ... and what they held: heavy reads, pass-2 calls as single items, of those one wave each, pass-2 whole reads
     int64_t n_hits = 0, n_cig = 0;
     int rc = SLX_OK;
     std::string err;
@@ -112,7 +113,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -165,6 +166,7 @@ struct slx_aligner {
                                   // measured on C3: 46.2 M reads/s against 48.4 M without -- the repeat reads' extensions are real DP work (hundreds per read),
                                   // and in the pipeline their serial walk hides behind the other workers while the extra k_ext_first jobs do not
     int p2_items = 1;             // seeding pass 2: 1 = one lane per re-seeding CALL (k_seed2_select's items), 0 = one lane per read
+    int p2_coop = 1;              // ... 1 = calls inside repeats (long work lists) one WAVE per call (k_seed2_coop)
     int p2_items_cap = 0;         // test hook: capacity of the item list (0 = one per read of the chunk); reads whose items do not fit are walked whole
     int top_reuse = 1;            // 1 = k_extend_reg takes top-seed regions from that table (heavy reads, and light reads it redoes) instead of extending in place
     int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
@@ -190,6 +192,7 @@ struct slx_aligner {
     float stage_ms[SLX_N_STAGES];
     float probe_ms[SLX_N_PROBES] = {0, 0, 0};   // kernel groups of the last batch, summed over the workers' launches (HIP events on the workers' streams)
     int64_t probe_reads = 0;
+    long long counters[4] = {0, 0, 0, 0};       // slx_aligner_counter: sums of the workers' cnt[] over the last batch
     int probe_launches = 0;                     // chunks (= launches of each kernel group) of the last batch, over all workers
     uint64_t h_first = 0, h_last = 0;           // host-buffer entry: offs[0] and offs[n] of the call in flight (bounds of every part's upload)
 };
@@ -660,6 +663,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "top_heavy")) al->top_heavy = value != 0;
     else if (!strcmp(key, "top_reuse")) al->top_reuse = value != 0;
     else if (!strcmp(key, "p2_items")) al->p2_items = value != 0;
+    else if (!strcmp(key, "p2_coop")) al->p2_coop = value != 0;
     else if (!strcmp(key, "p2_items_cap")) al->p2_items_cap = (int)value;
     else if (!strcmp(key, "seed_free_cus")) {   // CUs (of every 32) the seeding kernels may NOT use; 0 = seeding on the worker's own stream
         if (value < 0 || value > 24) return SLX_EINVAL;
@@ -709,6 +713,20 @@ extern "C" int slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES
     for (int i = 0; i < SLX_N_PROBES; ++i) ms[i] = al->probe_ms[i];
     if (n_reads) *n_reads = al->probe_reads;
     return SLX_OK;
+}
+
+extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
+{   // what the last batch held (diagnostics and tests: "did that kernel see any work?"); -1 for an unknown key
+    if (!al || !key) return -1;
+    static const char *const names[4] = {"heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads"};
+    for (int i = 0; i < 4; ++i)
+        if (!strcmp(key, names[i])) {
+            if (!al->is_group) return al->counters[i];
+            long long n = 0;
+            for (const slx_aligner *sub : al->subs) n += sub->counters[i];
+            return n;
+        }
+    return -1;
 }
 
 extern "C" int slx_aligner_probe_launches(const slx_aligner *al)
@@ -892,7 +910,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(lists, (size_t)2 * cap_list * n_threads * sizeof(IntvE<I>));
     ENS(zarena, caps.zcap); ENS(cigpool, caps.cigcap * 4);
     ENS(hit_cnt, ((size_t)n + 1) * 8); ENS(cig_cnt, ((size_t)n + 1) * 8); ENS(hit_off_c, ((size_t)n + 1) * 8); ENS(cig_off_c, ((size_t)n + 1) * 8);
-    ENS(counters, 64); ENS(p2mask, (size_t)n * 8); ENS(p2list, (size_t)n * 4); ENS(p2items, (size_t)n * 4);
+    ENS(counters, 64); ENS(p2mask, (size_t)n * 8); ENS(p2list, (size_t)n * 4); ENS(p2items, (size_t)n * 4); ENS(p2long, (size_t)n * 4);
     // counters: [0] zused, [1] cigused, [2] flags(u32)
     HIPCHK(hipMemsetAsync(wk->counters.p, 0, 64, st));
     ENS(queues, 256);
@@ -958,13 +976,17 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         // then those calls -- a few per cent of the reads
         unsigned int *qq = wk->queues.as<unsigned int>();
         hipLaunchKernelGGL((k_seed12m<I, 1>), dim3(seed_grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 29, seed_quota,
-                           (const int *)nullptr, (const unsigned int *)nullptr, (const unsigned long long *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr, 0u);
+                           (const int *)nullptr, (const unsigned int *)nullptr, (const unsigned long long *)nullptr, (const uint32_t *)nullptr, (const unsigned int *)nullptr, 0u,
+                           (uint32_t *)nullptr, (unsigned int *)nullptr, 0u);
         // pass-2 calls as single items (read << 6 | interval): at most one per read on average, else whole reads (k_seed2_select)
         const uint32_t cap_items = (al->p2_items && n < (1 << 26)) ? (uint32_t)(al->p2_items_cap > 0 ? std::min(al->p2_items_cap, n) : n) : 0u;
+        const uint32_t cap_long = (cap_items && al->p2_coop) ? cap_items : 0u;
         hipLaunchKernelGGL(k_seed2_select<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, ck, dopt, wk->p2mask.as<unsigned long long>(), wk->p2list.as<int>(), qq + 35,
                            wk->p2items.as<uint32_t>(), qq + 37, cap_items);
         hipLaunchKernelGGL((k_seed12m<I, 2>), dim3(grid), dim3(bs), 0, ss, fm, al->ref, ck, dopt, qq + 36, 0u, wk->p2list.as<int>(), qq + 35,
-                           wk->p2mask.as<unsigned long long>(), wk->p2items.as<uint32_t>(), qq + 37, cap_items);
+                           wk->p2mask.as<unsigned long long>(), wk->p2items.as<uint32_t>(), qq + 37, cap_items, wk->p2long.as<uint32_t>(), qq + 38, cap_long);
+        // the calls inside repeats that the lanes put aside: one wave per call
+        if (cap_long) hipLaunchKernelGGL(k_seed2_coop<I>, dim3((unsigned)(al->n_cu * 8)), dim3(64), 0, ss, fm, al->ref, ck, dopt, qq + 39, wk->p2long.as<uint32_t>(), qq + 38, cap_long);
         hipLaunchKernelGGL(k_seed3m<I>, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ss, fm, al->ref, ck, dopt);
         hipLaunchKernelGGL(k_seed_epi<I>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ss, ck, dopt, wk->queues.as<unsigned int>() + 31,
                            (unsigned int)al->heavy_seeds, wk->queues.as<unsigned int>() + 34);
@@ -990,13 +1012,14 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     unsigned int n_heavy_h = 0;                   // reads with at least heavy_seeds seed occurrences (the heavy list of the production schedule)
     HIPCHK(hipMemcpyAsync(&n_heavy_h, wk->queues.as<unsigned int>() + 34, 4, hipMemcpyDeviceToHost, st));
     unsigned int n_p2_h = 0;                      // reads whose pass 2 was run (SLX_DEBUG_SEED)
+    unsigned int n_long_h = 0;                    // ... and those of them handed to k_seed2_coop
     unsigned int n_it_h = 0;                      // ... and single calls on the item list
-    if (getenv("SLX_DEBUG_SEED")) {
-        HIPCHK(hipMemcpyAsync(&n_p2_h, wk->queues.as<unsigned int>() + 35, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&n_it_h, wk->queues.as<unsigned int>() + 37, 4, hipMemcpyDeviceToHost, st));
-    }
+    unsigned int p2c[4] = {0, 0, 0, 0};          // queue words 35..38: whole reads, (queue), items, items one wave each
+    HIPCHK(hipMemcpyAsync(p2c, wk->queues.as<unsigned int>() + 35, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (getenv("SLX_DEBUG_SEED")) fprintf(stderr, "[seed] worker %d: %d reads, pass 2: %u single calls + %u whole reads (repeat filter k = %d), %u heavy\n", wk->id, n, n_it_h, n_p2_h, fm.rep ? fm.rep_k : 0, n_heavy_h);
+    n_p2_h = p2c[0]; n_it_h = p2c[2]; n_long_h = p2c[3];
+    wk->cnt[0] += n_heavy_h; wk->cnt[1] += n_it_h; wk->cnt[2] += n_long_h; wk->cnt[3] += n_p2_h;
+    if (getenv("SLX_DEBUG_SEED")) fprintf(stderr, "[seed] worker %d: %d reads, pass 2: %u single calls (%u of them one wave each) + %u whole reads (repeat filter k = %d), %u heavy\n", wk->id, n, n_it_h, n_long_h, n_p2_h, fm.rep ? fm.rep_k : 0, n_heavy_h);
     if (fl0) { *flags_out = fl0; return SLX_OK; }
     wk->max_seed_cnt = max_cnt;
     const size_t S1 = (size_t)S + 1;
@@ -1186,8 +1209,11 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (hipEventElapsedTime(&ms, wk->ev_probe[2 * i], wk->ev_probe[2 * i + 1]) == hipSuccess) wk->probe_ms[i] += ms;
     }
     if (ck.dbg_cyc && ck.dbg_stage == 3) {
-        unsigned long long c6[16];
-        HIPCHK(hipMemcpy(c6, wk->dbg_cyc.p, 128, hipMemcpyDeviceToHost));
+        unsigned long long c6[32];
+        HIPCHK(hipMemcpy(c6, wk->dbg_cyc.p, 256, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[seed12m] calls with min_intv <= 2: %llu, %.1f backward steps each; others: %llu, %.1f each; by length < 64 / < 256 / < 1024 / more: %llu (%.3g steps), %llu (%.3g), %llu (%.3g), %llu (%.3g); longest %llu\n",
+                c6[16], c6[16] ? (double)c6[17] / (double)c6[16] : 0., c6[18], c6[18] ? (double)c6[19] / (double)c6[18] : 0., c6[20], (double)c6[21], c6[22], (double)c6[23], c6[24], (double)c6[25],
+                c6[26], (double)c6[27], c6[30]);
         {
             std::vector<unsigned long long> life((size_t)grid * 2);
             HIPCHK(hipMemcpy(life.data(), wk->dbg_cyc.as<unsigned long long>() + 64, life.size() * 8, hipMemcpyDeviceToHost));
@@ -1294,6 +1320,7 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
     for (int i = 0; i < SLX_N_STAGES; ++i) wk->stage_ms[i] = 0;
     for (int i = 0; i < SLX_N_PROBES; ++i) wk->probe_ms[i] = 0;
     wk->n_chunks = 0;
+    for (long long &c : wk->cnt) c = 0;
     int rc;
     const int64_t n_part = r_hi - r_lo;
     if ((rc = wk->o_hit_off.ensure(((size_t)n_part + 1) * 8)) != SLX_OK) return rc;
@@ -1424,6 +1451,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
     al->probe_reads = n_reads;
     al->probe_launches = 0;
     for (int k = 0; k < K; ++k) al->probe_launches += al->workers[(size_t)k]->n_chunks;
+    for (int i = 0; i < 4; ++i) { al->counters[i] = 0; for (int k = 0; k < K; ++k) al->counters[i] += al->workers[(size_t)k]->cnt[i]; }
     for (int i = 0; i < SLX_N_PROBES; ++i) {
         al->probe_ms[i] = 0;
         for (int k = 0; k < K; ++k) al->probe_ms[i] += al->workers[(size_t)k]->probe_ms[i];

@@ -91,7 +91,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
+@pytest.mark.parametrize("knob,val", [("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
                                       ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("ext_split", 0), ("wide_index", 1),
                                       ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
@@ -441,6 +441,7 @@ def _synth_config_vs_oracle(sl, orc, tmp_path, cfg_name, n_reads, pairs=False):
     got = al.align_flat(reads.tobytes(), offs)
     exp = orc.align_batch_flat(orc.default_opt(), oidx, reads.tobytes(), offs)
     assert_same(got, exp, cfg["name"])
+    got["counters"] = {k: al.counter(k) for k in ("heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads")}
     return got
 
 
@@ -454,7 +455,10 @@ def test_config_C3_chr20_block(sl, orc, tmp_path):
     """BASELINE config 3 (the bench default): GPU-built chr20_syn index (64.4 Mb, 129 M BWT symbols), 131 072 reads =
     65 536 pairs generated per SURVEY 8d (two single-end reads 300+-30 bp apart, opposite strands) -- bit-exact vs the
     oracle loading the index the GPU wrote"""
-    _synth_config_vs_oracle(sl, orc, tmp_path, "C3", 1 << 17)
+    got = _synth_config_vs_oracle(sl, orc, tmp_path, "C3", 1 << 17)
+    # the sample must reach the kernels that only repeats reach: pass-2 calls one per lane and, inside repeats, one per wave
+    c = got["counters"]
+    assert c["p2_calls"] > 1000 and c["p2_coop_calls"] > 50 and c["heavy_reads"] > 50, c
 
 
 def test_config_C4_wide_index(sl, orc, tmp_path):
