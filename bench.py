@@ -19,6 +19,8 @@ Beside `value` (reads resident in HBM -> hits resident in HBM) the line carries 
 it: `value_host_to_host` (pinned host reads -> host SoA hits through slx_align_batch) and `value_bamrecords`
 (the C++ class: UnalignedSequenceVector -> BamRecordPtrVector, on a bounded sample, tools/bamrec_bench.cpp).
 """
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # six workers' streams on eight hardware queues (the library asks for the same when it is loaded; here: before torch can initialise HIP)
 import argparse
 import ctypes as C
 import json
@@ -229,12 +231,12 @@ def main():
     idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])     # suffix sort + BWT/Occ/SA on the GPU
     t_index = time.time() - t0
     al = seqlib_amd.BWAAligner(idx, device=local_rank)
-    per_worker = (n + 2) // 3
-    if per_worker > (1 << 23):
-        al.set("chunk_reads", 1 << 23)       # 50 M reads: each of the three workers takes its part in chunks of 8 M reads
+    if (n + max(1, al.counter("workers")) - 1) // max(1, al.counter("workers")) > (1 << 23):
+        al.set("chunk_reads", 1 << 23)       # each worker takes its part in chunks of at most 8 M reads (50 M reads, six workers: one chunk each)
     for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=workers=2
         k, v = kv.split("=")
         al.set(k, int(v))
+    n_workers = al.counter("workers")
     d_bases = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offs = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * read_len
     torch.cuda.synchronize()
@@ -403,7 +405,7 @@ def main():
                                    "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], sum(len(g) for _, g in refs), len(refs),
                                                                                       "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
                                                                                       " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
-                       "reads_per_gpu": n, "read_len": read_len, "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
+                       "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
                        "headline": "value = reads resident in HBM -> hits resident in HBM (the contract's timed region); value_host_to_host = host reads -> host "
                                    "SoA hits through slx_align_batch (the metric as SURVEY 8d words it); value_bamrecords = SeqLib::BWAAligner::alignSequences "
                                    "with BamRecord output (the north-star sentence read literally)"},

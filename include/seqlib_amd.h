@@ -113,7 +113,9 @@ int  slx_device_count(void);   /* visible HIP devices (0 without a GPU) */
 int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
 void slx_aligner_free(slx_aligner *al);
 /* Tuning / test knobs; none of them changes a result (tests/test_gpu_parity.py runs each against the oracle).
- *   "workers" 1..8 (3)        host workers = HIP streams a batch is split over
+ *   "workers" 1..8 (6 | 3)    host workers = HIP streams a batch is split over.  6 when the HIP runtime exposes eight hardware queues
+ *                             (GPU_MAX_HW_QUEUES >= 8: the library sets that variable to 8 when it is loaded unless the environment has a value,
+ *                             which takes effect if no HIP call has been made yet), else 3
  *   "chunk_reads" (1 << 24)   reads per launch of a worker;  "min_split"  smallest batch that is split over workers at all
  *   "dense_sa" 0|1 (1)        1 = suffix array decompressed to sa_intv 1 in HBM, 0 = bwa's sampled-SA walk
  *   "lut_k" -1|0|2..14 (-1)   width of the k-mer table of the seeding kernels (4^k x 8 or 16 bytes); -1 = by index size, 0 = none
@@ -206,7 +208,8 @@ int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t
 /* how many launches of each of those groups the sums cover (= chunks of the last batch over all workers and devices) */
 int  slx_aligner_probe_launches(const slx_aligner *al);
 /* what the last batch held, by name (diagnostics and tests; -1 = unknown name): "heavy_reads" (reads on the wave-per-read schedule),
- * "p2_calls" (re-seeding calls of pass 2 run one per lane), "p2_coop_calls" (those of them run one per wave), "p2_whole_reads" */
+ * "p2_calls" (re-seeding calls of pass 2 run one per lane), "p2_coop_calls" (those of them run one per wave), "p2_whole_reads";
+ * "workers" = the aligner's worker count (per device) */
 int64_t slx_aligner_counter(const slx_aligner *al, const char *key);
 
 /* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work

@@ -25,6 +25,11 @@ run() {  # name, env...
   env "$@" SEQLIB_AMD_TRACE=1 timeout 600 $R/seqlib_amd/bamrec_bench /tmp/bamrec/c3 /tmp/bamrec/reads.bin 150 $N > $OUT/$name.json 2> $OUT/$name.err
   echo "$name: $(cut -c1-120 $OUT/$name.json)"
 }
+if [ -n "$RUNS" ]; then
+  # RUNS="name:VAR=val,VAR=val name2:..."  (custom settings instead of the default sweep)
+  for spec in $RUNS; do name=${spec%%:*}; vars=${spec#*:}; run $name ${vars//,/ }; done
+  exit 0
+fi
 run t16         SEQLIB_AMD_THREADS=16
 run t16_pad     SEQLIB_AMD_THREADS=16 MALLOC_TOP_PAD_=268435456 MALLOC_TRIM_THRESHOLD_=4294967296
 run t24_pad     SEQLIB_AMD_THREADS=24 MALLOC_TOP_PAD_=268435456 MALLOC_TRIM_THRESHOLD_=4294967296

@@ -295,8 +295,12 @@ __device__ __forceinline__ int kmer_codes(QB &qb, int p, int K, uint32_t &fw, ui
 #define SEED4_BATCH 20
 #endif
 #if SEED4_SCHED == 1
+#ifndef SEED4_SHORT_FLOOR_SHIFT
 #define SEED4_SHORT_FLOOR_SHIFT 3
+#endif
+#ifndef SEED4_ITERS_B
 #define SEED4_ITERS_B 96
+#endif
 #else
 #define SEED4_SHORT_FLOOR_SHIFT SEED4_FLOOR_SHIFT
 #define SEED4_ITERS_B SEED4_ITERS

@@ -411,6 +411,19 @@ static int build_rep_filter(slx_aligner *al)
 }
 
 #define SLX_MAX_WORKERS 8
+
+// The workers' streams map onto the runtime's hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise; read once,
+// when the HIP runtime initialises).  Three workers fill four queues; with eight queues six workers -- one 8 M-read chunk each of a
+// 50 M-read batch -- overlap their single-read tails with more of the others' work (C3 +6 %, C2 +3 %), while six workers on four
+// queues lose 10 %.  The library asks for eight queues when it is loaded unless the environment has a value; that only takes effect
+// if the process has not made a HIP call yet, so a host that initialises HIP before loading the library and wants six workers sets
+// GPU_MAX_HW_QUEUES=8 itself, or "workers" to 3.
+__attribute__((constructor)) static void slx_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+static int default_workers()
+{
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    return (q && atoi(q) >= 8) ? 6 : 3;
+}
 #define CAND_REP_AUTO_READS (5 << 20)
 #ifndef COOP_N1
 #define COOP_N1 768      // chains the first LDS table of k_chain_coop holds: 25 KB per wave, six waves per CU (measured on C3: 1536 -> 47.8,
@@ -466,7 +479,8 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     al->n_cu = prop.multiProcessorCount;
     al->max_threads = al->n_cu * al->threads_per_cu;
     int rcw;
-    for (int k = 0; k < 3; ++k) if ((rcw = add_worker(al)) != SLX_OK) return rcw;
+    al->n_workers = default_workers();
+    for (int k = 0; k < al->n_workers; ++k) if ((rcw = add_worker(al)) != SLX_OK) return rcw;
     HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     al->host_idx = idx;
     int rc;
@@ -718,6 +732,7 @@ extern "C" int slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES
 extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
 {   // what the last batch held (diagnostics and tests: "did that kernel see any work?"); -1 for an unknown key
     if (!al || !key) return -1;
+    if (!strcmp(key, "workers")) return al->is_group ? al->subs[0]->n_workers : al->n_workers;     // (per device)
     static const char *const names[4] = {"heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads"};
     for (int i = 0; i < 4; ++i)
         if (!strcmp(key, names[i])) {
