@@ -19,8 +19,6 @@ Beside `value` (reads resident in HBM -> hits resident in HBM) the line carries 
 it: `value_host_to_host` (pinned host reads -> host SoA hits through slx_align_batch) and `value_bamrecords`
 (the C++ class: UnalignedSequenceVector -> BamRecordPtrVector, on a bounded sample, tools/bamrec_bench.cpp).
 """
-import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # six workers' streams on eight hardware queues (the library asks for the same when it is loaded; here: before torch can initialise HIP)
 import argparse
 import ctypes as C
 import json
@@ -231,8 +229,8 @@ def main():
     idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])     # suffix sort + BWT/Occ/SA on the GPU
     t_index = time.time() - t0
     al = seqlib_amd.BWAAligner(idx, device=local_rank)
-    if (n + max(1, al.counter("workers")) - 1) // max(1, al.counter("workers")) > (1 << 23):
-        al.set("chunk_reads", 1 << 23)       # each worker takes its part in chunks of at most 8 M reads (50 M reads, six workers: one chunk each)
+    # (chunks: the library's default -- up to 16.8 M reads -- so each of the three workers takes its 16.7 M of the 50 M reads as ONE chunk: one launch
+    # of each kernel per worker and step; 8 M-read chunks measured 3 % slower)
     for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=workers=2
         k, v = kv.split("=")
         al.set(k, int(v))
@@ -356,7 +354,7 @@ def main():
                 src = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % PMC_SUMMARY
             mean_launch_ms = seed_ms / launches
             physical = traffic / (mean_launch_ms * 1e-3) / 1e9 if traffic else None
-            roof = dict(bound="hbm", kernel="seeding: k_seed12m<1> + k_seed2_select + k_seed12m<2> + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            roof = dict(bound="hbm", kernel="seeding: k_seed12m<1> + k_seed2_select + k_seed12m<2> + k_seed2_coop + k_seed3m + k_seed_epi", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=src,
                         achieved_basis="ALGORITHMIC bytes (SURVEY 8d: the oracle's count on bwa's own layout, 64 B per Occ block touched + the read) per launch / "
                                        "mean launch duration; the kernel itself moves fewer bytes (32-byte occ planes, k-mer table, direct text steps): see physical_gbs",

@@ -113,9 +113,7 @@ int  slx_device_count(void);   /* visible HIP devices (0 without a GPU) */
 int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
 void slx_aligner_free(slx_aligner *al);
 /* Tuning / test knobs; none of them changes a result (tests/test_gpu_parity.py runs each against the oracle).
- *   "workers" 1..8 (6 | 3)    host workers = HIP streams a batch is split over.  6 when the HIP runtime exposes eight hardware queues
- *                             (GPU_MAX_HW_QUEUES >= 8: the library sets that variable to 8 when it is loaded unless the environment has a value,
- *                             which takes effect if no HIP call has been made yet), else 3
+ *   "workers" 1..8 (3)        host workers = HIP streams a batch is split over (six pay only with GPU_MAX_HW_QUEUES=8 in the environment: +2 %)
  *   "chunk_reads" (1 << 24)   reads per launch of a worker;  "min_split"  smallest batch that is split over workers at all
  *   "dense_sa" 0|1 (1)        1 = suffix array decompressed to sa_intv 1 in HBM, 0 = bwa's sampled-SA walk
  *   "lut_k" -1|0|2..14 (-1)   width of the k-mer table of the seeding kernels (4^k x 8 or 16 bytes); -1 = by index size, 0 = none
@@ -201,7 +199,7 @@ int  slx_hits_pack(slx_aligner *al, const slx_hits *h, void *dst, uint64_t dst_b
 int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
 const char *slx_stage_name(int i);
 /* kernel groups of the last batch: duration summed over the workers' launches, from HIP events recorded on the worker's own
- * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m<1>, k_seed2_select, k_seed12m<2>, k_seed3m, k_seed_epi), [1] the extension
+ * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m<1>, k_seed2_select, k_seed12m<2>, k_seed2_coop, k_seed3m, k_seed_epi), [1] the extension
  * family (k_extend_cand, k_first_prep, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_dp) */
 #define SLX_N_PROBES 3
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);

@@ -2,6 +2,7 @@
 # Everything the round's documentation quotes, in one GPU call: parity suite, smoke, the default bench line (C3, with CPU baseline and
 # extras), the C2 line, the rocprofv3 kernel stats + PMC passes of the C3 command, and the nothing-overlapping per-kernel profile.
 # Usage: scripts/round_evidence.sh <tag>      (writes gpurun_out/<tag>/...)
+exec < /dev/null
 ulimit -c 0          # a GPU memory fault makes ROCr dump the whole HBM image: 288 GB onto a 79 GB disk
 TAG=${1:-r03}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

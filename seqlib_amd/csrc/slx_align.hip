@@ -412,18 +412,12 @@ static int build_rep_filter(slx_aligner *al)
 
 #define SLX_MAX_WORKERS 8
 
-// The workers' streams map onto the runtime's hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise; read once,
-// when the HIP runtime initialises).  Three workers fill four queues; with eight queues six workers -- one 8 M-read chunk each of a
-// 50 M-read batch -- overlap their single-read tails with more of the others' work (C3 +6 %, C2 +3 %), while six workers on four
-// queues lose 10 %.  The library asks for eight queues when it is loaded unless the environment has a value; that only takes effect
-// if the process has not made a HIP call yet, so a host that initialises HIP before loading the library and wants six workers sets
-// GPU_MAX_HW_QUEUES=8 itself, or "workers" to 3.
-__attribute__((constructor)) static void slx_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-static int default_workers()
-{
-    const char *q = getenv("GPU_MAX_HW_QUEUES");
-    return (q && atoi(q) >= 8) ? 6 : 3;
-}
+// Three workers, each taking its part of a batch in chunks of up to 16 M reads.  Measured alternatives on C3 (50 M reads): chunks of 8 M reads
+// (two per worker) 53.4 M reads/s against 55.1 M (the single-read tails of a chunk are paid once per chunk); four / five workers
+// lose on the runtime's default four hardware queues; with GPU_MAX_HW_QUEUES=8 in the environment (read once, when the HIP runtime
+// initialises) six workers reach 56.2 M (C2 +3 %) -- but every launch then shares the chip with five others (the mean seeding launch of
+// 8.3 M reads takes 209 ms instead of 110) and six workers on four queues lose 10 %, so that stays a setting ("workers"), not the default.
+static int default_workers() { return 3; }
 #define CAND_REP_AUTO_READS (5 << 20)
 #ifndef COOP_N1
 #define COOP_N1 768      // chains the first LDS table of k_chain_coop holds: 25 KB per wave, six waves per CU (measured on C3: 1536 -> 47.8,
