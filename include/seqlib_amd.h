@@ -122,6 +122,9 @@ void slx_aligner_free(slx_aligner *al);
  *   "heavy_seeds", "cand_mode", "cand_seeds", "cand_top", "cand_rep", "cand_rep_max", "cand_cap", "ext_split", "heavy_sorted", "regs_big", "chain_mode",
  *   "coop_lim1/2", "split_min", "zarena_bytes"   routing thresholds between the kernels of a stage
  *   "rep_k" 0..31 (19)        k of the repeat filter of seeding pass 2 (one bit per hashed k-mer that occurs twice in the text; 0 = none)
+ *   "cand_lanes" -1|0|1 (-1)  ahead-of-time extension of the heavy reads one LANE per seed (k_ext_lanes: 64 ksw_extend2 per wave, H/E rows in LDS) for every heavy
+ *                             read with >= "cand_lane_seeds" (64) seed slots; 0 = one wave per four seeds for the reads cand_top / cand_rep select; -1 = on for
+ *                             chunks of at most 5 M reads
  *   "p2_coop" 0|1 (1)         seeding pass 2: re-seeding calls inside repeats one wave per call (k_seed2_coop); needs p2_items
  *   "p2_items" 0|1 (1)        seeding pass 2: 1 = one lane per re-seeding call, 0 = one lane per read;  "p2_items_cap" (0 = one per read): test hook,
  *                             capacity of the call list (reads whose calls do not fit are walked whole)

@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
 
 // per heavy read: seed slots (table space) and (chain, part) jobs
 __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_heavy, unsigned int *slot_cnt, unsigned int *job_cnt, unsigned int min_seeds,
-                             unsigned int top, unsigned int rep_pct, unsigned int *n_part, unsigned int part_max, int count_only)
+                             unsigned int top, unsigned int rep_pct, unsigned int *n_part, unsigned int part_max, int count_only, int per_job)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= *n_heavy) return;
@@ -671,14 +671,17 @@ __global__ void k_cand_count(Chunk ck, const int *heavy, const unsigned int *n_h
     if (s >= top && !(part && *n_part <= part_max)) return;
     slot_cnt[s] = cap;
     unsigned int jobs = 0;
-    for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + CAND_PART - 1) / CAND_PART;
+    for (int ci = 0; ci < nc; ++ci) jobs += (unsigned int)(ck.c_n[so + ck.ia[so + ci]] + per_job - 1) / (unsigned int)per_job;   // (per_job = 1: a job per seed, k_ext_lanes)
     job_cnt[s] = jobs;
 }
 
-__global__ void k_cand_base(const int *heavy, const unsigned int *n_heavy, const unsigned int *slot_off, unsigned int cand_cap, int32_t *cand_base)
-{
+__global__ void k_cand_base(const int *heavy, const unsigned int *n_heavy, const unsigned int *slot_off, unsigned int cand_cap, int32_t *cand_base, unsigned int *job_cnt)
+{   // a read whose slots do not fit the table is extended in place: no table base, and no jobs (the job offsets are scanned after this)
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < *n_heavy) cand_base[heavy[s]] = (slot_off[s + 1] > slot_off[s] && slot_off[s + 1] <= cand_cap) ? (int32_t)slot_off[s] : -1;
+    if (s >= *n_heavy) return;
+    const bool fits = slot_off[s + 1] > slot_off[s] && slot_off[s + 1] <= cand_cap;
+    cand_base[heavy[s]] = fits ? (int32_t)slot_off[s] : -1;
+    if (!fits) job_cnt[s] = 0;
 }
 
 // one (read, chain, part) job; out of line so that the queue loop of the kernel stays a plain fetch / test / call (see dev_cig_dp_job)

@@ -24,6 +24,7 @@
 #include "dev_fin.h"
 #include "dev_ext_wave.h"
 #include "dev_ext_reg.h"
+#include "dev_ext_lane.h"
 #include "dev_fin2.h"
 #include "dev_chain_coop.h"
 #include "dev_long.h"
@@ -88,7 +89,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
-    DevBuf p2mask, p2list, p2items, p2long;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf p2mask, p2list, p2items, p2long, lane_jobs;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -113,7 +114,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -146,6 +147,11 @@ struct slx_aligner {
     int ext_split = 1;            // 1 = light reads: top-seed extensions one wave per chain (k_ext_first) + decision sequence one read per lane
                                   // (k_ext_replay); k_extend_reg keeps the heavy reads and the reads that need more
     int heavy_sorted = 1;         // 1 = the heavy list is ordered heaviest-first and the extension kernel takes it before the light reads
+    int cand_lanes = -1;          // 1 = the ahead-of-time extensions run one LANE per seed (k_ext_lanes) and take every heavy read with at least
+                                  // cand_lane_seeds seed slots; 0 = one wave per four seeds (k_extend_cand) for the reads cand_top / cand_rep select;
+                                  // -1 = 1 for chunks of at most CAND_REP_AUTO_READS reads (C2 +2.6 %, C3's 16 M-read chunks -6 %: there the serial walk
+                                  // of those reads hides behind the other workers, and the lane kernel extends every seed, twice what the walk extends)
+    int cand_lane_seeds = 64;
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_top = 512;           // ... and only for the first cand_top reads of the heaviest-first list
@@ -154,7 +160,7 @@ struct slx_aligner {
                                   // chunk of 8.3 M (C3) loses 5 %: there the walk hides behind the other workers and the extra extensions do not.
                                   // -1 = by chunk size: 75 for chunks of at most CAND_REP_AUTO_READS reads, else 0
     int cand_rep_max = 4096;      // ... when the chunk has at most this many of them
-    int cand_cap = 1 << 22;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
+    int cand_cap = 1 << 23;       // seed slots that table holds per chunk (96 B each); reads beyond it are extended in place
     int lut_k = -1;               // k-mer table of the seeding kernels (dev_seed4.h, k_kmer_lut): 4^k entries of 8 / 16 bytes; 0 = none,
                                   // -1 = by index size (measured best where a k-mer still has a handful of occurrences: log4(symbols) - 1)
     int keep_stages = 0;          // test hook: keep what slx_debug_stage reads (copies of the chain order / region list before de-duplication)
@@ -651,6 +657,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
+    else if (!strcmp(key, "cand_lanes")) { if (value < -1 || value > 1) return SLX_EINVAL; al->cand_lanes = (int)value; }
+    else if (!strcmp(key, "cand_lane_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_lane_seeds = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
     else if (!strcmp(key, "heavy_seeds")) { if (value < 1) return SLX_EINVAL; al->heavy_seeds = (int)value; }
@@ -1112,17 +1120,37 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 HIPCHK(hipMemsetAsync(wk->cand_cnt.p, 0, ((size_t)nh + 2) * 8, st));
                 unsigned int *slot_cnt = wk->cand_cnt.as<unsigned int>(), *job_cnt = slot_cnt + (nh + 2);
                 unsigned int *slot_off = wk->cand_off.as<unsigned int>(), *job_off = slot_off + (nh + 2);
-                const int cand_rep = al->cand_rep >= 0 ? al->cand_rep : (n <= CAND_REP_AUTO_READS ? 75 : 0);
+                // one lane per seed (k_ext_lanes): every heavy read is worth taking; it needs the H/E row of 64 extensions in LDS and 14-bit scores
+                int amax = 0;
+                for (int i = 0; i < 25; ++i) amax = std::max(amax, (int)opt->mat[i]);
+                // -- and pays where the heavy reads' serial walk is a large part of a chunk's time, i.e. for small chunks (like cand_rep)
+                const int lane_cols = max_len - std::min(opt->min_seed_len, max_len) + 2;          // columns 0 .. longest extension query
+                const bool lanes = (al->cand_lanes > 0 || (al->cand_lanes < 0 && n <= CAND_REP_AUTO_READS)) && max_len <= 704 && lane_cols * 256 <= 64 * 1024 &&
+                                   (int64_t)amax * max_len < LANE_SCORE_LIMIT;
+                const int cand_rep = lanes ? 0 : (al->cand_rep >= 0 ? al->cand_rep : (n <= CAND_REP_AUTO_READS ? 75 : 0));
                 for (int pass = cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
-                    hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt, (unsigned int)al->cand_seeds,
-                                       hsort ? (unsigned int)al->cand_top : 0xffffffffu, (unsigned int)cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass);
+                    hipLaunchKernelGGL(k_cand_count, dim3(gb), dim3(256), 0, st, ck, wk->order_out.as<int>(), counts + 1, slot_cnt, job_cnt,
+                                       (unsigned int)(lanes ? al->cand_lane_seeds : al->cand_seeds), (hsort && !lanes) ? (unsigned int)al->cand_top : 0xffffffffu,
+                                       (unsigned int)cand_rep, q + 30, (unsigned int)al->cand_rep_max, pass, lanes ? 1 : CAND_PART);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, slot_cnt, slot_off, nh + 1, st));
+                hipLaunchKernelGGL(k_cand_base, dim3(gb), dim3(256), 0, st, wk->order_out.as<int>(), counts + 1, slot_off, (unsigned int)al->cand_cap,
+                                   wk->cand_base.as<int32_t>(), job_cnt);
                 tb = wk->scan_tmp.cap;
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, job_cnt, job_off, nh + 1, st));
-                hipLaunchKernelGGL(k_cand_base, dim3(gb), dim3(256), 0, st, wk->order_out.as<int>(), counts + 1, slot_off, (unsigned int)al->cand_cap,
-                                   wk->cand_base.as<int32_t>());
                 const int gc = al->n_cu * 32;
+                if (lanes) {
+                    const size_t max_jobs = std::min<size_t>((size_t)al->cand_cap, S1);      // (a job per seed slot of the selected reads, and those fit the table)
+                    ENS(lane_jobs, max_jobs * sizeof(LaneJob));
+                    auto go = [&](auto mq) {
+                        constexpr int MAXQ = decltype(mq)::value;
+                        hipLaunchKernelGGL(k_cand_lane_prep<MAXQ>, dim3(std::max(1, std::min(nh, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
+                                           job_off, wk->lane_jobs.as<LaneJob>());
+                        hipLaunchKernelGGL(k_ext_lanes, dim3(al->n_cu * 4), dim3(64), (size_t)lane_cols * 256, st, al->ref, ck, dopt, counts + 1, job_off, q + 14,
+                                           wk->lane_jobs.as<LaneJob>(), wk->cand.as<DReg>());
+                    };
+                    with_maxq(max_len, go);
+                } else
                 with_maxq(max_len, [&](auto mq) {
                     hipLaunchKernelGGL(k_extend_cand<decltype(mq)::value>, dim3(gc), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
                                        job_off, q + 14, wk->cand.as<DReg>());
