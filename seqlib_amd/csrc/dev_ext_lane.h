@@ -5,8 +5,8 @@
 // kernel is a serial walk of 10-40 ms on one wave (the extension stage's tail) and on the wave-per-seed job kernel (k_extend_cand)
 // ~10 000 wave instructions per extension.  The extensions of different seeds do not depend on each other, and for these reads there
 // are hundreds of them with the same query: here a wave takes 64 seeds and every lane runs ksw_extend2's scalar loops on its own -- the
-// H/E row of a lane lives in LDS, column-major across the lanes (word j * 64 + lane: no bank conflicts), packed with the query code of
-// its column into one 32-bit word -- ~25 instructions per cell for 64 extensions at once instead of ~150 per row for one.
+// H/E row of a lane lives in LDS, column-major across the lanes (cell j * 64 + lane: no bank conflicts; layouts below) -- ~36 instructions
+// per cell for 64 extensions at once instead of ~170 per row for one.
 // k_extend_reg then replays mem_chain2aln's decisions and takes the regions from the table (cand), as it does after k_extend_cand.
 // /root/reference/src/BWAAligner.cpp:104 -> mem_align1 -> mem_chain2aln -> ksw_extend2.
 #pragma once
@@ -22,24 +22,55 @@ struct alignas(8) LaneJob {    // one seed extension (k_cand_lane_prep -> k_ext_
     int r, c;                   // read and chain (for seedcov)
 };
 
-#define LANE_H_BITS 14          // H and E of a cell in 14 bits each, the query code of the column above them
-#define LANE_H_MASK ((1u << LANE_H_BITS) - 1u)
 #define LANE_SCORE_LIMIT 16000  // (read length) x max(mat) has to stay below this for the lane kernel to be used (host check)
 
-// ksw_extend2, scalar, one extension per lane.  eh = this lane's word of column 0 (stride 64 words); the caller has NOT initialised it.
-template <typename QF, typename TF>
-__device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0, uint32_t *eh)
+// Where a lane keeps its H/E row.  WIDE: one 32-bit word per column -- 14-bit H, 14-bit E, the column's query code above them.  NARROW: when
+// no score can reach 256 (150 bp reads with bwa's default scores: read length x max(mat) < 256) a column is 8-bit H + 8-bit E in a 16-bit
+// word and the query codes sit apart, eight 4-bit codes per word: half the LDS per wave, twice the waves per CU -- and the kernel's time
+// is inversely proportional to its waves per CU (measured by padding the rows: 4 / 3 / 2 waves per CU -> 30.8 / 40.4 / 60.3 ms).
+struct LaneWide {
+    uint32_t *eh;                                   // this lane's word of column 0; stride WAVE words
+    static __host__ __device__ size_t bytes(int cols) { return (size_t)cols * WAVE * 4; }
+    __device__ __forceinline__ void init(uint32_t *base, int, int lane) { eh = base + lane; }
+    __device__ __forceinline__ void put_all(int j, int h, int e, int q) { eh[j * WAVE] = (uint32_t)h | (uint32_t)e << 14 | (uint32_t)q << 28; }
+    __device__ __forceinline__ uint32_t get(int j) const { return eh[j * WAVE]; }
+    __device__ __forceinline__ int q_of(uint32_t v, int) const { return (int)(v >> 28); }
+    static __device__ __forceinline__ int h_of(uint32_t v) { return (int)(v & 0x3fffu); }
+    static __device__ __forceinline__ int e_of(uint32_t v) { return (int)((v >> 14) & 0x3fffu); }
+    __device__ __forceinline__ void put(int j, int h, int e, uint32_t old) { eh[j * WAVE] = (uint32_t)h | (uint32_t)e << 14 | (old & 0xf0000000u); }
+    static __device__ __forceinline__ bool zero(uint32_t v) { return (v & 0x0fffffffu) == 0; }
+};
+struct LaneNarrow {
+    uint16_t *eh;                                   // 16-bit cells, stride WAVE
+    uint32_t *qa;                                   // eight 4-bit query codes per word, stride WAVE words
+    static __host__ __device__ size_t bytes(int cols) { return (size_t)cols * WAVE * 2 + (size_t)((cols + 7) / 8) * WAVE * 4; }
+    __device__ __forceinline__ void init(uint32_t *base, int cols, int lane) { eh = (uint16_t *)base + lane; qa = base + (size_t)cols * WAVE / 2 + lane; }
+    __device__ __forceinline__ void put_all(int j, int h, int e, int q)
+    {
+        eh[j * WAVE] = (uint16_t)(h | e << 8);
+        uint32_t w = (j & 7) ? qa[(j >> 3) * WAVE] : 0u;        // (columns are written in ascending order: a word starts at its column 0)
+        w |= (uint32_t)q << ((j & 7) * 4);
+        qa[(j >> 3) * WAVE] = w;
+    }
+    __device__ __forceinline__ uint32_t get(int j) const { return eh[j * WAVE]; }
+    __device__ __forceinline__ int q_of(uint32_t, int j) const { return (int)((qa[(j >> 3) * WAVE] >> ((j & 7) * 4)) & 7u); }
+    static __device__ __forceinline__ int h_of(uint32_t v) { return (int)(v & 0xffu); }
+    static __device__ __forceinline__ int e_of(uint32_t v) { return (int)(v >> 8); }
+    __device__ __forceinline__ void put(int j, int h, int e, uint32_t) { eh[j * WAVE] = (uint16_t)(h | e << 8); }
+    static __device__ __forceinline__ bool zero(uint32_t v) { return v == 0; }
+};
+
+// ksw_extend2, scalar, one extension per lane; L = the lane's row (not initialised by the caller)
+template <typename L, typename QF, typename TF>
+__device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0, L &row)
 {
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    auto H_of = [](uint32_t v) { return (int)(v & LANE_H_MASK); };
-    auto E_of = [](uint32_t v) { return (int)((v >> LANE_H_BITS) & LANE_H_MASK); };
-    // row -1: eh[0].h = h0, then the insertion ramp while it stays positive; the query code of column j rides in the top bits
+    // row -1: eh[0].h = h0, then the insertion ramp while it stays positive; the query code of column j rides along
     for (int j = 0; j <= qlen; ++j) {
         const int v = h0 - oe_ins - (j - 1) * e_ins;
         const int h = j == 0 ? h0 : (v > 0 ? v : 0);
-        const uint32_t q = j < qlen ? (uint32_t)qf(j) : 0u;
-        eh[j * WAVE] = (uint32_t)h | q << (2 * LANE_H_BITS);
+        row.put_all(j, h, 0, j < qlen ? qf(j) : 0);
     }
     int max = 0;
     for (int i = 0; i < 25; ++i) max = max > o.mat[i] ? max : o.mat[i];
@@ -63,11 +94,11 @@ __device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
         if (end > qlen) end = qlen;
         int h1 = 0;
         if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
-        uint32_t cur = beg < end ? eh[beg * WAVE] : 0u;
+        uint32_t cur = beg < end ? row.get(beg) : 0u;
         for (int j = beg; j < end; ++j) {
-            const uint32_t nxt = eh[(j + 1) * WAVE];                // (column j + 1 <= qlen exists; read ahead of this cell's arithmetic)
-            int M = H_of(cur), e = E_of(cur);
-            const uint32_t q = cur >> (2 * LANE_H_BITS);
+            const uint32_t nxt = row.get(j + 1);                    // (column j + 1 <= qlen exists; read ahead of this cell's arithmetic)
+            int M = L::h_of(cur), e = L::e_of(cur);
+            const uint32_t q = (uint32_t)row.q_of(cur, j);
             const int s = q < 4 ? __builtin_amdgcn_sbfe((int)rowp, q << 3, 8u) : row4;
             M = M ? M + s : 0;
             int h = M > e ? M : e;
@@ -78,15 +109,12 @@ __device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
             m = m > h ? m : h;
             int t2 = M - oe_del; t2 = t2 > 0 ? t2 : 0;
             e -= e_del; e = e > t2 ? e : t2;
-            eh[j * WAVE] = (uint32_t)hl | (uint32_t)e << LANE_H_BITS | q << (2 * LANE_H_BITS);
+            row.put(j, hl, e, cur);
             t2 = M - oe_ins; t2 = t2 > 0 ? t2 : 0;
             f -= e_ins; f = f > t2 ? f : t2;
             cur = nxt;
         }
-        {   // eh[end].h = h1; eh[end].e = 0 (the column keeps its query code)
-            const uint32_t v = beg < end ? cur : eh[end * WAVE];
-            eh[end * WAVE] = (uint32_t)h1 | (v >> (2 * LANE_H_BITS)) << (2 * LANE_H_BITS);
-        }
+        row.put(end, h1, 0, beg < end ? cur : row.get(end));        // eh[end].h = h1; eh[end].e = 0 (the column keeps its query code)
         if ((end > beg ? end : beg) == qlen) {                       // (the scalar loop's j after its last trip)
             max_ie = gscore > h1 ? max_ie : i;
             gscore = gscore > h1 ? gscore : h1;
@@ -101,9 +129,9 @@ __device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
             else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
         }
         int j;
-        for (j = beg; j < end && (eh[j * WAVE] & ((1u << (2 * LANE_H_BITS)) - 1u)) == 0; ++j) {}
+        for (j = beg; j < end && L::zero(row.get(j)); ++j) {}
         beg = j;
-        for (j = end; j >= beg && (eh[j * WAVE] & ((1u << (2 * LANE_H_BITS)) - 1u)) == 0; --j) {}
+        for (j = end; j >= beg && L::zero(row.get(j)); --j) {}
         end = j + 2 < qlen ? j + 2 : qlen;
     }
     ExtResult r;
@@ -112,8 +140,9 @@ __device__ ExtResult lane_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
 }
 
 // dev_extend_core, one seed per lane (the same statements, the scalar extension above in place of the wave-wide one)
+template <typename L>
 __device__ DReg lane_extend_core(const DevRef &R, const slx_opt &opt, const MatRows &mr, const uint8_t *query, int l_query, int s_qbeg, int s_len,
-                                 int64_t s_rbeg, int64_t rmax0, int64_t rmax1, int rid, float frac_rep, uint32_t *eh)
+                                 int64_t s_rbeg, int64_t rmax0, int64_t rmax1, int rid, float frac_rep, L &eh)
 {
     DReg a;
     a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
@@ -225,14 +254,18 @@ __global__ void __launch_bounds__(64) k_cand_lane_prep(DevRef R, Chunk ck, DevOp
     }
 }
 
-// (dynamic LDS: 64 words per column, columns 0 .. longest query of an extension = longest read - min_seed_len: 34 KB for 150 bp reads, four waves per CU)
+// (dynamic LDS: columns 0 .. longest query of an extension = longest read - min_seed_len: 34 KB per wave for 150 bp reads in the wide layout -- four waves
+// per CU -- 21 KB in the narrow one)
+template <typename L>
 __global__ void __launch_bounds__(64) k_ext_lanes(DevRef R, Chunk ck, DevOpt dopt, const unsigned int *n_heavy, const unsigned int *job_off, unsigned int *queue,
-                                                   const LaneJob *jobs, DReg *cand)
+                                                   const LaneJob *jobs, DReg *cand, int cols)
 {
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
-    extern __shared__ uint32_t eh[];
+    extern __shared__ uint32_t lane_lds[];
+    L row;
+    row.init(lane_lds, cols, lane);
     const unsigned int nh = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_heavy);
     const unsigned int n_jobs = nh ? (unsigned int)__builtin_amdgcn_readfirstlane((int)job_off[nh]) : 0u;
     for (;;) {
@@ -244,7 +277,7 @@ __global__ void __launch_bounds__(64) k_ext_lanes(DevRef R, Chunk ck, DevOpt dop
         if (job < n_jobs) {
             const LaneJob j = jobs[job];
             const uint8_t *query = ck.codes + j.q_off;
-            DReg a = lane_extend_core(R, opt, mr, query, j.l_query, j.s_qbeg, j.s_len, j.s_rbeg, j.rmax0, j.rmax1, j.rid, j.frac_rep, eh + lane);
+            DReg a = lane_extend_core<L>(R, opt, mr, query, j.l_query, j.s_qbeg, j.s_len, j.s_rbeg, j.rmax0, j.rmax1, j.rid, j.frac_rep, row);
             // seedcov: the chain's seeds that lie inside the region
             const ReadWS w = make_ws(ck, j.r);
             const int n = w.c_n[j.c];

@@ -152,6 +152,8 @@ struct slx_aligner {
                                   // -1 = 1 for chunks of at most CAND_REP_AUTO_READS reads (C2 +2.6 %, C3's 16 M-read chunks -6 %: there the serial walk
                                   // of those reads hides behind the other workers, and the lane kernel extends every seed, twice what the walk extends)
     int cand_lane_seeds = 64;
+    int lane_narrow = 1;          // 1 = 8-bit H / E cells in k_ext_lanes when no score can reach 256 (half the LDS per wave)
+    int lane_pad = 0;             // tuning: extra LDS columns per lane of k_ext_lanes (lowers its occupancy)
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
     int cand_seeds = 256;         // ... for reads with at least this many seed occurrences (shorter heavy reads finish in place soon enough)
     int cand_top = 512;           // ... and only for the first cand_top reads of the heaviest-first list
@@ -658,6 +660,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
     else if (!strcmp(key, "cand_lanes")) { if (value < -1 || value > 1) return SLX_EINVAL; al->cand_lanes = (int)value; }
+    else if (!strcmp(key, "lane_narrow")) al->lane_narrow = value != 0;
+    else if (!strcmp(key, "lane_pad")) al->lane_pad = (int)value;
     else if (!strcmp(key, "cand_lane_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_lane_seeds = (int)value; }
     else if (!strcmp(key, "cand_cap")) { if (value < 1) return SLX_EINVAL; al->cand_cap = (int)value; }
     else if (!strcmp(key, "split_min")) al->split_min = (int)value;
@@ -1124,8 +1128,9 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 int amax = 0;
                 for (int i = 0; i < 25; ++i) amax = std::max(amax, (int)opt->mat[i]);
                 // -- and pays where the heavy reads' serial walk is a large part of a chunk's time, i.e. for small chunks (like cand_rep)
-                const int lane_cols = max_len - std::min(opt->min_seed_len, max_len) + 2;          // columns 0 .. longest extension query
-                const bool lanes = (al->cand_lanes > 0 || (al->cand_lanes < 0 && n <= CAND_REP_AUTO_READS)) && max_len <= 704 && lane_cols * 256 <= 64 * 1024 &&
+                const int lane_cols = max_len - std::min(opt->min_seed_len, max_len) + 2 + al->lane_pad;   // columns 0 .. longest extension query
+                const bool lane_narrow = al->lane_narrow && amax * max_len < 256;      // 8-bit H / E cells: no score can reach 256
+                const bool lanes = (al->cand_lanes > 0 || (al->cand_lanes < 0 && n <= CAND_REP_AUTO_READS)) && max_len <= 704 && (lane_narrow ? LaneNarrow::bytes(lane_cols) : LaneWide::bytes(lane_cols)) <= 64 * 1024 &&
                                    (int64_t)amax * max_len < LANE_SCORE_LIMIT;
                 const int cand_rep = lanes ? 0 : (al->cand_rep >= 0 ? al->cand_rep : (n <= CAND_REP_AUTO_READS ? 75 : 0));
                 for (int pass = cand_rep > 0 ? 1 : 0; pass >= 0; --pass)      // (first the count of partly repetitive reads, then the selection)
@@ -1146,8 +1151,10 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                         constexpr int MAXQ = decltype(mq)::value;
                         hipLaunchKernelGGL(k_cand_lane_prep<MAXQ>, dim3(std::max(1, std::min(nh, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, wk->order_out.as<int>(), counts + 1,
                                            job_off, wk->lane_jobs.as<LaneJob>());
-                        hipLaunchKernelGGL(k_ext_lanes, dim3(al->n_cu * 4), dim3(64), (size_t)lane_cols * 256, st, al->ref, ck, dopt, counts + 1, job_off, q + 14,
-                                           wk->lane_jobs.as<LaneJob>(), wk->cand.as<DReg>());
+                        if (lane_narrow) hipLaunchKernelGGL(k_ext_lanes<LaneNarrow>, dim3(al->n_cu * 8), dim3(64), LaneNarrow::bytes(lane_cols), st, al->ref, ck, dopt, counts + 1, job_off,
+                                                            q + 14, wk->lane_jobs.as<LaneJob>(), wk->cand.as<DReg>(), lane_cols);
+                        else hipLaunchKernelGGL(k_ext_lanes<LaneWide>, dim3(al->n_cu * 4), dim3(64), LaneWide::bytes(lane_cols), st, al->ref, ck, dopt, counts + 1, job_off, q + 14,
+                                                wk->lane_jobs.as<LaneJob>(), wk->cand.as<DReg>(), lane_cols);
                     };
                     with_maxq(max_len, go);
                 } else
