@@ -1127,6 +1127,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 // one lane per seed (k_ext_lanes): every heavy read is worth taking; it needs the H/E row of 64 extensions in LDS and 14-bit scores
                 int amax = 0;
                 for (int i = 0; i < 25; ++i) amax = std::max(amax, (int)opt->mat[i]);
+                amax = std::max(amax, opt->a);                 // (a seed's score is its length x opt->a, whatever the matrix says)
                 // -- and pays where the heavy reads' serial walk is a large part of a chunk's time, i.e. for small chunks (like cand_rep)
                 const int lane_cols = max_len - std::min(opt->min_seed_len, max_len) + 2 + al->lane_pad;   // columns 0 .. longest extension query
                 const bool lane_narrow = al->lane_narrow && amax * max_len < 256;      // 8-bit H / E cells: no score can reach 256
