@@ -294,3 +294,92 @@ __global__ void __launch_bounds__(64) k_ext_lanes(DevRef R, Chunk ck, DevOpt dop
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------- light reads: the diagonal, one lane per job
+// Most top-seed extensions of the light reads are answered by the diagonal alone (diag_extend, dev_ext_reg.h: at most oe - 1 lost against a
+// perfect match).  One wave per job that is ~1 000 instructions around two short scans -- 12.8 of k_ext_first's 20 ms per 8.3 M reads;
+// one LANE per job it is a loop over the query with both sequences read through register windows.  k_first_diag answers those jobs (the
+// region goes straight into the table) and lists the others for k_ext_first, which keeps the dynamic program.
+template <typename QF, typename TF>
+__device__ __forceinline__ bool lane_diag_extend(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int amax, int h0, ExtResult &out)
+{   // the conditions and the result of diag_extend, computed by one lane
+    if (tlen < qlen || qlen > 3 * WAVE || qlen < 1) return false;
+    if ((long long)h0 + (long long)qlen * amax >= (1 << 22)) return false;
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    const int oe = oe_del < oe_ins ? oe_del : oe_ins;
+    int loss = 0, run = h0, best = h0, best_p = -1;
+    for (int p = 0; p < qlen; ++p) {
+        const int t = tf(p), q = qf(p);
+        const uint32_t rowp = t == 0 ? mr.packed[0] : t == 1 ? mr.packed[1] : t == 2 ? mr.packed[2] : mr.packed[3];
+        const int row4 = t == 0 ? mr.q4[0] : t == 1 ? mr.q4[1] : t == 2 ? mr.q4[2] : mr.q4[3];
+        const int sc = q < 4 ? __builtin_amdgcn_sbfe((int)rowp, (uint32_t)q << 3, 8u) : row4;
+        loss += amax - sc;
+        if (loss > oe - 1) return false;                 // (the loss only grows: amax is the largest entry)
+        run += sc;
+        if (run > best) { best = run; best_p = p; }      // the largest prefix above h0 at its FIRST position
+    }
+    if (h0 <= loss) return false;
+    out.score = best; out.qle = best_p + 1; out.tle = best_p + 1; out.gtle = qlen; out.gscore = run; out.max_off = 0;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_first_diag(DevRef R, Chunk ck, DevOpt dopt, int n, const unsigned int *first_off, unsigned int cap, const FirstJob *jobs, DReg *first,
+                                                    unsigned int *dp_list, unsigned int *n_dp)
+{
+    const slx_opt &opt = dopt.o;
+    const MatRows mr = make_matrows(opt.mat);
+    int amax = 0;
+    for (int i = 0; i < 25; ++i) amax = amax > opt.mat[i] ? amax : opt.mat[i];
+    unsigned int n_jobs = first_off[n];
+    if (n_jobs > cap) n_jobs = cap;
+    const unsigned int job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= n_jobs) return;
+    const FirstJob j = jobs[job];
+    if (j.l_query <= 0) return;                           // an empty job (a read whose slots pass the table end): k_extend_reg has the read
+    const uint8_t *codes = ck.codes;
+    QWin qw; qw.bits = 0; qw.chunk = 0xffffffffu;
+    RWin rw; rw.bits = 0; rw.chunk = -1;
+    DReg a;
+    a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
+    a.n_comp = 0; a.hash = 0;
+    a.score = a.truesc = -1; a.rid = j.rid;
+    // the diagonal's max_off is 0, so the band-doubling loop of dev_extend_core ends after its first trip (band opt.w) -- unless the band is so
+    // narrow that (w >> 1) + (w >> 2) is 0: then it takes the second trip, finds the same score and ends with band 2 w
+    const int aw_ext = ((opt.w >> 1) + (opt.w >> 2)) > 0 ? opt.w : opt.w << 1;
+    int aw0 = opt.w, aw1 = opt.w;
+    bool ok = true;
+    const int s_qbeg = j.s_qbeg, s_len = j.s_len, l_query = j.l_query;
+    const int64_t s_rbeg = j.s_rbeg;
+    if (s_qbeg) {
+        aw0 = aw_ext;
+        ExtResult er;
+        ok = lane_diag_extend(s_qbeg, [&](int p) { return q_at(codes, j.q_off + (uint64_t)(s_qbeg - 1 - p), qw); }, (int)(s_rbeg - j.rmax0),
+                              [&](int t) { return text_at(R, s_rbeg - 1 - t, rw); }, opt, mr, amax, s_len * opt.a, er);
+        if (ok) {
+            a.score = er.score;
+            if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = s_qbeg - er.qle; a.rb = s_rbeg - er.tle; a.truesc = a.score; }
+            else { a.qb = 0; a.rb = s_rbeg - er.gtle; a.truesc = er.gscore; }
+        }
+    } else { a.score = a.truesc = s_len * opt.a; a.qb = 0; a.rb = s_rbeg; }
+    if (ok) {
+        if (s_qbeg + s_len != l_query) {
+            aw1 = aw_ext;
+            const int sc0 = a.score, qe = s_qbeg + s_len;
+            const int64_t re0 = s_rbeg + s_len;
+            ExtResult er;
+            ok = lane_diag_extend(l_query - qe, [&](int p) { return q_at(codes, j.q_off + (uint64_t)(qe + p), qw); }, (int)(j.rmax1 - re0),
+                                  [&](int t) { return text_at(R, re0 + t, rw); }, opt, mr, amax, sc0, er);
+            if (ok) {
+                a.score = er.score;
+                if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
+                else { a.qe = l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
+            }
+        } else { a.qe = l_query; a.re = s_rbeg + s_len; }
+    }
+    if (ok) {
+        a.w = aw0 > aw1 ? aw0 : aw1;
+        a.seedlen0 = s_len;
+        a.frac_rep = j.frac_rep;
+        first[job] = a;                                   // seedcov is filled in by k_ext_replay
+    } else dp_list[wave_fetch_inc(n_dp)] = job;
+}

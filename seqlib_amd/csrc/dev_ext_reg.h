@@ -61,6 +61,19 @@ __device__ __forceinline__ uint32_t dpp_incl_umax_scan(uint32_t v)
     v = dpp_umax_step<0x143, 0xc>(v);
     return v;
 }
+// inclusive prefix SUM over the 64 lanes, same DPP sequence (rows the row mask leaves out add the zero fill)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_step(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
+__device__ __forceinline__ int dpp_incl_add_scan(int v)
+{
+    v = dpp_add_step<0x111, 0xf>(v);
+    v = dpp_add_step<0x112, 0xf>(v);
+    v = dpp_add_step<0x114, 0xf>(v);
+    v = dpp_add_step<0x118, 0xf>(v);
+    v = dpp_add_step<0x142, 0xa>(v);
+    v = dpp_add_step<0x143, 0xc>(v);
+    return v;
+}
 __device__ __forceinline__ int dpp_shr1_z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane 0 receives 0
 
 #ifdef EXT_STATS
@@ -270,7 +283,7 @@ __device__ __forceinline__ bool diag_extend(int qlen_, QF qf, int tlen_, TF tf, 
             loss += amax - sc[k];
         }
     }
-    for (int d = 32; d >= 1; d >>= 1) loss += __shfl_xor(loss, d, WAVE);
+    loss = __builtin_amdgcn_readlane(dpp_incl_add_scan(loss), WAVE - 1);       // (DPP scans: no LDS permutes on this path)
     const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
     const int oe = oe_del < oe_ins ? oe_del : oe_ins;
     if (loss > oe - 1 || h0 <= loss) return false;
@@ -278,15 +291,13 @@ __device__ __forceinline__ bool diag_extend(int qlen_, QF qf, int tlen_, TF tf, 
     uint32_t key = 0;                                   // (S_p << 8 | 255 - p) of the best prefix above h0: the maximum is the largest S_p at its first p
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int v = sc[k];
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) { const int u = __shfl_up(v, d, WAVE); if (lane >= d) v += u; }
+        const int v = dpp_incl_add_scan(sc[k]);
         const int S = run + v;
         const int p = k * WAVE + lane;
         if (p < qlen && S > h0) { const uint32_t kk = (uint32_t)S << 8 | (uint32_t)(255 - p); key = key > kk ? key : kk; }
-        run += __shfl(v, WAVE - 1, WAVE);
+        run += __builtin_amdgcn_readlane(v, WAVE - 1);
     }
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)key, d, WAVE); key = key > u ? key : u; }
+    key = (uint32_t)__builtin_amdgcn_readlane((int)dpp_incl_umax_scan(key), WAVE - 1);
     const int idx = key ? 255 - (int)(key & 255u) : -1;
     out.score = key ? (int)(key >> 8) : h0;
     out.qle = idx + 1; out.tle = idx + 1;
@@ -888,7 +899,7 @@ __device__ __noinline__ void dev_first_job(const DevRef &R, const Chunk &ck, con
 #define FIRST_BATCH 8        // jobs per queue fetch of k_ext_first (one fetch-add on a shared address costs ~10 ns device-wide)
 template <int MAXQ>
 __global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_ext_first(DevRef R, Chunk ck, DevOpt dopt, int n, const unsigned int *first_off, unsigned int cap,
-                                                                  unsigned int *queue, const FirstJob *jobs, DReg *first)
+                                                                  unsigned int *queue, const FirstJob *jobs, DReg *first, const unsigned int *dp_list, const unsigned int *n_dp)
 {
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
@@ -896,13 +907,17 @@ __global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_ext_first(DevRef R, Chunk
     __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
     unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)first_off[n]);
     if (n_jobs > cap) n_jobs = cap;                  // (reads whose slots pass the table end are not prepared either)
+    if (dp_list) n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_dp);       // only the jobs k_first_diag left (dev_ext_lane.h)
     for (;;) {
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(queue, (unsigned int)FIRST_BATCH);
         base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_jobs) break;
         const unsigned int end = base + FIRST_BATCH < n_jobs ? base + FIRST_BATCH : n_jobs;
-        for (unsigned int job = base; job < end; ++job) dev_first_job<MAXQ>(R, ck, opt, mr, eh_h, eh_e, jobs + job, first + job, lane);
+        for (unsigned int k = base; k < end; ++k) {
+            const unsigned int job = dp_list ? (unsigned int)__builtin_amdgcn_readfirstlane((int)dp_list[k]) : k;
+            dev_first_job<MAXQ>(R, ck, opt, mr, eh_h, eh_e, jobs + job, first + job, lane);
+        }
     }
 }
 

@@ -89,7 +89,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
-    DevBuf p2mask, p2list, p2items, p2long, lane_jobs;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -114,7 +114,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -152,6 +152,7 @@ struct slx_aligner {
                                   // -1 = 1 for chunks of at most CAND_REP_AUTO_READS reads (C2 +2.6 %, C3's 16 M-read chunks -6 %: there the serial walk
                                   // of those reads hides behind the other workers, and the lane kernel extends every seed, twice what the walk extends)
     int cand_lane_seeds = 64;
+    int first_diag = 1;           // 1 = the top-seed extensions the diagonal answers run one LANE per job (k_first_diag); k_ext_first keeps the others
     int lane_narrow = 1;          // 1 = 8-bit H / E cells in k_ext_lanes when no score can reach 256 (half the LDS per wave)
     int lane_pad = 0;             // tuning: extra LDS columns per lane of k_ext_lanes (lowers its occupancy)
     int cand_mode = 1;            // 1 = every seed of a heavy read's kept chains is extended ahead of time, a few seeds per wave (k_extend_cand)
@@ -660,6 +661,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
     else if (!strcmp(key, "cand_lanes")) { if (value < -1 || value > 1) return SLX_EINVAL; al->cand_lanes = (int)value; }
+    else if (!strcmp(key, "first_diag")) al->first_diag = value != 0;
     else if (!strcmp(key, "lane_narrow")) al->lane_narrow = value != 0;
     else if (!strcmp(key, "lane_pad")) al->lane_pad = (int)value;
     else if (!strcmp(key, "cand_lane_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_lane_seeds = (int)value; }
@@ -1178,12 +1180,17 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
                 HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->first_cnt.as<unsigned int>(), wk->first_off.as<unsigned int>(), n + 1, st));
                 const int gf = al->n_cu * 32;
                 ENS(first_jobs, (size_t)top_cap * sizeof(FirstJob));
+                if (al->first_diag) ENS(first_dp, (size_t)top_cap * 4);
                 hipLaunchKernelGGL(k_first_prep, dim3(std::max(1, std::min(n / 128 + 1, al->n_cu * 12))), dim3(128), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(),
                                    top_cap, wk->first_jobs.as<FirstJob>());
                 with_maxq(max_len, [&](auto mq) {
                     constexpr int MAXQ = decltype(mq)::value;
+                    if (al->first_diag) {   // what the diagonal answers, one lane per job; k_ext_first keeps the jobs that need the dynamic program
+                        hipLaunchKernelGGL(k_first_diag, dim3((top_cap + 255) / 256), dim3(256), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), top_cap,
+                                           wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>(), wk->first_dp.as<unsigned int>(), q + 40);
+                    }
                     hipLaunchKernelGGL(k_ext_first<MAXQ>, dim3(gf), dim3(64), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(), top_cap, q + 22,
-                                       wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>());
+                                       wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>(), al->first_diag ? wk->first_dp.as<unsigned int>() : (const unsigned int *)nullptr, q + 40);
 #ifdef EXT_STATS
                     ext_stats_print(st, "cand + ext_first", n, wk->first_off.as<unsigned int>() + n);
 #endif

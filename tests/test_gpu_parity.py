@@ -82,7 +82,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         al.set("coop_lim1", lim1)
         al.set("coop_lim2", lim2)
         assert_same(al.alignSequences(seqs), exp, "coop_lim1=%d coop_lim2=%d" % (lim1, lim2))
-    for knob, val in (("cand_lanes", 0), ("cand_lanes", 1), ("lane_narrow", 0), ("cand_lane_seeds", 1), ("top_heavy", 0), ("top_reuse", 0), ("seed_free_cus", 4), ("stream_prio", 1), ("cand_mode", 0), ("cand_cap", 7), ("cand_cap", 1 << 20), ("heavy_sorted", 0), ("cand_top", 0), ("cand_rep", 0), ("cand_rep", 101), ("cand_rep_max", 0)):
+    for knob, val in (("cand_lanes", 0), ("cand_lanes", 1), ("first_diag", 0), ("lane_narrow", 0), ("cand_lane_seeds", 1), ("top_heavy", 0), ("top_reuse", 0), ("seed_free_cus", 4), ("stream_prio", 1), ("cand_mode", 0), ("cand_cap", 7), ("cand_cap", 1 << 20), ("heavy_sorted", 0), ("cand_top", 0), ("cand_rep", 0), ("cand_rep", 101), ("cand_rep_max", 0)):
         al = sl.BWAAligner(tiny_gpu)
         al.set("split_min", 16)
         al.set("heavy_seeds", 3)
