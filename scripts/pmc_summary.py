@@ -65,7 +65,7 @@ seed12_p2 = ([k for k in pick("k_seed12") if ", 2>" in k] or [None])[0]
 seed_all = pick("k_seed")                     # k_seed12m, k_seed3m, k_seed_epi
 fetch = sum(g(k, "FETCH_SIZE") for k in seed_all) * 1024.0 / reads
 write = sum(g(k, "WRITE_SIZE") for k in seed_all) * 1024.0 / reads
-ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep")]
+ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep", "k_first_diag", "k_ext_lanes", "k_cand_lane_prep")]
 ext_inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ext)
 ext_gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ext)
 res = {
