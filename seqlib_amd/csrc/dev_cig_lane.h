@@ -1,0 +1,183 @@
+// dev_cig_lane.h -- CIGARs that need the dynamic program (mem_reg2aln -> bwa_gen_cigar2 -> ksw_global2 + traceback,
+// /root/reference/src/BWAAligner.cpp:117-129), ONE LANE PER JOB.
+//
+// k_cig_dp gives a job a wave: 150 rows of ~180 instructions of which a band of 7-23 cells uses a third of the lanes, 19 ms per 8.3 M
+// reads for 0.42 M jobs.  The jobs are independent, so here a wave takes 64 of them and every lane runs ksw_global2's scalar loops on its
+// own (the statements of dev_ksw_global2, dev_fin.h): the H/E row of a lane sits in LDS, cell j at word j * 64 + lane, as two 16-bit
+// values.  16 bits are enough because ksw_global2's "minus infinity" only has to stay below every score a real path can have: unreachable
+// cells hold something <= LANE_NEG + (a read's worth of match scores), reachable ones stay above -LANE_FIN_LIMIT (host check on the scores),
+// every comparison between a reachable and an unreachable value comes out as in 32 bits, and the comparisons among unreachable values
+// decide nothing that is read: the traceback walks reachable cells only, and a reachable cell's chosen predecessor is reachable.
+// The direction bytes go to the traceback arena (one allocation per wave and band width), the traceback, NM and the hit are the lane's own.
+// Jobs whose first band is wide (2 w + 1 > LANE_CIG_BAND) or whose read is long stay on k_cig_dp.
+#pragma once
+#include "dev_seed4.h"
+#include "dev_fin2.h"
+
+#define LANE_NEG (-16000)
+#define LANE_FIN_LIMIT 8000       // (lq + rlen) x the largest penalty + the gap opens must stay below this (host check)
+#define LANE_CIG_BAND 33          // jobs with a first band of at most this many columns (w <= 16)
+#define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases: 160 LDS words per lane
+
+// dev_ksw_global2 with the row in LDS: row[j * WAVE] = (uint16)h | (uint16)e << 16
+template <typename QF, typename TF>
+__device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, uint32_t *row)
+{
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    auto pack = [](int h, int e) { h = h > LANE_NEG ? h : LANE_NEG; e = e > LANE_NEG ? e : LANE_NEG; return (uint32_t)(uint16_t)(int16_t)h | (uint32_t)(uint16_t)(int16_t)e << 16; };
+    auto h_of = [](uint32_t v) { return (int)(int16_t)(uint16_t)(v & 0xffffu); };
+    auto e_of = [](uint32_t v) { return (int)(int16_t)(uint16_t)(v >> 16); };
+    int i, j;
+    row[0] = pack(0, LANE_NEG);
+    for (j = 1; j <= qlen && j <= w; ++j) row[j * WAVE] = pack(-(o_ins + e_ins * j), LANE_NEG);
+    for (; j <= qlen; ++j) row[j * WAVE] = pack(LANE_NEG, LANE_NEG);
+    for (i = 0; i < tlen; ++i) {
+        int f = LANE_NEG, h1, beg, end, t;
+        const int tb = tf(i);
+        const uint32_t rowp = tb == 0 ? mr.packed[0] : tb == 1 ? mr.packed[1] : tb == 2 ? mr.packed[2] : tb == 3 ? mr.packed[3] : mr.packed[4];
+        const int row4 = tb == 0 ? mr.q4[0] : tb == 1 ? mr.q4[1] : tb == 2 ? mr.q4[2] : tb == 3 ? mr.q4[3] : mr.q4[4];
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : LANE_NEG;
+        uint8_t *zi = z + (size_t)i * n_col;
+        uint32_t cur = beg < end ? row[beg * WAVE] : 0u;
+        for (j = beg; j < end; ++j) {
+            const uint32_t nxt = row[(j + 1) * WAVE];
+            int h, m = h_of(cur), e = e_of(cur);
+            uint8_t d;
+            const int q = qf(j);
+            m += q < 4 ? __builtin_amdgcn_sbfe((int)rowp, (uint32_t)q << 3, 8u) : row4;
+            d = m >= e ? 0 : 1;
+            h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            const int hl = h1;
+            h1 = h;
+            t = m - oe_del;
+            e -= e_del;
+            d |= e > t ? 1 << 2 : 0;
+            e = e > t ? e : t;
+            row[j * WAVE] = pack(hl, e);
+            t = m - oe_ins;
+            f -= e_ins;
+            d |= f > t ? 2 << 4 : 0;
+            f = f > t ? f : t;
+            f = f > LANE_NEG ? f : LANE_NEG;          // (an unreachable F stays at the floor instead of drifting down)
+            zi[j - beg] = d;
+            cur = nxt;
+        }
+        row[end * WAVE] = pack(h1, LANE_NEG);
+    }
+    return h_of(row[qlen * WAVE]);
+}
+
+// what a lane needs from its wave: `bytes` (0 for lanes that need nothing) of the traceback arena / words of the CIGAR pool, one atomic per wave.
+// Called by all 64 lanes.
+__device__ __forceinline__ unsigned long long lane_wave_alloc(unsigned long long *ctr, unsigned long long bytes, int lane)
+{
+    unsigned long long incl = bytes;
+    for (int d = 1; d < WAVE; d <<= 1) { const unsigned long long u = __shfl_up(incl, d, WAVE); if (lane >= d) incl += u; }
+    const unsigned long long total = __shfl(incl, WAVE - 1, WAVE);
+    unsigned long long base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(ctr, total);
+        base = __shfl(base, 0, WAVE);
+    }
+    return base + incl - bytes;
+}
+
+__global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const uint32_t *lane_list, const unsigned int *n_lane, unsigned int *queue)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(opt.mat);
+    __shared__ uint32_t rows[(LANE_CIG_MAXQ + 2) * WAVE];
+    uint32_t *row = rows + lane;
+    const unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_lane);
+    for (;;) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(queue, (unsigned int)WAVE);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_jobs) break;
+        const bool live = base + (unsigned int)lane < n_jobs;
+        const uint32_t slot = live ? lane_list[base + lane] : 0u;
+        DJob j; j.rb = j.re = 0; j.qb = j.qe = 0; j.w2 = 0; j.truesc = 0; j.r = 0; j.pad = 0;
+        DHit h; h.pos = 0; h.rid = -1; h.flag = 0; h.mapq = 0; h.score = 0; h.nm = -1; h.n_cigar = 0; h.cig_start = 0;
+        if (live) { j = fl.jobs[slot]; h = ck.hits[slot]; }
+        const uint64_t q_off = live ? ck.offs[j.r] : 0;
+        const int l_query = live ? (int)(ck.offs[j.r + 1] - q_off) : 0;
+        const int lq = j.qe - j.qb;
+        const int64_t rb = j.rb, re = j.re;
+        const bool valid = live && !(lq <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac));
+        const int rlen = (int)(re - rb);
+        const bool rev = rb >= R.l_pac;
+        QWin qw; qw.bits = 0; qw.chunk = 0xffffffffu;
+        RWin rw; rw.bits = 0; rw.chunk = -1;
+        const uint64_t qa = q_off + (uint64_t)j.qb;
+        auto qf = [&](int x) { return q_at(ck.codes, rev ? qa + (uint64_t)(lq - 1 - x) : qa + (uint64_t)x, qw); };
+        auto tf = [&](int y) { return text_at(R, rev ? re - 1 - y : rb + y, rw); };
+        // bwa_gen_cigar2 inside mem_reg2aln's do/while: up to three band widths; the wave walks the three trips together
+        int w2 = j.w2, score = 0, last_sc = -(1 << 30), w_used = 0, n_col = 0;
+        uint8_t *z = nullptr;
+        bool going = valid, failed = false;
+        for (int it = 0; it < 3; ++it) {
+            if (!__any(going)) break;
+            unsigned long long need = 0;
+            int ww = 0;
+            if (going) {
+                w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+                int max_gap, max_ins, max_del, min_w;
+                max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+                max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+                max_gap = max_ins > max_del ? max_ins : max_del;
+                max_gap = max_gap > 1 ? max_gap : 1;
+                const int dl = rlen - lq < 0 ? lq - rlen : rlen - lq;
+                ww = (max_gap + dl + 1) >> 1;
+                ww = ww < w2 ? ww : w2;
+                min_w = dl + 3;
+                ww = ww > min_w ? ww : min_w;
+                w_used = ww;
+                n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
+                need = (unsigned long long)n_col * (unsigned long long)rlen;
+            }
+            const unsigned long long off = lane_wave_alloc(ck.zused, need, lane);
+            if (going) {
+                if (off + need > ck.zcap) { atomicOr(ck.flags, OVF_ZARENA); going = false; failed = true; }
+                else {
+                    z = ck.zarena + off;
+                    score = lane_ksw_global2(lq, qf, rlen, tf, opt, mr, ww, z, n_col, row);
+                    // mem_reg2aln: `if (score == last_sc || w2 == opt->w<<2) break; last_sc = score; w2 <<= 1;` then `while (++i < 3 && score < truesc - a)`
+                    if (score == last_sc || w2 == opt.w << 2) going = false;
+                    else { last_sc = score; w2 <<= 1; if (!(score < j.truesc - opt.a)) going = false; }
+                }
+            }
+        }
+        // CIGAR words: count, reserve (one atomic per wave), write
+        int n_ops = 0;
+        const bool emit = live && !failed;
+        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int, int) { ++n_ops; });
+        const unsigned long long cneed = emit ? (unsigned long long)n_ops + 2 : 0ull;
+        const unsigned long long cbase = lane_wave_alloc(ck.cigused, cneed, lane);
+        if (!emit) continue;
+        if (cbase + cneed > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
+        uint32_t *cg = ck.cigpool + cbase + 1;
+        if (valid) {
+            int wp = n_ops;
+            dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });
+            // NM = mismatches in M + inserted + deleted bases (a D that is the first or last op is not counted)
+            int x = 0, y = 0, n_mm = 0, n_gap = 0;
+            for (int k = 0; k < n_ops; ++k) {
+                const int op = (int)(cg[k] & 0xf), len = (int)(cg[k] >> 4);
+                if (op == 0) {
+                    for (int u = 0; u < len; ++u) n_mm += qf(x + u) != tf(y + u);
+                    x += len; y += len;
+                } else if (op == 2) { if (k > 0 && k < n_ops - 1) n_gap += len; y += len; }
+                else if (op == 1) { x += len; n_gap += len; }
+            }
+            h.nm = n_mm + n_gap;
+        }
+        dev_finish_hit(R, ck, j, l_query, h, (int64_t)cbase + 1, n_ops);
+        ck.hits[slot] = h;
+    }
+}

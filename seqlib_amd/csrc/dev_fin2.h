@@ -24,6 +24,8 @@ struct FinLists {
     DJob *jobs;               // per seed slot, parallel to Chunk::hits
     uint32_t *fast_list, *dp_list;
     unsigned int *n_fast, *n_dp, *q_dp;
+    uint32_t *lane_list;      // DP jobs with a narrow first band and a short query: one lane per job (k_cig_lanes, dev_cig_lane.h); null = none
+    unsigned int *n_lane;
 };
 
 // ---------------------------------------------------------------- wave-cooperative ksw_global2
@@ -263,7 +265,21 @@ __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt
     const int wc = w2 < opt.w << 2 ? w2 : opt.w << 2;
     const bool fast = (qe - qb) == (int)(re - rb) && wc == 0;
     if (leader) {
+        bool lanes = false;
+        if (!fast && fl.lane_list && qe - qb <= 158) {        // (LANE_CIG_MAXQ) the band bwa_gen_cigar2 starts with: at most LANE_CIG_BAND columns?
+            const int lq = qe - qb, rlen = (int)(re - rb);
+            const int max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            const int max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = rlen - lq < 0 ? lq - rlen : rlen - lq;
+            int ww = (max_gap + dl + 1) >> 1;
+            ww = ww < wc ? ww : wc;
+            ww = ww > dl + 3 ? ww : dl + 3;
+            lanes = 2 * ww + 1 <= 33 && lq > 0 && rlen > 0 && rlen <= 400;
+        }
         if (fast) fl.fast_list[wave_fetch_inc(fl.n_fast)] = (uint32_t)slot;
+        else if (lanes) fl.lane_list[wave_fetch_inc(fl.n_lane)] = (uint32_t)slot;
         else fl.dp_list[wave_fetch_inc(fl.n_dp)] = (uint32_t)slot;
     }
     return true;

@@ -28,6 +28,7 @@
 #include "dev_fin2.h"
 #include "dev_chain_coop.h"
 #include "dev_long.h"
+#include "dev_cig_lane.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -89,7 +90,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
-    DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -114,7 +115,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -152,6 +153,7 @@ struct slx_aligner {
                                   // -1 = 1 for chunks of at most CAND_REP_AUTO_READS reads (C2 +2.6 %, C3's 16 M-read chunks -6 %: there the serial walk
                                   // of those reads hides behind the other workers, and the lane kernel extends every seed, twice what the walk extends)
     int cand_lane_seeds = 64;
+    int cig_lanes = 1;            // 1 = CIGAR jobs with a narrow band run one lane per job (k_cig_lanes); k_cig_dp keeps the wide ones
     int first_diag = 1;           // 1 = the top-seed extensions the diagonal answers run one LANE per job (k_first_diag); k_ext_first keeps the others
     int lane_narrow = 1;          // 1 = 8-bit H / E cells in k_ext_lanes when no score can reach 256 (half the LDS per wave)
     int lane_pad = 0;             // tuning: extra LDS columns per lane of k_ext_lanes (lowers its occupancy)
@@ -661,6 +663,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
     else if (!strcmp(key, "cand_lanes")) { if (value < -1 || value > 1) return SLX_EINVAL; al->cand_lanes = (int)value; }
+    else if (!strcmp(key, "cig_lanes")) al->cig_lanes = value != 0;
     else if (!strcmp(key, "first_diag")) al->first_diag = value != 0;
     else if (!strcmp(key, "lane_narrow")) al->lane_narrow = value != 0;
     else if (!strcmp(key, "lane_pad")) al->lane_pad = (int)value;
@@ -842,6 +845,15 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     fl.fast_list = wk->fast_list.as<uint32_t>();
     fl.dp_list = wk->dp_list.as<uint32_t>();
     fl.n_fast = q + 4; fl.n_dp = q + 5; fl.q_dp = q + 6;
+    // DP jobs with a narrow band one lane per job (k_cig_lanes): 16-bit rows need small scores
+    bool cig_lanes = al->cig_lanes && MAXQ <= 704;
+    {
+        int pen = std::max(std::max(dopt.o.e_del, dopt.o.e_ins), 1), amax = 0;
+        for (int i = 0; i < 25; ++i) { pen = std::max(pen, -(int)dopt.o.mat[i]); amax = std::max(amax, (int)dopt.o.mat[i]); }
+        if ((int64_t)(LANE_CIG_MAXQ + 400) * pen + dopt.o.o_del + dopt.o.o_ins >= LANE_FIN_LIMIT || (int64_t)amax * LANE_CIG_MAXQ >= LANE_FIN_LIMIT ||
+            dopt.o.o_del < 0 || dopt.o.o_ins < 0 || dopt.o.e_del < 1 || dopt.o.e_ins < 1) cig_lanes = false;
+    }
+    fl.lane_list = cig_lanes ? wk->cig_lane_list.as<uint32_t>() : nullptr; fl.n_lane = q + 42;
     // reads with <= 1 region: straight-line kernel; the rest: many regions (low-complexity tracts) first, one wave each with the sorts
     // staged in LDS, the others one per lane.  order_in / order_out are free again after chaining + extension.
     unsigned int *cnt2 = q + 32;
@@ -868,6 +880,7 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     (void)hipEventRecord(wk->ev_probe[4], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
     if constexpr (MAXQ <= 704) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
+    if (cig_lanes) hipLaunchKernelGGL(k_cig_lanes, dim3(al->n_cu * 4), dim3(64), 0, st, al->ref, ck, dopt, fl, wk->cig_lane_list.as<uint32_t>(), q + 42, q + 43);
     else hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl);
     (void)hipEventRecord(wk->ev_probe[5], st);
     if (dbg_on) (void)hipEventRecord(dbg[4], st);
@@ -1049,7 +1062,7 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     ENS(s_rbeg, S1 * 8); ENS(s_ql, S1 * 4); ENS(s_next, S1 * 4); ENS(c_pos, S1 * 8); ENS(c_head, S1 * 4); ENS(c_tail, S1 * 4);
     ENS(c_n, S1 * 4); ENS(c_rid, S1 * 4); ENS(c_w, S1 * 4); ENS(c_first, S1 * 4); ENS(c_kept, S1); ENS(ia, S1 * 4); ENS(ib, S1 * 4);
     ENS(ic, S1 * 4); ENS(srt, S1 * 8); ENS(regs, S1 * sizeof(DReg)); ENS(hits, S1 * sizeof(DHit));
-    ENS(jobs, S1 * sizeof(DJob)); ENS(fast_list, S1 * 4); ENS(dp_list, S1 * 4);
+    ENS(jobs, S1 * sizeof(DJob)); ENS(fast_list, S1 * 4); ENS(dp_list, S1 * 4); ENS(cig_lane_list, S1 * 4);
     ck.s_rbeg = wk->s_rbeg.as<int64_t>(); ck.s_ql = wk->s_ql.as<uint32_t>(); ck.s_next = wk->s_next.as<int32_t>();
     ck.c_pos = wk->c_pos.as<int64_t>(); ck.c_head = wk->c_head.as<int32_t>(); ck.c_tail = wk->c_tail.as<int32_t>();
     ck.c_n = wk->c_n.as<int32_t>(); ck.c_rid = wk->c_rid.as<int32_t>(); ck.c_w = wk->c_w.as<int32_t>();

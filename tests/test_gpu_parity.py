@@ -91,7 +91,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
         assert_same(al.alignSequences(seqs), exp, "%s=%d" % (knob, val))
 
 
-@pytest.mark.parametrize("knob,val", [("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
+@pytest.mark.parametrize("knob,val", [("cig_lanes", 0), ("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
                                       ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("ext_split", 0), ("wide_index", 1),
                                       ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
