@@ -19,6 +19,7 @@
 #define LANE_CIG_BAND 33          // jobs with a first band of at most this many columns (w <= 16)
 #define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases: 160 LDS words per lane
 
+typedef uint32_t __attribute__((aligned(1))) z32u;
 // dev_ksw_global2 with the row in LDS: row[j * WAVE] = (uint16)h | (uint16)e << 16
 template <typename QF, typename TF>
 __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, uint32_t *row)
@@ -41,6 +42,7 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         end = i + w + 1 < qlen ? i + w + 1 : qlen;
         h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : LANE_NEG;
         uint8_t *zi = z + (size_t)i * n_col;
+        uint32_t zacc = 0;                                  // four direction bytes per store (the arena stretch of a job is padded by 4 bytes)
         uint32_t cur = beg < end ? row[beg * WAVE] : 0u;
         for (j = beg; j < end; ++j) {
             const uint32_t nxt = row[(j + 1) * WAVE];
@@ -64,9 +66,12 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             d |= f > t ? 2 << 4 : 0;
             f = f > t ? f : t;
             f = f > LANE_NEG ? f : LANE_NEG;          // (an unreachable F stays at the floor instead of drifting down)
-            zi[j - beg] = d;
+            const int zk = (j - beg) & 3;
+            zacc |= (uint32_t)d << (zk * 8);
+            if (zk == 3) { *(z32u *)(zi + (j - beg - 3)) = zacc; zacc = 0; }
             cur = nxt;
         }
+        if (end > beg && ((end - beg) & 3)) *(z32u *)(zi + ((end - beg) & ~3)) = zacc;     // (the bytes past the row's end are the next row's, written later)
         row[end * WAVE] = pack(h1, LANE_NEG);
     }
     return h_of(row[qlen * WAVE]);
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
                 ww = ww > min_w ? ww : min_w;
                 w_used = ww;
                 n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
-                need = (unsigned long long)n_col * (unsigned long long)rlen;
+                need = (unsigned long long)n_col * (unsigned long long)rlen + 4;
             }
             const unsigned long long off = lane_wave_alloc(ck.zused, need, lane);
             if (going) {
@@ -154,17 +159,19 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
             }
         }
         // CIGAR words: count, reserve (one atomic per wave), write
+        // one traceback: the ops (end of the alignment first) wait in the lane's LDS row, free now, until the words are reserved
         int n_ops = 0;
         const bool emit = live && !failed;
-        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int, int) { ++n_ops; });
+        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { if (n_ops < LANE_CIG_MAXQ + 2) row[n_ops * WAVE] = (uint32_t)len << 4 | (uint32_t)op; ++n_ops; });
+        const bool ops_in_lds = n_ops <= LANE_CIG_MAXQ + 2;
         const unsigned long long cneed = emit ? (unsigned long long)n_ops + 2 : 0ull;
         const unsigned long long cbase = lane_wave_alloc(ck.cigused, cneed, lane);
         if (!emit) continue;
         if (cbase + cneed > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
         uint32_t *cg = ck.cigpool + cbase + 1;
         if (valid) {
-            int wp = n_ops;
-            dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });
+            if (ops_in_lds) for (int k = 0; k < n_ops; ++k) cg[k] = row[(n_ops - 1 - k) * WAVE];
+            else { int wp = n_ops; dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; }); }
             // NM = mismatches in M + inserted + deleted bases (a D that is the first or last op is not counted)
             int x = 0, y = 0, n_mm = 0, n_gap = 0;
             for (int k = 0; k < n_ops; ++k) {
