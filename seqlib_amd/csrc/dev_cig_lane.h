@@ -126,7 +126,9 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
         int w2 = j.w2, score = 0, last_sc = -(1 << 30), w_used = 0, n_col = 0;
         uint8_t *z = nullptr;
         bool going = valid, failed = false;
-        for (int it = 0; it < 3; ++it) {
+        // (the lanes of a wave run in lock step: a job that asks for a second, wider band -- twice the cells, then four times -- would hold the
+        // other 63 up, so it is handed to k_cig_dp, which runs after this kernel and starts it over)
+        for (int it = 0; it < 1; ++it) {
             if (!__any(going)) break;
             unsigned long long need = 0;
             int ww = 0;
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
             }
         }
         // CIGAR words: count, reserve (one atomic per wave), write
+        if (going) { fl.dp_list[wave_fetch_inc(fl.n_dp)] = slot; failed = true; }      // not settled by its first band: k_cig_dp's
         // one traceback: the ops (end of the alignment first) wait in the lane's LDS row, free now, until the words are reserved
         int n_ops = 0;
         const bool emit = live && !failed;
