@@ -369,7 +369,7 @@ def main():
             if cells > 0 and ext_ms + cig_ms > 0:
                 ops = 14.0 * cells * n
                 ach = ops / ((ext_ms + cig_ms) * 1e-3)
-                roof_ext = dict(bound="valu", kernel="extension family (k_extend_cand | k_ext_lanes, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg) + k_cig_fast/k_cig_dp",
+                roof_ext = dict(bound="valu", kernel="extension family (k_extend_cand | k_ext_lanes, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg) + k_cig_fast/k_cig_lanes/k_cig_dp",
                                 cells_per_read=cells, ext_cells_per_read=per_read.get("ext_cells"), glb_cells_per_read=per_read.get("glb_cells"), ops_per_cell=14,
                                 kernel_ms=ext_ms + cig_ms, extend_ms=ext_ms, cigar_ms=cig_ms, achieved=ach / 1e12, peak=VALU_PEAK_LANE_OPS / 1e12,
                                 unit="T int32 lane-op/s", frac=ach / VALU_PEAK_LANE_OPS,

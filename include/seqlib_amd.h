@@ -125,6 +125,7 @@ void slx_aligner_free(slx_aligner *al);
  *   "cand_lanes" -1|0|1 (-1)  ahead-of-time extension of the heavy reads one LANE per seed (k_ext_lanes: 64 ksw_extend2 per wave, H/E rows in LDS) for every heavy
  *                             read with >= "cand_lane_seeds" (64) seed slots; 0 = one wave per four seeds for the reads cand_top / cand_rep select; -1 = on for
  *                             chunks of at most 5 M reads
+ *   "cig_lanes" 0|1 (1)       CIGAR jobs with a narrow band (<= 33 columns, query <= 158 bases) run one lane per job (k_cig_lanes); k_cig_dp keeps the others
  *   "first_diag" 0|1 (1)      the top-seed extensions that the diagonal answers run one lane per job (k_first_diag); k_ext_first keeps the dynamic program
  *   "lane_narrow" 0|1 (1)     k_ext_lanes keeps 8-bit H / E cells when no score can reach 256
  *   "p2_coop" 0|1 (1)         seeding pass 2: re-seeding calls inside repeats one wave per call (k_seed2_coop); needs p2_items
@@ -205,7 +206,7 @@ int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
 const char *slx_stage_name(int i);
 /* kernel groups of the last batch: duration summed over the workers' launches, from HIP events recorded on the worker's own
  * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m<1>, k_seed2_select, k_seed12m<2>, k_seed2_coop, k_seed3m, k_seed_epi), [1] the extension
- * family (k_extend_cand | k_cand_lane_prep + k_ext_lanes, k_first_prep, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_dp) */
+ * family (k_extend_cand | k_cand_lane_prep + k_ext_lanes, k_first_prep, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_lanes + k_cig_dp) */
 #define SLX_N_PROBES 3
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
 /* how many launches of each of those groups the sums cover (= chunks of the last batch over all workers and devices) */
