@@ -17,22 +17,28 @@
 #define LANE_NEG (-16000)
 #define LANE_FIN_LIMIT 8000       // (lq + rlen) x the largest penalty + the gap opens must stay below this (host check)
 #define LANE_CIG_BAND 33          // jobs with a first band of at most this many columns (w <= 16)
-#define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases: 160 LDS words per lane
+#define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases
+#define LANE_CIG_SLOTS 34         // LDS words per lane: the band (2 w + 2 columns for w <= 16)
 
 typedef uint32_t __attribute__((aligned(1))) z32u;
-// dev_ksw_global2 with the row in LDS: row[j * WAVE] = (uint16)h | (uint16)e << 16
+// dev_ksw_global2 with the row in LDS: (uint16)h | (uint16)e << 16 per column, and only the band of it: row i touches the columns
+// [i - w, i + w + 1], every column it reads was written by row i - 1 (in its loop or as its eh[end]) or, in row 0, by the initialisation,
+// so column j can live at slot j mod P for any P >= 2 w + 2 -- 34 words per lane for the bands this kernel takes instead of qlen + 1.
 template <typename QF, typename TF>
 __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, uint32_t *row)
 {
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int P = 2 * w + 2;
     auto pack = [](int h, int e) { h = h > LANE_NEG ? h : LANE_NEG; e = e > LANE_NEG ? e : LANE_NEG; return (uint32_t)(uint16_t)(int16_t)h | (uint32_t)(uint16_t)(int16_t)e << 16; };
     auto h_of = [](uint32_t v) { return (int)(int16_t)(uint16_t)(v & 0xffffu); };
     auto e_of = [](uint32_t v) { return (int)(int16_t)(uint16_t)(v >> 16); };
     int i, j;
+    // row -1, the columns row 0 can read: 0 .. w + 1 (slot = column: w + 1 < P)
     row[0] = pack(0, LANE_NEG);
     for (j = 1; j <= qlen && j <= w; ++j) row[j * WAVE] = pack(-(o_ins + e_ins * j), LANE_NEG);
-    for (; j <= qlen; ++j) row[j * WAVE] = pack(LANE_NEG, LANE_NEG);
+    for (; j <= qlen && j <= w + 1; ++j) row[j * WAVE] = pack(LANE_NEG, LANE_NEG);
+    int sbeg = 0;                                           // slot of column beg
     for (i = 0; i < tlen; ++i) {
         int f = LANE_NEG, h1, beg, end, t;
         const int tb = tf(i);
@@ -40,12 +46,15 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         const int row4 = tb == 0 ? mr.q4[0] : tb == 1 ? mr.q4[1] : tb == 2 ? mr.q4[2] : tb == 3 ? mr.q4[3] : mr.q4[4];
         beg = i > w ? i - w : 0;
         end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        if (i > w) { ++sbeg; if (sbeg == P) sbeg = 0; }     // (beg moved one column to the right)
         h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : LANE_NEG;
         uint8_t *zi = z + (size_t)i * n_col;
         uint32_t zacc = 0;                                  // four direction bytes per store (the arena stretch of a job is padded by 4 bytes)
-        uint32_t cur = beg < end ? row[beg * WAVE] : 0u;
+        int sj = sbeg;                                      // slot of column j
+        uint32_t cur = beg < end ? row[sj * WAVE] : 0u;
         for (j = beg; j < end; ++j) {
-            const uint32_t nxt = row[(j + 1) * WAVE];
+            const int sn = sj + 1 == P ? 0 : sj + 1;
+            const uint32_t nxt = row[sn * WAVE];
             int h, m = h_of(cur), e = e_of(cur);
             uint8_t d;
             const int q = qf(j);
@@ -60,7 +69,7 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             e -= e_del;
             d |= e > t ? 1 << 2 : 0;
             e = e > t ? e : t;
-            row[j * WAVE] = pack(hl, e);
+            row[sj * WAVE] = pack(hl, e);
             t = m - oe_ins;
             f -= e_ins;
             d |= f > t ? 2 << 4 : 0;
@@ -70,11 +79,15 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             zacc |= (uint32_t)d << (zk * 8);
             if (zk == 3) { *(z32u *)(zi + (j - beg - 3)) = zacc; zacc = 0; }
             cur = nxt;
+            sj = sn;
         }
         if (end > beg && ((end - beg) & 3)) *(z32u *)(zi + ((end - beg) & ~3)) = zacc;     // (the bytes past the row's end are the next row's, written later)
-        row[end * WAVE] = pack(h1, LANE_NEG);
+        if (beg >= end) { sj = sbeg + (end - beg); sj = sj < 0 ? sj + P : sj; }             // (an empty row: column end lies left of beg)
+        row[sj * WAVE] = pack(h1, LANE_NEG);               // eh[end]
     }
-    return h_of(row[qlen * WAVE]);
+    // eh_h[qlen]: written by the last row as its eh[end] (tlen + w >= qlen: the band covers the length difference)
+    int sq = qlen % P;
+    return h_of(row[sq * WAVE]);
 }
 
 // what a lane needs from its wave: `bytes` (0 for lanes that need nothing) of the traceback arena / words of the CIGAR pool, one atomic per wave.
@@ -97,7 +110,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
-    __shared__ uint32_t rows[(LANE_CIG_MAXQ + 2) * WAVE];
+    __shared__ uint32_t rows[LANE_CIG_SLOTS * WAVE];
     uint32_t *row = rows + lane;
     const unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_lane);
     for (;;) {
@@ -125,7 +138,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
         // bwa_gen_cigar2 inside mem_reg2aln's do/while: up to three band widths; the wave walks the three trips together
         int w2 = j.w2, score = 0, last_sc = -(1 << 30), w_used = 0, n_col = 0;
         uint8_t *z = nullptr;
-        bool going = valid, failed = false;
+        bool going = valid, failed = false, wide = false;
         // (the lanes of a wave run in lock step: a job that asks for a second, wider band -- twice the cells, then four times -- would hold the
         // other 63 up, so it is handed to k_cig_dp, which runs after this kernel and starts it over)
         for (int it = 0; it < 1; ++it) {
@@ -147,6 +160,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
                 w_used = ww;
                 n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
                 need = (unsigned long long)n_col * (unsigned long long)rlen + 4;
+                if (2 * ww + 2 > LANE_CIG_SLOTS) { need = 0; going = false; wide = true; }     // (cannot happen: the routing in dev_reg_emit computes the same band)
             }
             const unsigned long long off = lane_wave_alloc(ck.zused, need, lane);
             if (going) {
@@ -161,12 +175,12 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
             }
         }
         // CIGAR words: count, reserve (one atomic per wave), write
-        if (going) { fl.dp_list[wave_fetch_inc(fl.n_dp)] = slot; failed = true; }      // not settled by its first band: k_cig_dp's
+        if (going || wide) { fl.dp_list[wave_fetch_inc(fl.n_dp)] = slot; failed = true; }      // not settled by its first band: k_cig_dp's
         // one traceback: the ops (end of the alignment first) wait in the lane's LDS row, free now, until the words are reserved
         int n_ops = 0;
         const bool emit = live && !failed;
-        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { if (n_ops < LANE_CIG_MAXQ + 2) row[n_ops * WAVE] = (uint32_t)len << 4 | (uint32_t)op; ++n_ops; });
-        const bool ops_in_lds = n_ops <= LANE_CIG_MAXQ + 2;
+        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { if (n_ops < LANE_CIG_SLOTS) row[n_ops * WAVE] = (uint32_t)len << 4 | (uint32_t)op; ++n_ops; });
+        const bool ops_in_lds = n_ops <= LANE_CIG_SLOTS;
         const unsigned long long cneed = emit ? (unsigned long long)n_ops + 2 : 0ull;
         const unsigned long long cbase = lane_wave_alloc(ck.cigused, cneed, lane);
         if (!emit) continue;

@@ -879,7 +879,7 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     if (dbg_on) (void)hipEventRecord(dbg[3], st);
     (void)hipEventRecord(wk->ev_probe[4], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
-    if (cig_lanes) hipLaunchKernelGGL(k_cig_lanes, dim3(al->n_cu * 4), dim3(64), 0, st, al->ref, ck, dopt, fl, wk->cig_lane_list.as<uint32_t>(), q + 42, q + 43);
+    if (cig_lanes) hipLaunchKernelGGL(k_cig_lanes, dim3(al->n_cu * 16), dim3(64), 0, st, al->ref, ck, dopt, fl, wk->cig_lane_list.as<uint32_t>(), q + 42, q + 43);
     if constexpr (MAXQ <= 704) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
     else hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl);
     (void)hipEventRecord(wk->ev_probe[5], st);
