@@ -10,7 +10,7 @@ resident in HBM, plus -- when N > 1 -- the single RCCL gather of the packed hits
 
 Workload at N = 1: the largest single-GPU configuration of BASELINE.json, configs[2] ("C3": chr20-sized
 64.4 Mb synthetic reference, 50 M synthetic 150 bp reads = 25 M pairs, a pair being two single-end reads
-as the API has no paired mode; the batch is aligned in chunks of 8 M reads per worker).  `--config C2`
+as the API has no paired mode; each of the three workers takes its 16.7 M reads as one chunk).  `--config C2`
 (E. coli-sized, 10 M reads), `C1` and `C4` (GRCh38-sized, u64 index) select the other configurations.
 With N ranks every rank aligns its own shard of that size (weak scaling, reads sharded by contiguous
 ordinal range, index replicated).  Rank 0 prints ONE JSON line.
