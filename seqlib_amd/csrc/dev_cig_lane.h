@@ -16,9 +16,8 @@
 
 #define LANE_NEG (-16000)
 #define LANE_FIN_LIMIT 8000       // (lq + rlen) x the largest penalty + the gap opens must stay below this (host check)
-#define LANE_CIG_BAND 33          // jobs with a first band of at most this many columns (w <= 16)
 #define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases
-#define LANE_CIG_SLOTS 34         // LDS words per lane: the band (2 w + 2 columns for w <= 16)
+#define LANE_CIG_SLOTS (LANE_CIG_BAND + 1)   // LDS words per lane: the band (2 w + 2 columns; LANE_CIG_BAND = 2 w + 1 is defined in dev_fin2.h, where the jobs are routed)
 
 typedef uint32_t __attribute__((aligned(1))) z32u;
 // dev_ksw_global2 with the row in LDS: (uint16)h | (uint16)e << 16 per column, and only the band of it: row i touches the columns

@@ -13,6 +13,9 @@
 #include "dev_fin.h"
 #include "dev_ext_reg.h"
 
+#ifndef LANE_CIG_BAND
+#define LANE_CIG_BAND 33          // CIGAR jobs whose first band has at most this many columns (w <= 16) run one lane per job (dev_cig_lane.h)
+#endif
 struct alignas(8) DJob {      // one pending bwa_gen_cigar2 sequence (mem_reg2aln's do/while)
     int64_t rb, re;
     int qb, qe;
@@ -276,7 +279,7 @@ __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt
             int ww = (max_gap + dl + 1) >> 1;
             ww = ww < wc ? ww : wc;
             ww = ww > dl + 3 ? ww : dl + 3;
-            lanes = 2 * ww + 1 <= 33 && lq > 0 && rlen > 0 && rlen <= 400;
+            lanes = 2 * ww + 1 <= LANE_CIG_BAND && lq > 0 && rlen > 0 && rlen <= 400;
         }
         if (fast) fl.fast_list[wave_fetch_inc(fl.n_fast)] = (uint32_t)slot;
         else if (lanes) fl.lane_list[wave_fetch_inc(fl.n_lane)] = (uint32_t)slot;
