@@ -1,0 +1,557 @@
+// dev_fml.h -- device side of the BFC half of the FermiAssembler window pipeline: bit-plane packing of the reads,
+// k-mer counting into per-window hash tables, the count histogram, error correction (bfc_ec1) and the unique-k-mer filter (max_streak).
+//
+// Reference behaviour: what fermi-lite's fml_correct / fml_fltuniq do for /root/reference/src/FermiAssembler.cpp:133-138 and what
+// fml_count / bfc_ch_hist / kmer_correct do for /root/reference/src/BFC.cpp:262-270,315,351 (fermi-lite is an un-vendored, empty
+// submodule of the reference: the behaviour is restated in oracle/orc_fml.c, which the parity tests compare this file with).
+//
+// Layout.  All reads of a batch of windows are one flat ASCII text in HBM.  k_fml_pack turns every 64 positions into five 64-bit
+// words -- low bit and high bit of the base code, "is N", "quality >= q", and (k_fml_starts) "first base of a read" -- with the LATER
+// position in the LOWER bit, which is how BFC holds a k-mer (last base in bit 0): the k-mer ending at any position is then a 128-bit
+// funnel shift of two neighbouring words and a mask, its reverse complement a bit reversal, its validity (no N, no read boundary
+// inside) and its "all bases high quality" flag two more masked shifts.  No per-read loop carries a rolling k-mer: one lane per
+// POSITION, every lane busy, the text read once through the planes (5 bits per base).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct FmlSlot { unsigned long long key, cnt; };      // key + 1 (0 = empty); cnt = occurrences | high-quality occurrences << 32
+
+struct FmlWin {                // per window, device-visible
+    unsigned long long tab_off;         // first slot of the window's table
+    unsigned int tab_mask;              // slots - 1 (a power of two)
+    int k, min_cov, mode;
+    long long read0, read1;             // reads [read0, read1)
+};
+
+struct FmlPlanes { const unsigned long long *p0, *p1, *pn, *pq, *ps; };      // index = block + 1 (block -1 is a guard: all N)
+
+__device__ __forceinline__ int fml_nt5(int c)
+{
+    c &= 0xdf;          // upper case
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+}
+
+__device__ __forceinline__ uint64_t fml_mix64(uint64_t h)
+{
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+    return h;
+}
+
+// the k bits of a plane that end at position p (later position = lower bit)
+__device__ __forceinline__ uint32_t fml_extract(const unsigned long long *pl, long long p, uint32_t mask)
+{
+    const long long b = p >> 6;
+    const int s = 63 - (int)(p & 63);
+    unsigned long long v = pl[b + 1] >> s;
+    if (s) v |= pl[b] << (64 - s);
+    return (uint32_t)v & mask;
+}
+
+// canonical key of a k-mer given its forward planes: bfc_kmer_hash's strand choice (the middle base decides; for odd k the strand whose
+// middle base is A or C)
+__device__ __forceinline__ unsigned long long fml_key(int k, uint32_t x0, uint32_t x1, uint32_t mask)
+{
+    const uint32_t x2 = __brev(~x0 & mask) >> (32 - k), x3 = __brev(~x1 & mask) >> (32 - k);
+    const int t = k >> 1;
+    const bool u = ((x1 >> t) & 1u) > ((x3 >> t) & 1u);
+    return u ? ((unsigned long long)x3 << 32 | x2) : ((unsigned long long)x1 << 32 | x0);
+}
+
+__device__ __forceinline__ int fml_val(unsigned long long cnt)          // the 14-bit value bfc keeps: (occurrences - 1) capped at 255 | high capped at 63
+{
+    const unsigned int lo = (unsigned int)cnt, hi = (unsigned int)(cnt >> 32);
+    return (int)((lo - 1 > 255u ? 255u : lo - 1) | (hi > 63u ? 63u : hi) << 8);
+}
+
+__device__ __forceinline__ int fml_get(const FmlSlot *tab, const FmlWin &w, unsigned long long key)          // bfc_ch_get: -1 = absent
+{
+    unsigned int i = (unsigned int)fml_mix64(key) & w.tab_mask;
+    const FmlSlot *t = tab + w.tab_off;
+    while (true) {
+        const unsigned long long kk = t[i].key;
+        if (kk == key + 1) return fml_val(t[i].cnt);
+        if (kk == 0) return -1;
+        i = (i + 1) & w.tab_mask;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ long long fml_upper(const T *a, long long n, T v)          // number of entries <= v in ascending a[0..n)
+{
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- planes
+
+static __global__ void k_fml_starts(const unsigned long long *offs, long long n_reads, unsigned long long *ps)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const unsigned long long p = offs[r];
+    if (offs[r + 1] == p) return;
+    atomicOr(&ps[(p >> 6) + 1], 1ULL << (63 - (int)(p & 63)));
+}
+
+// one wave per 64 positions: ballots ARE the planes
+static __global__ void __launch_bounds__(256) k_fml_pack(const char *bases, const char *quals, long long total, int q,
+                                                  unsigned long long *p0, unsigned long long *p1, unsigned long long *pn, unsigned long long *pq)
+{
+    const long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blk * 64 >= total) return;
+    const long long p = blk * 64 + 63 - lane;
+    int c = 4, hq = 0;
+    if (p < total) {
+        c = fml_nt5((unsigned char)bases[p]);
+        hq = quals ? ((int)(unsigned char)quals[p] - 33 >= q) : 1;
+    }
+    const unsigned long long b0 = __ballot(c < 4 && (c & 1)), b1 = __ballot(c < 4 && (c & 2)), bn = __ballot(c > 3), bq = __ballot(hq != 0);
+    if (lane == 0) { p0[blk + 1] = b0; p1[blk + 1] = b1; pn[blk + 1] = bn; pq[blk + 1] = bq; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- counting
+
+// fml_count: one lane per position = per k-mer ending there
+static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long long total, const unsigned long long *offs, long long n_reads,
+                                                   const FmlWin *wins, int n_win, FmlSlot *tab, unsigned long long *n_inserted)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = p < total;
+    unsigned long long key = 0, inc = 1;
+    FmlWin w;
+    if (ok) {
+        const long long r = fml_upper(offs, n_reads + 1, (unsigned long long)p) - 1;          // the read holding position p
+        int lo = 0, hi = n_win;          // the window holding read r
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
+        w = wins[lo];
+        const int k = w.k;
+        const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+        ok = k > 0 && fml_extract(pl.pn, p, mask) == 0 && (fml_extract(pl.ps, p, mask) & (mask >> 1)) == 0;
+        if (ok) {
+            key = fml_key(k, fml_extract(pl.p0, p, mask), fml_extract(pl.p1, p, mask), mask);
+            if (fml_extract(pl.pq, p, mask) == mask) inc |= 1ULL << 32;
+        }
+    }
+    if (ok) {
+        FmlSlot *t = tab + w.tab_off;
+        unsigned int i = (unsigned int)fml_mix64(key) & w.tab_mask;
+        while (true) {
+            unsigned long long old = t[i].key;
+            if (old == 0) old = atomicCAS(&t[i].key, 0ULL, key + 1);
+            if (old == 0 || old == key + 1) { atomicAdd(&t[i].cnt, inc); break; }
+            i = (i + 1) & w.tab_mask;
+        }
+    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inserted, (unsigned long long)__popcll(m));
+}
+
+// bfc_ch_hist: blocks of 1024 slots never straddle two windows (tables are powers of two >= 1024, laid end to end)
+static __global__ void __launch_bounds__(256) k_fml_hist(const FmlSlot *tab, unsigned long long n_slots, const FmlWin *wins, int n_win, unsigned long long *hist /* n_win x 320 */)
+{
+    __shared__ unsigned int h[320];
+    for (int i = threadIdx.x; i < 320; i += 256) h[i] = 0;
+    __syncthreads();
+    const unsigned long long base = (unsigned long long)blockIdx.x * 1024;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long s = base + j * 256 + threadIdx.x;
+        if (s < n_slots && tab[s].key) {
+            const int v = fml_val(tab[s].cnt);
+            atomicAdd(&h[v & 0xff], 1u);
+            atomicAdd(&h[256 + (v >> 8)], 1u);
+        }
+    }
+    __syncthreads();
+    int lo = 0, hi = n_win;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].tab_off <= base) lo = mid; else hi = mid; }
+    for (int i = threadIdx.x; i < 320; i += 256)
+        if (h[i]) atomicAdd(&hist[(size_t)lo * 320 + i], (unsigned long long)h[i]);
+}
+
+static __global__ void k_fml_dump(const FmlSlot *tab, FmlWin w, unsigned long long *keys, unsigned short *vals, unsigned long long cap, unsigned long long *n)
+{
+    const unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > w.tab_mask) return;
+    const FmlSlot e = tab[w.tab_off + s];
+    if (!e.key) return;
+    const unsigned long long at = atomicAdd(n, 1ULL);
+    if (at < cap) { keys[at] = e.key - 1; vals[at] = (unsigned short)fml_val(e.cnt); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- correction
+
+#define FML_EC_HIST 5
+#define FML_EC_HIST_HIGH 2
+#define FML_HEAP_CAP 112
+#define FML_STACK_CAP(n) (8 * (n) + 64)          // [CHOICE] shared with the oracle: a search that pushes more states is given up
+
+struct FmlEcOpt { int q, win_multi_ec, max_end_ext, w_ec, w_ec_high, w_absent, w_absent_high, max_heap; };
+
+struct __align__(16) FmlHeap1 {          // echeap1_t
+    int tot_pen, i, k;
+    int eh[FML_EC_HIST_HIGH];
+    int ep[FML_EC_HIST];
+    uint32_t x0, x1;          // forward planes of the last k - 1 (then k) bases; the reverse strand is derived when a key is needed
+    int pad[4];
+};
+
+struct FmlEcScratch {          // one per resident lane
+    unsigned char *B;          // per base: b | q << 3 | ob << 4
+    unsigned short *cv;        // per base: lcov | hcov << 6 | solid_end << 12 | high_end << 13
+    FmlHeap1 *heap;
+    uint2 *stack;              // x = parent, y = i | b << 16
+};
+
+__host__ __device__ inline size_t fml_scratch_bytes(int max_len)
+{
+    size_t b = ((size_t)max_len + 15) & ~(size_t)15;
+    size_t c = (2 * (size_t)max_len + 15) & ~(size_t)15;
+    size_t h = sizeof(FmlHeap1) * FML_HEAP_CAP;
+    size_t s = ((size_t)(FML_STACK_CAP(max_len) + 8) * 8 + 15) & ~(size_t)15;
+    return b + c + h + s;
+}
+
+__device__ __forceinline__ void fml_append(int k, uint32_t &x0, uint32_t &x1, int c)
+{
+    const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+    x0 = (x0 << 1 | (uint32_t)(c & 1)) & mask;
+    x1 = (x1 << 1 | (uint32_t)(c >> 1)) & mask;
+}
+
+__device__ __forceinline__ int fml_occ(const FmlSlot *tab, const FmlWin &w, uint32_t x0, uint32_t x1)
+{
+    const uint32_t mask = (uint32_t)((1ULL << w.k) - 1);
+    return fml_get(tab, w, fml_key(w.k, x0, x1, mask));
+}
+
+// klib's ks_heapdown / ks_heapup on tot_pen (smallest on top), operation for operation: the order in which equal penalties leave
+// the heap decides between equally cheap paths
+__device__ inline void fml_heapdown(FmlHeap1 *l, int n)
+{
+    int i = 0, k = 0;
+    const FmlHeap1 tmp = l[0];
+    while ((k = (k << 1) + 1) < n) {
+        if (k != n - 1 && l[k].tot_pen > l[k + 1].tot_pen) ++k;
+        if (l[k].tot_pen > tmp.tot_pen) break;
+        l[i] = l[k]; i = k;
+    }
+    l[i] = tmp;
+}
+__device__ inline void fml_heapup(FmlHeap1 *l, int n)
+{
+    int i = n - 1;
+    const FmlHeap1 tmp = l[i];
+    while (i > 0) {
+        const int k = (i - 1) >> 1;
+        if (tmp.tot_pen > l[k].tot_pen) break;
+        l[i] = l[k]; i = k;
+    }
+    l[i] = tmp;
+}
+
+struct FmlPen { int ec, ec_high, absent, absent_high, b; };
+
+// bfc_ec1dir in search coordinates: position i is base i of the read (dir 0) or base n - 1 - i of it, complemented (dir 1); the
+// corrected read is written back in place
+__device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, int n, int dir, int start, int end)
+{
+    const int k = w.k;
+    FmlHeap1 z;
+    int l, n_heap = 0, n_stack = 0, n_failures = 0, path = -1;
+    bool found = false;
+    auto base_at = [&](int i, int &b, int &q, int &ob, int &lc, int &hc) {
+        const int fi = dir ? n - 1 - i : i;
+        const int v = sc.B[fi];
+        b = v & 7; q = v >> 3 & 1; ob = v >> 4 & 7;
+        if (dir) { b = b < 4 ? 3 - b : 4; ob = ob < 4 ? 3 - ob : 4; }
+        const int c = sc.cv[fi];
+        lc = c & 63; hc = c >> 6 & 63;
+    };
+    z.tot_pen = 0; z.x0 = z.x1 = 0; z.k = -1;
+    for (z.i = start, l = 0; z.i < end; ++z.i) {
+        int b, q, ob, lc, hc;
+        base_at(z.i, b, q, ob, lc, hc);
+        if (b < 4) {
+            if (++l == k) break;
+            fml_append(k, z.x0, z.x1, b);
+        } else l = 0, z.x0 = z.x1 = 0;
+    }
+    if (z.i >= end) return -1;
+    for (int i = 0; i < FML_EC_HIST; ++i) z.ep[i] = -1;
+    for (int i = 0; i < FML_EC_HIST_HIGH; ++i) z.eh[i] = -1;
+    sc.heap[n_heap++] = z;
+    while (true) {
+        bool stop = false;
+        if (n_heap == 0) return -2;
+        z = sc.heap[0];
+        sc.heap[0] = sc.heap[--n_heap];
+        if (n_heap) fml_heapdown(sc.heap, n_heap);
+        if (z.i - end > o.max_end_ext) stop = true;
+        if (!stop) {
+            const bool have = z.i < n;
+            int cb = 4, cq = 0, cob = 4, lc = 0, hc = 0;
+            if (have) base_at(z.i, cb, cq, cob, lc, hc);
+            int os = -1, n_added = 0, other_ext = 0;
+            bool fixed = false;
+            FmlPen added[4];
+            if (have && cb < 4) {
+                uint32_t x0 = z.x0, x1 = z.x1;
+                fml_append(k, x0, x1, cb);
+                os = fml_occ(tab, w, x0, x1);
+                if (cq && os >= 0 && (os & 0xff) >= w.min_cov + 1 && lc >= w.min_cov + 1) fixed = true;
+                else if ((double)hc > k * .75) fixed = true;
+            }
+            for (int b = 0; b < 4; ++b) {
+                FmlPen pen;
+                if (fixed && have && b != cb) continue;
+                if (!have || b != cb) {
+                    if (have) {
+                        if (cq && z.eh[FML_EC_HIST_HIGH - 1] >= 0 && z.i - z.eh[FML_EC_HIST_HIGH - 1] < o.win_multi_ec) continue;
+                        if (z.ep[FML_EC_HIST - 1] >= 0 && z.i - z.ep[FML_EC_HIST - 1] < o.win_multi_ec) continue;
+                    }
+                    uint32_t x0 = z.x0, x1 = z.x1;
+                    fml_append(k, x0, x1, b);
+                    const int s = fml_occ(tab, w, x0, x1);
+                    if (s < 0 || (s & 0xff) < w.min_cov) continue;
+                    pen.ec = have && cob < 4 ? 1 : 0;
+                    pen.ec_high = pen.ec ? cq : 0;
+                    pen.absent = pen.absent_high = 0;
+                    pen.b = b;
+                    added[n_added++] = pen;
+                    ++other_ext;
+                } else {
+                    pen.ec = pen.ec_high = 0;
+                    pen.absent = (os < 0 || (os & 0xff) < w.min_cov) ? 1 : 0;
+                    pen.absent_high = pen.absent ? cq : 0;
+                    pen.b = b;
+                    added[n_added++] = pen;
+                }
+            }
+            if (!fixed && other_ext == 0) ++n_failures;
+            if (n_failures > n * 2 || n_stack > FML_STACK_CAP(n)) return -3;
+            if (have || n_added == 1) {
+                int first = 0, last = n_added;
+                if (n_added > 1 && n_heap > o.max_heap) {
+                    int min_b = -1, mn = 0x7fffffff;
+                    for (int b = 0; b < n_added; ++b) {
+                        const int t = o.w_ec * added[b].ec + o.w_ec_high * added[b].ec_high + o.w_absent * added[b].absent + o.w_absent_high * added[b].absent_high;
+                        if (mn > t) mn = t, min_b = b;
+                    }
+                    first = min_b; last = min_b + 1;
+                }
+                for (int a = first; a < last; ++a) {          // buf_update
+                    const FmlPen pen = added[a];
+                    FmlHeap1 r = z;
+                    sc.stack[n_stack] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
+                    r.tot_pen = z.tot_pen + o.w_ec * pen.ec + o.w_ec_high * pen.ec_high + o.w_absent * pen.absent + o.w_absent_high * pen.absent_high;
+                    r.i = z.i + 1;
+                    r.k = n_stack++;
+                    if (pen.ec_high) { r.eh[1] = z.eh[0]; r.eh[0] = z.i; }
+                    if (pen.ec) { r.ep[4] = z.ep[3]; r.ep[3] = z.ep[2]; r.ep[2] = z.ep[1]; r.ep[1] = z.ep[0]; r.ep[0] = z.i; }
+                    fml_append(k, r.x0, r.x1, pen.b);
+                    sc.heap[n_heap++] = r;
+                    fml_heapup(sc.heap, n_heap);
+                }
+            } else stop = true;
+        }
+        if (stop) { path = z.k; found = true; break; }
+    }
+    if (!found) return -1;
+    for (l = path; l >= 0; l = (int)sc.stack[l].x) {
+        const uint2 e = sc.stack[l];
+        const int i = (int)(e.y & 0xffff), b = (int)(e.y >> 16);
+        if (i < n) {
+            const int fi = dir ? n - 1 - i : i;
+            sc.B[fi] = (unsigned char)((sc.B[fi] & ~7) | (dir ? 3 - b : b));
+        }
+    }
+    return 0;
+}
+
+// bfc_ec1 for one read, in place in the ASCII text
+__device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, char *seq, char *qual, int n)
+{
+    const int k = w.k;
+    int n_n = 0;
+    for (int i = 0; i < n; ++i) {          // bfc_seq_conv
+        const int c = fml_nt5((unsigned char)seq[i]);
+        int q = !qual ? 1 : ((int)(unsigned char)qual[i] - 33 >= o.q ? 1 : 0);
+        if (c > 3) q = 0, ++n_n;
+        sc.B[i] = (unsigned char)(c | q << 3 | c << 4);
+    }
+    if ((double)n_n > n * .05) return -10;
+    if (n < k) return -11;
+    {          // bfc_ec_kcov: solid / high ends, then the number of solid (and solid high-quality) k-mers over each base as a sliding count
+        uint32_t x0 = 0, x1 = 0;
+        int l = 0;
+        for (int i = 0; i < n; ++i) {
+            const int c = sc.B[i] & 7;
+            int f = 0;
+            if (c < 4) {
+                fml_append(k, x0, x1, c);
+                if (++l >= k) {
+                    const int r = fml_occ(tab, w, x0, x1);
+                    if (r >= 0) {
+                        const int high = (r >> 8 & 0x3f) >= w.min_cov + 1;
+                        if ((r & 0xff) >= w.min_cov) f = 1 << 12 | high << 13;
+                        else f = high << 13;
+                    }
+                }
+            } else l = 0, x0 = x1 = 0;
+            sc.cv[i] = (unsigned short)f;
+        }
+        int lc = 0, hc = 0;          // ends in [j, j + k - 1]
+        for (int i = 0; i < k - 1 && i < n; ++i) { const int f = sc.cv[i]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
+        for (int j = 0; j < n; ++j) {
+            if (j + k - 1 < n) { const int f = sc.cv[j + k - 1]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
+            const int fj = sc.cv[j];
+            sc.cv[j] = (unsigned short)((fj & 0x3000) | lc | hc << 6);
+            lc -= fj >> 12 & 1; hc -= (fj >> 12 & 1) & (fj >> 13 & 1);
+        }
+    }
+    int start = 0, end = 0;
+    {          // bfc_ec_best_island
+        int l = 0, mx = 0, mx_i = -1, i;
+        for (i = k - 1; i < n; ++i) {
+            if (!(sc.cv[i] >> 12 & 1)) {
+                if (l > mx) mx = l, mx_i = i;
+                l = 0;
+            } else ++l;
+        }
+        if (l > mx) mx = l, mx_i = i;
+        if (mx > 0) { start = mx_i - mx - k + 1; end = mx_i; }
+        else {          // no solid k-mer: bfc_ec_first_kmer + bfc_ec_greedy_k
+            int ec = -1;
+            uint32_t x0 = 0, x1 = 0;
+            while (true) {
+                int ll = 0;
+                x0 = x1 = 0;
+                for (end = start; end < n; ++end) {
+                    const int c = sc.B[end] & 7;
+                    if (c < 4) {
+                        fml_append(k, x0, x1, c);
+                        if (++ll == k) break;
+                    } else ll = 0, x0 = x1 = 0;
+                }
+                if (end >= n) break;
+                {
+                    int mx1 = 0, mx_ec = -1, mx2 = 0;
+                    for (int d = 0; d < k; ++d) {
+                        const int c = (int)((x1 >> d & 1) << 1 | (x0 >> d & 1));
+                        for (int j = 0; j < 4; ++j) {
+                            if (j == c) continue;
+                            const uint32_t y0 = (uint32_t)(j & 1) << d | (x0 & ~(1u << d)), y1 = (uint32_t)(j >> 1) << d | (x1 & ~(1u << d));
+                            const int ret = fml_occ(tab, w, y0, y1);
+                            if (ret < 0) continue;
+                            if ((mx1 & 0xff) < (ret & 0xff)) mx2 = mx1, mx1 = ret, mx_ec = d << 2 | j;
+                            else if ((mx2 & 0xff) < (ret & 0xff)) mx2 = ret;
+                        }
+                    }
+                    ec = (mx1 & 0xff) * 3 > w.mode && (mx2 & 0xff) < 3 ? mx_ec : -1;
+                }
+                if (ec >= 0) break;
+                if (end + (k >> 1) >= n) break;
+                start = end - (k >> 1);
+            }
+            if (ec < 0 || end >= n) return -12;
+            const int at = end - (ec >> 2);
+            sc.B[at] = (unsigned char)((sc.B[at] & ~7) | (ec & 3));
+            ++end; start = end - k;
+        }
+    }
+    if (fml_ec1dir(tab, w, o, sc, n, 0, start, n) < 0) return -13;
+    if (fml_ec1dir(tab, w, o, sc, n, 1, n - end, n) < 0) {
+        // the oracle leaves the read untouched when the second direction fails: nothing has been written to the text yet
+        return -14;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int v = sc.B[i], b = v & 7, ob = v >> 4 & 7;
+        const bool diff = b != ob;
+        seq[i] = diff ? "acgtn"[b] : "ACGTN"[b];
+        if (qual) qual[i] = diff ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+');
+    }
+    return 0;
+}
+
+// kmer_correct (flt_uniq = 0): persistent lanes, one read at a time each, reads handed out by an atomic counter
+static __global__ void __launch_bounds__(256) k_fml_ec(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
+                                                const unsigned long long *offs, long long n_reads, unsigned char *scratch, size_t lane_bytes, int max_len,
+                                                unsigned long long *next, int *status)
+{
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned char *p = scratch + lane * lane_bytes;
+    FmlEcScratch sc;
+    sc.B = p; p += ((size_t)max_len + 15) & ~(size_t)15;
+    sc.cv = (unsigned short *)p; p += (2 * (size_t)max_len + 15) & ~(size_t)15;
+    sc.heap = (FmlHeap1 *)p; p += sizeof(FmlHeap1) * FML_HEAP_CAP;
+    sc.stack = (uint2 *)p;
+    while (true) {
+        const long long r = (long long)atomicAdd(next, 1ULL);
+        if (r >= n_reads) break;
+        const unsigned long long b = offs[r];
+        const int n = (int)(offs[r + 1] - b);
+        int rc = 1;
+        if (n > 0) {
+            int lo = 0, hi = n_win;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
+            const FmlWin w = wins[lo];
+            rc = w.k > 0 ? fml_ec_read(tab, w, o, sc, bases + b, quals ? quals + b : nullptr, n) : 1;
+        }
+        if (status) status[r] = rc;
+    }
+}
+
+// worker_ec with flt_uniq: max_streak per read and the keep / trim / drop decision
+static __global__ void __launch_bounds__(256) k_fml_streak(const FmlSlot *tab, const FmlWin *wins, int n_win, const char *bases, const unsigned long long *offs,
+                                                    long long n_reads, float min_trim_frac, int *new_start, int *new_len)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const unsigned long long b = offs[r];
+    const int n = (int)(offs[r + 1] - b);
+    int ns = 0, nl = 0;
+    if (n > 0) {
+        int lo = 0, hi = n_win;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
+        const FmlWin w = wins[lo];
+        const int k = w.k;
+        if (k > 0) {
+            unsigned long long mx = 0, t = 0;
+            uint32_t x0 = 0, x1 = 0;
+            int l = 0;
+            for (int i = 0; i < n; ++i) {
+                const int c = fml_nt5((unsigned char)bases[b + i]);
+                if (c < 4) {
+                    fml_append(k, x0, x1, c);
+                    if (++l >= k) {
+                        if (fml_occ(tab, w, x0, x1) > 0) t += 1ULL << 32;
+                        else t = (unsigned long long)(i + 1);
+                    } else t = (unsigned long long)(i + 1);
+                } else l = 0, x0 = x1 = 0, t = (unsigned long long)(i + 1);
+                mx = mx > t ? mx : t;
+            }
+            if (mx >> 32 && (double)((mx >> 32) + k - 1) / n > (double)min_trim_frac) {
+                const int start = (int)(unsigned int)mx, end = start + (int)(mx >> 32);
+                ns = start - (k - 1); nl = end - ns;
+            }
+        }
+    }
+    new_start[r] = ns; new_len[r] = nl;
+}
+
+// the trimmed reads as a new flat text (fml_fltuniq's memmove): read r keeps [new_start, new_start + new_len)
+static __global__ void __launch_bounds__(256) k_fml_trim_copy(const char *src, const char *srcq, const unsigned long long *offs, const int *new_start, const unsigned long long *new_offs,
+                                                       long long n_reads, char *dst, char *dstq)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const unsigned long long s = offs[r] + (unsigned long long)new_start[r], d = new_offs[r];
+    const int n = (int)(new_offs[r + 1] - d);
+    for (int i = threadIdx.x & 63; i < n; i += 64) { dst[d + i] = src[s + i]; if (srcq) dstq[d + i] = srcq[s + i]; }
+}

@@ -1,0 +1,76 @@
+// slx_fml_internal.h -- the device context of the FermiAssembler / BFC window pipeline, shared by slx_fml.hip (correction) and
+// slx_fml_asm.hip (assembly).  Nothing here is part of the C-ABI (include/seqlib_amd_fml.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+#include "seqlib_amd_fml.h"
+#include "dev_fml.h"
+
+void slx_set_error(const char *fmt, ...);
+
+#define FML_HIPCHK(x)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) {                                                                     \
+            slx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); \
+            return e_ == hipErrorOutOfMemory ? SLX_ENOMEM : SLX_ENODEVICE;                          \
+        }                                                                                           \
+    } while (0)
+
+struct FmlDevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SLX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        FML_HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return SLX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct slx_fml {
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+    // the batch resident in HBM
+    int64_t n_reads = 0, total = 0;
+    int max_len = 0, n_win = 0, last_q = 20;
+    bool has_qual = false;
+    uint64_t n_slots = 0;
+    std::vector<uint64_t> h_offs;          // rebased to 0
+    std::vector<FmlWin> wins;
+    std::vector<slx_fml_opt> wopt;         // per window: the caller's options after fml_opt_adjust on the window's reads
+    std::vector<float> kcov;
+    std::vector<uint64_t> h_hist;
+    // BFC::Train's table, kept between calls
+    bool have_count = false;
+    FmlWin count_win;
+    FmlDevBuf d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+    float probe[SLX_FML_N_PROBES] = {0, 0, 0, 0, 0, 0};
+    int64_t n_inserted = 0, n_bases = 0;
+    std::vector<FmlDevBuf *> all_bufs()
+    {
+        return {&d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5};
+    }
+    void reset_probes() { for (float &p : probe) p = 0; n_inserted = 0; n_bases = 0; }
+};
+
+int fml_probe_begin(slx_fml *f);
+int fml_probe_end(slx_fml *f, int which);
+int fml_upload(slx_fml *f, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads);
+int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off, int n_win, int k_fixed);
+int fml_run_count(slx_fml *f, int q);
+int fml_run_hist(slx_fml *f);
+int fml_run_ec(slx_fml *f);
+int fml_run_streak(slx_fml *f);
+int fml_correct_core_device(slx_fml *f, int flt_uniq);
+void slx_fml_opt_adjust_window(slx_fml_opt *opt, int64_t n, uint64_t tot_len);
