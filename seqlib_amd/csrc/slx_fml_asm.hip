@@ -1,15 +1,220 @@
-// slx_fml_asm.hip -- fml_assemble behind the C-ABI (placeholder until the assembly stage lands: fails loudly)
+// slx_fml_asm.hip -- fml_assemble behind the C-ABI (include/seqlib_amd_fml.h): correction and the unique-k-mer filter on the reads in
+// HBM (slx_fml.hip), the overlap graph of every window by a seed join and a transitive reduction on the GPU (dev_fml_asm.h), and the
+// chaining into unitigs plus fermi-lite's graph cleaning per window on the host (fml_graph.h).
+// Replaces fml_assemble / fml_seq2fmi + fml_fmi2mag + fml_mag_clean + fml_mag2utg as /root/reference/src/FermiAssembler.cpp:26-44,140-151 call them.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 #include "slx_fml_internal.h"
+#include "dev_fml_asm.h"
+#include "fml_graph.h"
+
+namespace {
+
+struct AsmWin { int64_t str0 = 0, str1 = 0; slx_magopt mag; int min_match = 0; };
+
+// The strings of the batch: for every read whose kept stretch is at least min_match long, the stretch and its reverse complement.
+// h_ns / h_nl: kept stretch per read (ns = 0, nl = length when nothing was filtered).
+int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vector<int> &h_nl, const std::vector<slx_fml_opt> &wopt,
+                       slx_fml_utg **utgs, int *n_utg)
+{
+    const int n_win = f->n_win;
+    if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
+    std::vector<FmlStr> strs;
+    std::vector<AsmWin> aw((size_t)n_win);
+    unsigned long long text_len = 0;
+    int kk = FML_SEED_MAX;
+    for (int w = 0; w < n_win; ++w) {
+        const slx_fml_opt &o = wopt[(size_t)w];
+        if (o.min_asm_ovlp < 1) { slx_set_error("fml: min_asm_ovlp = %d", o.min_asm_ovlp); return SLX_EINVAL; }
+        aw[(size_t)w].str0 = (int64_t)strs.size();
+        aw[(size_t)w].mag = o.mag_opt;
+        aw[(size_t)w].mag.min_merge_len = o.min_merge_len;          // misc.c: fml_mag_clean
+        aw[(size_t)w].min_match = o.min_asm_ovlp;
+        kk = std::min(kk, o.min_asm_ovlp);
+        for (int64_t r = f->wins[(size_t)w].read0; r < f->wins[(size_t)w].read1; ++r) {
+            const int l = h_nl[(size_t)r];
+            if (l < o.min_asm_ovlp || l <= 0) continue;
+            for (int s = 0; s < 2; ++s) {
+                FmlStr t;
+                t.off = text_len; t.src = f->h_offs[(size_t)r] + (unsigned long long)h_ns[(size_t)r]; t.len = l; t.win = w;
+                strs.push_back(t);
+                text_len += (unsigned long long)l;
+            }
+        }
+        aw[(size_t)w].str1 = (int64_t)strs.size();
+    }
+    const long long n_str = (long long)strs.size();
+    // one min_match per batch on the device (the windows of a batch share the caller's options)
+    const int min_match = n_win ? aw[0].min_match : 1;
+    std::vector<unsigned char> h_text((size_t)text_len + 1), h_cont((size_t)n_str + 1);
+    std::vector<int> h_rep((size_t)n_str + 1);
+    std::vector<unsigned int> h_cnt((size_t)n_str + 1), h_nirr((size_t)n_str + 1);
+    std::vector<unsigned long long> h_eoff((size_t)n_str + 2), h_stroff((size_t)n_str + 2), h_irroff((size_t)n_str + 1);
+    std::vector<FmlEdge> h_out;
+    if (n_str > 0) {
+        int rc;
+        FmlDevBuf &d_strs = f->d_tmp0, &d_text = f->d_tmp1, &d_keys = f->d_tmp2, &d_vals = f->d_tmp3, &d_sort = f->d_tmp4, &d_graph = f->d_tmp5;
+        for (long long t = 0; t <= n_str; ++t) h_stroff[(size_t)t] = t < n_str ? strs[(size_t)t].off : text_len;
+        // d_graph: rep | cnt | cur | n_irr | irr_off | str_off | eoff | contained, one allocation
+        const size_t ns = (size_t)n_str + 2;
+        const size_t g_bytes = ns * (4 + 4 + 4 + 4 + 8 + 8 + 8 + 1) + 256;
+        if ((rc = d_strs.ensure(ns * sizeof(FmlStr))) || (rc = d_text.ensure((size_t)text_len + 64)) || (rc = d_keys.ensure(ns * 8 * 2)) ||
+            (rc = d_vals.ensure(ns * 4 * 2)) || (rc = d_graph.ensure(g_bytes)) || (rc = f->d_misc.ensure(256))) return rc;
+        unsigned long long *d_irroff = d_graph.as<unsigned long long>(), *d_stroff = d_irroff + ns, *d_eoff = d_stroff + ns;
+        int *d_rep = (int *)(d_eoff + ns);
+        unsigned int *d_cnt = (unsigned int *)(d_rep + ns), *d_cur = d_cnt + ns, *d_nirr = d_cur + ns;
+        unsigned char *d_cont = (unsigned char *)(d_nirr + ns);
+        unsigned long long *keys_in = d_keys.as<unsigned long long>(), *keys_out = keys_in + ns;
+        unsigned int *vals_in = d_vals.as<unsigned int>(), *vals_out = vals_in + ns;
+        if ((rc = fml_probe_begin(f))) return rc;
+        FML_HIPCHK(hipMemcpyAsync(d_strs.p, strs.data(), (size_t)n_str * sizeof(FmlStr), hipMemcpyHostToDevice, f->st));
+        FML_HIPCHK(hipMemcpyAsync(d_stroff, h_stroff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
+        FML_HIPCHK(hipMemsetAsync(d_cnt, 0, ns * 4 * 3, f->st));          // cnt, cur, n_irr
+        FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
+        hipLaunchKernelGGL(k_asm_strings, dim3((unsigned)((n_str + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), d_strs.as<FmlStr>(), n_str, d_text.as<unsigned char>());
+        hipLaunchKernelGGL(k_asm_keys, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, kk, keys_in, vals_in, d_rep, d_cont);
+        FML_HIPCHK(hipGetLastError());
+        size_t tmp_bytes = 0;
+        FML_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n_str, 0, 64, f->st));
+        if ((rc = d_sort.ensure(tmp_bytes + 256))) return rc;
+        FML_HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_sort.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n_str, 0, 64, f->st));
+        const unsigned grid = (unsigned)((text_len + 255) / 256);
+        hipLaunchKernelGGL((k_asm_join<1>), dim3(grid), dim3(256), 0, f->st, d_text.as<unsigned char>(), text_len, d_strs.as<FmlStr>(), d_stroff, n_str, kk, min_match, keys_out, vals_out,
+                           d_rep, d_cont, d_cnt, (const unsigned long long *)nullptr, (unsigned int *)nullptr, (FmlEdge *)nullptr);
+        FML_HIPCHK(hipGetLastError());
+        FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipStreamSynchronize(f->st));
+        unsigned long long n_edges = 0;
+        for (long long t = 0; t < n_str; ++t) { h_eoff[(size_t)t] = n_edges; n_edges += h_cnt[(size_t)t]; }
+        h_eoff[(size_t)n_str] = n_edges;
+        // edges | sorted edges | irreducible edges | flags
+        FmlDevBuf &d_edges = f->d_scratch;
+        if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 3 + 1) + 256))) return rc;
+        FmlEdge *e_raw = d_edges.as<FmlEdge>(), *e_sorted = e_raw + n_edges + 1, *e_out = e_sorted + n_edges + 1;
+        unsigned char *e_flags = (unsigned char *)(e_out + n_edges + 1);
+        FML_HIPCHK(hipMemcpyAsync(d_eoff, h_eoff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
+        hipLaunchKernelGGL((k_asm_join<2>), dim3(grid), dim3(256), 0, f->st, d_text.as<unsigned char>(), text_len, d_strs.as<FmlStr>(), d_stroff, n_str, kk, min_match, keys_out, vals_out,
+                           d_rep, d_cont, d_cnt, (const unsigned long long *)d_eoff, d_cur, e_raw);
+        hipLaunchKernelGGL(k_asm_reduce, dim3((unsigned)((n_str + 3) / 4)), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, (const unsigned long long *)d_eoff,
+                           (const unsigned int *)d_cur, e_raw, e_sorted, e_flags, d_nirr, d_irroff, e_out, f->d_misc.as<unsigned long long>());
+        FML_HIPCHK(hipGetLastError());
+        unsigned long long n_out = 0;
+        FML_HIPCHK(hipMemcpyAsync(&n_out, f->d_misc.p, 8, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_rep.data(), d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_cont.data(), d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_nirr.data(), d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_irroff.data(), d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_text.data(), d_text.p, (size_t)text_len, hipMemcpyDeviceToHost, f->st));
+        if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
+        h_out.resize((size_t)n_out + 1);
+        if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
+        f->n_overlaps = (int64_t)n_edges; f->n_irreducible = (int64_t)n_out; f->asm_text_len = (int64_t)text_len;
+    }
+    // ---- per window on the host: chains, cleaning, records
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> ev(h_out.size()), el(h_out.size());
+    for (int w = 0; w < n_win; ++w) {
+        const AsmWin &a = aw[(size_t)w];
+        const int n = (int)(a.str1 - a.str0);
+        std::vector<int> len((size_t)n + 1), rep((size_t)n + 1);
+        std::vector<const unsigned char *> txt((size_t)n + 1);
+        for (int t = 0; t < n; ++t) {
+            const FmlStr &s = strs[(size_t)(a.str0 + t)];
+            len[(size_t)t] = s.len; txt[(size_t)t] = h_text.data() + s.off;
+            rep[(size_t)t] = h_rep[(size_t)(a.str0 + t)] - (int)a.str0;
+            const unsigned long long o = h_irroff[(size_t)(a.str0 + t)];
+            for (unsigned int j = 0; j < h_nirr[(size_t)(a.str0 + t)]; ++j) { ev[(size_t)(o + j)] = h_out[(size_t)(o + j)].v - (int)a.str0; el[(size_t)(o + j)] = h_out[(size_t)(o + j)].len; }
+        }
+        fmlg::Overlaps O;
+        O.n_str = n; O.len = len.data(); O.text = txt.data(); O.rep = rep.data(); O.contained = h_cont.data() + a.str0;
+        O.n_irr = h_nirr.data() + a.str0; O.irr_off = h_irroff.data() + a.str0; O.edge_v = ev.data(); O.edge_len = el.data(); O.min_match = a.min_match;
+        fmlg::Graph g;
+        g.build(O);
+        g.clean_graph(a.mag);
+        utgs[w] = g.to_utgs(&n_utg[w]);
+    }
+    f->probe[5] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SLX_OK;
+}
+
+int check_assemble_opt(const slx_fml_opt *opt)
+{
+    if (!(opt->mag_opt.flag & SLX_MAG_F_NO_SIMPL)) {
+        slx_set_error("fml: bubble simplification (MAG_F_NO_SIMPL cleared, FermiAssembler::SetSimplifyBubble) is not built");
+        return SLX_EUNSUPPORTED;
+    }
+    return SLX_OK;
+}
+
+}          // namespace
 
 extern "C" int slx_fml_assemble(slx_fml *f, const slx_fml_opt *opt, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads,
                                 const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg)
 {
-    slx_set_error("slx_fml_assemble: not built yet");
-    return SLX_EUNSUPPORTED;
+    if (!f || !opt || !utgs || !n_utg) { slx_set_error("slx_fml_assemble: bad argument"); return SLX_EINVAL; }
+    int rc;
+    if ((rc = check_assemble_opt(opt))) return rc;
+    if (opt->ec_k < 0) { slx_set_error("slx_fml_assemble: ec_k = %d (fml_fltuniq needs a k-mer size)", opt->ec_k); return SLX_EINVAL; }
+    std::lock_guard<std::mutex> g(f->mu);
+    FML_HIPCHK(hipSetDevice(f->device));
+    f->reset_probes();
+    f->have_count = false;
+    for (int w = 0; w < n_win; ++w) { utgs[w] = nullptr; n_utg[w] = 0; }
+    if ((rc = fml_upload(f, bases, quals, offs, n_reads)) || (rc = fml_setup_windows(f, opt, win_off, n_win, 0))) return rc;
+    // fml_assemble: fml_correct, then fml_fltuniq on the corrected reads (its kcov sets min_ensr), then the graph
+    if ((rc = fml_correct_core_device(f, 0)) || (rc = fml_correct_core_device(f, 1))) return rc;
+    std::vector<int> ns((size_t)n_reads + 1), nl((size_t)n_reads + 1);
+    if (n_reads) {
+        FML_HIPCHK(hipMemcpyAsync(ns.data(), f->d_ns.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(nl.data(), f->d_nl.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, f->st));
+    }
+    FML_HIPCHK(hipStreamSynchronize(f->st));
+    std::vector<slx_fml_opt> wopt(f->wopt);
+    for (int w = 0; w < n_win; ++w) {
+        slx_magopt &m = wopt[(size_t)w].mag_opt;
+        const float kcov = f->kcov[(size_t)w];
+        m.min_ensr = m.min_ensr > kcov * .1 ? m.min_ensr : (int)(kcov * .1 + .499);
+        m.min_ensr = m.min_ensr < opt->max_cnt ? m.min_ensr : opt->max_cnt;
+        m.min_ensr = m.min_ensr > opt->min_cnt ? m.min_ensr : opt->min_cnt;
+        m.min_insr = m.min_ensr - 1;
+    }
+    return build_and_assemble(f, ns, nl, wopt, utgs, n_utg);
 }
+
 extern "C" int slx_fml_direct_assemble(slx_fml *f, slx_fml_opt *opt, float kcov, const char *bases, const uint64_t *offs, int64_t n_reads, slx_fml_utg **utgs, int *n_utg)
 {
-    slx_set_error("slx_fml_direct_assemble: not built yet");
-    return SLX_EUNSUPPORTED;
+    if (!f || !opt || !utgs || !n_utg) { slx_set_error("slx_fml_direct_assemble: bad argument"); return SLX_EINVAL; }
+    int rc;
+    if ((rc = check_assemble_opt(opt))) return rc;
+    std::lock_guard<std::mutex> g(f->mu);
+    FML_HIPCHK(hipSetDevice(f->device));
+    f->reset_probes();
+    f->have_count = false;
+    *utgs = nullptr; *n_utg = 0;
+    // src/FermiAssembler.cpp:32-41: min_ensr only ever raised, min_insr follows; the caller's options keep the change
+    opt->mag_opt.min_ensr = opt->mag_opt.min_ensr > kcov * .1 ? opt->mag_opt.min_ensr : (int)(kcov * .1 + .499);
+    opt->mag_opt.min_insr = opt->mag_opt.min_ensr - 1;
+    if ((rc = fml_upload(f, bases, nullptr, offs, n_reads))) return rc;
+    // no tables: windows are set up only for their read ranges (a k of 0 makes no table entries)
+    const int64_t win_off[2] = {0, n_reads};
+    f->wins.assign(1, FmlWin()); f->wins[0].read0 = 0; f->wins[0].read1 = n_reads; f->wins[0].k = 0;
+    f->n_win = 1;
+    std::vector<slx_fml_opt> wopt(1, *opt);          // NOT fml_opt_adjust'ed: DirectAssemble uses the options as they are
+    (void)win_off;
+    std::vector<int> ns((size_t)n_reads + 1, 0), nl((size_t)n_reads + 1, 0);
+    for (int64_t r = 0; r < n_reads; ++r) nl[(size_t)r] = (int)(f->h_offs[(size_t)r + 1] - f->h_offs[(size_t)r]);
+    return build_and_assemble(f, ns, nl, wopt, utgs, n_utg);
 }
-extern "C" void slx_fml_utgs_free(int n_utg, slx_fml_utg *utgs) {}
+
+extern "C" void slx_fml_utgs_free(int n_utg, slx_fml_utg *utgs)
+{
+    if (!utgs) return;
+    for (int i = 0; i < n_utg; ++i) { free(utgs[i].seq); free(utgs[i].cov); free(utgs[i].ovlp); }
+    free(utgs);
+}

@@ -57,6 +57,7 @@ struct slx_fml {
     FmlDevBuf d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
     float probe[SLX_FML_N_PROBES] = {0, 0, 0, 0, 0, 0};
     int64_t n_inserted = 0, n_bases = 0;
+    int64_t n_overlaps = 0, n_irreducible = 0, asm_text_len = 0;          // of the last assemble call
     std::vector<FmlDevBuf *> all_bufs()
     {
         return {&d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5};

@@ -143,3 +143,103 @@ def test_bfc_train_then_correct_other_reads(F, G, ctx, genome):
     kcov, mc, _, _ = ctx.error_correct(G.default_opt(), b2, q2, of2)
     assert (np.float32(kcov), mc) == (np.float32(ekcov), emc)
     assert G.unflatten(b2, of2) == es and G.unflatten(q2, of2) == eq
+
+
+# ---------------------------------------------------------------------------------------------------------------- fml_assemble
+
+def _fixture_reads():
+    import os
+    out = []
+    for name in ("sim1_bcr.head3000.fq", "sim2_bcr.head3000.fq"):
+        L = open(os.path.join(U.GOLDEN, name)).read().split("\n")
+        out.append(([L[i + 1].encode() for i in range(0, len(L) - 3, 4)], [L[i + 3].encode() for i in range(0, len(L) - 3, 4)]))
+    return out[0][0] + out[1][0], out[0][1] + out[1][1]
+
+
+def _het_genome(g, seed):
+    """a second haplotype: a SNP every ~400 bp and a few small indels (bubbles and open bubbles in the graph)"""
+    rng = np.random.default_rng(seed)
+    b = bytearray(g)
+    for p in sorted(rng.integers(200, len(g) - 200, len(g) // 400), reverse=True):
+        r = rng.random()
+        if r < 0.8:
+            b[p] = b"ACGT"[(b"ACGT".index(b[p]) + 1) % 4]
+        elif r < 0.9:
+            del b[p:p + int(rng.integers(1, 4))]
+        else:
+            b[p:p] = b"ACGT"[int(rng.integers(0, 4)):][:1] * int(rng.integers(1, 4))
+    return bytes(b)
+
+
+def _asm_windows(genome):
+    w = []
+    w.append(U.sim_window(genome["bcr"][20000:50000], 8000, seed=7)[:2])                         # clean 40x window
+    g2 = genome["abl"][50000:62000]
+    a = U.sim_window(g2, 2000, seed=41)
+    b = U.sim_window(_het_genome(g2, 5), 2000, seed=42)
+    w.append((a[0] + b[0], a[1] + b[1]))                                                         # two haplotypes
+    rep = genome["tp53"][3000:3600]
+    g3 = genome["tp53"][0:9000] + rep + genome["tp53"][9000:15000] + U.revcomp(rep) + genome["tp53"][15000:19000]
+    w.append(U.sim_window(g3, 5000, seed=43, err=0.005)[:2])                                     # a 600 bp repeat in three copies, one inverted
+    w.append(_fixture_reads())                                                                   # the reference's own fixture reads: 17x, bcr/abl fusion
+    w.append(U.sim_window(genome["myc"][0:3000], 150, seed=44)[:2])                              # too thin to assemble
+    return w
+
+
+def _same_utgs(got, exp, tag):
+    assert len(got) == len(exp), "%s: %d unitigs, oracle %d" % (tag, len(got), len(exp))
+    for i, (a, b) in enumerate(zip(got, exp)):
+        for k in ("len", "nsr", "seq", "cov", "n_ovlp", "ovlp"):
+            assert a[k] == b[k], "%s: unitig %d differs in %s" % (tag, i, k)
+
+
+def test_assemble_windows_match_oracle(F, G, ctx, genome):
+    wins = _asm_windows(genome)
+    seqs = [s for w in wins for s in w[0]]
+    quals = [q for w in wins for q in w[1]]
+    win_off = np.cumsum([0] + [len(w[0]) for w in wins])
+    b, q, o = G.flatten(seqs, quals)
+    got = ctx.assemble(G.default_opt(), b, q, o, win_off)
+    n_long = 0
+    for wi, w in enumerate(wins):
+        exp = F.assemble(F.default_opt(), F.Reads(w[0], w[1]))
+        _same_utgs(got[wi], exp, "window %d" % wi)
+        n_long += sum(u["len"] > 1000 for u in exp)
+    assert n_long >= 10
+    ms, _, _ = ctx.probe_ms()
+    assert ms["overlap"] > 0
+
+
+def test_assemble_contigs_are_the_genome(G, ctx, genome):
+    gen = genome["bcr"][60000:100000]
+    seqs, quals, _ = U.sim_window(gen, 12000, seed=51)
+    b, q, o = G.flatten(seqs, quals)
+    utgs = ctx.assemble(G.default_opt(), b, q, o, [0, len(seqs)])[0]
+    rc = U.revcomp(gen)
+    # within the error model: all but a handful of the 100-mers of every contig are in the genome (a residual read error costs <= 100 of them)
+    tot = bad = 0
+    for u in utgs:
+        s = u["seq"]
+        for i in range(0, len(s) - 100 + 1, 10):
+            tot += 1
+            bad += not (s[i:i + 100] in gen or s[i:i + 100] in rc)
+    assert utgs and tot > 3000 and bad <= 0.01 * tot, (tot, bad)
+    assert sum(u["len"] for u in utgs) > 0.95 * len(gen)
+
+
+def test_direct_assemble_and_options(F, G, ctx, genome):
+    seqs, quals, _ = U.sim_window(genome["abl"][20000:32000], 3000, seed=61, err=0.0)
+    for min_ovlp, aggressive in ((33, False), (51, False), (33, True)):
+        o = G.default_opt(); fo = F.default_opt()
+        o.min_asm_ovlp = fo.min_asm_ovlp = min_ovlp
+        if aggressive:
+            o.mag_opt.flag |= G.MAG_F_AGGRESSIVE; fo.mag_opt.flag |= G.MAG_F_AGGRESSIVE
+        b, _, of = G.flatten(seqs)
+        got = ctx.direct_assemble(o, 30.0, b, of)
+        exp = F.direct_assemble(fo, 30.0, F.Reads(seqs))
+        _same_utgs(got, exp, "direct %d %s" % (min_ovlp, aggressive))
+        assert o.mag_opt.min_ensr == fo.mag_opt.min_ensr and o.mag_opt.min_insr == fo.mag_opt.min_insr
+    o = G.default_opt()
+    o.mag_opt.flag &= ~G.MAG_F_NO_SIMPL
+    with pytest.raises(Exception):
+        ctx.direct_assemble(o, 30.0, b, of)
