@@ -138,6 +138,16 @@ public:
         for (int i = 0; i < b->core.l_qseq; ++i) out.push_back(BASES[bam_seqi(s, i)]);
         return out;
     }
+    /** the quality string, `offset` added to every value (src/BamRecord.cpp:1073-1083) */
+    std::string Qualities(int offset = 33) const
+    {
+        if (!b) return {};
+        const uint8_t *q = bam_get_qual(b.get());
+        std::string out;
+        out.reserve((size_t)b->core.l_qseq);
+        for (int i = 0; i < b->core.l_qseq; ++i) out.push_back((char)(q[i] + offset));
+        return out;
+    }
     Cigar GetCigar() const
     {
         Cigar cig;

@@ -3,7 +3,7 @@
 //
 // Reference behaviour: what fermi-lite's fml_correct / fml_fltuniq do for /root/reference/src/FermiAssembler.cpp:133-138 and what
 // fml_count / bfc_ch_hist / kmer_correct do for /root/reference/src/BFC.cpp:262-270,315,351 (fermi-lite is an un-vendored, empty
-// submodule of the reference: the behaviour is restated in oracle/orc_fml.c, which the parity tests compare this file with).
+// submodule of the reference: the behaviour is the one DESIGN.md section 8 writes down, which the parity tests hold this file to).
 //
 // Layout.  All reads of a batch of windows are one flat ASCII text in HBM.  k_fml_pack turns every 64 positions into five 64-bit
 // words -- low bit and high bit of the base code, "is N", "quality >= q", and (k_fml_starts) "first base of a read" -- with the LATER

@@ -2,7 +2,7 @@
 //
 // Reference behaviour: what fermi-lite's fml_seq2fmi + fml_fmi2mag compute for /root/reference/src/FermiAssembler.cpp:26-31,140-143 --
 // which reads are duplicates of or contained in others, every exact suffix-prefix overlap of at least min_asm_ovlp bases, and of those
-// the irreducible ones -- as DEFINED in oracle/orc_fml_asm.c (fermi-lite's source is not in the reference tree).
+// the irreducible ones -- as DEFINED in DESIGN.md section 8 (fermi-lite is not in the reference tree).
 //
 // fermi walks an FM-index of the reads one read at a time.  Here the same relations come out of a JOIN: every string (a read or its
 // reverse complement, 1 byte per base in one flat text) is keyed by its first 16 bases, the keys are radix-sorted, and ONE LANE PER TEXT

@@ -2,7 +2,7 @@
 // fermi-lite's graph cleaning (mag.c: mag_g_clean and the passes it runs) on the unitig graph, to fml_utg_t records.
 //
 // Reference behaviour: fml_fmi2mag's chaining of reads into unitigs, fml_mag_clean, fml_mag2utg as reached from
-// /root/reference/src/FermiAssembler.cpp:26-44,140-151; defined (fermi-lite is not in the reference tree) in oracle/orc_fml_asm.c.
+// /root/reference/src/FermiAssembler.cpp:26-44,140-151; defined (fermi-lite is not in the reference tree) in DESIGN.md section 8.
 // The graph of a window has 10^2..10^4 vertices after chaining: control-plane work, done here on the host, one window at a time;
 // the data-parallel work (10^7 positions per window) is on the GPU.
 #pragma once

@@ -35,6 +35,46 @@ def test_exports_match_header(ffi):
     assert "src/BWAAligner.cpp:89-146" in hdr and "src/BWAIndex.cpp:83-180" in hdr
 
 
+def test_fml_exports_match_header(ffi):
+    """include/seqlib_amd_fml.h (the FermiAssembler / BFC path): every declared symbol is exported and bound, every entry cites what it replaces"""
+    from seqlib_amd import fml
+    hdr = open(os.path.join(ROOT, "include", "seqlib_amd_fml.h")).read()
+    body = hdr[hdr.index("extern \"C\""):]
+    declared = set(re.findall(r"\b(slx_fml_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(fml.EXPORTS), declared ^ set(fml.EXPORTS)
+    L = fml.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    head = hdr[:hdr.index("#ifndef")]
+    for name in ("slx_fml_opt_init", "slx_fml_correct", "slx_fml_count", "slx_fml_error_correct", "slx_fml_assemble", "slx_fml_direct_assemble"):
+        assert name in head
+    assert "src/FermiAssembler.cpp:133-138" in hdr and "src/BFC.cpp:262-270" in hdr and "src/FermiAssembler.cpp:26-44" in hdr
+
+
+def test_fml_options_and_no_gpu(ffi):
+    from oracle import orc_fml
+    from seqlib_amd import fml
+    o, e = fml.default_opt(), orc_fml.default_opt()
+    for name, _ in fml.FmlOpt._fields_:
+        if name != "mag_opt":
+            assert getattr(o, name) == getattr(e, name), name
+    for name, _ in fml.MagOpt._fields_:
+        assert getattr(o.mag_opt, name) == getattr(e.mag_opt, name), name
+    import numpy as np
+    for n, L in ((8000, 150), (100000, 150), (2000, 100), (5, 100)):
+        o, e = fml.default_opt(), orc_fml.default_opt()
+        lens = np.full(n, L, dtype=np.int32)
+        fml.lib().slx_fml_opt_adjust(C.byref(o), n, lens.ctypes.data)
+        R = orc_fml.Reads([b"A" * L] * n)
+        orc_fml.opt_adjust(e, R)
+        assert (o.ec_k, o.mag_opt.min_elen) == (e.ec_k, e.mag_opt.min_elen)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(ffi.SlxError) as ex:
+            fml.Context()
+        assert ex.value.code == ffi.SLX_ENODEVICE
+
+
 def test_opt_init_matches_oracle(ffi, orc):
     o = ffi.Opt()
     ffi.lib().slx_opt_init(C.byref(o))
