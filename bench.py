@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CU x 4 SIMD x 16 lanes/cycle x 2.4 GHz = 39.3 T int32 lane-ops/s
 DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000, "C4h": 25_000_000}
-ROUND = "r03"
+ROUND = "r04"
 PMC_SUMMARY = os.environ.get("SLX_PMC_SUMMARY") or os.path.join("profiles", ROUND + "_pmc_summary.json")     # follows the round
 
 _G = {}
@@ -167,6 +167,179 @@ def spawn_ranks(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def c5_workload(rank, n_win, reads_per_win, coverage, read_len=150):
+    """BASELINE config 5: `n_win` windows of `reads_per_win` synthetic reads each (150 bp at `coverage`x over consecutive slices of the
+    E. coli-sized synthetic reference, wgsim-like errors as for the other configs; a base has a low quality 5 % of the time)."""
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    refs = synth.make_reference(cfg)
+    g = refs[0][1]
+    span = int(reads_per_win * read_len / coverage)
+    n_slices = max(1, len(g) // span)
+    parts = []
+    for w in range(n_win):
+        sl = (rank * n_win + w) % n_slices
+        parts.append(np.ascontiguousarray(synth.make_reads(g[sl * span:(sl + 1) * span], reads_per_win, read_len, 7000 + rank * n_win + w)[:reads_per_win]).reshape(-1))
+    bases = np.concatenate(parts)
+    rng = np.random.Generator(np.random.PCG64(99 + rank))
+    quals = np.full(bases.shape, ord("I"), dtype=np.uint8)
+    quals[rng.random(bases.shape[0]) < 0.05] = ord("#")
+    offs = np.arange(n_win * reads_per_win + 1, dtype=np.uint64) * np.uint64(read_len)
+    win_off = np.arange(n_win + 1, dtype=np.int64) * reads_per_win
+    return cfg, refs, bases, quals, offs, win_off, span
+
+
+def c5_cpu_baseline(bases, quals, read_len, reads_per_win, sample_reads):
+    """fml_assemble of the CPU checker (a restatement: fermi-lite is an empty submodule of the reference) on one thread -- the reference
+    runs fermi-lite with n_threads = 1 (fml_opt_init) -- on the first `sample_reads` reads of window 0 at the same coverage."""
+    from oracle import orc_fml
+    n = min(sample_reads, reads_per_win)
+    raw_b = bases[:n * read_len].tobytes()
+    raw_q = quals[:n * read_len].tobytes()
+    seqs = [raw_b[i * read_len:(i + 1) * read_len] for i in range(n)]
+    qs = [raw_q[i * read_len:(i + 1) * read_len] for i in range(n)]
+    R = orc_fml.Reads(seqs, qs)
+    t0 = time.time()
+    utgs = orc_fml.assemble(orc_fml.default_opt(), R)
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="reads/s", cores=1, kind="port",
+                sample="fml_assemble of the CPU checker on the first %d reads of window 0 (%.1f s, %d contigs); one thread, as the reference runs fermi-lite "
+                       "(fml_opt_init: n_threads = 1); the sample keeps the window's error rate but is a fifth of its size, so its coverage is a fifth" % (n, dt, len(utgs)))
+
+
+def main_c5(args):
+    """`--config C5`: FermiAssembler local-assembly pipeline, window-parallel.  A step = every window of the rank through BFC correction,
+    the unique-k-mer filter, the overlap graph and the graph cleaning (slx_fml_assemble_staged: the reads are resident in HBM before the
+    timed region), then all contigs realigned through the BWAAligner path in one batch."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_win = args.windows
+    per_win = args.reads or 100_000
+    read_len = 150
+    t_setup = time.time()
+    cfg, refs, bases, quals, offs, win_off, span = c5_workload(rank, n_win, per_win, args.coverage, read_len)
+    t_gen = time.time() - t_setup
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the FermiAssembler / BFC path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import seqlib_amd
+    from seqlib_amd import fml, synth
+    idx = seqlib_amd.BWAIndex()
+    idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])
+    al = seqlib_amd.BWAAligner(idx, device=local_rank)
+    ctx = fml.Context(local_rank)
+    opt = fml.default_opt()
+    ctx.stage(bases, quals, offs)
+    max_len = seqlib_amd._ffi.SLX_MAX_READ_LEN
+
+    def step():
+        wins = ctx.assemble_staged(opt, win_off)
+        ms, ins, nb = ctx.probe_ms()
+        contigs = [u["seq"] for w in wins for u in w]
+        fit = [c for c in contigs if len(c) <= max_len]
+        hits = al.alignSequences(fit) if fit else None
+        return wins, contigs, fit, hits, ms, ins, nb
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc = {}
+    ins_acc = nb_acc = 0
+    fence()
+    t0 = time.time()
+    marks = [t0]
+    for _ in range(args.steps):
+        wins, contigs, fit, hits, ms, ins, nb = step()
+        marks.append(time.time())
+        for k, v in ms.items():
+            acc[k] = acc.get(k, 0.0) + v
+        ins_acc += ins; nb_acc += nb
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_reads = n_win * per_win
+    value = n_reads * world / (dt / args.steps)
+    if rank == 0:
+        lens = sorted((len(c) for c in contigs), reverse=True)
+        half, run, n50 = sum(lens) / 2, 0, 0
+        for L in lens:
+            run += L
+            if run >= half:
+                n50 = L
+                break
+        # parity spot check: a small window through the GPU path and through the CPU checker
+        match = None
+        if args.verify > 0:
+            from oracle import orc_fml
+            m = min(args.verify, per_win)
+            raw_b, raw_q = bases[:m * read_len].tobytes(), quals[:m * read_len].tobytes()
+            seqs = [raw_b[i * read_len:(i + 1) * read_len] for i in range(m)]
+            qs = [raw_q[i * read_len:(i + 1) * read_len] for i in range(m)]
+            exp = orc_fml.assemble(orc_fml.default_opt(), orc_fml.Reads(seqs, qs))
+            b2, q2, o2 = fml.flatten(seqs, qs)
+            got = ctx.assemble(opt, b2, q2, o2, [0, m])[0]
+            match = float(len(got) == len(exp) and all(a["seq"] == e["seq"] and a["cov"] == e["cov"] and a["ovlp"] == e["ovlp"] for a, e in zip(got, exp)))
+            ctx.stage(bases, quals, offs)
+        cpu = None if args.no_cpu_baseline else c5_cpu_baseline(bases, quals, read_len, per_win, 20000)
+        # the k-mer counting kernel against the HBM roofline: per inserted k-mer one 16-byte table slot read and written back, per base
+        # the ASCII base and quality read once by the plane kernel (DESIGN.md section 8)
+        steps = max(args.steps, 1)
+        count_ms = acc.get("count", 0.0) / steps / 2.0          # two launches per step: before the correction and before the filter
+        alg = (32.0 * ins_acc + 2.0 * nb_acc) / steps / 2.0
+        achieved = alg / (count_ms * 1e-3) / 1e9 if count_ms > 0 else None
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", ROUND + "_c5_pmc_summary.json")))
+        except Exception:
+            pass
+        traffic = pmc.get("count_fetch_plus_write_bytes_per_launch") if pmc and pmc.get("reads_per_launch") == n_reads else None
+        roof = dict(bound="hbm", kernel="k_fml_count (+ k_fml_pack, k_fml_starts): k-mer counting of the FermiAssembler pipeline, one lane per text position, "
+                                         "atomic insert into per-window open-addressing tables", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS if achieved else None, traffic=traffic,
+                    traffic_source=("profiles/%s_c5_pmc_summary.json (separate rocprofv3 --pmc passes of this command)" % ROUND) if traffic else None,
+                    achieved_basis="ALGORITHMIC bytes per launch (32 B per inserted k-mer: its 16-byte slot read and written; 2 B per base: ASCII base + quality) / "
+                                   "mean launch duration from HIP events on the context's stream (two launches per step)",
+                    kernel_ms_mean_launch=count_ms, kmers_per_launch=ins_acc / steps / 2.0, bases_per_launch=nb_acc / steps / 2.0,
+                    table_slots=ctx.counter("table_slots"), kmers_distinct=ctx.counter("kmers_distinct"))
+        out = {
+            "metric": "reads/sec through the FermiAssembler window pipeline (BFC correct -> fml_assemble -> contigs realigned via BWAAligner)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C5: %d windows x %d synthetic %d bp reads per GPU at %.0fx over %d bp slices of %s (wgsim-like errors), assembled per window "
+                                   "(fml_opt defaults: ec_k by window size = %d, min_asm_ovlp 33), contigs realigned to the %d bp reference with hardclip=false "
+                                   "keepSecFrac=0.9 maxSecondary=10" % (n_win, per_win, read_len, args.coverage, span, cfg["name"], 19 if per_win * read_len > 1 << 23 else 0,
+                                                                      sum(len(g) for _, g in refs)),
+                       "windows_per_gpu": n_win, "reads_per_window": per_win, "read_len": read_len, "parallelism": "window-sharded x%d, no data-path collective" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+            "windows_per_s": n_win * world / (dt / args.steps),
+            "contigs": {"n": len(contigs), "total_bp": sum(lens), "longest": lens[:5], "n50": n50, "realigned": len(fit), "realigned_bp": sum(len(c) for c in fit),
+                        "skipped_longer_than_max_read_len": len(contigs) - len(fit), "records": int(hits["n_hits"]) if hits is not None else 0},
+            "contig_bit_match_rate": match, "verified_reads": min(args.verify, per_win) if args.verify > 0 else 0,
+            "probe_ms_per_step": {k: v / steps for k, v in acc.items()},
+            "counters": {k: ctx.counter(k) for k in ("strings", "text_bytes", "overlaps", "irreducible", "big_vertices", "huge_vertices", "host_threads")},
+            "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])], "read_generation_s": t_gen,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +350,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / value_bamrecords")
     ap.add_argument("--verify", type=int, default=20000, help="reads of the timed batch checked bit-for-bit against the oracle")
+    ap.add_argument("--windows", type=int, default=8, help="C5: windows per GPU and step")
+    ap.add_argument("--coverage", type=float, default=30.0, help="C5: read coverage of a window")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -187,6 +362,10 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
         sys.exit(2)
+    if args.config == "C5":
+        if args.verify == 20000:
+            args.verify = 4000
+        return main_c5(args)
 
     # ---- workload, generated before this process touches the GPU (forked generator workers)
     from seqlib_amd import synth

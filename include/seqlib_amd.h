@@ -41,9 +41,10 @@ extern "C" {
 #define SLX_EUNSUPPORTED (-5)  /* read longer than the GPU path supports (SLX_MAX_READ_LEN) */
 #define SLX_EINTERNAL   (-6)
 
-/* Longest read the GPU path takes.  Reads of ~727 bp and more (5.5*ln(L) <= 0.05*L) also run bwa's
- * mem_flt_chained_seeds/ksw_align2 seed filter and take the long-read kernels (dev_long.h). */
-#define SLX_MAX_READ_LEN 8000
+/* Longest read the GPU path takes: query positions travel as 16-bit halves of one word through the seeding, chaining and
+ * extension kernels.  Reads of ~727 bp and more (5.5*ln(L) <= 0.05*L) also run bwa's mem_flt_chained_seeds/ksw_align2 seed filter
+ * and take the long-read kernels (dev_long.h); beyond 8 000 bp the extension kernel keeps its H/E row in HBM instead of LDS. */
+#define SLX_MAX_READ_LEN 65000
 
 /* mirrors bwa's mem_opt_t (fields the single-end path reads) */
 typedef struct {

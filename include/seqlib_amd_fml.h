@@ -15,6 +15,7 @@
  *   slx_fml_error_correct the histogram -> kcov -> min_cov -> kmer_correct block    src/BFC.cpp:289-362 (BFC::ErrorCorrect)
  *   slx_fml_count_dump    (new) test hook: the count table as sorted (k-mer, value) pairs
  *   slx_fml_assemble      fml_assemble                       src/FermiAssembler.cpp:140-143 (PerformAssembly)
+ *   slx_fml_stage, slx_fml_assemble_staged   (new) fml_assemble on reads already resident in HBM; no reference counterpart
  *   slx_fml_direct_assemble  fml_seq2fmi + fml_fmi2mag + fml_mag_clean + fml_mag2utg   src/FermiAssembler.cpp:26-44 (DirectAssemble)
  *   slx_fml_utgs_free     fml_utg_destroy                    src/FermiAssembler.cpp:103
  *
@@ -100,6 +101,10 @@ int  slx_fml_count_dump(slx_fml *f, uint64_t *keys, uint16_t *vals, uint64_t cap
  * slx_fml_utgs_free. */
 int  slx_fml_assemble(slx_fml *f, const slx_fml_opt *opt, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads,
                       const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg);
+/* The same with the reads resident in HBM: slx_fml_stage uploads them once, slx_fml_assemble_staged assembles the staged reads (any
+ * number of times; every call starts from the reads as staged).  What bench.py times: the reads are in HBM before the timed region. */
+int  slx_fml_stage(slx_fml *f, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads);
+int  slx_fml_assemble_staged(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg);
 /* FermiAssembler::DirectAssemble: no correction, no filter; min_ensr / min_insr derived from kcov as src/FermiAssembler.cpp:32-41 does
  * (the caller's opt is updated the same way) */
 int  slx_fml_direct_assemble(slx_fml *f, slx_fml_opt *opt, float kcov, const char *bases, const uint64_t *offs, int64_t n_reads,
@@ -110,6 +115,9 @@ void slx_fml_utgs_free(int n_utg, slx_fml_utg *utgs);
  * [2] correction, [3] filter, [4] suffix sort + overlaps, [5] graph (host); and what the count kernels processed */
 #define SLX_FML_N_PROBES 6
 int  slx_fml_probe_ms(const slx_fml *f, float ms[SLX_FML_N_PROBES], int64_t *n_kmers_inserted, int64_t *n_bases);
+/* what the last batch call held, by name (-1 = unknown name): "kmers_distinct", "table_slots", "strings", "text_bytes", "overlaps",
+ * "irreducible", "big_vertices" (> 64 overlaps), "huge_vertices" (> 4096), "host_threads" */
+int64_t slx_fml_counter(const slx_fml *f, const char *key);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,280 @@
+// dev_cig_band.h -- ksw_global2 + traceback for LONG queries (assembly contigs realigned through BWAAligner,
+// /root/reference/src/seqtools/seqtools.cpp:198-210 -> mem_reg2aln at /root/reference/src/BWAAligner.cpp:123-128): one wave per job,
+// the dynamic program in BAND coordinates with several band offsets per lane.
+//
+// bwa_gen_cigar2 aligns a contig of tens of kilobases inside a band of 2 w + 1 columns (w <= 4 * opt.w = 400 at the defaults):
+// rows x band cells, whatever the query length.  wave_ksw_global2_band (dev_fin2.h) holds one band offset per lane and the packed
+// scores of the whole query in registers: fine for 150 bp reads, impossible here.  This variant gives every lane CPB consecutive
+// offsets (CPB = 1, 2, 4, 8, 13: bands up to 832 columns), keeps H / E / the query's score words per offset in registers, carries E and
+// the sliding query window between neighbouring offsets as register moves inside a lane and one DPP shift between lanes, computes F as
+// an in-lane running maximum plus one wave-wide scan of the lanes' totals, and feeds the query through a rolling 64-position block
+// (fetched 64 rows ahead) -- so a row costs CPB x ~30 VALU + two scans, and a 60 kb contig in a 201-column band is ~60 k rows of ~200
+// instructions on one wave instead of 12 M cells on one lane (k_cig_long).  Same cell arithmetic, same direction bytes, same
+// band-relative z layout as wave_ksw_global2_band: the traceback (dev_traceback_wave) and everything after it are shared.
+#pragma once
+#include "dev_fin2.h"
+
+template <int CPB, typename QF, typename TF>
+__device__ int wave_ksw_global2_bandn(int qlen_, QF qf, int tlen_, TF tf, const slx_opt &o, int w_, uint8_t *z, int n_col_, int lane)
+{
+    const int qlen = __builtin_amdgcn_readfirstlane(qlen_), tlen = __builtin_amdgcn_readfirstlane(tlen_);
+    const int w = __builtin_amdgcn_readfirstlane(w_), n_col = __builtin_amdgcn_readfirstlane(n_col_);
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const MatCols mc = make_matcols(o.mat);
+    auto pack_of = [&](int j) -> uint32_t {
+        const int q = j >= 0 && j < qlen ? qf(j) : 4;
+        return q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
+    };
+    const int b0 = lane * CPB;                    // this lane holds band offsets b0 .. b0 + CPB - 1; offset b of row i is column j = i - w + b
+    int H[CPB], E[CPB];
+    uint32_t P[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) {
+        const int j = b0 + c - w;
+        P[c] = pack_of(j);
+        H[c] = j == 0 ? 0 : (j > 0 && j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
+        E[c] = DEV_MINUS_INF;
+    }
+    // the query enters at offset 2 w, one position per row: a rolling block of 64 packed score words, the next one fetched ahead
+    int q_blk = (w + 1) >> 6;
+    uint32_t q_cur = pack_of(q_blk * WAVE + lane), q_next = pack_of((q_blk + 1) * WAVE + lane);
+    int tb_cur = lane < tlen ? tf(lane) : 0;
+    int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+#pragma unroll 1
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = lane_read(tb_cur, i & (WAVE - 1));
+        const uint32_t sh = (uint32_t)t << 3;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int b_lo = beg - (i - w), b_hi = end - (i - w);     // active offsets [b_lo, b_hi)
+        int m[CPB], exl[CPB];
+        bool act[CPB];
+        int run = G_NEG;
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int b = b0 + c;
+            act[c] = b >= b_lo && b < b_hi;
+            m[c] = H[c] + __builtin_amdgcn_sbfe((int)P[c], sh, 8u);
+            exl[c] = run;                          // max of u over the lower offsets of this lane
+            const int u = act[c] ? m[c] - oe_ins + b * e_ins : G_NEG;
+            run = imax(run, u);
+        }
+        const int incl = dpp_incl_max_scan_g(run);
+        const int lane_ex = dpp_get<0x138, 0xf, 0xf>(G_NEG, incl);          // max of u over all lower lanes
+        int e2v[CPB];
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int b = b0 + c;
+            const int ex = imax(lane_ex, exl[c]);
+            // F(i,j): the initial -inf decays by e_ins per column, exactly as the scalar recurrence carries it
+            int f = DEV_MINUS_INF - (b - b_lo) * e_ins;
+            if (b > b_lo) f = imax(f, ex - (b - 1) * e_ins);
+            const int e = E[c];
+            int d = m[c] >= e ? 0 : 1;
+            int hh = m[c] >= e ? m[c] : e;
+            d = hh >= f ? d : 2;
+            hh = hh >= f ? hh : f;
+            int tt = m[c] - oe_del;
+            int e2 = e - e_del;
+            d |= e2 > tt ? 1 << 2 : 0;
+            e2 = e2 > tt ? e2 : tt;
+            tt = m[c] - oe_ins;
+            const int f2 = f - e_ins;
+            d |= f2 > tt ? 2 << 4 : 0;
+            if (act[c] && z) z[(size_t)i * n_col + (b - b_lo)] = (uint8_t)d;
+            // next row: H stays in place (H(i, j) is the diagonal input of (i+1, j+1), same offset); the offset whose column becomes 0
+            // gets the first-column boundary
+            if (act[c]) H[c] = hh;
+            if (b == w - (i + 1)) H[c] = -(o_del + e_del * (i + 1));
+            e2v[c] = act[c] ? e2 : DEV_MINUS_INF;
+        }
+        // E'(i+1, j) and the query window move one offset down: inside the lane a register move, across lanes one wave_shl
+        const int e_in = dpp_get<0x130, 0xf, 0xf>(DEV_MINUS_INF, e2v[0]);            // from lane + 1's lowest offset
+        const uint32_t p_in = (uint32_t)dpp_get<0x130, 0xf, 0xf>(0, (int)P[0]);
+        const int jn = i + 1 + w;                                                    // query position entering at the top offset 2 w
+        if ((jn >> 6) != q_blk) { q_blk = jn >> 6; q_cur = q_next; q_next = pack_of((q_blk + 1) * WAVE + lane); }
+        const uint32_t p_new = jn < qlen ? (uint32_t)lane_read((int)q_cur, jn & (WAVE - 1)) : mc.c[4];
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            E[c] = c + 1 < CPB ? e2v[c + 1 < CPB ? c + 1 : c] : e_in;
+            const uint32_t p_up = c + 1 < CPB ? P[c + 1 < CPB ? c + 1 : c] : p_in;
+            P[c] = (b0 + c) == 2 * w ? p_new : p_up;
+        }
+    }
+    // H(tlen-1, qlen-1) sits at offset qlen-1 - (tlen-1-w)
+    const int bf = qlen - 1 - (tlen - 1 - w);
+    const int src = bf / CPB, kk = bf - src * CPB;
+    int pick = H[0];
+#pragma unroll
+    for (int c = 1; c < CPB; ++c) pick = kk == c ? H[c] : pick;
+    return lane_read(pick, src);
+}
+
+#define CIG_BAND_MAX_COLS (13 * WAVE)          // widest band the wave kernel takes (2 w + 1 columns)
+
+// One CIGAR job of a long read on one wave: mem_reg2aln's bwa_gen_cigar2 sequence (up to three band widths), traceback, NM, position.
+// Mirrors dev_cig_dp_job (dev_fin2.h) with the band kernel above in place of the register-per-column ones.
+static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, uint32_t slot, int lane)
+{
+    const DJob j = fl.jobs[slot];
+    DHit h = ck.hits[slot];
+    const uint8_t *query = ck.codes + ck.offs[j.r];
+    const int l_query = (int)(ck.offs[j.r + 1] - ck.offs[j.r]);
+    const int lq = j.qe - j.qb;
+    const int64_t rb = j.rb, re = j.re;
+    const uint8_t *qseg = query + j.qb;
+    const bool valid = !(lq <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac));
+    const int rlen = (int)(re - rb);
+    const bool rev = rb >= R.l_pac;
+    auto qf = [&](int x) { return (int)(rev ? qseg[lq - 1 - x] : qseg[x]); };
+    auto tf = [&](int y) { return rev ? ref_base(R, re - 1 - y) : ref_base(R, rb + y); };
+    int w2 = j.w2, score = 0, last_sc = -(1 << 30), w_used = 0, n_col = 0;
+    uint8_t *z = nullptr;
+    if (valid) {
+        for (int it = 0; it < 3; ++it) {
+            w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+            int ww, max_gap, max_ins, max_del, min_w;
+            max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = rlen - lq < 0 ? lq - rlen : rlen - lq;
+            ww = (max_gap + dl + 1) >> 1;
+            ww = ww < w2 ? ww : w2;
+            min_w = dl + 3;
+            ww = ww > min_w ? ww : min_w;
+            w_used = ww;
+            n_col = lq < 2 * ww + 1 ? lq : 2 * ww + 1;
+            if (2 * ww + 1 > CIG_BAND_MAX_COLS) return false;          // a band this wide (a long gap between the region's ends): left to k_cig_long
+            const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
+            unsigned long long off = 0;
+            if (lane == 0) off = atomicAdd(ck.zused, need);
+            off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
+            if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return true; }
+            z = ck.zarena + off;
+            const int cols = 2 * ww + 1;
+            if (cols <= WAVE) score = wave_ksw_global2_bandn<1>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            else if (cols <= 2 * WAVE) score = wave_ksw_global2_bandn<2>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            else if (cols <= 4 * WAVE) score = wave_ksw_global2_bandn<4>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            else if (cols <= 8 * WAVE) score = wave_ksw_global2_bandn<8>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            else score = wave_ksw_global2_bandn<13>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
+            if (score == last_sc || w2 == opt.w << 2) break;
+            last_sc = score;
+            w2 <<= 1;
+            if (!(score < j.truesc - opt.a)) break;
+        }
+    }
+    int n_ops = 0;
+    if (valid) {
+        __threadfence();                          // the direction bytes were written by other lanes of this wave
+        dev_traceback_wave(z, n_col, lq, rlen, w_used, lane, [&](int, int) { ++n_ops; });
+    }
+    n_ops = __builtin_amdgcn_readfirstlane(n_ops);
+    unsigned long long base = 0;
+    const unsigned long long need = (unsigned long long)n_ops + 2;
+    if (lane == 0) base = atomicAdd(ck.cigused, need);
+    base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+    if (base + need > ck.cigcap) { if (lane == 0) atomicOr(ck.flags, OVF_CIGAR); return true; }
+    uint32_t *cg = ck.cigpool + base + 1;
+    if (valid) {
+        int wp = n_ops;
+        dev_traceback_wave(z, n_col, lq, rlen, w_used, lane, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; });   // every lane stores the same words
+        int x = 0, y = 0, n_mm = 0, n_gap = 0;          // NM: lanes share the comparisons of each M run
+        for (int k = 0; k < n_ops; ++k) {
+            const uint32_t cw = cg[k];
+            const int op = (int)(cw & 0xf), len = (int)(cw >> 4);
+            if (op == 0) {
+                for (int u = lane; u < len; u += WAVE) n_mm += qf(x + u) != tf(y + u);
+                x += len; y += len;
+            } else if (op == 2) { if (k > 0 && k < n_ops - 1) n_gap += len; y += len; }
+            else if (op == 1) { x += len; n_gap += len; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) n_mm += __shfl_xor(n_mm, d, WAVE);
+        h.nm = n_mm + n_gap;
+    }
+    dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, n_ops);
+    if (lane == 0) ck.hits[slot] = h;
+    return true;
+}
+
+// jobs the wave kernel does not take go on `rest` (for k_cig_long)
+__global__ void __launch_bounds__(64) k_cig_band(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, uint32_t *rest, unsigned int *n_rest)
+{
+    const int lane = threadIdx.x;
+    const unsigned int n_jobs = *fl.n_dp;
+    for (;;) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_jobs) break;
+        const uint32_t slot = fl.dp_list[t];
+        if (!dev_cig_band_job(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+    }
+}
+
+// bwa_gen_cigar2 (score only) for mem_patch_reg on a long read, one wave: the band kernel above without direction bytes; a band beyond
+// its 832 columns falls back to the scalar loops on one lane (rows in this wave's stretch of the per-thread scratch).
+struct WaveScorerLong {
+    const DevRef &R; const slx_opt &o; const Chunk &ck; int lane; int *eh_h, *eh_e;
+    __device__ int operator()(int w_, int l_query, const uint8_t *qseg, int64_t rb, int64_t re) const
+    {
+        if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return 0;
+        const int rlen = (int)(re - rb);
+        const bool rev = rb >= R.l_pac;
+        auto qf = [&](int x) { return (int)(rev ? qseg[l_query - 1 - x] : qseg[x]); };
+        auto tf = [&](int y) { return rev ? ref_base(R, re - 1 - y) : ref_base(R, rb + y); };
+        if (l_query == rlen && w_ == 0) {
+            int sc = 0;
+            for (int i = lane; i < l_query; i += WAVE) sc += o.mat[tf(i) * 5 + qf(i)];
+            for (int d = 32; d >= 1; d >>= 1) sc += __shfl_xor(sc, d, WAVE);
+            return sc;
+        }
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_ins) / o.e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * o.mat[0] - o.o_del) / o.e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
+        int w = (max_gap + dl + 1) >> 1;
+        w = w < w_ ? w : w_;
+        const int min_w = dl + 3;
+        w = w > min_w ? w : min_w;
+        const int cols = 2 * w + 1;
+        if (cols <= WAVE) return wave_ksw_global2_bandn<1>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
+        if (cols <= 2 * WAVE) return wave_ksw_global2_bandn<2>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
+        if (cols <= 4 * WAVE) return wave_ksw_global2_bandn<4>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
+        if (cols <= 8 * WAVE) return wave_ksw_global2_bandn<8>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
+        if (cols <= CIG_BAND_MAX_COLS) return wave_ksw_global2_bandn<13>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
+        int sc = 0;
+        if (lane == 0) sc = dev_gen_cigar2<0>(R, o, ck, w_, l_query, qseg, rb, re, false, eh_h, eh_e).score;
+        return lane_read(sc, 0);
+    }
+};
+
+// mem_sort_dedup_patch .. hit emission for the multi-region reads of a long-read chunk: one wave per read (k_regs would run
+// mem_patch_reg's contig-long global alignment on a single lane)
+template <int MAXQ, int NB>
+__global__ void __launch_bounds__(64) k_regs_wave_long(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
+{
+    __shared__ int s_idx[NB], s_ka[NB], s_kb[NB], s_qe[NB], s_rid[NB], s_w[NB];
+    __shared__ int64_t s_k64[NB], s_rb[NB];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x * WAVE >= ck.long_threads) return;          // (this wave's stretch of the per-thread rows: threads blockIdx.x * 64 ..)
+    SortStage ss;
+    ss.idx = s_idx; ss.k64 = s_k64; ss.ka = s_ka; ss.kb = s_kb; ss.m_rb = s_rb; ss.m_qe = s_qe; ss.m_rid = s_rid; ss.m_w = s_w;
+    ss.nmax = NB; ss.lane = lane;
+    int *eh_h = ck.long_scratch + (size_t)blockIdx.x * WAVE * 2 * ck.long_stride, *eh_e = eh_h + ck.long_stride;
+    WaveScorerLong sc{R, dopt.o, ck, lane, eh_h, eh_e};
+    const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = (int)atomicAdd(queue, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= n_todo) break;
+        const int r = order ? order[slot] : slot;
+        dev_regs_read<MAXQ>(R, ck, dopt.o, fl, r, sc, lane == 0, &ss);
+    }
+}

@@ -396,11 +396,24 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
-    __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];                // H/E row of the (rare) extensions wider than two columns per lane
-    __shared__ int gap_lut[MAXQ + 2];                             // cal_max_gap(q) for every q a 0..MAXQ query distance can take
-    for (int q = lane; q < MAXQ + 2; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
+    // H/E row of the (rare) extensions wider than two columns per lane, and cal_max_gap(q) for every query distance q.  Reads up to 704 bp:
+    // static LDS.  Longer reads (contigs): rows of the chunk's longest read + 8 -- in dynamic LDS while three of them fit 64 KB (so that
+    // several waves share a CU: a 2 kb contig needs 24 KB, not the 96 KB of an 8 kb one), else in HBM (ck.huge_rows; the row is only ever
+    // touched inside the band, a few hundred columns at a time)
+    __shared__ int sh_eh_h[MAXQ > 704 ? 1 : MAXQ + 2], sh_eh_e[MAXQ > 704 ? 1 : MAXQ + 2], sh_gap_lut[MAXQ > 704 ? 1 : MAXQ + 2];
+    extern __shared__ int sh_dyn[];
+    int *eh_h = sh_eh_h, *eh_e = sh_eh_e, *gap_lut = sh_gap_lut;
+    int lut_n = MAXQ + 2;
+    if constexpr (MAXQ > 704) {
+        lut_n = ck.long_stride;
+        if (ck.huge_rows) {
+            int *base = ck.huge_rows + (size_t)blockIdx.x * 3 * (size_t)lut_n;
+            eh_h = base; eh_e = base + lut_n; gap_lut = base + 2 * (size_t)lut_n;
+        } else { eh_h = sh_dyn; eh_e = sh_dyn + lut_n; gap_lut = sh_dyn + 2 * lut_n; }
+    }
+    for (int q = lane; q < lut_n; q += WAVE) gap_lut[q] = dev_cal_max_gap(opt, q);
     __syncthreads();
-    auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > MAXQ + 1 ? MAXQ + 1 : q)]; };
+    auto max_gap_of = [&](int q) { return gap_lut[q < 0 ? 0 : (q > lut_n - 1 ? lut_n - 1 : q)]; };
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     const int n_head = first ? __builtin_amdgcn_readfirstlane((int)*n_first) : 0;
     while (true) {

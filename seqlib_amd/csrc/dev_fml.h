@@ -117,9 +117,10 @@ static __global__ void __launch_bounds__(256) k_fml_pack(const char *bases, cons
 
 // ---------------------------------------------------------------------------------------------------------------- counting
 
-// fml_count: one lane per position = per k-mer ending there
+// fml_count: one lane per position = per k-mer ending there.  stats[0] = k-mers inserted, stats[1] = a table ran full (the host
+// enlarges the tables and counts again; it also does so when the histogram that follows shows a table more than 70 % full).
 static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long long total, const unsigned long long *offs, long long n_reads,
-                                                   const FmlWin *wins, int n_win, FmlSlot *tab, unsigned long long *n_inserted)
+                                                   const FmlWin *wins, int n_win, FmlSlot *tab, unsigned long long *stats)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = p < total;
@@ -140,16 +141,17 @@ static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long lon
     }
     if (ok) {
         FmlSlot *t = tab + w.tab_off;
-        unsigned int i = (unsigned int)fml_mix64(key) & w.tab_mask;
+        unsigned int i = (unsigned int)fml_mix64(key) & w.tab_mask, probes = 0;
         while (true) {
             unsigned long long old = t[i].key;
             if (old == 0) old = atomicCAS(&t[i].key, 0ULL, key + 1);
             if (old == 0 || old == key + 1) { atomicAdd(&t[i].cnt, inc); break; }
             i = (i + 1) & w.tab_mask;
+            if (++probes > w.tab_mask) { stats[1] = 1; break; }
         }
     }
     const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inserted, (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&stats[0], (unsigned long long)__popcll(m));
 }
 
 // bfc_ch_hist: blocks of 1024 slots never straddle two windows (tables are powers of two >= 1024, laid end to end)
@@ -193,28 +195,42 @@ static __global__ void k_fml_dump(const FmlSlot *tab, FmlWin w, unsigned long lo
 
 struct FmlEcOpt { int q, win_multi_ec, max_end_ext, w_ec, w_ec_high, w_absent, w_absent_high, max_heap; };
 
-struct __align__(16) FmlHeap1 {          // echeap1_t
+struct __align__(16) FmlHeap1 {          // echeap1_t, 48 bytes
     int tot_pen, i, k;
     int eh[FML_EC_HIST_HIGH];
     int ep[FML_EC_HIST];
     uint32_t x0, x1;          // forward planes of the last k - 1 (then k) bases; the reverse strand is derived when a key is needed
-    int pad[4];
 };
 
-struct FmlEcScratch {          // one per resident lane
+// Per-lane work areas of the correction kernel, INTERLEAVED across the 64 lanes of a wave: element j of a lane's array sits at
+// index j * 64 + lane, so that lanes working on the same position of their reads -- the common case, every lane advances one base
+// per step -- touch one contiguous stretch.  The pointers below are already offset by the lane; index with FML_L(j).
+#define FML_L(j) ((size_t)(j) * 64)
+struct FmlEcScratch {
     unsigned char *B;          // per base: b | q << 3 | ob << 4
     unsigned short *cv;        // per base: lcov | hcov << 6 | solid_end << 12 | high_end << 13
-    FmlHeap1 *heap;
+    FmlHeap1 *heap;            // heap entries 1 .. (entry 0, the top, lives in registers)
     uint2 *stack;              // x = parent, y = i | b << 16
 };
 
-__host__ __device__ inline size_t fml_scratch_bytes(int max_len)
+__host__ __device__ inline size_t fml_scratch_bytes(int max_len)          // per LANE (a wave owns 64 times this, contiguous)
 {
     size_t b = ((size_t)max_len + 15) & ~(size_t)15;
     size_t c = (2 * (size_t)max_len + 15) & ~(size_t)15;
     size_t h = sizeof(FmlHeap1) * FML_HEAP_CAP;
     size_t s = ((size_t)(FML_STACK_CAP(max_len) + 8) * 8 + 15) & ~(size_t)15;
     return b + c + h + s;
+}
+
+__device__ __forceinline__ FmlEcScratch fml_scratch_of(unsigned char *scratch, size_t lane_bytes, int max_len, size_t wave, int lane)
+{
+    unsigned char *p = scratch + wave * 64 * lane_bytes;
+    FmlEcScratch sc;
+    sc.B = p + lane; p += 64 * (((size_t)max_len + 15) & ~(size_t)15);
+    sc.cv = (unsigned short *)p + lane; p += 64 * ((2 * (size_t)max_len + 15) & ~(size_t)15);
+    sc.heap = (FmlHeap1 *)p + lane; p += 64 * sizeof(FmlHeap1) * FML_HEAP_CAP;
+    sc.stack = (uint2 *)p + lane;
+    return sc;
 }
 
 __device__ __forceinline__ void fml_append(int k, uint32_t &x0, uint32_t &x1, int c)
@@ -230,30 +246,44 @@ __device__ __forceinline__ int fml_occ(const FmlSlot *tab, const FmlWin &w, uint
     return fml_get(tab, w, fml_key(w.k, x0, x1, mask));
 }
 
-// klib's ks_heapdown / ks_heapup on tot_pen (smallest on top), operation for operation: the order in which equal penalties leave
-// the heap decides between equally cheap paths
-__device__ inline void fml_heapdown(FmlHeap1 *l, int n)
-{
-    int i = 0, k = 0;
-    const FmlHeap1 tmp = l[0];
-    while ((k = (k << 1) + 1) < n) {
-        if (k != n - 1 && l[k].tot_pen > l[k + 1].tot_pen) ++k;
-        if (l[k].tot_pen > tmp.tot_pen) break;
-        l[i] = l[k]; i = k;
+// klib's ks_heapdown / ks_heapup on tot_pen (smallest on top), operation for operation -- the order in which equal penalties leave the
+// heap decides between equally cheap paths -- over a heap whose entry 0 is the register `top` and whose entries 1 .. are mem[0 ..].
+// Nearly always the heap holds one state (the read's own path), and then no heap traffic reaches memory at all.
+struct FmlHeap {
+    FmlHeap1 top;
+    FmlHeap1 *mem;
+    int n;
+    __device__ __forceinline__ FmlHeap1 get(int i) const { return i == 0 ? top : mem[FML_L(i - 1)]; }
+    __device__ __forceinline__ void set(int i, const FmlHeap1 &e) { if (i == 0) top = e; else mem[FML_L(i - 1)] = e; }
+    __device__ inline FmlHeap1 pop()          // z = l[0]; l[0] = l[--n]; ks_heapdown(0, n, l)
+    {
+        const FmlHeap1 z = top;
+        --n;
+        if (n > 0) {
+            const FmlHeap1 tmp = mem[FML_L(n - 1)];
+            int i = 0, k = 0;
+            while ((k = (k << 1) + 1) < n) {
+                FmlHeap1 ck = mem[FML_L(k - 1)];
+                if (k != n - 1) { const FmlHeap1 c2 = mem[FML_L(k)]; if (ck.tot_pen > c2.tot_pen) { ++k; ck = c2; } }
+                if (ck.tot_pen > tmp.tot_pen) break;
+                set(i, ck); i = k;
+            }
+            set(i, tmp);
+        }
+        return z;
     }
-    l[i] = tmp;
-}
-__device__ inline void fml_heapup(FmlHeap1 *l, int n)
-{
-    int i = n - 1;
-    const FmlHeap1 tmp = l[i];
-    while (i > 0) {
-        const int k = (i - 1) >> 1;
-        if (tmp.tot_pen > l[k].tot_pen) break;
-        l[i] = l[k]; i = k;
+    __device__ inline void push(const FmlHeap1 &r)          // l[n++] = r; ks_heapup(n, l)
+    {
+        int i = n++;
+        while (i > 0) {
+            const int k = (i - 1) >> 1;
+            const FmlHeap1 pk = get(k);
+            if (r.tot_pen > pk.tot_pen) break;
+            set(i, pk); i = k;
+        }
+        set(i, r);
     }
-    l[i] = tmp;
-}
+};
 
 struct FmlPen { int ec, ec_high, absent, absent_high, b; };
 
@@ -263,14 +293,16 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
 {
     const int k = w.k;
     FmlHeap1 z;
-    int l, n_heap = 0, n_stack = 0, n_failures = 0, path = -1;
+    FmlHeap hp;
+    int l, n_stack = 0, n_failures = 0, path = -1;
     bool found = false;
+    hp.mem = sc.heap; hp.n = 0;
     auto base_at = [&](int i, int &b, int &q, int &ob, int &lc, int &hc) {
         const int fi = dir ? n - 1 - i : i;
-        const int v = sc.B[fi];
+        const int v = sc.B[FML_L(fi)];
         b = v & 7; q = v >> 3 & 1; ob = v >> 4 & 7;
         if (dir) { b = b < 4 ? 3 - b : 4; ob = ob < 4 ? 3 - ob : 4; }
-        const int c = sc.cv[fi];
+        const int c = sc.cv[FML_L(fi)];
         lc = c & 63; hc = c >> 6 & 63;
     };
     z.tot_pen = 0; z.x0 = z.x1 = 0; z.k = -1;
@@ -285,13 +317,11 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
     if (z.i >= end) return -1;
     for (int i = 0; i < FML_EC_HIST; ++i) z.ep[i] = -1;
     for (int i = 0; i < FML_EC_HIST_HIGH; ++i) z.eh[i] = -1;
-    sc.heap[n_heap++] = z;
+    hp.push(z);
     while (true) {
         bool stop = false;
-        if (n_heap == 0) return -2;
-        z = sc.heap[0];
-        sc.heap[0] = sc.heap[--n_heap];
-        if (n_heap) fml_heapdown(sc.heap, n_heap);
+        if (hp.n == 0) return -2;
+        z = hp.pop();
         if (z.i - end > o.max_end_ext) stop = true;
         if (!stop) {
             const bool have = z.i < n;
@@ -337,7 +367,7 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
             if (n_failures > n * 2 || n_stack > FML_STACK_CAP(n)) return -3;
             if (have || n_added == 1) {
                 int first = 0, last = n_added;
-                if (n_added > 1 && n_heap > o.max_heap) {
+                if (n_added > 1 && hp.n > o.max_heap) {
                     int min_b = -1, mn = 0x7fffffff;
                     for (int b = 0; b < n_added; ++b) {
                         const int t = o.w_ec * added[b].ec + o.w_ec_high * added[b].ec_high + o.w_absent * added[b].absent + o.w_absent_high * added[b].absent_high;
@@ -348,27 +378,26 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
                 for (int a = first; a < last; ++a) {          // buf_update
                     const FmlPen pen = added[a];
                     FmlHeap1 r = z;
-                    sc.stack[n_stack] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
+                    sc.stack[FML_L(n_stack)] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
                     r.tot_pen = z.tot_pen + o.w_ec * pen.ec + o.w_ec_high * pen.ec_high + o.w_absent * pen.absent + o.w_absent_high * pen.absent_high;
                     r.i = z.i + 1;
                     r.k = n_stack++;
                     if (pen.ec_high) { r.eh[1] = z.eh[0]; r.eh[0] = z.i; }
                     if (pen.ec) { r.ep[4] = z.ep[3]; r.ep[3] = z.ep[2]; r.ep[2] = z.ep[1]; r.ep[1] = z.ep[0]; r.ep[0] = z.i; }
                     fml_append(k, r.x0, r.x1, pen.b);
-                    sc.heap[n_heap++] = r;
-                    fml_heapup(sc.heap, n_heap);
+                    hp.push(r);
                 }
             } else stop = true;
         }
         if (stop) { path = z.k; found = true; break; }
     }
     if (!found) return -1;
-    for (l = path; l >= 0; l = (int)sc.stack[l].x) {
-        const uint2 e = sc.stack[l];
+    for (l = path; l >= 0; l = (int)sc.stack[FML_L(l)].x) {
+        const uint2 e = sc.stack[FML_L(l)];
         const int i = (int)(e.y & 0xffff), b = (int)(e.y >> 16);
         if (i < n) {
             const int fi = dir ? n - 1 - i : i;
-            sc.B[fi] = (unsigned char)((sc.B[fi] & ~7) | (dir ? 3 - b : b));
+            sc.B[FML_L(fi)] = (unsigned char)((sc.B[FML_L(fi)] & ~7) | (dir ? 3 - b : b));
         }
     }
     return 0;
@@ -383,7 +412,7 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
         const int c = fml_nt5((unsigned char)seq[i]);
         int q = !qual ? 1 : ((int)(unsigned char)qual[i] - 33 >= o.q ? 1 : 0);
         if (c > 3) q = 0, ++n_n;
-        sc.B[i] = (unsigned char)(c | q << 3 | c << 4);
+        sc.B[FML_L(i)] = (unsigned char)(c | q << 3 | c << 4);
     }
     if ((double)n_n > n * .05) return -10;
     if (n < k) return -11;
@@ -391,7 +420,7 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
         uint32_t x0 = 0, x1 = 0;
         int l = 0;
         for (int i = 0; i < n; ++i) {
-            const int c = sc.B[i] & 7;
+            const int c = sc.B[FML_L(i)] & 7;
             int f = 0;
             if (c < 4) {
                 fml_append(k, x0, x1, c);
@@ -404,14 +433,14 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
                     }
                 }
             } else l = 0, x0 = x1 = 0;
-            sc.cv[i] = (unsigned short)f;
+            sc.cv[FML_L(i)] = (unsigned short)f;
         }
         int lc = 0, hc = 0;          // ends in [j, j + k - 1]
-        for (int i = 0; i < k - 1 && i < n; ++i) { const int f = sc.cv[i]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
+        for (int i = 0; i < k - 1 && i < n; ++i) { const int f = sc.cv[FML_L(i)]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
         for (int j = 0; j < n; ++j) {
-            if (j + k - 1 < n) { const int f = sc.cv[j + k - 1]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
-            const int fj = sc.cv[j];
-            sc.cv[j] = (unsigned short)((fj & 0x3000) | lc | hc << 6);
+            if (j + k - 1 < n) { const int f = sc.cv[FML_L(j + k - 1)]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
+            const int fj = sc.cv[FML_L(j)];
+            sc.cv[FML_L(j)] = (unsigned short)((fj & 0x3000) | lc | hc << 6);
             lc -= fj >> 12 & 1; hc -= (fj >> 12 & 1) & (fj >> 13 & 1);
         }
     }
@@ -419,7 +448,7 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
     {          // bfc_ec_best_island
         int l = 0, mx = 0, mx_i = -1, i;
         for (i = k - 1; i < n; ++i) {
-            if (!(sc.cv[i] >> 12 & 1)) {
+            if (!(sc.cv[FML_L(i)] >> 12 & 1)) {
                 if (l > mx) mx = l, mx_i = i;
                 l = 0;
             } else ++l;
@@ -433,7 +462,7 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
                 int ll = 0;
                 x0 = x1 = 0;
                 for (end = start; end < n; ++end) {
-                    const int c = sc.B[end] & 7;
+                    const int c = sc.B[FML_L(end)] & 7;
                     if (c < 4) {
                         fml_append(k, x0, x1, c);
                         if (++ll == k) break;
@@ -461,17 +490,14 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
             }
             if (ec < 0 || end >= n) return -12;
             const int at = end - (ec >> 2);
-            sc.B[at] = (unsigned char)((sc.B[at] & ~7) | (ec & 3));
+            sc.B[FML_L(at)] = (unsigned char)((sc.B[FML_L(at)] & ~7) | (ec & 3));
             ++end; start = end - k;
         }
     }
     if (fml_ec1dir(tab, w, o, sc, n, 0, start, n) < 0) return -13;
-    if (fml_ec1dir(tab, w, o, sc, n, 1, n - end, n) < 0) {
-        // the oracle leaves the read untouched when the second direction fails: nothing has been written to the text yet
-        return -14;
-    }
+    if (fml_ec1dir(tab, w, o, sc, n, 1, n - end, n) < 0) return -14;          // (nothing has been written to the text yet: the read stays as it was)
     for (int i = 0; i < n; ++i) {
-        const int v = sc.B[i], b = v & 7, ob = v >> 4 & 7;
+        const int v = sc.B[FML_L(i)], b = v & 7, ob = v >> 4 & 7;
         const bool diff = b != ob;
         seq[i] = diff ? "acgtn"[b] : "ACGTN"[b];
         if (qual) qual[i] = diff ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+');
@@ -484,16 +510,16 @@ static __global__ void __launch_bounds__(256) k_fml_ec(const FmlSlot *tab, const
                                                 const unsigned long long *offs, long long n_reads, unsigned char *scratch, size_t lane_bytes, int max_len,
                                                 unsigned long long *next, int *status)
 {
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned char *p = scratch + lane * lane_bytes;
-    FmlEcScratch sc;
-    sc.B = p; p += ((size_t)max_len + 15) & ~(size_t)15;
-    sc.cv = (unsigned short *)p; p += (2 * (size_t)max_len + 15) & ~(size_t)15;
-    sc.heap = (FmlHeap1 *)p; p += sizeof(FmlHeap1) * FML_HEAP_CAP;
-    sc.stack = (uint2 *)p;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const FmlEcScratch sc = fml_scratch_of(scratch, lane_bytes, max_len, wave, threadIdx.x & 63);
     while (true) {
-        const long long r = (long long)atomicAdd(next, 1ULL);
-        if (r >= n_reads) break;
+        // a wave takes 64 consecutive reads: its lanes then walk reads of the same window and (nearly always) the same length in step
+        unsigned long long r0 = 0;
+        if ((threadIdx.x & 63) == 0) r0 = atomicAdd(next, 64ULL);
+        r0 = __shfl(r0, 0);
+        if ((long long)r0 >= n_reads) break;
+        const long long r = (long long)r0 + (threadIdx.x & 63);
+        if (r >= n_reads) continue;
         const unsigned long long b = offs[r];
         const int n = (int)(offs[r + 1] - b);
         int rc = 1;

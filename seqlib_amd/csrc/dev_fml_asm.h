@@ -67,67 +67,267 @@ static __global__ void __launch_bounds__(256) k_asm_keys(const unsigned char *te
     contained[t] = same ? 1 : 0;
 }
 
-// The join.  PASS 1: duplicates (rep), containment, overlaps counted per source string.  PASS 2: the overlaps between vertices written out.
-template <int PASS>
-static __global__ void __launch_bounds__(256) k_asm_join(const unsigned char *text, unsigned long long text_len, const FmlStr *strs, const unsigned long long *str_off /* n_str + 1 */,
-                                                         long long n_str, int kk, int min_match, const unsigned long long *keys, const unsigned int *vals,
-                                                         int *rep, unsigned char *contained, unsigned int *cnt, const unsigned long long *eoff, unsigned int *cur, FmlEdge *edges)
+struct FmlTriple { int u, v, len; };
+
+// An index over the sorted seed keys: key -> position of its first occurrence, open addressing (slot key + 1, 0 = empty).  One probe
+// sequence replaces a 20-step binary search per text position; most positions' seeds start no string and end at the first empty slot.
+static __global__ void __launch_bounds__(256) k_asm_index(const unsigned long long *keys, long long n_str, unsigned long long *hkey, unsigned int *hval, unsigned int hmask)
 {
-    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= text_len) return;
-    // the string holding text position g
-    long long lo = 0, hi = n_str;
-    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (str_off[mid] <= g) lo = mid; else hi = mid; }
-    const int u = (int)lo;
-    const FmlStr su = strs[u];
-    const int p = (int)(g - su.off), rest = su.len - p;
-    if (rest < min_match) return;
-    if (PASS == 2 && (p == 0 || rep[u] != u || contained[u])) return;
-    const unsigned long long key = fml_seed_key(text + g, kk, su.win);
-    long long a = 0, b = n_str;
-    while (a < b) { const long long mid = (a + b) >> 1; if (keys[mid] < key) a = mid + 1; else b = mid; }
-    for (; a < n_str && keys[a] == key; ++a) {
-        const int v = (int)vals[a];
-        if (v == u) continue;
-        const FmlStr sv = strs[v];
-        const int m = rest < sv.len ? rest : sv.len;
-        const unsigned char *x = text + g, *y = text + sv.off;
-        bool same = true;
-        for (int i = kk; i < m; ++i)
-            if (x[i] != y[i]) { same = false; break; }
-        if (!same) continue;
-        if (sv.len <= rest) {          // v lies inside u
-            if (PASS == 1) {
-                if (p == 0 && sv.len == su.len) { if (v < u) atomicMin(&rep[u], v); }
-                else contained[v] = 1;
-            }
-        } else if (p > 0) {          // v runs past the end of u: an overlap of `rest` bases
-            if (PASS == 1) atomicAdd(&cnt[u], 1u);
-            else if (rep[v] == v && !contained[v]) {
-                const unsigned int slot = atomicAdd(&cur[u], 1u);
-                edges[eoff[u] + slot] = FmlEdge{v, rest};
-            }
-        }
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_str) return;
+    const unsigned long long key = keys[i];
+    if (i > 0 && keys[i - 1] == key) return;
+    unsigned int h = (unsigned int)(key * 0x9E3779B97F4A7C15ULL >> 32) & hmask;
+    while (atomicCAS(&hkey[h], 0ULL, key + 1) != 0) h = (h + 1) & hmask;          // keys are distinct here: a slot taken is another key's
+    hval[h] = (unsigned int)i;
+}
+
+__device__ __forceinline__ long long fml_index_find(const unsigned long long *hkey, const unsigned int *hval, unsigned int hmask, unsigned long long key)
+{
+    unsigned int h = (unsigned int)(key * 0x9E3779B97F4A7C15ULL >> 32) & hmask;
+    while (true) {
+        const unsigned long long k = hkey[h];
+        if (k == key + 1) return (long long)hval[h];
+        if (k == 0) return -1;
+        h = (h + 1) & hmask;
     }
 }
 
-// Transitive reduction, one wave per source vertex: edges ordered by (overlap descending, target ascending), one edge per target (the longest),
-// and u -> v_j dropped when a longer overlap u -> v_k exists whose string agrees with v_j's wherever both lie beyond the end of u.
-// The irreducible edges of u go to out[] at an offset reserved with one atomic per wave; n_irr / irr_off say where.
+__device__ __forceinline__ unsigned long long fml_load8(const unsigned char *p)          // 8 bytes from any address
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// equal over [from, to)?  32 bytes per step -- eight independent loads in flight, one branch -- then 8, then a masked tail (both texts
+// have 8 readable bytes past any string: the buffers are padded).  A candidate that shares its 16-base seed with the text nearly
+// always matches to the end, so the loop is a chain of round trips to memory: fewer, wider steps are what count.
+__device__ __forceinline__ bool fml_same(const unsigned char *x, const unsigned char *y, int from, int to)
+{
+    int i = from;
+    for (; i + 32 <= to; i += 32) {
+        const unsigned long long a0 = fml_load8(x + i), a1 = fml_load8(x + i + 8), a2 = fml_load8(x + i + 16), a3 = fml_load8(x + i + 24);
+        const unsigned long long b0 = fml_load8(y + i), b1 = fml_load8(y + i + 8), b2 = fml_load8(y + i + 16), b3 = fml_load8(y + i + 24);
+        if ((a0 ^ b0) | (a1 ^ b1) | (a2 ^ b2) | (a3 ^ b3)) return false;
+    }
+    for (; i + 8 <= to; i += 8)
+        if (fml_load8(x + i) != fml_load8(y + i)) return false;
+    if (i < to) {
+        const unsigned long long m = ~0ULL >> (8 * (8 - (to - i)));
+        if ((fml_load8(x + i) ^ fml_load8(y + i)) & m) return false;
+    }
+    return true;
+}
+
+// The join, one wave per string u, one lane per position p of it: the strings whose first kk bases are u[p .. p + kk) come from a binary
+// search in the sorted keys and are verified against u[p ..).  A string that ends inside u is contained (over the whole of u at p = 0: a
+// duplicate, the smaller index stands for both); one that runs past the end of u overlaps it by |u| - p bases.  Overlaps leave as
+// (u, v, length) triples, a wave reserving room for its lanes' finds with one atomic; cnt[u] counts them per source.
+static __global__ void __launch_bounds__(256) k_asm_join(const unsigned char *text, const FmlStr *strs, long long n_str, int kk, int min_match,
+                                                         const unsigned long long *keys, const unsigned int *vals, const unsigned long long *hkey, const unsigned int *hval, unsigned int hmask,
+                                                         int *rep, unsigned char *contained, unsigned int *cnt, FmlTriple *tri, unsigned long long tri_cap, unsigned long long *tri_n)
+{
+    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (u >= n_str) return;
+    const FmlStr su = strs[u];
+    const unsigned char *ut = text + su.off;
+    unsigned int n_mine = 0;
+    for (int p0 = 0; p0 + min_match <= su.len; p0 += 64) {
+        const int p = p0 + lane, rest = su.len - p;
+        FmlTriple found[4];
+        int nf = 0;
+        if (rest >= min_match) {
+            const unsigned long long key = fml_seed_key(ut + p, kk, su.win);
+            long long a = fml_index_find(hkey, hval, hmask, key);
+            for (; a >= 0 && a < n_str && keys[a] == key; ++a) {
+                const int v = (int)vals[a];
+                if (v == (int)u) continue;
+                const FmlStr sv = strs[v];
+                const int m = rest < sv.len ? rest : sv.len;
+                if (!fml_same(ut + p, text + sv.off, kk, m)) continue;
+                if (sv.len <= rest) {          // v lies inside u
+                    if (p == 0 && sv.len == su.len) { if (v < (int)u) atomicMin(&rep[u], v); }
+                    else contained[v] = 1;
+                } else if (p > 0) {          // v runs past the end of u
+                    if (nf < 4) found[nf] = FmlTriple{(int)u, v, rest};
+                    else { const unsigned long long at = atomicAdd(tri_n, 1ULL); if (at < tri_cap) tri[at] = FmlTriple{(int)u, v, rest}; }
+                    ++nf;
+                }
+            }
+        }
+        // the wave's finds of this round (at most four per lane; the rare rest went out one by one above)
+        const int mine = nf < 4 ? nf : 4;
+        int incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int total = __shfl(incl, 63);
+        if (total) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(tri_n, (unsigned long long)total);
+            base = __shfl(base, 0) + (unsigned long long)(incl - mine);
+            for (int j = 0; j < mine; ++j) if (base + j < tri_cap) tri[base + j] = found[j];
+        }
+        n_mine += (unsigned int)nf;
+    }
+    for (int o = 32; o > 0; o >>= 1) n_mine += __shfl_xor(n_mine, o);
+    if (lane == 0 && n_mine) cnt[u] = n_mine;
+}
+
+// the overlaps between vertices, grouped by source (eoff = exclusive scan of cnt)
+static __global__ void __launch_bounds__(256) k_asm_scatter(const FmlTriple *tri, unsigned long long n_tri, const int *rep, const unsigned char *contained,
+                                                            const unsigned long long *eoff, unsigned int *cur, FmlEdge *edges)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tri) return;
+    const FmlTriple t = tri[i];
+    if (rep[t.u] != t.u || contained[t.u] || rep[t.v] != t.v || contained[t.v]) return;
+    const unsigned int slot = atomicAdd(&cur[t.u], 1u);
+    edges[eoff[t.u] + slot] = FmlEdge{t.v, t.len};
+}
+
+// Transitive reduction, one wave per source vertex: edges ordered by (overlap descending, target ascending), one edge per target (the
+// longest), and u -> v_j dropped when a longer overlap u -> v_k exists whose string agrees with v_j's wherever both lie beyond the end of
+// u.  Up to 64 edges (the rule: ~coverage x (1 - min_overlap / read length)) live one per lane in registers -- ranks by 64 shuffles, the
+// sort as one cross-lane push, the witnesses' descriptors by shuffle; more go through memory (k_asm_reduce_big).  The irreducible edges of
+// u go to out[] at an offset reserved with one atomic per wave; n_irr / irr_off say where.
 static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *text, const FmlStr *strs, long long n_str, const unsigned long long *eoff, const unsigned int *cur,
-                                                           FmlEdge *edges, FmlEdge *sorted, unsigned char *flags, unsigned int *n_irr, unsigned long long *irr_off,
-                                                           FmlEdge *out, unsigned long long *out_n)
+                                                           const FmlEdge *edges, unsigned int *n_irr, unsigned long long *irr_off, FmlEdge *out, unsigned long long *out_n,
+                                                           int *big_list, unsigned int *n_big)
 {
     const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (u >= n_str) return;
     const int d = (int)cur[u];
     if (d == 0) { if (lane == 0) { n_irr[u] = 0; irr_off[u] = 0; } return; }
+    if (d > 64) { if (lane == 0) big_list[atomicAdd(n_big, 1u)] = (int)u; return; }
+    const FmlEdge me = lane < d ? edges[eoff[u] + (unsigned long long)lane] : FmlEdge{0x7fffffff, -1};
+    int r = 0;
+    for (int j = 0; j < d; ++j) {
+        const int ov = __shfl(me.v, j), ol = __shfl(me.len, j);
+        r += (ol > me.len) || (ol == me.len && ov < me.v);
+    }
+    if (lane >= d) r = lane;
+    // lane r receives the edge of rank r
+    const int sv = __builtin_amdgcn_ds_permute(r << 2, me.v), sl = __builtin_amdgcn_ds_permute(r << 2, me.len);
+    bool dup = false;
+    for (int k = 0; k < d; ++k) { const int vk = __shfl(sv, k); dup |= (k < lane && vk == sv); }
+    const FmlStr su = strs[u];
+    FmlStr sj = su;
+    if (lane < d) sj = strs[sv];
+    const int aj = su.len - sl;
+    bool drop = false;
+    for (int k = 0; k < d; ++k) {
+        const int lk = __shfl(sl, k), slen_k = __shfl(sj.len, k);
+        const unsigned long long off_k = __shfl(sj.off, k);
+        const bool dup_k = __shfl((int)dup, k) != 0;
+        if (k < lane && lane < d && !dup && !drop && !dup_k && lk != sl) {
+            const int ak = su.len - lk, end_k = ak + slen_k, end_j = aj + sj.len;
+            const int end = end_k < end_j ? end_k : end_j;
+            // both strings equal u up to its end: compare what lies beyond
+            if (fml_same(text + off_k + (su.len - ak), text + sj.off + (su.len - aj), 0, end - su.len)) drop = true;
+        }
+    }
+    const bool keep = lane < d && !dup && !drop;
+    const unsigned long long m = __ballot(keep);
+    const int n_keep = __popcll(m);
+    unsigned long long at = 0;
+    if (lane == 0) { at = atomicAdd(out_n, (unsigned long long)n_keep); n_irr[u] = (unsigned int)n_keep; irr_off[u] = at; }
+    at = __shfl(at, 0);
+    if (keep) out[at + __popcll(m & ((1ULL << lane) - 1))] = FmlEdge{sv, sl};
+}
+
+// The same for the vertices with more than 64 overlaps (reads inside repeats and low-complexity tracts: hundreds to thousands of
+// overlaps each): one BLOCK per vertex, the edge list in LDS.  Rank and "a longer overlap with the same target exists" come out of one
+// all-against-all pass (both are order-free); the witnesses of the reduction are tried longest overlap first.  More than
+// FML_BIG_CAP edges: k_asm_reduce_huge, through memory.
+#define FML_BIG_CAP 4096
+static __global__ void __launch_bounds__(256) k_asm_reduce_big(const unsigned char *text, const FmlStr *strs, const int *big_list, const unsigned int *n_big,
+                                                               const unsigned long long *eoff, const unsigned int *cur, const FmlEdge *edges,
+                                                               unsigned int *n_irr, unsigned long long *irr_off, FmlEdge *out, unsigned long long *out_n,
+                                                               int *huge_list, unsigned int *n_huge, int big_cap)
+{
+    __shared__ int ev[FML_BIG_CAP], el[FML_BIG_CAP], sv[FML_BIG_CAP], sl[FML_BIG_CAP];
+    __shared__ unsigned char fl[FML_BIG_CAP];
+    __shared__ int wave_cnt[4];
+    __shared__ unsigned long long at_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x >= *n_big) return;
+    const long long u = big_list[blockIdx.x];
+    const int d = (int)cur[u];
+    if (d > big_cap) { if (tid == 0) huge_list[atomicAdd(n_huge, 1u)] = (int)u; return; }
+    const FmlEdge *e = edges + eoff[u];
+    for (int i = tid; i < d; i += 256) { const FmlEdge x = e[i]; ev[i] = x.v; el[i] = x.len; }
+    __syncthreads();
+    for (int i = tid; i < d; i += 256) {
+        const int v = ev[i], l = el[i];
+        int r = 0, dup = 0;
+        for (int j = 0; j < d; ++j) {
+            const int ov = ev[j], ol = el[j];
+            r += (ol > l) || (ol == l && ov < v);
+            dup |= (ov == v && ol > l);
+        }
+        sv[r] = v; sl[r] = l; fl[r] = (unsigned char)dup;
+    }
+    __syncthreads();
+    const FmlStr su = strs[u];
+    for (int j = tid; j < d; j += 256) {
+        if (fl[j] == 1) continue;
+        const int lj = sl[j];
+        const FmlStr sj = strs[sv[j]];
+        const int aj = su.len - lj;
+        bool drop = false;
+        for (int k = 0; k < j && !drop; ++k) {
+            if (fl[k] == 1 || sl[k] == lj) continue;          // (fl[k] may be turning from 0 into 2 right now: either reads as "not a copy")
+            const FmlStr sk = strs[sv[k]];
+            const int ak = su.len - sl[k], end_k = ak + sk.len, end_j = aj + sj.len;
+            const int end = end_k < end_j ? end_k : end_j;
+            drop = fml_same(text + sk.off + (su.len - ak), text + sj.off + (su.len - aj), 0, end - su.len);
+        }
+        if (drop) fl[j] = 2;
+    }
+    __syncthreads();
+    int keep = 0;
+    for (int j = tid; j < d; j += 256) keep += fl[j] == 0;
+    for (int o = 32; o > 0; o >>= 1) keep += __shfl_xor(keep, o);
+    if (lane == 0) wave_cnt[wv] = keep;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        at_s = atomicAdd(out_n, (unsigned long long)tot);
+        n_irr[u] = (unsigned int)tot; irr_off[u] = at_s;
+    }
+    __syncthreads();
+    int done = 0;
+    for (int j0 = 0; j0 < d; j0 += 256) {          // in sorted order: per round the waves' counts, then a ballot prefix inside each wave
+        const int j = j0 + tid;
+        const bool k = j < d && fl[j] == 0;
+        const unsigned long long m = __ballot(k);
+        __syncthreads();
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w2 = 0; w2 < wv; ++w2) before += wave_cnt[w2];
+        if (k) out[at_s + done + before + __popcll(m & ((1ULL << lane) - 1))] = FmlEdge{sv[j], sl[j]};
+        done += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
+}
+
+// the same through memory, for a vertex with more overlaps than k_asm_reduce_big's LDS holds
+static __global__ void __launch_bounds__(256) k_asm_reduce_huge(const unsigned char *text, const FmlStr *strs, const int *big_list, const unsigned int *n_big,
+                                                               const unsigned long long *eoff, const unsigned int *cur,
+                                                               const FmlEdge *edges, FmlEdge *sorted, unsigned char *flags, unsigned int *n_irr, unsigned long long *irr_off,
+                                                               FmlEdge *out, unsigned long long *out_n)
+{
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= (long long)*n_big) return;
+    const long long u = big_list[b];
+    const int d = (int)cur[u];
     const unsigned long long base = eoff[u];
     const FmlEdge *e = edges + base;
     FmlEdge *s = sorted + base;
     unsigned char *fl = flags + base;
-    // rank by counting: (len desc, v asc); equal (v, len) pairs cannot occur (one hit per position and target)
     for (int i = lane; i < d; i += 64) {
         const FmlEdge me = e[i];
         int r = 0;
@@ -140,7 +340,6 @@ static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one edge per target: of several overlap lengths with the same string the longest (the first in this order) stays
     for (int j = lane; j < d; j += 64) {
         const int vj = s[j].v;
         int f = 0;
@@ -165,17 +364,13 @@ static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *
             const FmlStr sk = strs[ek.v];
             const int ak = su.len - ek.len, end_k = ak + sk.len, end_j = aj + sj.len;
             const int end = end_k < end_j ? end_k : end_j;
-            bool ok = true;
-            for (int x = su.len; x < end; ++x)
-                if (text[sk.off + (unsigned long long)(x - ak)] != text[sj.off + (unsigned long long)(x - aj)]) { ok = false; break; }
-            drop = ok;
+            drop = fml_same(text + sk.off + (su.len - ak), text + sj.off + (su.len - aj), 0, end - su.len);
         }
         if (drop) fl[j] = 2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // count, reserve, compact in order
     int keep = 0;
     for (int j = lane; j < d; j += 64) keep += fl[j] == 0;
     for (int o = 32; o > 0; o >>= 1) keep += __shfl_xor(keep, o);

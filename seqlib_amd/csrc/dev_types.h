@@ -110,6 +110,8 @@ struct Chunk {
     void *lists; int cap_list; int n_threads;
     // long-read chunks: per-thread H/E rows of the lane-per-read alignment kernels, 2 * long_stride ints per thread
     int *long_scratch; int long_stride; int long_threads;
+    // chunks with a read beyond the LDS rows of k_extend_reg (8 004 columns): three rows of huge_stride ints per block of that kernel, in HBM
+    int *huge_rows; int huge_stride;
     // glue parameters (src/BWAAligner.cpp:89-95)
     int hardclip; double keepSecFrac; int maxSecondary;
     // SLX_F_REG2SAM: bwa's own record selection (mem_reg2sam / mem_gen_alt) instead of the SeqLib glue's sort + filters

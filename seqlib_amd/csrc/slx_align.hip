@@ -29,6 +29,7 @@
 #include "dev_chain_coop.h"
 #include "dev_long.h"
 #include "dev_cig_lane.h"
+#include "dev_cig_band.h"
 
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
@@ -89,7 +90,7 @@ struct Worker {
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
-        cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch;
+        cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
@@ -115,7 +116,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -142,6 +143,7 @@ struct slx_aligner {
     // knobs
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
+    int cap_intv_long = 0;          // what chunks of long reads needed (kept apart from cap_intv)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
                                   // quadratic de-duplication scan 64 candidates at a time; 1 << 30 = off
     int coop_lim1 = 1 << 30, coop_lim2 = 1 << 30;   // test hooks: chains the two LDS tables of k_chain_coop take before giving a read up
@@ -795,7 +797,8 @@ static void with_maxq(int max_len, F f)
     else if (max_len <= 320) f(std::integral_constant<int, 320>());
     else f(std::integral_constant<int, 704>());
 }
-#define MAXQ_LONG (SLX_MAX_READ_LEN + 4)
+#define HUGE_BLOCKS 512          // blocks of k_extend_reg on a chunk whose rows live in HBM (ck.huge_rows holds three rows for each)
+#define MAXQ_LONG 8004          // columns of the H/E row k_extend_reg keeps in LDS for long reads; longer reads (up to SLX_MAX_READ_LEN) keep it in HBM
 
 #ifdef EXT_STATS
 static void ext_stats_print(hipStream_t st, const char *what, int n, const unsigned int *d_jobs)
@@ -822,10 +825,11 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     hipEvent_t *dbg = wk->dbg_ev;
     const bool dbg_on = getenv("SLX_DEBUG_SUB") != nullptr;
     if (dbg_on) (void)hipEventRecord(dbg[1], st);
-    const int g = std::max(1, std::min(n, al->n_cu * 32));
-    if (ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, ext_light, q + 1, ext_slots ? ext_slots : n_slots, 0,
+    const int g = std::max(1, std::min(n, ck.huge_rows ? HUGE_BLOCKS : al->n_cu * 32));
+    const unsigned ext_smem = (MAXQ > 704 && !ck.huge_rows) ? (unsigned)(3 * ck.long_stride * 4) : 0u;
+    if (ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), ext_smem, st, al->ref, ck, dopt, ext_light, q + 1, ext_slots ? ext_slots : n_slots, 0,
                                       ext_heavy, n_heavy, top_off, top_cap, top_tab);
-    else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
+    else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), ext_smem, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
                             (const unsigned int *)nullptr);
 #ifdef EXT_STATS
     ext_stats_print(st, "extend_reg", n, nullptr);
@@ -874,14 +878,20 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
                                    wk->order_out.as<int>(), q + 15, cnt2 + 1, al->regs_big <= REGS_MID_N ? mid + 1 : al->regs_big, 1 << 30);
         }
         hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, al->regs_big);
-    } else   // long reads: every multi-region read on the lane-per-read kernel (its alignment rows in the per-thread scratch)
-        hipLaunchKernelGGL(k_regs<MAXQ>, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl, wk->order_out.as<int>(), q + 9, cnt2 + 1, 0, 0);
+    } else   // long reads: every multi-region read one wave each, mem_patch_reg's contig-long alignment in band coordinates (dev_cig_band.h)
+        hipLaunchKernelGGL((k_regs_wave_long<MAXQ, REGS_BIG_N>), dim3(std::max(1, std::min(n, ck.long_threads / 64))), dim3(64), 0, st, al->ref, ck, dopt, fl,
+                           wk->order_out.as<int>(), q + 9, cnt2 + 1);
     if (dbg_on) (void)hipEventRecord(dbg[3], st);
     (void)hipEventRecord(wk->ev_probe[4], st);
     hipLaunchKernelGGL(k_cig_fast, dim3(std::max(1, std::min(n / 256 + 1, al->n_cu * 8))), dim3(256), 0, st, al->ref, ck, fl);
     if (cig_lanes) hipLaunchKernelGGL(k_cig_lanes, dim3(al->n_cu * 16), dim3(64), 0, st, al->ref, ck, dopt, fl, wk->cig_lane_list.as<uint32_t>(), q + 42, q + 43);
     if constexpr (MAXQ <= 704) hipLaunchKernelGGL(k_cig_dp<MAXQ>, dim3(g), dim3(64), 0, st, al->ref, ck, dopt, fl, 0);
-    else hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, fl);
+    else {   // long reads: one wave per job in band coordinates; what it leaves (bands beyond its 832 columns) one lane per job
+        FinLists rest = fl;
+        rest.dp_list = wk->cig_lane_list.as<uint32_t>(); rest.n_dp = q + 42; rest.q_dp = q + 43;
+        hipLaunchKernelGGL(k_cig_band, dim3(std::max(1, std::min(n * 4, al->n_cu * 16))), dim3(64), 0, st, al->ref, ck, dopt, fl, wk->cig_lane_list.as<uint32_t>(), q + 42);
+        hipLaunchKernelGGL(k_cig_long, dim3(grid), dim3(bs), 0, st, al->ref, ck, dopt, rest);
+    }
     (void)hipEventRecord(wk->ev_probe[5], st);
     if (dbg_on) (void)hipEventRecord(dbg[4], st);
     // single-region reads are final already; the others: the glue's std::sort + secondary filters, or (SLX_F_REG2SAM) bwa's own selection
@@ -928,6 +938,11 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
     // chunks holding a read long enough for bwa's seed filter (mem_flt_chained_seeds, live from ~727 bp) take the long-read path
     const bool has_long = max_len > 704 || flt_live(*opt, max_len, log((double)std::max(max_len, 1)), nullptr);
     int n_threads = (int)std::min<int64_t>(((int64_t)n + bs - 1) / bs * bs, (int64_t)(has_long ? std::min(al->max_threads, 16384) : al->max_threads));
+    if (has_long) {   // the per-thread work lists and H/E rows grow with the longest read: at most ~8 GB of them per worker
+        const int64_t per_thread = (int64_t)2 * (max_len + 1) * (int64_t)sizeof(IntvE<I>) + (int64_t)2 * (max_len + 8) * 4;
+        const int64_t fit = std::max<int64_t>(bs, ((int64_t)8 << 30) / per_thread / bs * bs);
+        n_threads = (int)std::min<int64_t>(n_threads, fit);
+    }
     const int grid = n_threads / bs;
     // seeding launch: persistent waves fed from the queue, or ("seed_quota" > 0) waves that take a fixed share of the reads and leave
     int seed_grid = grid;
@@ -1076,6 +1091,11 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         ck.long_stride = max_len + 8; ck.long_threads = n_threads;
         ENS(long_scratch, (size_t)n_threads * 2 * ck.long_stride * 4);
         ck.long_scratch = wk->long_scratch.as<int>();
+        if (3 * (max_len + 8) * 4 > 64 * 1024) {          // three rows beyond 64 KB of LDS: in HBM
+            ck.huge_stride = max_len + 8;
+            ENS(huge_rows, (size_t)HUGE_BLOCKS * 3 * ck.huge_stride * 4);
+            ck.huge_rows = wk->huge_rows.as<int>();
+        }
     }
     (void)hipEventRecord(wk->ev[3], st);
     {
@@ -1411,6 +1431,10 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
             std::lock_guard<std::mutex> g(al->mu);
             caps.cap_intv = al->cap_intv;
             caps.zcap = std::max<unsigned long long>(al->zcap, (unsigned long long)n * al->z_per_read);
+            if (max_len > 704) {   // long reads: an interval every ~12 bases and traceback bands of 2 * 100 + 1 columns are the rule, not an overflow to learn from
+                caps.cap_intv = std::max(std::max(caps.cap_intv, al->cap_intv_long), max_len / 8 + 64);
+                caps.zcap = std::max(caps.zcap, std::min<unsigned long long>((unsigned long long)n * (unsigned long long)max_len * 208ull, 4ull << 30));
+            }
             caps.cigcap = std::max<unsigned long long>(al->cig_floor, (unsigned long long)n * al->cig_per_read + 4096);
         }
         // on top of the per-read budgets: the stretches the waves of k_cig_dp take for themselves and the CIGAR words they reserve ahead
@@ -1428,7 +1452,8 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
                 hit_base = hb; cig_base = cb;
                 ++wk->n_chunks;
                 std::lock_guard<std::mutex> g(al->mu);   // remember what this workload needed: the next batch does not pay for the retry again
-                al->cap_intv = std::max(al->cap_intv, caps.cap_intv);
+                if (max_len > 704) al->cap_intv_long = std::max(al->cap_intv_long, caps.cap_intv);          // (kept apart: the arrays of a 50 M-read batch are n x cap_intv)
+                else al->cap_intv = std::max(al->cap_intv, caps.cap_intv);
                 if (attempt > 0) {   // only what an overflow taught -- per read from a large chunk, as a floor from a small one (a batch
                                      // of a few long reads says nothing about the bytes per read of the next 50 M-read batch)
                     if (n >= 65536) {

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <string>
 #include <vector>
 #include "slx_internal.h"
 #include "slx_fml_internal.h"
@@ -102,6 +103,24 @@ extern "C" int slx_fml_probe_ms(const slx_fml *f, float ms[SLX_FML_N_PROBES], in
     return SLX_OK;
 }
 
+int fml_host_cpus();
+
+extern "C" int64_t slx_fml_counter(const slx_fml *f, const char *key)
+{
+    if (!f || !key) return -1;
+    const std::string k(key);
+    if (k == "kmers_distinct") return f->n_distinct;
+    if (k == "table_slots") return (int64_t)f->n_slots;
+    if (k == "strings") return f->n_strings;
+    if (k == "text_bytes") return f->asm_text_len;
+    if (k == "overlaps") return f->n_overlaps;
+    if (k == "irreducible") return f->n_irreducible;
+    if (k == "big_vertices") return f->n_big_vertices;
+    if (k == "huge_vertices") return f->n_huge_vertices;
+    if (k == "host_threads") return fml_host_cpus();
+    return -1;
+}
+
 int fml_probe_begin(slx_fml *f) { FML_HIPCHK(hipEventRecord(f->ev0, f->st)); return SLX_OK; }
 int fml_probe_end(slx_fml *f, int which)
 {
@@ -162,8 +181,10 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
         d.k = k > 0 ? k : 0;          // ec_k < 0: no table
         d.min_cov = o.min_cnt; d.mode = -1;
         d.read0 = r0; d.read1 = r1;
+        // a table of (bases of the window) / tab_div slots: at 30x coverage a tenth of the k-mers are distinct, and a table that small
+        // stays in the last-level cache, where the atomics are; fml_run_count enlarges it (x 4) when a window fills it past 70 %
         uint64_t cap = 1024;
-        while (cap < 2 * tot) cap <<= 1;
+        while (cap < 2 * tot * (uint64_t)f->tab_grow / (uint64_t)f->tab_div) cap <<= 1;
         if (cap > (1ULL << 32)) { slx_set_error("fml: window %d holds %llu bases: too large for one table", w, (unsigned long long)tot); return SLX_EUNSUPPORTED; }
         d.tab_off = slots; d.tab_mask = (unsigned int)(cap - 1);
         slots += cap;
@@ -176,38 +197,7 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
 }
 
 // planes of the text now in d_bases / d_quals, then fml_count into freshly cleared tables
-int fml_run_count(slx_fml *f, int q)
-{
-    const int64_t total = f->total;
-    const size_t nblk = (size_t)((total + 63) >> 6), words = nblk + 2;
-    int rc;
-    if ((rc = f->d_planes.ensure(words * 8 * 5)) || (rc = f->d_misc.ensure(256))) return rc;
-    unsigned long long *pl = f->d_planes.as<unsigned long long>();
-    unsigned long long *p0 = pl, *p1 = pl + words, *pn = pl + 2 * words, *pq = pl + 3 * words, *ps = pl + 4 * words;
-    if ((rc = fml_probe_begin(f))) return rc;
-    FML_HIPCHK(hipMemsetAsync(pl, 0, words * 8 * 5, f->st));
-    FML_HIPCHK(hipMemsetAsync(pn, 0xff, 8, f->st));          // the guard block before the text: all N
-    FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
-    FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
-    if (total > 0) {
-        hipLaunchKernelGGL(k_fml_starts, dim3((unsigned)((f->n_reads + 255) / 256)), dim3(256), 0, f->st, f->d_offs.as<unsigned long long>(), (long long)f->n_reads, ps);
-        hipLaunchKernelGGL(k_fml_pack, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr,
-                           (long long)total, q, p0, p1, pn, pq);
-        FmlPlanes P{p0, p1, pn, pq, ps};
-        hipLaunchKernelGGL(k_fml_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, f->st, P, (long long)total, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
-                           f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_misc.as<unsigned long long>());
-        FML_HIPCHK(hipGetLastError());
-    }
-    unsigned long long ins = 0;
-    FML_HIPCHK(hipMemcpyAsync(&ins, f->d_misc.p, 8, hipMemcpyDeviceToHost, f->st));
-    if ((rc = fml_probe_end(f, 0))) return rc;
-    f->n_inserted += (int64_t)ins; f->n_bases += total;
-    f->last_q = q;
-    return SLX_OK;
-}
-
-// bfc_ch_hist per window, then what fml_correct_core derives from it: mode, kcov, min_cov (src/BFC.cpp:315-348)
-int fml_run_hist(slx_fml *f)
+static int launch_hist(slx_fml *f)          // bfc_ch_hist of every window's table -> f->h_hist (synchronises)
 {
     const int nw = std::max(f->n_win, 1);
     int rc;
@@ -221,7 +211,82 @@ int fml_run_hist(slx_fml *f)
         FML_HIPCHK(hipGetLastError());
     }
     FML_HIPCHK(hipMemcpyAsync(f->h_hist.data(), f->d_hist.p, (size_t)nw * 320 * 8, hipMemcpyDeviceToHost, f->st));
-    if ((rc = fml_probe_end(f, 1))) return rc;
+    return fml_probe_end(f, 1);
+}
+
+static int run_count_once(slx_fml *f, int q, bool *too_small)
+{
+    const int64_t total = f->total;
+    const size_t nblk = (size_t)((total + 63) >> 6), words = nblk + 2;
+    int rc;
+    if ((rc = f->d_planes.ensure(words * 8 * 5)) || (rc = f->d_stats.ensure(256))) return rc;
+    unsigned long long *pl = f->d_planes.as<unsigned long long>();
+    unsigned long long *p0 = pl, *p1 = pl + words, *pn = pl + 2 * words, *pq = pl + 3 * words, *ps = pl + 4 * words;
+    if ((rc = fml_probe_begin(f))) return rc;
+    FML_HIPCHK(hipMemsetAsync(pl, 0, words * 8 * 5, f->st));
+    FML_HIPCHK(hipMemsetAsync(pn, 0xff, 8, f->st));          // the guard block before the text: all N
+    FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
+    FML_HIPCHK(hipMemsetAsync(f->d_stats.p, 0, 256, f->st));
+    if (total > 0) {
+        hipLaunchKernelGGL(k_fml_starts, dim3((unsigned)((f->n_reads + 255) / 256)), dim3(256), 0, f->st, f->d_offs.as<unsigned long long>(), (long long)f->n_reads, ps);
+        hipLaunchKernelGGL(k_fml_pack, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr,
+                           (long long)total, q, p0, p1, pn, pq);
+        FmlPlanes P{p0, p1, pn, pq, ps};
+        hipLaunchKernelGGL(k_fml_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, f->st, P, (long long)total, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
+                           f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
+        FML_HIPCHK(hipGetLastError());
+    }
+    unsigned long long st[2] = {0, 0};
+    FML_HIPCHK(hipMemcpyAsync(st, f->d_stats.p, 16, hipMemcpyDeviceToHost, f->st));
+    if ((rc = fml_probe_end(f, 0))) return rc;
+    *too_small = st[1] != 0;
+    if (*too_small) return SLX_OK;
+    // how full the tables are: the histogram counts every occupied slot once
+    if ((rc = launch_hist(f))) return rc;
+    int64_t distinct = 0;
+    for (int w = 0; w < f->n_win; ++w) {
+        uint64_t d = 0;
+        for (int i = 0; i < 256; ++i) d += f->h_hist[(size_t)w * 320 + (size_t)i];
+        if ((double)d > 0.7 * ((double)f->wins[(size_t)w].tab_mask + 1.0)) *too_small = true;
+        distinct += (int64_t)d;
+    }
+    if (!*too_small) { f->n_inserted += (int64_t)st[0]; f->n_bases += total; f->n_distinct = distinct; }
+    f->last_q = q;
+    return SLX_OK;
+}
+
+int fml_run_count(slx_fml *f, int q)
+{
+    while (true) {
+        bool too_small = false;
+        int rc = run_count_once(f, q, &too_small);
+        if (rc) return rc;
+        if (!too_small) return SLX_OK;
+        if (f->tab_div <= 1 && f->tab_grow >= 4) { slx_set_error("fml: a k-mer table overflowed at its largest size"); return SLX_EINTERNAL; }
+        // larger tables for every window of the batch, same k, same read ranges
+        if (f->tab_div > 1) f->tab_div /= 4; else f->tab_grow *= 4;
+        if (f->tab_div < 1) f->tab_div = 1;
+        uint64_t slots = 0;
+        for (int w = 0; w < f->n_win; ++w) {
+            FmlWin &d = f->wins[(size_t)w];
+            const uint64_t tot = f->h_offs[(size_t)d.read1] - f->h_offs[(size_t)d.read0];
+            uint64_t cap = 1024;
+            while (cap < 2 * tot * (uint64_t)f->tab_grow / (uint64_t)f->tab_div) cap <<= 1;
+            if (cap > (1ULL << 32)) cap = 1ULL << 32;
+            d.tab_off = slots; d.tab_mask = (unsigned int)(cap - 1);
+            slots += cap;
+        }
+        f->n_slots = slots;
+        if ((rc = f->d_tab.ensure((size_t)std::max<uint64_t>(slots, 1) * sizeof(FmlSlot)))) return rc;
+        FML_HIPCHK(hipMemcpyAsync(f->d_wins.p, f->wins.data(), f->wins.size() * sizeof(FmlWin), hipMemcpyHostToDevice, f->st));
+    }
+}
+
+// what fml_correct_core derives from bfc_ch_hist (the histograms are in f->h_hist since the count): mode, kcov, min_cov (src/BFC.cpp:315-348)
+int fml_run_hist(slx_fml *f)
+{
+    const int nw = std::max(f->n_win, 1);
+    if (f->h_hist.size() < (size_t)nw * 320) { int rc = launch_hist(f); if (rc) return rc; }
     f->kcov.assign((size_t)nw, 0.0f);
     for (int w = 0; w < f->n_win; ++w) {
         const uint64_t *hist = &f->h_hist[(size_t)w * 320];

@@ -5,14 +5,33 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 #include "slx_fml_internal.h"
 #include "dev_fml_asm.h"
 #include "fml_graph.h"
+
+// CPUs this process may use: hardware threads cut down to the cgroup CPU quota (the GPU boxes show 256 under a quota of 16)
+int fml_host_cpus()
+{
+    static int cached = 0;
+    if (cached) return cached;
+    if (const char *e = getenv("SEQLIB_AMD_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string q; long long per = 0;
+    if (f >> q >> per) { if (q != "max" && per > 0) { const long long c = (atoll(q.c_str()) + per - 1) / per; if (c >= 1 && c < n) n = (long)c; } }
+    cached = (int)n;
+    return cached;
+}
 
 namespace {
 
@@ -84,28 +103,67 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         FML_HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n_str, 0, 64, f->st));
         if ((rc = d_sort.ensure(tmp_bytes + 256))) return rc;
         FML_HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_sort.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n_str, 0, 64, f->st));
-        const unsigned grid = (unsigned)((text_len + 255) / 256);
-        hipLaunchKernelGGL((k_asm_join<1>), dim3(grid), dim3(256), 0, f->st, d_text.as<unsigned char>(), text_len, d_strs.as<FmlStr>(), d_stroff, n_str, kk, min_match, keys_out, vals_out,
-                           d_rep, d_cont, d_cnt, (const unsigned long long *)nullptr, (unsigned int *)nullptr, (FmlEdge *)nullptr);
-        FML_HIPCHK(hipGetLastError());
-        FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipStreamSynchronize(f->st));
+        // an index over the sorted keys (key -> first position), then
+        // the join: overlaps as (u, v, length) triples; room for 40 per string at first (about the coverage), more when they do not fit
+        unsigned long long *d_trin = f->d_misc.as<unsigned long long>(), *d_outn = d_trin + 1;
+        unsigned int *d_nbig = (unsigned int *)(d_trin + 2), *d_nhuge = d_nbig + 1;
+        unsigned int hmask = 1023;
+        while ((unsigned long long)hmask + 1 < 2ULL * (unsigned long long)n_str) hmask = hmask * 2 + 1;
+        if ((rc = f->d_index.ensure(((size_t)hmask + 1) * 12))) return rc;
+        unsigned long long *d_hkey = f->d_index.as<unsigned long long>();
+        unsigned int *d_hval = (unsigned int *)(d_hkey + (size_t)hmask + 1);
+        FML_HIPCHK(hipMemsetAsync(d_hkey, 0, ((size_t)hmask + 1) * 8, f->st));
+        hipLaunchKernelGGL(k_asm_index, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, f->st, (const unsigned long long *)keys_out, n_str, d_hkey, d_hval, hmask);
+        unsigned long long tri_cap = std::max<unsigned long long>(f->tri_per_str * (unsigned long long)n_str + (1u << 20), 1u << 20), n_tri = 0;
+        const unsigned grid_str = (unsigned)((n_str + 3) / 4);
+        while (true) {
+            if ((rc = f->d_tri.ensure((size_t)tri_cap * sizeof(FmlTriple)))) return rc;
+            FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
+            hipLaunchKernelGGL(k_asm_join, dim3(grid_str), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, kk, min_match, keys_out, vals_out,
+                               (const unsigned long long *)d_hkey, (const unsigned int *)d_hval, hmask, d_rep, d_cont, d_cnt, f->d_tri.as<FmlTriple>(), tri_cap, d_trin);
+            FML_HIPCHK(hipGetLastError());
+            FML_HIPCHK(hipMemcpyAsync(&n_tri, d_trin, 8, hipMemcpyDeviceToHost, f->st));
+            FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+            FML_HIPCHK(hipStreamSynchronize(f->st));
+            if (n_tri <= tri_cap) break;
+            tri_cap = n_tri + n_tri / 8;          // (the marks of containment and the counts are idempotent: the join simply runs again)
+            f->tri_per_str = std::max<unsigned long long>(f->tri_per_str, tri_cap / (unsigned long long)n_str + 1);
+        }
         unsigned long long n_edges = 0;
         for (long long t = 0; t < n_str; ++t) { h_eoff[(size_t)t] = n_edges; n_edges += h_cnt[(size_t)t]; }
         h_eoff[(size_t)n_str] = n_edges;
-        // edges | sorted edges | irreducible edges | flags
+        // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
         FmlDevBuf &d_edges = f->d_scratch;
-        if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 3 + 1) + 256))) return rc;
+        if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 3 + 1) + ns * 8 + 256))) return rc;
         FmlEdge *e_raw = d_edges.as<FmlEdge>(), *e_sorted = e_raw + n_edges + 1, *e_out = e_sorted + n_edges + 1;
         unsigned char *e_flags = (unsigned char *)(e_out + n_edges + 1);
+        int *big_list = (int *)(((uintptr_t)(e_flags + n_edges + 1) + 15) & ~(uintptr_t)15), *huge_list = big_list + ns;
         FML_HIPCHK(hipMemcpyAsync(d_eoff, h_eoff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
-        hipLaunchKernelGGL((k_asm_join<2>), dim3(grid), dim3(256), 0, f->st, d_text.as<unsigned char>(), text_len, d_strs.as<FmlStr>(), d_stroff, n_str, kk, min_match, keys_out, vals_out,
-                           d_rep, d_cont, d_cnt, (const unsigned long long *)d_eoff, d_cur, e_raw);
-        hipLaunchKernelGGL(k_asm_reduce, dim3((unsigned)((n_str + 3) / 4)), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, (const unsigned long long *)d_eoff,
-                           (const unsigned int *)d_cur, e_raw, e_sorted, e_flags, d_nirr, d_irroff, e_out, f->d_misc.as<unsigned long long>());
+        if (n_tri)
+            hipLaunchKernelGGL(k_asm_scatter, dim3((unsigned)((n_tri + 255) / 256)), dim3(256), 0, f->st, f->d_tri.as<FmlTriple>(), n_tri, (const int *)d_rep, (const unsigned char *)d_cont,
+                               (const unsigned long long *)d_eoff, d_cur, e_raw);
+        hipLaunchKernelGGL(k_asm_reduce, dim3(grid_str), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, (const unsigned long long *)d_eoff,
+                           (const unsigned int *)d_cur, (const FmlEdge *)e_raw, d_nirr, d_irroff, e_out, d_outn, big_list, d_nbig);
         FML_HIPCHK(hipGetLastError());
+        int big_cap = FML_BIG_CAP;          // SLX_FML_BIG_CAP: test hook, sends smaller lists down the through-memory path
+        if (const char *e = getenv("SLX_FML_BIG_CAP")) { const int v = atoi(e); if (v >= 64 && v < FML_BIG_CAP) big_cap = v; }
+        unsigned int n_big = 0, n_huge = 0;
+        FML_HIPCHK(hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipStreamSynchronize(f->st));
+        if (n_big) {
+            hipLaunchKernelGGL(k_asm_reduce_big, dim3(n_big), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), (const int *)big_list, (const unsigned int *)d_nbig,
+                               (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, d_nirr, d_irroff, e_out, d_outn, huge_list, d_nhuge, big_cap);
+            FML_HIPCHK(hipGetLastError());
+            FML_HIPCHK(hipMemcpyAsync(&n_huge, d_nhuge, 4, hipMemcpyDeviceToHost, f->st));
+            FML_HIPCHK(hipStreamSynchronize(f->st));
+            if (n_huge) {
+                hipLaunchKernelGGL(k_asm_reduce_huge, dim3((n_huge + 3) / 4), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), (const int *)huge_list, (const unsigned int *)d_nhuge,
+                                   (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, e_sorted, e_flags, d_nirr, d_irroff, e_out, d_outn);
+                FML_HIPCHK(hipGetLastError());
+            }
+        }
         unsigned long long n_out = 0;
-        FML_HIPCHK(hipMemcpyAsync(&n_out, f->d_misc.p, 8, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_rep.data(), d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_cont.data(), d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_nirr.data(), d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
@@ -114,30 +172,42 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
         h_out.resize((size_t)n_out + 1);
         if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
-        f->n_overlaps = (int64_t)n_edges; f->n_irreducible = (int64_t)n_out; f->asm_text_len = (int64_t)text_len;
+        f->n_strings = (int64_t)n_str; f->n_overlaps = (int64_t)n_tri; f->n_irreducible = (int64_t)n_out; f->asm_text_len = (int64_t)text_len; f->n_big_vertices = (int64_t)n_big; f->n_huge_vertices = (int64_t)n_huge;
     }
-    // ---- per window on the host: chains, cleaning, records
+    // ---- per window on the host: chains, cleaning, records -- the windows are independent, so they go over the host's CPUs
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> ev(h_out.size()), el(h_out.size());
-    for (int w = 0; w < n_win; ++w) {
-        const AsmWin &a = aw[(size_t)w];
-        const int n = (int)(a.str1 - a.str0);
-        std::vector<int> len((size_t)n + 1), rep((size_t)n + 1);
-        std::vector<const unsigned char *> txt((size_t)n + 1);
-        for (int t = 0; t < n; ++t) {
-            const FmlStr &s = strs[(size_t)(a.str0 + t)];
-            len[(size_t)t] = s.len; txt[(size_t)t] = h_text.data() + s.off;
-            rep[(size_t)t] = h_rep[(size_t)(a.str0 + t)] - (int)a.str0;
-            const unsigned long long o = h_irroff[(size_t)(a.str0 + t)];
-            for (unsigned int j = 0; j < h_nirr[(size_t)(a.str0 + t)]; ++j) { ev[(size_t)(o + j)] = h_out[(size_t)(o + j)].v - (int)a.str0; el[(size_t)(o + j)] = h_out[(size_t)(o + j)].len; }
+    std::atomic<int> next_win(0);
+    auto work = [&]() {
+        for (;;) {
+            const int w = next_win.fetch_add(1);
+            if (w >= n_win) break;
+            const AsmWin &a = aw[(size_t)w];
+            const int n = (int)(a.str1 - a.str0);
+            std::vector<int> len((size_t)n + 1), rep((size_t)n + 1);
+            std::vector<const unsigned char *> txt((size_t)n + 1);
+            for (int t = 0; t < n; ++t) {
+                const FmlStr &s = strs[(size_t)(a.str0 + t)];
+                len[(size_t)t] = s.len; txt[(size_t)t] = h_text.data() + s.off;
+                rep[(size_t)t] = h_rep[(size_t)(a.str0 + t)] - (int)a.str0;
+                const unsigned long long o = h_irroff[(size_t)(a.str0 + t)];
+                for (unsigned int j = 0; j < h_nirr[(size_t)(a.str0 + t)]; ++j) { ev[(size_t)(o + j)] = h_out[(size_t)(o + j)].v - (int)a.str0; el[(size_t)(o + j)] = h_out[(size_t)(o + j)].len; }
+            }
+            fmlg::Overlaps O;
+            O.n_str = n; O.len = len.data(); O.text = txt.data(); O.rep = rep.data(); O.contained = h_cont.data() + a.str0;
+            O.n_irr = h_nirr.data() + a.str0; O.irr_off = h_irroff.data() + a.str0; O.edge_v = ev.data(); O.edge_len = el.data(); O.min_match = a.min_match;
+            fmlg::Graph g;
+            g.build(O);
+            g.clean_graph(a.mag);
+            utgs[w] = g.to_utgs(&n_utg[w]);
         }
-        fmlg::Overlaps O;
-        O.n_str = n; O.len = len.data(); O.text = txt.data(); O.rep = rep.data(); O.contained = h_cont.data() + a.str0;
-        O.n_irr = h_nirr.data() + a.str0; O.irr_off = h_irroff.data() + a.str0; O.edge_v = ev.data(); O.edge_len = el.data(); O.min_match = a.min_match;
-        fmlg::Graph g;
-        g.build(O);
-        g.clean_graph(a.mag);
-        utgs[w] = g.to_utgs(&n_utg[w]);
+    };
+    {
+        const int n_thr = std::max(1, std::min(n_win, fml_host_cpus()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
     }
     f->probe[5] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLX_OK;
@@ -154,20 +224,12 @@ int check_assemble_opt(const slx_fml_opt *opt)
 
 }          // namespace
 
-extern "C" int slx_fml_assemble(slx_fml *f, const slx_fml_opt *opt, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads,
-                                const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg)
+// fml_assemble on the reads now in d_bases / d_quals: fml_correct, then fml_fltuniq on the corrected reads (its kcov sets min_ensr), then the graph
+static int assemble_resident(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg)
 {
-    if (!f || !opt || !utgs || !n_utg) { slx_set_error("slx_fml_assemble: bad argument"); return SLX_EINVAL; }
+    const int64_t n_reads = f->n_reads;
     int rc;
-    if ((rc = check_assemble_opt(opt))) return rc;
-    if (opt->ec_k < 0) { slx_set_error("slx_fml_assemble: ec_k = %d (fml_fltuniq needs a k-mer size)", opt->ec_k); return SLX_EINVAL; }
-    std::lock_guard<std::mutex> g(f->mu);
-    FML_HIPCHK(hipSetDevice(f->device));
-    f->reset_probes();
-    f->have_count = false;
-    for (int w = 0; w < n_win; ++w) { utgs[w] = nullptr; n_utg[w] = 0; }
-    if ((rc = fml_upload(f, bases, quals, offs, n_reads)) || (rc = fml_setup_windows(f, opt, win_off, n_win, 0))) return rc;
-    // fml_assemble: fml_correct, then fml_fltuniq on the corrected reads (its kcov sets min_ensr), then the graph
+    if ((rc = fml_setup_windows(f, opt, win_off, n_win, 0))) return rc;
     if ((rc = fml_correct_core_device(f, 0)) || (rc = fml_correct_core_device(f, 1))) return rc;
     std::vector<int> ns((size_t)n_reads + 1), nl((size_t)n_reads + 1);
     if (n_reads) {
@@ -185,6 +247,63 @@ extern "C" int slx_fml_assemble(slx_fml *f, const slx_fml_opt *opt, const char *
         m.min_insr = m.min_ensr - 1;
     }
     return build_and_assemble(f, ns, nl, wopt, utgs, n_utg);
+}
+
+static int check_assemble_args(slx_fml *f, const slx_fml_opt *opt, slx_fml_utg **utgs, int *n_utg, int n_win)
+{
+    if (!f || !opt || !utgs || !n_utg) { slx_set_error("slx_fml_assemble: bad argument"); return SLX_EINVAL; }
+    int rc;
+    if ((rc = check_assemble_opt(opt))) return rc;
+    if (opt->ec_k < 0) { slx_set_error("slx_fml_assemble: ec_k = %d (fml_fltuniq needs a k-mer size)", opt->ec_k); return SLX_EINVAL; }
+    for (int w = 0; w < n_win; ++w) { utgs[w] = nullptr; n_utg[w] = 0; }
+    return SLX_OK;
+}
+
+extern "C" int slx_fml_assemble(slx_fml *f, const slx_fml_opt *opt, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads,
+                                const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg)
+{
+    int rc;
+    if ((rc = check_assemble_args(f, opt, utgs, n_utg, n_win))) return rc;
+    std::lock_guard<std::mutex> g(f->mu);
+    FML_HIPCHK(hipSetDevice(f->device));
+    f->reset_probes();
+    f->have_count = false; f->staged = false;
+    if ((rc = fml_upload(f, bases, quals, offs, n_reads))) return rc;
+    return assemble_resident(f, opt, win_off, n_win, utgs, n_utg);
+}
+
+extern "C" int slx_fml_stage(slx_fml *f, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads)
+{
+    if (!f) { slx_set_error("slx_fml_stage: bad argument"); return SLX_EINVAL; }
+    std::lock_guard<std::mutex> g(f->mu);
+    FML_HIPCHK(hipSetDevice(f->device));
+    f->have_count = false; f->staged = false;
+    int rc;
+    if ((rc = fml_upload(f, bases, quals, offs, n_reads))) return rc;
+    if ((rc = f->d_bases0.ensure((size_t)f->total + 64)) || (f->has_qual && (rc = f->d_quals0.ensure((size_t)f->total + 64)))) return rc;
+    if (f->total) {
+        FML_HIPCHK(hipMemcpyAsync(f->d_bases0.p, f->d_bases.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
+        if (f->has_qual) FML_HIPCHK(hipMemcpyAsync(f->d_quals0.p, f->d_quals.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
+    }
+    FML_HIPCHK(hipStreamSynchronize(f->st));
+    f->staged = true;
+    return SLX_OK;
+}
+
+extern "C" int slx_fml_assemble_staged(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off, int n_win, slx_fml_utg **utgs, int *n_utg)
+{
+    int rc;
+    if ((rc = check_assemble_args(f, opt, utgs, n_utg, n_win))) return rc;
+    std::lock_guard<std::mutex> g(f->mu);
+    if (!f->staged) { slx_set_error("slx_fml_assemble_staged: no staged reads (slx_fml_stage first)"); return SLX_EINVAL; }
+    FML_HIPCHK(hipSetDevice(f->device));
+    f->reset_probes();
+    f->have_count = false;
+    if (f->total) {          // the correction rewrites the working copy: start from the staged reads every time
+        FML_HIPCHK(hipMemcpyAsync(f->d_bases.p, f->d_bases0.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
+        if (f->has_qual) FML_HIPCHK(hipMemcpyAsync(f->d_quals.p, f->d_quals0.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
+    }
+    return assemble_resident(f, opt, win_off, n_win, utgs, n_utg);
 }
 
 extern "C" int slx_fml_direct_assemble(slx_fml *f, slx_fml_opt *opt, float kcov, const char *bases, const uint64_t *offs, int64_t n_reads, slx_fml_utg **utgs, int *n_utg)

@@ -13,7 +13,7 @@ from . import _ffi
 # every symbol include/seqlib_amd_fml.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "slx_fml_opt_init", "slx_fml_opt_adjust", "slx_fml_create", "slx_fml_free", "slx_fml_correct", "slx_fml_count", "slx_fml_count_hist",
-    "slx_fml_error_correct", "slx_fml_count_dump", "slx_fml_assemble", "slx_fml_direct_assemble", "slx_fml_utgs_free", "slx_fml_probe_ms",
+    "slx_fml_error_correct", "slx_fml_count_dump", "slx_fml_assemble", "slx_fml_direct_assemble", "slx_fml_utgs_free", "slx_fml_probe_ms", "slx_fml_stage", "slx_fml_assemble_staged", "slx_fml_counter",
 ]
 SLX_FML_N_PROBES = 6
 MAG_F_AGGRESSIVE, MAG_F_POPOPEN, MAG_F_NO_SIMPL = 0x20, 0x40, 0x80
@@ -59,6 +59,10 @@ def lib():
                                        C.POINTER(C.POINTER(Utg)), C.POINTER(C.c_int)]
         L.slx_fml_direct_assemble.argtypes = [C.c_void_p, C.POINTER(FmlOpt), C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.POINTER(Utg)), C.POINTER(C.c_int)]
         L.slx_fml_utgs_free.argtypes = [C.c_int, C.POINTER(Utg)]
+        L.slx_fml_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.slx_fml_assemble_staged.argtypes = [C.c_void_p, C.POINTER(FmlOpt), C.c_void_p, C.c_int, C.POINTER(C.POINTER(Utg)), C.POINTER(C.c_int)]
+        L.slx_fml_counter.argtypes = [C.c_void_p, C.c_char_p]
+        L.slx_fml_counter.restype = C.c_int64
         L.slx_fml_probe_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _READY = True
     return L
@@ -173,6 +177,28 @@ class Context:
         _ffi.check(lib().slx_fml_assemble(self.h, C.byref(opt), bases.ctypes.data, quals.ctypes.data if quals is not None else None, offs.ctypes.data, len(offs) - 1,
                                           win_off.ctypes.data, nw, pu, nu))
         return [_utgs(pu[w], nu[w]) for w in range(nw)]
+
+    def stage(self, bases, quals, offs):
+        _ffi.check(lib().slx_fml_stage(self.h, bases.ctypes.data, quals.ctypes.data if quals is not None else None, offs.ctypes.data, len(offs) - 1))
+
+    def assemble_staged(self, opt, win_off, keep=True):
+        """fml_assemble over the staged reads; keep=False frees the records at once and returns per-window (n_contigs, total length, lengths)"""
+        nw = len(win_off) - 1
+        win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+        pu = (C.POINTER(Utg) * max(nw, 1))()
+        nu = (C.c_int * max(nw, 1))()
+        _ffi.check(lib().slx_fml_assemble_staged(self.h, C.byref(opt), win_off.ctypes.data, nw, pu, nu))
+        if keep:
+            return [_utgs(pu[w], nu[w]) for w in range(nw)]
+        out = []
+        for w in range(nw):
+            lens = [pu[w][i].len for i in range(nu[w])]
+            out.append((nu[w], sum(lens), lens))
+            lib().slx_fml_utgs_free(nu[w], pu[w])
+        return out
+
+    def counter(self, key):
+        return int(lib().slx_fml_counter(self.h, key.encode()))
 
     def direct_assemble(self, opt, kcov, bases, offs):
         pu = C.POINTER(Utg)()

@@ -210,6 +210,20 @@ def test_assemble_windows_match_oracle(F, G, ctx, genome):
     assert ms["overlap"] > 0
 
 
+def test_assemble_repeat_tracts_take_the_many_overlap_paths(F, G, ctx, genome, monkeypatch):
+    """reads inside tandem repeats have hundreds of overlaps each: the block-per-vertex reduction, and (forced) the through-memory one"""
+    g = genome["abl"][70000:76000]
+    gen = g[:2000] + b"AC" * 300 + g[2000:4000] + b"GATTACA" * 60 + g[4000:]
+    seqs, quals, _ = U.sim_window(gen, 6000, seed=71, err=0.002)
+    b, q, o = G.flatten(seqs, quals)
+    exp = F.assemble(F.default_opt(), F.Reads(seqs, quals))
+    got = ctx.assemble(G.default_opt(), b.copy(), q.copy(), o, [0, len(seqs)])[0]
+    _same_utgs(got, exp, "tandem")
+    monkeypatch.setenv("SLX_FML_BIG_CAP", "100")
+    got = ctx.assemble(G.default_opt(), b.copy(), q.copy(), o, [0, len(seqs)])[0]
+    _same_utgs(got, exp, "tandem, small LDS cap")
+
+
 def test_assemble_contigs_are_the_genome(G, ctx, genome):
     gen = genome["bcr"][60000:100000]
     seqs, quals, _ = U.sim_window(gen, 12000, seed=51)

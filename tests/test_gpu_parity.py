@@ -250,6 +250,38 @@ def test_long_reads_seed_filter_path(sl, orc, tiny_gpu, tiny_index, golden_dir):
     assert_same(al.alignSequences(mixed), exp, "long + short reads, u64 index")
 
 
+def test_contig_length_reads_beyond_the_lds_row(sl, orc, tiny_gpu, tiny_index, golden_dir):
+    """reads of 8 001 .. 64 000 bp -- assembly contigs realigned through BWAAligner (src/seqtools/seqtools.cpp:198-210): the extension
+    kernel's H/E row no longer fits LDS and lives in HBM; bit-exact vs the oracle, alone and mixed with short reads, on both index widths"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    rng = np.random.default_rng(11)
+    seqs = []
+    for L, ci in ((8001, 0), (8005, 1), (12000, 0), (20000, 1), (33000, 0), (64000, 1)):
+        for rep in range(2):
+            p = int(rng.integers(0, len(refs[ci]) - L))
+            s = list(refs[ci][p:p + L])
+            for _ in range(int(L * (0.0005, 0.01)[rep])):          # a het site every 2 kb / a diverged copy
+                s[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+            if rep == 1:                                           # indels and a chimeric junction to another contig
+                q = L // 3
+                s[q:q] = list("ACGTTGCAACGT")
+                del s[2 * q:2 * q + 9]
+                cj = (ci + 2) % len(refs)
+                s[-1500:] = list(refs[cj][2000:3500])
+            t = "".join(s)
+            seqs.append(orc_revcomp(t) if rng.random() < 0.5 else t)
+    exp = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+    al = sl.BWAAligner(tiny_gpu)
+    assert_same(al.alignSequences(seqs), exp, "contig-length reads")
+    mixed = seqs[:3] + [refs[1][2000 + 150 * i:2150 + 150 * i] for i in range(40)] + [refs[0][100:1900]] + seqs[3:6]
+    exp = orc.align_batch(orc.default_opt(), tiny_index, mixed)
+    al = sl.BWAAligner(tiny_gpu)
+    assert_same(al.alignSequences(mixed), exp, "contigs + short reads")
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("wide_index", 1)
+    assert_same(al.alignSequences(mixed), exp, "contigs + short reads, u64 index")
+
+
 def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
     """per-stage differential check (localises a mismatch): SMEM intervals after mem_collect_intv, kept chains with their seeds in
     extension order, and the region list as mem_chain2aln leaves it -- read by read against the oracle's stages, through the
