@@ -130,7 +130,7 @@ def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
     eff = rate / (rate1 * cores) if rate1 > 0 else None
     del idx
     return dict(value=rate, unit="reads/s", cores=cores, kind="port",
-                sample="%d reads of the same synthetic %s reads, one oracle process, %d std::threads over disjoint read ranges sharing one index "
+                sample="%d reads of the same synthetic %s reads, one oracle process, %d std::threads taking chunks of 64 reads from one counter and sharing one index "
                        "(= the CPUs this process may use: %d hardware threads under the container's CPU quota; single thread on %d reads: %.0f reads/s; "
                        "parallel efficiency %.2f; slowest / fastest thread %.1f / %.1f s)"
                        % (m, cfg_name, cores, os.cpu_count() or 1, cal, rate1, eff or 0.0, max(ts), min(ts)),
@@ -189,22 +189,29 @@ def c5_workload(rank, n_win, reads_per_win, coverage, read_len=150):
     return cfg, refs, bases, quals, offs, win_off, span
 
 
-def c5_cpu_baseline(bases, quals, read_len, reads_per_win, sample_reads):
+def c5_cpu_baseline(coverage, read_len, sample_reads):
     """fml_assemble of the CPU checker (a restatement: fermi-lite is an empty submodule of the reference) on one thread -- the reference
-    runs fermi-lite with n_threads = 1 (fml_opt_init) -- on the first `sample_reads` reads of window 0 at the same coverage."""
+    runs fermi-lite with n_threads = 1 (fml_opt_init) -- on a window of `sample_reads` reads made by the same generator at the same
+    coverage (a fifth of a bench window in reads and in span)."""
     from oracle import orc_fml
-    n = min(sample_reads, reads_per_win)
-    raw_b = bases[:n * read_len].tobytes()
-    raw_q = quals[:n * read_len].tobytes()
-    seqs = [raw_b[i * read_len:(i + 1) * read_len] for i in range(n)]
-    qs = [raw_q[i * read_len:(i + 1) * read_len] for i in range(n)]
+    from seqlib_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    g = synth.make_reference(cfg)[0][1]
+    span = int(sample_reads * read_len / coverage)
+    r = np.ascontiguousarray(synth.make_reads(g[:span], sample_reads, read_len, 6999)[:sample_reads])
+    rng = np.random.Generator(np.random.PCG64(98))
+    q = np.full(r.shape, ord("I"), dtype=np.uint8)
+    q[rng.random(r.shape) < 0.05] = ord("#")
+    seqs = [r[i].tobytes() for i in range(sample_reads)]
+    qs = [q[i].tobytes() for i in range(sample_reads)]
     R = orc_fml.Reads(seqs, qs)
     t0 = time.time()
     utgs = orc_fml.assemble(orc_fml.default_opt(), R)
     dt = time.time() - t0
-    return dict(value=n / dt, unit="reads/s", cores=1, kind="port",
-                sample="fml_assemble of the CPU checker on the first %d reads of window 0 (%.1f s, %d contigs); one thread, as the reference runs fermi-lite "
-                       "(fml_opt_init: n_threads = 1); the sample keeps the window's error rate but is a fifth of its size, so its coverage is a fifth" % (n, dt, len(utgs)))
+    return dict(value=sample_reads / dt, unit="reads/s", cores=1, kind="port",
+                sample="fml_assemble of the CPU checker on a window of %d reads at %.0fx over %d bp made by the bench's generator (%.1f s, %d contigs, longest %d bp); "
+                       "one thread, as the reference runs fermi-lite (fml_opt_init: n_threads = 1); assembly only, no realignment"
+                       % (sample_reads, coverage, span, dt, len(utgs), max([u["len"] for u in utgs] + [0])))
 
 
 def main_c5(args):
@@ -239,12 +246,20 @@ def main_c5(args):
     ctx.stage(bases, quals, offs)
     max_len = seqlib_amd._ffi.SLX_MAX_READ_LEN
 
+    split = {"assemble_s": 0.0, "realign_s": 0.0, "realign_stage_ms": {}}
+
     def step():
+        t_a = time.time()
         wins = ctx.assemble_staged(opt, win_off)
         ms, ins, nb = ctx.probe_ms()
         contigs = [u["seq"] for w in wins for u in w]
         fit = [c for c in contigs if len(c) <= max_len]
+        t_b = time.time()
         hits = al.alignSequences(fit) if fit else None
+        t_c = time.time()
+        split["assemble_s"] += t_b - t_a; split["realign_s"] += t_c - t_b
+        for k, v in al.stage_ms().items():
+            split["realign_stage_ms"][k] = split["realign_stage_ms"].get(k, 0.0) + v
         return wins, contigs, fit, hits, ms, ins, nb
 
     def fence():
@@ -256,6 +271,7 @@ def main_c5(args):
         step()
     acc = {}
     ins_acc = nb_acc = 0
+    split.update(assemble_s=0.0, realign_s=0.0, realign_stage_ms={})
     fence()
     t0 = time.time()
     marks = [t0]
@@ -281,6 +297,7 @@ def main_c5(args):
             if run >= half:
                 n50 = L
                 break
+        counters = {k: ctx.counter(k) for k in ("strings", "text_bytes", "overlaps", "irreducible", "big_vertices", "huge_vertices", "host_threads", "table_slots", "kmers_distinct")}
         # parity spot check: a small window through the GPU path and through the CPU checker
         match = None
         if args.verify > 0:
@@ -294,7 +311,7 @@ def main_c5(args):
             got = ctx.assemble(opt, b2, q2, o2, [0, m])[0]
             match = float(len(got) == len(exp) and all(a["seq"] == e["seq"] and a["cov"] == e["cov"] and a["ovlp"] == e["ovlp"] for a, e in zip(got, exp)))
             ctx.stage(bases, quals, offs)
-        cpu = None if args.no_cpu_baseline else c5_cpu_baseline(bases, quals, read_len, per_win, 20000)
+        cpu = None if args.no_cpu_baseline else c5_cpu_baseline(args.coverage, read_len, 20000)
         # the k-mer counting kernel against the HBM roofline: per inserted k-mer one 16-byte table slot read and written back, per base
         # the ASCII base and quality read once by the plane kernel
         steps = max(args.steps, 1)
@@ -314,7 +331,7 @@ def main_c5(args):
                     achieved_basis="ALGORITHMIC bytes per launch (32 B per inserted k-mer: its 16-byte slot read and written; 2 B per base: ASCII base + quality) / "
                                    "mean launch duration from HIP events on the context's stream (two launches per step)",
                     kernel_ms_mean_launch=count_ms, kmers_per_launch=ins_acc / steps / 2.0, bases_per_launch=nb_acc / steps / 2.0,
-                    table_slots=ctx.counter("table_slots"), kmers_distinct=ctx.counter("kmers_distinct"))
+                    table_slots=counters["table_slots"], kmers_distinct=counters["kmers_distinct"])
         out = {
             "metric": "reads/sec through the FermiAssembler window pipeline (BFC correct -> fml_assemble -> contigs realigned via BWAAligner)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -328,9 +345,13 @@ def main_c5(args):
             "windows_per_s": n_win * world / (dt / args.steps),
             "contigs": {"n": len(contigs), "total_bp": sum(lens), "longest": lens[:5], "n50": n50, "realigned": len(fit), "realigned_bp": sum(len(c) for c in fit),
                         "skipped_longer_than_max_read_len": len(contigs) - len(fit), "records": int(hits["n_hits"]) if hits is not None else 0},
+            "step_split_ms": {"assemble (slx_fml_assemble_staged + contig strings)": split["assemble_s"] / max(args.steps, 1) * 1e3,
+                              "realign (BWAAligner.alignSequences of the contigs)": split["realign_s"] / max(args.steps, 1) * 1e3,
+                              "realign_stage_ms": {k: v / max(args.steps, 1) for k, v in split["realign_stage_ms"].items()}},
+            "contigs_per_s_realign": len(fit) * args.steps / split["realign_s"] if split["realign_s"] > 0 else None,
             "contig_bit_match_rate": match, "verified_reads": min(args.verify, per_win) if args.verify > 0 else 0,
             "probe_ms_per_step": {k: v / steps for k, v in acc.items()},
-            "counters": {k: ctx.counter(k) for k in ("strings", "text_bytes", "overlaps", "irreducible", "big_vertices", "huge_vertices", "host_threads")},
+            "counters": counters,
             "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])], "read_generation_s": t_gen,
         }
         print(json.dumps(out))
@@ -557,11 +578,11 @@ def main():
                                 if pmc and pmc.get("config") == args.config else None)
         # ---- the C++ class end to end with BamRecord materialisation (tools/bamrec_bench.cpp), last: it is a process of its own with
         # its own copy of the index in HBM, so this process lets go of its aligner and reads first
-        bam = None
+        bam, percall = None, None
         if not args.no_extras:
             tool = os.path.join(ROOT, "seqlib_amd", "bamrec_bench")
             if os.path.exists(tool):
-                m = min(n, int(os.environ.get("SLX_BAM_SAMPLE", "10000000")))     # >= 10 M reads of the timed batch
+                m = min(n, int(os.environ.get("SLX_BAM_SAMPLE", str(n))))     # the whole timed batch
                 sample = os.path.join(tmp, "bam_sample.bin")
                 reads[:m].tofile(sample)
                 del al, d_bases, d_offs
@@ -573,6 +594,19 @@ def main():
                         bam = json.loads(o.stdout.decode().strip().splitlines()[-1])
                 except Exception as e:          # the extra must not take the bench line down
                     bam = dict(error=str(e))
+                # the reference's own calling convention: one alignSequence call per read (and the deferred form of the same loop)
+                tool2 = os.path.join(ROOT, "seqlib_amd", "percall_bench")
+                if os.path.exists(tool2):
+                    try:
+                        n1, n2 = min(m, int(os.environ.get("SLX_PERCALL_READS", "100000"))), min(m, 2_000_000)
+                        o = subprocess.run([tool2, prefix, sample, str(read_len), str(n1), str(n2)], stdout=subprocess.PIPE, timeout=900,
+                                           env=dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank)))
+                        if o.returncode == 0:
+                            percall = json.loads(o.stdout.decode().strip().splitlines()[-1])
+                            if cpu:
+                                percall["cpu_port_single_thread_reads_per_s"] = cpu.get("single_thread")
+                    except Exception as e:
+                        percall = dict(error=str(e))
                 os.remove(sample)
         out = {
             "metric": "aligned reads/sec (150 bp) via BWAAligner", "value": value, "unit": "reads/s", "n_gpus": world,
@@ -583,11 +617,13 @@ def main():
                                                                                       "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
                                                                                       " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
                        "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
-                       "headline": "value = reads resident in HBM -> hits resident in HBM (the contract's timed region); value_host_to_host = host reads -> host "
-                                   "SoA hits through slx_align_batch (the metric as SURVEY 8d words it); value_bamrecords = SeqLib::BWAAligner::alignSequences "
-                                   "with BamRecord output (the north-star sentence read literally)"},
+                       "headline": "value = reads resident in HBM -> hits resident in HBM over the K timed steps (the contract's timed region); value_host_to_host = host "
+                                   "reads -> host SoA hits through slx_align_batch (the metric as SURVEY 8d words it, PCIe inside); value_bamrecords = SeqLib::BWAAligner::alignSequences with BamRecord output over the whole batch (the north-star "
+                                   "sentence read literally); value_per_call = one alignSequence call per read, the reference's calling convention"},
             "roofline": roof, "roofline_ext": roof_ext, "cpu_baseline": cpu,
-            "value_host_to_host": h2h, "value_bamrecords": bam,
+            "value_is": "device_resident: the bench contract's timed region starts with the reads in HBM (VERDICT r3 asked for the host-to-host rate as the headline; "
+                        "the contract rules the PCIe-inclusive rate out as `value`, so it stays beside it as value_host_to_host)",
+            "value_host_to_host": h2h, "value_bamrecords": bam, "value_per_call": percall,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
             "gather_equals_single_process": gather_ok,
             "seed_launches_per_step": launches if rank == 0 else None, "reads_per_seed_launch": n / launches,

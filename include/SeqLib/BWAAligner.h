@@ -139,6 +139,7 @@ public:
     explicit BWAAligner(BWAIndexPtr idx) : index_(std::move(idx)) { slx_opt_init(&memopt_); }   // mem_opt_init + MEM_F_SOFTCLIP
     ~BWAAligner()
     {
+        try { Flush(); } catch (...) {}          // calls still queued by alignSequenceAsync
         for (Staging &st : stage_) { slx_host_free(st.bases); slx_host_free(st.offs); }
         if (al_) slx_aligner_free(al_);
     }
@@ -233,6 +234,34 @@ public:
         if (index_->IsEmpty() || reads.empty()) return;
         run_batch(reads, out, hardclip, keepSecFrac, maxSecondary);
     }
+    // ---- deferred per-read calls (new): the reference's calling convention at batch speed ----------------
+    // Every reference caller loops `alignSequence` over its reads (README.md:174-180, src/seqtools/seqtools.cpp:198-210).  Here one such
+    // call is one GPU round trip (~1 ms: dozens of launches for one read), so a loop over 10^6 reads is slower than the CPU library.
+    // alignSequenceAsync queues the call instead -- same arguments, the caller's own output vector -- and Flush() runs everything queued
+    // as ONE batch: the i-th queued read is the i-th successive alignSequence call (same lrand48 draw, records appended to its vector in
+    // call order).  Queued calls flush by themselves when the arguments after the name change, when 2 M reads are waiting, and in the
+    // destructor.  The output vectors must stay alive until then.  Not thread-safe (one queue per aligner).
+    void alignSequenceAsync(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double keepSecFrac, int maxSecondary)
+    {
+        if (index_->IsEmpty()) return;
+        if (!q_reads_.empty() && (hardclip != q_hardclip_ || keepSecFrac != q_ksf_ || maxSecondary != q_maxsec_)) Flush();
+        q_hardclip_ = hardclip; q_ksf_ = keepSecFrac; q_maxsec_ = maxSecondary;
+        q_reads_.emplace_back(name, seq);
+        q_outs_.push_back(&out);
+        if (q_reads_.size() >= (size_t)2 << 20) Flush();
+    }
+    void Flush()
+    {
+        if (q_reads_.empty()) return;
+        std::vector<BamRecordPtrVector> res;
+        UnalignedSequenceVector reads;
+        std::vector<BamRecordPtrVector *> outs;
+        reads.swap(q_reads_); outs.swap(q_outs_);
+        alignSequences(reads, res, q_hardclip_, q_ksf_, q_maxsec_);
+        for (size_t i = 0; i < res.size(); ++i)
+            for (auto &r : res[i]) outs[i]->push_back(std::move(r));
+    }
+    size_t Pending() const { return q_reads_.size(); }
     // The GPUs this aligner drives (HIP ordinals; before the first alignment).  Default: the current device, or what the
     // environment variable SEQLIB_AMD_DEVICES names ("all", or a comma-separated list).  With several devices a batch is
     // sharded over them by contiguous read ranges inside the C-ABI (slx_aligner_create with n_dev > 1); results are identical.
@@ -249,6 +278,9 @@ public:
     }
 
 private:
+    UnalignedSequenceVector q_reads_;               // alignSequenceAsync's queue
+    std::vector<BamRecordPtrVector *> q_outs_;
+    bool q_hardclip_ = false; double q_ksf_ = 0; int q_maxsec_ = 0;
     BWAIndexPtr index_;
     slx_opt memopt_;
     mutable slx_aligner *al_ = nullptr;

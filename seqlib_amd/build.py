@@ -45,16 +45,17 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    # tools/bamrec_bench: the C++ drop-in class timed end to end (bench.py's value_bamrecords); host-only code over the C-ABI
-    tool_src = os.path.join(ROOT, "tools", "bamrec_bench.cpp")
-    tool = os.path.join(HERE, "bamrec_bench")
+    # tools/*: the C++ drop-in class timed end to end (bench.py's value_bamrecords, value_per_call); host-only code over the C-ABI
     hdrs = [os.path.join(ROOT, "include", "SeqLib", f) for f in os.listdir(os.path.join(ROOT, "include", "SeqLib"))]
-    if force or _stale(tool, [tool_src, SO] + hdrs):
-        cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), tool_src, "-o", tool, "-L" + HERE, "-lseqlib_amd",
-               "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    for name in ("bamrec_bench", "percall_bench"):
+        tool_src = os.path.join(ROOT, "tools", name + ".cpp")
+        tool = os.path.join(HERE, name)
+        if force or _stale(tool, [tool_src, SO] + hdrs):
+            cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), tool_src, "-o", tool, "-L" + HERE, "-lseqlib_amd",
+                   "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
     return SO
 
 

@@ -917,16 +917,23 @@ __global__ void __launch_bounds__(64, EXT_JOB_WAVES) k_ext_first(DevRef R, Chunk
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x;
     const MatRows mr = make_matrows(opt.mat);
-    __shared__ int eh_h[MAXQ + 2], eh_e[MAXQ + 2];
+    __shared__ int sh_eh_h[MAXQ > 704 ? 1 : MAXQ + 2], sh_eh_e[MAXQ > 704 ? 1 : MAXQ + 2];
+    extern __shared__ int sh_dyn[];
+    int *eh_h = sh_eh_h, *eh_e = sh_eh_e;
+    if constexpr (MAXQ > 704) {          // long reads: rows of the chunk's longest read, in dynamic LDS or (ck.huge_rows) in HBM, as in k_extend_reg
+        if (ck.huge_rows) { eh_h = ck.huge_rows + (size_t)blockIdx.x * 3 * (size_t)ck.long_stride; eh_e = eh_h + ck.long_stride; }
+        else { eh_h = sh_dyn; eh_e = sh_dyn + ck.long_stride; }
+    }
     unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)first_off[n]);
     if (n_jobs > cap) n_jobs = cap;                  // (reads whose slots pass the table end are not prepared either)
     if (dp_list) n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_dp);       // only the jobs k_first_diag left (dev_ext_lane.h)
     for (;;) {
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(queue, (unsigned int)FIRST_BATCH);
+        constexpr unsigned int BATCH = MAXQ > 704 ? 1u : (unsigned int)FIRST_BATCH;          // (a contig's extension is milliseconds: one per fetch)
+        if (lane == 0) base = atomicAdd(queue, BATCH);
         base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= n_jobs) break;
-        const unsigned int end = base + FIRST_BATCH < n_jobs ? base + FIRST_BATCH : n_jobs;
+        const unsigned int end = base + BATCH < n_jobs ? base + BATCH : n_jobs;
         for (unsigned int k = base; k < end; ++k) {
             const unsigned int job = dp_list ? (unsigned int)__builtin_amdgcn_readfirstlane((int)dp_list[k]) : k;
             dev_first_job<MAXQ>(R, ck, opt, mr, eh_h, eh_e, jobs + job, first + job, lane);

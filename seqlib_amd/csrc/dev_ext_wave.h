@@ -18,25 +18,26 @@
 #define WAVE 64
 #define NEG_BIG (-0x3fffffff)
 
-__device__ __forceinline__ int wave_incl_max_scan(int v, int lane)
+// Wave-wide max scan / max on DPP (row_shr 1, 2, 4, 8, row_bcast15, row_bcast31: LLVM's gfx9 scan sequence).  The shuffle forms these
+// replace (__shfl_up / __shfl_xor = ds_bpermute, a trip through the LDS crossbar per step) put ~14 dependent ~100-cycle steps into every
+// DP row of the LDS-row extension -- on a wave that is alone on its SIMD (a contig's extension) most of the row's time.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int xw_dpp(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, BANK_MASK, false); }
+
+__device__ __forceinline__ int wave_incl_max_scan(int v, int)
 {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const int o = __shfl_up(v, d, WAVE);
-        if (lane >= d) v = v > o ? v : o;
-    }
+    constexpr int ID = (int)0x80000000;
+    int o;
+    o = xw_dpp<0x111, 0xf, 0xf>(ID, v); v = v > o ? v : o;
+    o = xw_dpp<0x112, 0xf, 0xf>(ID, v); v = v > o ? v : o;
+    o = xw_dpp<0x114, 0xf, 0xf>(ID, v); v = v > o ? v : o;
+    o = xw_dpp<0x118, 0xf, 0xf>(ID, v); v = v > o ? v : o;
+    o = xw_dpp<0x142, 0xa, 0xf>(ID, v); v = v > o ? v : o;
+    o = xw_dpp<0x143, 0xc, 0xf>(ID, v); v = v > o ? v : o;
     return v;
 }
 
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(v, d, WAVE);
-        v = v > o ? v : o;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_incl_max_scan(v, 0), WAVE - 1); }
 
 struct MatRows {              // score matrix repacked for a per-lane lookup: row t -> 4 packed int8 for q = 0..3, plus the q = 4 column
     uint32_t packed[5];
@@ -72,6 +73,7 @@ __device__ __forceinline__ int ext_tail_bound0(const slx_opt &o, int qlen, int h
 }
 __device__ __forceinline__ bool ext_tail_done(int b, int max, int gscore) { return b <= max && (b > 0 ? b : 0) < gscore; }
 
+#define EXT_RING 1024         // LDS ring of the long-read extension row (ints per array): bands up to 2 w + 2 + 128 <= 1024 columns
 // wave-cooperative ksw_extend2; every lane returns the same result.  eh_h / eh_e are LDS rows of qlen+2 ints.
 template <int NCH, typename QF, typename TF>
 __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int end_bonus, int h0,
@@ -84,12 +86,6 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     int qc[NCH > 0 ? NCH : 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { const int j = c * WAVE + lane; qc[c] = j < qlen ? qf(j) : 4; }
-    // row -1: eh[0].h = h0, then the insertion ramp while it stays positive
-    for (int j = lane; j <= qlen; j += WAVE) {
-        int v = h0 - oe_ins - (j - 1) * e_ins;
-        eh_h[j] = j == 0 ? h0 : (v > 0 ? v : 0);
-        eh_e[j] = 0;
-    }
     int max = 0;
     for (int i = 0; i < 25; ++i) max = max > o.mat[i] ? max : o.mat[i];
     int max_ins = (int)((double)(qlen * max + end_bonus - o_ins) / e_ins + 1.);
@@ -98,17 +94,45 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     int max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
     max_del = max_del > 1 ? max_del : 1;
     w = w < max_del ? w : max_del;
+    // Long reads (NCH = 0): the row lives in a RING in LDS whenever the band allows it.  Row i only touches columns i - w .. i + w + 1, so
+    // column j can sit in slot j mod EXT_RING; a column is given its row -1 value (the insertion ramp, else 0) when it first comes
+    // within reach of the band -- `fresh` is the first column not yet set up, kept at least one past the band's upper end -- and by then the
+    // column EXT_RING to its left has left the band for good (beg never decreases).  With the full-length row in HBM (a contig's row
+    // does not fit LDS) every row paid several dependent round trips to memory: ~1.4 us per row, seconds for one contig.
+    bool ring = false;
+    int fresh = 0;
+    if constexpr (NCH == 0) {
+        __shared__ int ring_h[EXT_RING], ring_e[EXT_RING];
+        if (2 * w + 2 + 2 * WAVE <= EXT_RING && qlen + 2 > EXT_RING) { ring = true; eh_h = ring_h; eh_e = ring_e; }
+    }
+    auto at = [&](int j) { return ring ? (j & (EXT_RING - 1)) : j; };
+    auto setup_to = [&](int upto) {          // row -1 of the columns fresh .. upto: eh[0].h = h0, then the insertion ramp while it stays positive
+        for (int j = fresh + lane; j <= upto; j += WAVE) {
+            int v = h0 - oe_ins - (j - 1) * e_ins;
+            eh_h[at(j)] = j == 0 ? h0 : (v > 0 ? v : 0);
+            eh_e[at(j)] = 0;
+        }
+        fresh = upto + 1;
+    };
+    if (!ring) setup_to(qlen);
     const int tail_top = ext_tail_bound0(o, qlen, h0, max);
     max = h0;
     int max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+    // long reads (NCH = 0): a contig's extension runs for tens of thousands of rows, and a target base fetched from HBM in every one of
+    // them -- a dependent load of ~1 us on a wave that is alone on its SIMD -- was most of a row's time: 64 rows' bases per lane block,
+    // the next block in flight while this one is consumed
+    int tb_cur = 0, tb_next = 0;
+    if (NCH == 0) { tb_cur = lane < tlen ? tf(lane) : 0; tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0; }
     for (int i = 0; i < tlen; ++i) {
         if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) break;      // rows that cannot matter (above)
-        const int t = tf(i);
+        if (NCH == 0 && (i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = NCH == 0 ? __builtin_amdgcn_readlane(tb_cur, __builtin_amdgcn_readfirstlane(i & (WAVE - 1))) : tf(i);
         const uint32_t rowp = mr.packed[t];
         const int row4 = mr.q4[t];
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
+        if (ring && fresh <= (end + 1 < qlen ? end + 1 : qlen)) { const int upto = i + w + 2 + WAVE < qlen ? i + w + 2 + WAVE : qlen; setup_to(upto); }
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
@@ -120,28 +144,27 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
             const int j = c * WAVE + lane;
             const bool act = j >= beg && j < end;
             int hd = 0, e = 0;
-            if (act) { hd = eh_h[j]; e = eh_e[j]; }
+            if (act) { hd = eh_h[at(j)]; e = eh_e[at(j)]; }
             if (c > c_lo && lane == 0) hd = carry_diag;
             const int nj = (c + 1) * WAVE;           // first column of the next tile
-            carry_diag = nj <= qlen ? eh_h[nj] : 0;  // same address in every lane: LDS broadcast
-            const int q = NCH > 0 ? qc[c < NCH ? c : NCH - 1] : (j < qlen ? qf(j) : 4);
+            carry_diag = nj <= qlen ? eh_h[at(nj)] : 0;  // same address in every lane: LDS broadcast
+            const int q = NCH > 0 ? qc[c < NCH ? c : NCH - 1] : (j < qlen ? qf(j) : 4);          // (long reads: an L1 hit per tile and row; keeping the tiles' codes in registers behind a compare chain measured slower)
             const int s = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
             int M = hd ? hd + s : 0;
             int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
             int u = act ? tins + j * e_ins : NEG_BIG;
             const int pm = wave_incl_max_scan(u, lane);
-            int pmx = __shfl_up(pm, 1, WAVE);
-            if (lane == 0) pmx = NEG_BIG;
+            int pmx = xw_dpp<0x138, 0xf, 0xf>(NEG_BIG, pm);          // wave_shr:1 -- the lane to the left; lane 0 gets the identity
             pmx = pmx > carry_u ? pmx : carry_u;
-            const int top = __shfl(pm, WAVE - 1, WAVE);
+            const int top = __builtin_amdgcn_readlane(pm, WAVE - 1);
             carry_u = carry_u > top ? carry_u : top;
             int f = j == beg ? 0 : pmx - (j - 1) * e_ins;
             int h = M > e ? M : e;
             h = h > f ? h : f;
             int tdel = M - oe_del; tdel = tdel > 0 ? tdel : 0;
             int en = e - e_del; en = en > tdel ? en : tdel;
-            if (act) { eh_e[j] = en; eh_h[j + 1] = h; }
-            if (j == beg) eh_h[beg] = h1_init;
+            if (act) { eh_e[at(j)] = en; eh_h[at(j + 1)] = h; }
+            if (j == beg) eh_h[at(beg)] = h1_init;
             // row maximum; ties -> the larger column, as `mj = m > h ? mj : j` does
             const int hv = act ? h : -1;
             const int mx = wave_max(hv);
@@ -150,11 +173,11 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
                 if (bal) { m = mx; mj = c * WAVE + (63 - __clzll((long long)bal)); }
             }
         }
-        if (end > beg) eh_e[end] = 0;                // eh[end].h was written by the lane of column end-1
-        else { eh_h[end] = h1_init; eh_e[end] = 0; } // empty band: the scalar loop still stores h1 into eh[end]
+        if (end > beg) eh_e[at(end)] = 0;                // eh[end].h was written by the lane of column end-1
+        else { eh_h[at(end)] = h1_init; eh_e[at(end)] = 0; } // empty band: the scalar loop still stores h1 into eh[end]
         const int jfin = end > beg ? end : beg;      // value of the scalar loop variable after the row
         if (jfin == qlen) {                           // the row reached the end of the query
-            const int h1 = end > beg ? eh_h[end] : h1_init;
+            const int h1 = end > beg ? eh_h[at(end)] : h1_init;
             max_ie = gscore > h1 ? max_ie : i;
             gscore = gscore > h1 ? gscore : h1;
         }
@@ -172,7 +195,7 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
         for (int c = beg / WAVE; c * WAVE <= end; ++c) {
             const int j = c * WAVE + lane;
             const bool in = j >= beg && j <= end;
-            const bool nz = in && (eh_h[j] != 0 || eh_e[j] != 0);
+            const bool nz = in && (eh_h[at(j)] != 0 || eh_e[at(j)] != 0);
             const unsigned long long bal = __ballot(nz);
             if (bal) {
                 if (first_nz < 0) first_nz = c * WAVE + (__ffsll((long long)bal) - 1);

@@ -1121,7 +1121,25 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
             }
             (void)hipEventRecord(wk->ev_probe[2], st);
             (void)hipEventRecord(wk->ev[4], st);
-            if (max_len > 704) launch_tail<MAXQ_LONG>(al, wk, ck, dopt, q, counts, grid, bs, n, nullptr, nullptr, nullptr, nullptr);
+            if (max_len > 704) {
+                // contigs: the top (longest) seed of every kept chain extended ahead of time, one wave per CHAIN (k_ext_first), and taken from the
+                // table by the per-read walk (k_extend_reg, top_reuse).  A contig that ends inside a tandem repeat keeps hundreds of chains on
+                // shifted diagonals, and bwa extends the top seed of each across the whole contig (a gap of a few repeat units, then tens of
+                // thousands of matching rows): on the read's own wave that walk took seconds for one contig
+                const unsigned int top_cap = (unsigned int)std::min<uint64_t>((uint64_t)S1, 0x7fffffffu);
+                ENS(first_tab, (size_t)top_cap * sizeof(DReg)); ENS(first_cnt, ((size_t)n + 2) * 4); ENS(first_off, ((size_t)n + 2) * 4);
+                ENS(first_jobs, (size_t)top_cap * sizeof(FirstJob));
+                HIPCHK(hipMemsetAsync(wk->first_cnt.p, 0, ((size_t)n + 2) * 4, st));
+                hipLaunchKernelGGL(k_first_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, n, 0xffffffffu, wk->first_cnt.as<unsigned int>(), 0);
+                size_t tb = wk->scan_tmp.cap;
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->first_cnt.as<unsigned int>(), wk->first_off.as<unsigned int>(), n + 1, st));
+                hipLaunchKernelGGL(k_first_prep, dim3(std::max(1, std::min(n / 128 + 1, al->n_cu * 12))), dim3(128), 0, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(),
+                                   top_cap, wk->first_jobs.as<FirstJob>());
+                const unsigned first_smem = ck.huge_rows ? 0u : (unsigned)(2 * ck.long_stride * 4);
+                hipLaunchKernelGGL(k_ext_first<MAXQ_LONG>, dim3(ck.huge_rows ? HUGE_BLOCKS : al->n_cu * 8), dim3(64), first_smem, st, al->ref, ck, dopt, n, wk->first_off.as<unsigned int>(),
+                                   top_cap, q + 22, wk->first_jobs.as<FirstJob>(), wk->first_tab.as<DReg>(), (const unsigned int *)nullptr, (const unsigned int *)nullptr);
+                launch_tail<MAXQ_LONG>(al, wk, ck, dopt, q, counts, grid, bs, n, nullptr, nullptr, nullptr, nullptr, wk->first_off.as<unsigned int>(), top_cap, wk->first_tab.as<DReg>());
+            }
             else with_maxq(max_len, [&](auto mq) {
                 launch_tail<decltype(mq)::value>(al, wk, ck, dopt, q, counts, grid, bs, n, nullptr, nullptr, nullptr, nullptr);
             });
