@@ -333,8 +333,13 @@ enum Seed4Phase : int { S4_FETCH = 0, S4_INIT, S4_START, S4_FWD, S4_DIR, S4_ROW,
 
 // MODE 1: pass 1 of every read of the chunk (all SMEMs).  MODE 2: pass 2 (re-seeding) of the reads on `list`, for the intervals
 // k_seed2_select marked in p2mask -- the two passes are separate launches so that the selection between them runs one lane per read.
+#ifdef SEED4_NUM_VGPR
+#define SEED4_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SEED4_NUM_VGPR)))
+#else
+#define SEED4_VGPR_ATTR
+#endif
 template <typename I, int MODE>
-__global__ void __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota,
+__global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_MIN_WAVES_U64 : SEED4_MIN_WAVES)) k_seed12m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, uint32_t wave_quota,
                                                                                                               const int *list, const unsigned int *n_list, const unsigned long long *p2mask,
                                                                                                               const uint32_t *items, const unsigned int *n_items, uint32_t cap_items,
                                                                                                               uint32_t *long_items, unsigned int *n_long, uint32_t cap_long)

@@ -369,8 +369,44 @@ static int bwamem_dump(const std::string &prefix, const std::string &fastq, long
     return 0;
 }
 
+// blob <index prefix> <reads file: one read per line, "name<TAB>sequence"> <hardclip> <bwa-mem records>: every record's bam1_t data block as hex
+// (qname, CIGAR, 4-bit sequence, qualities, tags: what /root/reference/src/BWAAligner.cpp:151-248 builds), through the per-read call AND the batch call
+static int blob_dump(const char *prefix, const char *reads_path, int hardclip, int sam)
+{
+    BWAIndexPtr idx = std::make_shared<BWAIndex>();
+    idx->LoadIndex(prefix);
+    BWAAligner al(idx);
+    if (sam) al.UseBwaMemRecords(true);
+    UnalignedSequenceVector reads;
+    std::ifstream in(reads_path);
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t t = line.find('\t');
+        if (t == std::string::npos) continue;
+        reads.push_back(UnalignedSequence(line.substr(0, t), line.substr(t + 1)));
+    }
+    auto dump = [](const char *tag, size_t i, const BamRecordPtrVector &v) {
+        for (size_t k = 0; k < v.size(); ++k) {
+            const bam1_t *b = v[k]->raw();
+            std::printf("%s\t%zu\t%zu\t%d\t%d\t%d\t%d\t%d\t", tag, i, k, b->core.tid, (int)b->core.pos, (int)b->core.flag, (int)b->core.qual, b->l_data);
+            for (int x = 0; x < b->l_data; ++x) std::printf("%02x", b->data[x]);
+            std::printf("\n");
+        }
+    };
+    std::vector<BamRecordPtrVector> batch;
+    al.alignSequences(reads, batch, hardclip != 0, 0.9, 10);
+    for (size_t i = 0; i < batch.size(); ++i) dump("B", i, batch[i]);
+    for (size_t i = 0; i < reads.size(); ++i) {
+        BamRecordPtrVector one;
+        al.alignSequence(reads[i], one, hardclip != 0, 0.9, 10);
+        dump("S", i, one);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 6 && std::string(argv[1]) == "blob") return blob_dump(argv[2], argv[3], std::atoi(argv[4]), std::atoi(argv[5]));
     if (argc >= 5 && std::string(argv[1]) == "bwamem") return bwamem_dump(argv[2], argv[3], std::atol(argv[4]));
     if (argc >= 6 && std::string(argv[1]) == "multidev") return multidev_checks(argv[2], argv[3], std::atol(argv[4]), std::atoi(argv[5]));
     if (argc >= 4 && std::string(argv[1]) == "cpu") return cpu_checks(argv[2], argv[3]);

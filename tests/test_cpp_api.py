@@ -296,3 +296,52 @@ def test_cpp_fastq_to_sam_pipeline(exe, golden_dir, tmp_path):
     text, refs, recs, _ = _parse_bam(pre + ".bam")
     assert [r_[0] for r_ in refs] == chrom and text == "\n".join(head) + "\n"
     assert [_sam_of(x, refs) for x in recs] == body
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hardclip", [0, 1])
+def test_cpp_record_blobs_match_oracle(exe, golden_dir, tmp_path, hardclip):
+    """The BamRecord data block byte for byte (src/BWAAligner.cpp:151-248): qname, CIGAR with op 3 rewritten to S / H, the hard-clip trimming
+    of the sequence (:164-177), the case-sensitive 4-bit packing (a lower-case base packs as 15, :214-231), N bases, the A<->T-only reversal of
+    reverse-strand reads, qual[0] = 0xff, tags NA, NM, AS in that order -- against the block the oracle restates (orc_hit.data), through the
+    batch call and the per-read call.  The quality bytes after the first are uninitialised in the reference: masked."""
+    from oracle import orc
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    _, s1 = orc.read_fastq(os.path.join(golden_dir, "sim1_bcr.head3000.fq"), 120)
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = list(s1[:100])
+    reads.append(refs[0][5000:5100] + refs[1][9000:9070])                      # chimeric: soft / hard clips on both records
+    reads.append((refs[1][20000:20090] + refs[2][700:790]).translate(comp)[::-1])          # the same on the reverse strand
+    reads.append(refs[0][7000:7150].lower())                                   # lower case: aligns like upper case, packs as N
+    reads.append(refs[0][8000:8060] + "NNNN" + refs[0][8064:8150])             # N bases
+    reads.append(refs[2][100:250][:75] + "acgtn" + refs[2][100:250][80:])     # mixed case inside
+    reads.append(refs[3][300:340])                                             # short
+    reads.append("ACGTACGTAC")                                                 # no alignment: no record
+    names_r = ["q%d" % i for i in range(len(reads))]
+    path = tmp_path / "reads.tsv"
+    path.write_text("".join("%s\t%s\n" % (n, r) for n, r in zip(names_r, reads)))
+    r = subprocess.run([exe, "blob", os.path.join(golden_dir, "tiny.fa"), str(path), str(hardclip), "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {"B": {}, "S": {}}
+    for line in r.stdout.strip().split("\n"):
+        tag, i, k, tid, pos, flag, mapq, l_data, hexd = line.split("\t")
+        got[tag].setdefault(int(i), []).append((int(tid), int(pos), int(flag), int(mapq), int(l_data), bytes.fromhex(hexd)))
+    idx = orc.Index.load(os.path.join(golden_dir, "tiny.fa"))
+    opt = orc.default_opt()
+    n_clip = n_rec = 0
+
+    def masked(d, l_qname, n_cig, l_qseq):
+        q0 = l_qname + 4 * n_cig + (l_qseq + 1) // 2
+        return d[:q0 + 1] + bytes(max(l_qseq - 1, 0)) + d[q0 + l_qseq:]
+
+    for tag, base in (("B", 0), ("S", len(reads))):          # the per-read calls follow the batch: read i of them is call number len(reads) + i of the process
+        for i, sq in enumerate(reads):
+            exp = orc.align_sequence(opt, idx, sq, name=names_r[i], hardclip=bool(hardclip), ordinal=base + i)
+            g = got[tag].get(i, [])
+            assert len(g) == len(exp), (tag, i, len(g), len(exp))
+            for a, e in zip(g, exp):
+                assert a[:4] == (e["rid"], e["pos"], e["flag"], e["mapq"]) and a[4] == len(e["data"]), (tag, i)
+                assert masked(a[5], e["l_qname"], len(e["cigar"]), e["l_qseq"]) == masked(e["data"], e["l_qname"], len(e["cigar"]), e["l_qseq"]), (tag, i)
+                n_rec += 1
+                n_clip += any((w & 0xf) in (4, 5) for w in e["cigar"])
+    assert n_rec > 200 and n_clip >= 4

@@ -692,6 +692,58 @@ def test_option_fuzz_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_
         assert_same(al.alignSequences(base), orc.align_batch(o, tiny_index, base), what)
 
 
+def test_option_fuzz_and_record_mode_on_a_repeat_rich_block(sl, orc, tmp_path):
+    """The option space and bwa's own record rules on data that reaches the repeat / heavy-read / big-table kernels: a chr20_syn
+    (C3) block thinned to 20 000 reads -- every read of a 131 072-read block with two or more hits, low-complexity reads, the rest at
+    random -- under eight option sets with max_occ, w, zdrop and min_seed_len at their extremes, bit-exact vs the oracle, the counters
+    showing that the cooperative seeding / chaining kernels saw work; then SLX_F_REG2SAM on 5 000 of them (max_XA_hits cut-offs on reads
+    with hundreds of regions)."""
+    from seqlib_amd import synth, _ffi
+    cfg = synth.CONFIGS["C3"]
+    refs = synth.make_reference(cfg)
+    idx = sl.BWAIndex()
+    idx.ConstructIndex([(nm, synth.genome_ascii(g)) for nm, g in refs])
+    idx.WriteIndex(str(tmp_path / "c3"))
+    oidx = orc.Index.load(str(tmp_path / "c3"))
+    block = synth.make_config_reads(cfg, refs, 1 << 17)
+    L = cfg["read_len"]
+    al = sl.BWAAligner(idx)
+    first = al.align_flat(block.tobytes(), synth.offsets_for(len(block), L))
+    nh = np.diff(first["hit_off"])
+    rng = np.random.default_rng(404)
+    heavy = np.nonzero(nh >= 2)[0]
+    rest = rng.choice(np.nonzero(nh < 2)[0], 20000 - 40 - min(len(heavy), 6000), replace=False)
+    pick = np.sort(np.concatenate([heavy[:6000], rest]))
+    g = synth.genome_ascii(refs[0][1])
+    low = [("A" * L), ("AC" * L)[:L], ("ACG" * L)[:L], ("GATTACA" * L)[:L]] * 5 + [g[p:p + 70] + "N" * 10 + g[p + 80:p + L] for p in range(1000, 21000, 1000)]
+    seqs = [block[i].tobytes().decode() for i in pick] + low
+    assert len(seqs) == 20000 and len(heavy) > 200
+    sets = [dict(), dict(max_occ=2000, w=300), dict(max_occ=2, zdrop=10), dict(min_seed_len=10, w=3), dict(min_seed_len=27, zdrop=0, max_occ=50),
+            dict(w=150, zdrop=200, split_width=40, max_mem_intv=0), dict(b=2, o_del=12, o_ins=3, e_del=3, e_ins=1, pen_clip5=0, pen_clip3=10),
+            dict(max_occ=2000, min_seed_len=12, mask_level=0.8, drop_ratio=0.3, max_chain_gap=50)]
+    saw = {"heavy_reads": 0, "p2_coop_calls": 0, "p2_calls": 0}
+    for t, kv in enumerate(sets):
+        o = orc.default_opt()
+        al = sl.BWAAligner(idx)
+        for k, v in kv.items():
+            setattr(o, k, v); setattr(al.opt, k, v)
+        orc.lib().orc_fill_scmat(o.a, o.b, o.mat)
+        for i in range(25):
+            al.opt.mat[i] = o.mat[i]
+        if t % 2:
+            al.set("split_min", 16)          # the production schedule on a batch this small
+        n = len(seqs) if t in (0, 1, 5) else 6000          # (the seed-length and occurrence extremes cost the scalar checker seconds per thousand reads)
+        sub = seqs[:3000] + seqs[-3000:] if n == 6000 else seqs
+        assert_same(al.alignSequences(sub), orc.align_batch(o, oidx, sub), "repeat block, set %d %s" % (t, kv))
+        for k in saw:
+            saw[k] = max(saw[k], al.counter(k))
+    assert saw["heavy_reads"] > 50 and saw["p2_coop_calls"] > 10 and saw["p2_calls"] > 100, saw
+    sub = seqs[:2500] + seqs[-2500:]
+    n_multi, n_xa = _check_sam_mode(sl, orc, idx, oidx, sub, "record mode on the repeat block")
+    assert n_xa > 100
+    n_multi, n_xa = _check_sam_mode(sl, orc, idx, oidx, sub[:1500], "record mode on the repeat block, production schedule", knobs=(("split_min", 16), ("heavy_seeds", 8), ("regs_big", 2)))
+
+
 def test_multi_device_handle_equals_single(sl, orc, tiny_gpu, tiny_index, sim_reads):
     """slx_aligner_create with n_dev > 1 (every visible GPU, each listed up to three times -- also the stand-in for several GPUs on a
     1-GPU box): slx_align_batch shards the batch by contiguous read-ordinal ranges, one host thread per device, results merged on
