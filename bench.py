@@ -439,13 +439,18 @@ def main():
     d_offs = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * read_len
     torch.cuda.synchronize()
 
+    gather_acc = [0.0]
+
     def step(m=n):
         h = al.align_device(d_bases.data_ptr(), d_offs.data_ptr(), m, first_ordinal=first_ordinal)
         if world > 1:
+            tg = time.time()                               # align_device returns synchronised: everything from here is the gather
             sz = al.packed_size(h)
             buf = torch.empty(sz, dtype=torch.uint8, device=dev)
             al.pack_into(h, buf.data_ptr(), sz)
             parts = gather.gather_packed(buf, dst=0)      # the one RCCL collective of the path
+            torch.cuda.synchronize()
+            gather_acc[0] += time.time() - tg
             return h, parts
         return h, None
 
@@ -458,6 +463,7 @@ def main():
         step()
     stage_acc, probe_acc, launches_acc = {}, {}, 0
     fence()
+    gather_acc[0] = 0.0
     t0 = time.time()
     step_marks = [t0]
     for _ in range(args.steps):
@@ -474,6 +480,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        t = torch.tensor([gather_acc[0]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_acc[0] = float(t.item())
+    gather_ms = gather_acc[0] / args.steps * 1e3 if world > 1 else None     # pack + byte counts + grouped send/recv, slowest rank, per step
     ms_per_step = dt / args.steps * 1e3
     total_reads = n * world
     value = total_reads / (dt / args.steps)
@@ -626,6 +636,7 @@ def main():
             "value_host_to_host": h2h, "value_bamrecords": bam, "value_per_call": percall,
             "cigar_bit_match_rate": match, "verified_reads": min(args.verify, n) if args.verify > 0 else 0,
             "gather_equals_single_process": gather_ok,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "seed_launches_per_step": launches if rank == 0 else None, "reads_per_seed_launch": n / launches,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
             "probe_ms_per_step": {k: v / args.steps for k, v in probe_acc.items()},

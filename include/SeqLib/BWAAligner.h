@@ -199,7 +199,7 @@ public:
     // threshold, the supplementary flag and the XA / SA tags `bwa mem` would give (src/BWAAligner.cpp:136-146, :240: h.XA is
     // always NULL).  With UseBwaMemRecords(true) a read yields what bwa's mem_reg2sam prints for it instead: its primaries
     // scoring >= T in bwa's order (0x800 on all but the first, mapq capped at the first's), XA:Z from mem_gen_alt through the
-    // branch of :240, XS:i and SA:Z; a read without such a record yields one unmapped record (flag 4).  keepSecFrac and
+    // branch of :240, MD:Z, XS:i and SA:Z; a read without such a record yields one unmapped record (flag 4).  keepSecFrac and
     // maxSecondary are not used then.
     void UseBwaMemRecords(bool on = true) { if (on) memopt_.flag |= SLX_F_REG2SAM; else memopt_.flag &= ~SLX_F_REG2SAM; }
     void SetOutputScoreThreshold(int T)
@@ -341,7 +341,7 @@ private:
     // for the data blob, sized for the tags it ends with (the reference reallocs at each bam_aux_append).  xa / sa / xs: the
     // extra tags of a UseBwaMemRecords record (XA:Z where :240 puts it, XS:i and SA:Z after AS:i).
     static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, size_t l_name, bool hardclip,
-                                    const std::string *xa = nullptr, const std::string *sa = nullptr, const int32_t *xs = nullptr)
+                                    const std::string *xa = nullptr, const std::string *sa = nullptr, const int32_t *xs = nullptr, const std::string *md = nullptr)
     {
         auto b = std::make_shared<BamRecord>();
         bam1_t *r = b->b.get();
@@ -367,7 +367,8 @@ private:
         r->core.l_qname = (uint16_t)(l_name + 1);
         r->core.l_qseq = (int32_t)clipped.size();
         const int l_core = r->core.l_qname + (n_cigar << 2) + ((r->core.l_qseq + 1) >> 1) + r->core.l_qseq;
-        const int l_tags = 3 * 7 + (xa && !xa->empty() ? 4 + (int)xa->size() : 0) + (sa && !sa->empty() ? 4 + (int)sa->size() : 0) + (xs ? 7 : 0);
+        const int l_tags = 3 * 7 + (xa && !xa->empty() ? 4 + (int)xa->size() : 0) + (sa && !sa->empty() ? 4 + (int)sa->size() : 0) + (xs ? 7 : 0) +
+                           (md && !md->empty() ? 4 + (int)md->size() : 0);
         r->data = static_cast<uint8_t *>(std::malloc((size_t)(l_core + l_tags)));
         if (!r->data) throw std::bad_alloc();
         r->m_data = (uint32_t)(l_core + l_tags);
@@ -392,6 +393,7 @@ private:
         if (sl > 0) bam_get_qual(r)[0] = 0xff;
         b->AddIntTag("NA", h.na[k]);
         b->AddIntTag("NM", h.nm[k]);
+        if (md && !md->empty()) b->AddZTag("MD", *md);       // bwa prints MD:Z right after NM:i (mem_aln2sam)
         if (xa && !xa->empty()) b->AddZTag("XA", *xa);       // `if (h.XA) b->AddZTag("XA", ...)` (:240)
         b->AddIntTag("AS", h.score[k]);
         if (xs && *xs >= 0) b->AddIntTag("XS", *xs);
@@ -432,6 +434,46 @@ private:
     {
         std::call_once(names_once_, [this]() { for (int i = 0; i < index_->NumSequences(); ++i) names_.push_back(index_->ChrIDToName(i)); });
         return names_[(size_t)rid];
+    }
+
+    // MD:Z of entry k as bwa_gen_cigar2 builds it next to NM: match run lengths, a mismatch as the reference base, a deletion as ^ + the
+    // deleted bases; from the finished record (position, CIGAR, strand) and the forward strand of the index (slx_index_fetch)
+    std::string md_string(const slx_hits &h, int64_t k, const std::string_view seq) const
+    {
+        const uint32_t *cig = h.cigar + h.cig_off[k];
+        const int n_cigar = h.n_cigar_ops[k];
+        int64_t rlen = 0;
+        for (int c = 0; c < n_cigar; ++c) if (bam_cigar_type(bam_cigar_op(cig[c])) & 2) rlen += bam_cigar_oplen(cig[c]);
+        std::string ref((size_t)rlen, 'N');
+        if (rlen && slx_index_fetch(index_->idx_, h.rid[k], h.pos[k], rlen, &ref[0]) != SLX_OK) return std::string();
+        const bool rev = (h.flag[k] & BAM_FREVERSE) != 0;
+        const int len = (int)seq.size();
+        auto qbase = [&](int x) -> char {          // base x of the read as the record shows it; anything but ACGT never equals a reference base
+            char c = rev ? seq[(size_t)(len - 1 - x)] : seq[(size_t)x];
+            c = (char)(c & 0xdf);
+            if (!rev) return c;
+            return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+        };
+        std::string md;
+        int x = 0, u = 0;
+        int64_t y = 0;
+        for (int c = 0; c < n_cigar; ++c) {
+            const uint32_t op = bam_cigar_op(cig[c]);
+            const int l = (int)bam_cigar_oplen(cig[c]);
+            if (op == BAM_CMATCH) {
+                for (int i = 0; i < l; ++i) {
+                    if (qbase(x + i) != ref[(size_t)(y + i)]) { md += std::to_string(u); md.push_back(ref[(size_t)(y + i)]); u = 0; }
+                    else ++u;
+                }
+                x += l; y += l;
+            } else if (op == BAM_CDEL) {
+                md += std::to_string(u); md.push_back('^');
+                md.append(ref, (size_t)y, (size_t)l);
+                u = 0; y += l;
+            } else x += l;          // insertion, soft clip, hard clip (the walk is over the whole read)
+        }
+        md += std::to_string(u);
+        return md;
     }
 
     // all records of read i of a result: the glue's (src/BWAAligner.cpp:136-248), or -- UseBwaMemRecords -- bwa's own, from the entries
@@ -488,7 +530,8 @@ private:
                 }
         dst.reserve(dst.size() + (size_t)n_rec);
         for (int64_t j = 0; j < n_rec; ++j) {
-            BamRecordPtr r = make_record(h, rec[(size_t)j], seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[rec[(size_t)j]]);
+            const std::string md = md_string(h, rec[(size_t)j], seq);
+            BamRecordPtr r = make_record(h, rec[(size_t)j], seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[rec[(size_t)j]], &md);
             if (com) r->AddZTag("BC", *com);
             dst.push_back(std::move(r));
         }

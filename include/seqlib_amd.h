@@ -15,6 +15,7 @@
  *   slx_index_write     BWAIndex::WriteIndex                      src/BWAIndex.cpp:382-406
  *   slx_index_free      BWAIndex::~BWAIndex -> bwa_idx_destroy    src/BWAIndex.cpp:16-21
  *   slx_index_nseq/name/len/l_pac/n_holes                         src/BWAIndex.cpp:44-78,408-417
+ *   slx_index_fetch     bns_get_seq as bwa_gen_cigar2 uses it (MD:Z of the opt-in bwa-mem record mode)
  *   slx_aligner_create  BWAAligner::BWAAligner(BWAIndexPtr)       SeqLib/BWAAligner.h:14-18
  *   slx_aligner_free    BWAAligner::~BWAAligner                   SeqLib/BWAAligner.h:20-22
  *   slx_align_batch     n successive BWAAligner::alignSequence calls: mem_align1 + mem_reg2aln +
@@ -102,6 +103,9 @@ const char *slx_index_name(const slx_index *idx, int i);
 int64_t slx_index_len(const slx_index *idx, int i);
 int64_t slx_index_l_pac(const slx_index *idx);
 int  slx_index_n_holes(const slx_index *idx);
+/* forward-strand bases [beg, beg + len) of contig rid as ACGT letters (the pac's content: an N of the input is the base bwa drew for it).
+ * What bns_get_seq hands bwa_gen_cigar2 for the MD:Z string (bwa-mem record mode). */
+int  slx_index_fetch(const slx_index *idx, int rid, int64_t beg, int64_t len, char *out);
 
 /* ---- aligner (device-resident FM-index + workspaces) ---- */
 /* devices/n_dev: HIP device ordinals; NULL/0 = the current device.  With n_dev > 1 the handle drives every listed device: the

@@ -254,6 +254,7 @@ typedef struct {
     int32_t  xa_parent;   /* the ordinal (among this read's records, in entry order) of the record it is an XA alternative of; -1 = of none */
     char    *xa;          /* records: the XA:Z value as bwa builds it (NULL if none) */
     char    *sa;          /* records: the SA:Z value (NULL if none) */
+    char    *md;          /* records: the MD:Z value bwa_gen_cigar2 builds next to NM (mismatched / deleted reference bases between match run lengths) */
 } orc_samhit;
 int  orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, const char *seq, int len, int hardclip,
                             uint64_t rng_base, uint64_t ordinal, orc_samhit **out);

@@ -62,7 +62,7 @@ class Hit(C.Structure):
 class SamHit(C.Structure):
     _fields_ = [("rid", C.c_int32), ("pos", C.c_int64), ("flag", C.c_uint16), ("mapq", C.c_uint8), ("score", C.c_int32), ("nm", C.c_int32),
                 ("na", C.c_int32), ("sub", C.c_int32), ("n_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint32)), ("xa_parent", C.c_int32),
-                ("xa", C.c_char_p), ("sa", C.c_char_p)]
+                ("xa", C.c_char_p), ("sa", C.c_char_p), ("md", C.c_char_p)]
 
 
 class BatchOut(C.Structure):
@@ -242,7 +242,7 @@ def align_sequence_sam(opt, index, seq, hardclip=False, rng_base=0, ordinal=0):
         h = out[i]
         recs.append(dict(rid=h.rid, pos=h.pos, flag=h.flag, mapq=h.mapq, AS=h.score, NM=h.nm, NA=h.na, XS=h.sub,
                          cigar=[h.cigar[k] for k in range(h.n_cigar)], xa_parent=h.xa_parent,
-                         XA=h.xa.decode() if h.xa else None, SA=h.sa.decode() if h.sa else None))
+                         XA=h.xa.decode() if h.xa else None, SA=h.sa.decode() if h.sa else None, MD=h.md.decode() if h.md else None))
     lib().orc_samhits_free(out, n)
     return recs
 

@@ -250,6 +250,41 @@ static int get_pri_idx(double XA_drop_ratio, const orc_reg *a, int i)
     return -1;
 }
 
+/* bwa.c: bwa_gen_cigar2's MD string, from the finished alignment: match run lengths, a mismatch as the reference base, a deletion as
+ * ^ + the deleted reference bases; insertions and clips leave no trace; a deletion that was the first or the last operation is not in
+ * the CIGAR any more (mem_reg2aln squeezed it out, as bwa skips it in MD).  bwa walks the reverse-strand alignments in reversed
+ * coordinates with complemented letters: the same comparisons and the same letters as the forward strand against the read as SAM shows it. */
+static std::string md_string(const orc_index *idx, const char *seq, int len, int rid, int64_t pos, bool is_rev, const uint32_t *cig, int n_cig)
+{
+    auto ref_at = [&](int64_t p) { return (int)(idx->pac[p >> 2] >> ((~p & 3) << 1) & 3); };
+    auto qcode = [&](int x) {          /* base x of the read as the record shows it (reverse strand: the reverse complement) */
+        const int c = is_rev ? seq[len - 1 - x] : seq[x];
+        int v;
+        switch (c) { case 'A': case 'a': v = 0; break; case 'C': case 'c': v = 1; break; case 'G': case 'g': v = 2; break; case 'T': case 't': v = 3; break; default: v = 4; }
+        return is_rev && v < 4 ? 3 - v : v;
+    };
+    std::string md;
+    int x = 0, u = 0;
+    int64_t y = idx->anns[rid].offset + pos;
+    for (int k = 0; k < n_cig; ++k) {
+        const int op = (int)(cig[k] & 0xf), l = (int)(cig[k] >> 4);
+        if (op == 0) {
+            for (int i = 0; i < l; ++i) {
+                if (qcode(x + i) != ref_at(y + i)) { md += std::to_string(u); md.push_back("ACGT"[ref_at(y + i)]); u = 0; }
+                else ++u;
+            }
+            x += l; y += l;
+        } else if (op == 2) {
+            md += std::to_string(u); md.push_back('^');
+            for (int i = 0; i < l; ++i) md.push_back("ACGT"[ref_at(y + i)]);
+            u = 0; y += l;
+        } else if (op == 1 || op == 3 || op == 4) x += l;          /* insertion, soft clip (bwa's op 3 / BAM 4); a hard clip (5) consumes nothing of the record's sequence -- but `seq` here is the whole read */
+        else if (op == 5) x += l;
+    }
+    md += std::to_string(u);
+    return md;
+}
+
 static void put_cigar(std::string &s, const uint32_t *cig, int n, const char *ops)
 {
     for (int k = 0; k < n; ++k) { s += std::to_string(cig[k] >> 4); s.push_back(ops[cig[k] & 0xf]); }
@@ -332,6 +367,7 @@ extern "C" int orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, 
             h.cigar[c] = w;
         }
         if (j >= 0) {
+            h.md = strdup(md_string(idx, seq, len, al.rid, al.pos, al.is_rev, h.cigar, al.n_cigar).c_str());
             if (!xa[(size_t)j].empty()) h.xa = strdup(xa[(size_t)j].c_str());
             if (recs.size() > 1) {                           /* mem_aln2sam: the other non-secondary hits of the list */
                 std::string sa;
@@ -363,6 +399,6 @@ extern "C" int orc_align_sequence_sam(const orc_opt *opt, const orc_index *idx, 
 extern "C" void orc_samhits_free(orc_samhit *h, int n)
 {
     if (!h) return;
-    for (int i = 0; i < n; ++i) { std::free(h[i].cigar); std::free(h[i].xa); std::free(h[i].sa); }
+    for (int i = 0; i < n; ++i) { std::free(h[i].cigar); std::free(h[i].xa); std::free(h[i].sa); std::free(h[i].md); }
     std::free(h);
 }

@@ -19,7 +19,7 @@ SLX_F_REG2SAM = 0x40000000
 # every symbol include/seqlib_amd.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "slx_opt_init", "slx_fill_scmat", "slx_index_build", "slx_index_load", "slx_index_write", "slx_index_free",
-    "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_aligner_create",
+    "slx_index_nseq", "slx_index_name", "slx_index_len", "slx_index_l_pac", "slx_index_n_holes", "slx_index_fetch", "slx_aligner_create",
     "slx_aligner_free", "slx_aligner_set", "slx_align_batch", "slx_align_batch_device", "slx_hits_free", "slx_hits_packed_size", "slx_hits_pack",
     "slx_aligner_stage_ms", "slx_stage_name", "slx_aligner_probe_ms", "slx_debug_stage", "slx_lrand48_advance", "slx_lrand48_peek_libc", "slx_lrand48_skip_libc",
     "slx_last_error", "slx_version", "slx_device_count", "slx_aligner_probe_launches", "slx_aligner_counter", "slx_host_alloc", "slx_host_free", "slx_host_trim",
@@ -70,6 +70,7 @@ def lib():
     L.slx_index_l_pac.argtypes = [C.c_void_p]
     L.slx_index_l_pac.restype = C.c_int64
     L.slx_index_n_holes.argtypes = [C.c_void_p]
+    L.slx_index_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_char_p]
     L.slx_aligner_create.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.slx_aligner_free.argtypes = [C.c_void_p]
     L.slx_aligner_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]

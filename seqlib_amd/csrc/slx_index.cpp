@@ -97,6 +97,19 @@ extern "C" int64_t slx_index_len(const slx_index *idx, int i)
 }
 extern "C" int64_t slx_index_l_pac(const slx_index *idx) { return idx ? idx->l_pac : 0; }
 extern "C" int slx_index_n_holes(const slx_index *idx) { return idx ? (int)idx->ambs.size() : 0; }
+extern "C" int slx_index_fetch(const slx_index *idx, int rid, int64_t beg, int64_t len, char *out)
+{
+    if (!idx || !out || rid < 0 || rid >= (int)idx->anns.size() || beg < 0 || len < 0 || beg + len > idx->anns[(size_t)rid].len) {
+        slx_set_error("slx_index_fetch: bad argument");
+        return SLX_EINVAL;
+    }
+    const int64_t p0 = idx->anns[(size_t)rid].offset + beg;
+    for (int64_t i = 0; i < len; ++i) {
+        const int64_t p = p0 + i;
+        out[i] = "ACGT"[idx->pac[(size_t)(p >> 2)] >> ((~p & 3) << 1) & 3];
+    }
+    return SLX_OK;
+}
 extern "C" void slx_index_free(slx_index *idx) { delete idx; }
 
 // ---------------------------------------------------------------- build

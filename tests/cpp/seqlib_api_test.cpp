@@ -359,12 +359,12 @@ static int bwamem_dump(const std::string &prefix, const std::string &fastq, long
         for (size_t j = 0; j < outs[i].size(); ++j) {
             const BamRecord &r = *outs[i][j];
             int32_t as = 0, nm = -1, na = 0, xs = -1;
-            std::string xa = "*", sa = "*";
+            std::string xa = "*", sa = "*", md = "*";
             r.GetIntTag("AS", as); r.GetIntTag("NM", nm); r.GetIntTag("NA", na);
             if (!r.GetIntTag("XS", xs)) xs = -1;
-            r.GetZTag("XA", xa); r.GetZTag("SA", sa);
-            std::printf("%zu\t%zu\t%u\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%d\t%s\t%s\n", i, j, r.AlignmentFlag(), r.ChrID(), r.Position(), r.MapQuality(),
-                        r.CigarString().empty() ? "*" : r.CigarString().c_str(), as, nm, na, xs, xa.c_str(), sa.c_str());
+            r.GetZTag("XA", xa); r.GetZTag("SA", sa); r.GetZTag("MD", md);
+            std::printf("%zu\t%zu\t%u\t%d\t%d\t%d\t%s\t%d\t%d\t%d\t%d\t%s\t%s\t%s\n", i, j, r.AlignmentFlag(), r.ChrID(), r.Position(), r.MapQuality(),
+                        r.CigarString().empty() ? "*" : r.CigarString().c_str(), as, nm, na, xs, xa.c_str(), sa.c_str(), md.c_str());
         }
     return 0;
 }

@@ -88,18 +88,19 @@ def test_cpp_bwa_mem_records(exe, golden_dir):
     oidx = orc.Index.load(os.path.join(golden_dir, "tiny.fa"))
     _, seqs = orc.read_fastq(fq, n)
     seqs.append("ACGTACGTACGTTGCATGCATGCAAACCGGTT")
-    n_sa = n_xa = 0
+    n_sa = n_xa = n_md = 0
     for i, sq in enumerate(seqs):
         recs = [e for e in orc.align_sequence_sam(orc.default_opt(), oidx, sq, ordinal=i) if e["XS"] >= 0]
         if not recs:                                   # bwa prints an unmapped record
-            assert got[i] == [["4", "-1", "-1", "0", "*", "0", "-1", "0", "0", "*", "*"]], (i, got[i])
+            assert got[i] == [["4", "-1", "-1", "0", "*", "0", "-1", "0", "0", "*", "*", "*"]], (i, got[i])
             continue
         exp = [[str(e["flag"]), str(e["rid"]), str(e["pos"]), str(e["mapq"]), orc.cigar_str(e["cigar"]), str(e["AS"]), str(e["NM"]), str(e["NA"]),
-                str(e["XS"]), e["XA"] or "*", e["SA"] or "*"] for e in recs]
+                str(e["XS"]), e["XA"] or "*", e["SA"] or "*", e["MD"] or "*"] for e in recs]
         assert got[i] == exp, (i, got[i], exp)
+        n_md += sum(1 for e in recs if e["MD"] and not e["MD"].isdigit())
         n_sa += any(e["SA"] for e in recs)
         n_xa += any(e["XA"] for e in recs)
-    assert n_sa >= 1 and len(got) == len(seqs)
+    assert n_sa >= 1 and n_md > 500 and len(got) == len(seqs)          # (wgsim's reads carry mismatches and indels: MD strings with letters and ^)
 
 
 # ---------------------------------------------------------------------------------------------- FastqReader / BamWriter
