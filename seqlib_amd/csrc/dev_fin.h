@@ -533,48 +533,23 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
         // ---------------- mem_mark_primary_se (salt = this read's lrand48() draw)
         if (n > 0) {
             const uint64_t id = dev_lrand48_nth(ck.rng_state, ck.first_ordinal + (uint64_t)r + 1);
-            if (R.ann_alt) {
-                // ALT-aware index: the two-round marking of bwa, serial (one lane of the wave when the lists are staged -- the handles and
-                // regions it reads were last written by other lanes)
-                if (staged) {
-                    __threadfence_block(); __syncthreads();
-                    if (ss->lane == 0) dev_mark_primary_alt(R, opt, w, n, id);
-                    __threadfence_block(); __syncthreads();
-                } else dev_mark_primary_alt(R, opt, w, n, id);
-            } else {
-            if (staged) {
-                for (int i = ss->lane; i < n; i += 64) { DReg &p = G[a[i]]; p.sub = 0; p.secondary = -1; p.hash = dev_hash_64(id + (uint64_t)i); }
-                __threadfence_block();
-            } else for (int i = 0; i < n; ++i) {
-                DReg &p = G[a[i]];
-                p.sub = 0; p.secondary = -1;
-                p.hash = dev_hash_64(id + (uint64_t)i);
-            }
-            sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
-                         [&](int x, int y) {
-                             const int sx = ss->ka[x], sy = ss->ka[y];
-                             return sx > sy || (sx == sy && (uint64_t)ss->k64[x] < (uint64_t)ss->k64[y]);
-                         },
-                         [&](int x, int y) {
-                             const DReg &X = G[x], &Y = G[y];
-                             return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // (no ALT contig in this index: is_alt is 0 for every region)
-                         });
             int tmp = opt.a + opt.b;
             tmp = opt.o_del + opt.e_del > tmp ? opt.o_del + opt.e_del : tmp;
             tmp = opt.o_ins + opt.e_ins > tmp ? opt.o_ins + opt.e_ins : tmp;
-            if (staged) {
-                // The scan over the primaries found so far (z) is the serial part: for a many-region read it is a few hundred entries
-                // long.  Region fields come from LDS (kb = qb, m_qe = qe, ka = score, by handle), 64 primaries are tested per step and a
-                // ballot finds the first that overlaps, as the scalar loop would; sub / sub_n / secondary are kept in LDS (m_rid, m_w and
-                // the two halves of k64, free after the last sort) and written back once.
+            // mem_mark_primary_se_core over ss->idx[0..m) on the wave.  The scan over the primaries found so far (z) is the serial
+            // part: for a many-region read it is a few hundred entries long.  Region fields come from LDS (kb = qb, m_qe = qe, ka = score,
+            // by handle; l_alt = is_alt by handle on an ALT-aware index), 64 primaries are tested per step and a ballot finds the first
+            // that overlaps, as the scalar loop would; sub / sub_n / secondary are kept in LDS (m_rid, m_w and the two halves of k64, free
+            // after a sort) and written back once.
+            auto core_staged = [&](int m, const int *l_alt) {
                 const int lane = ss->lane;
                 int *l_sub = ss->m_rid, *l_subn = ss->m_w, *l_sec = (int *)ss->k64, *l_z = (int *)ss->k64 + ss->nmax;
                 __syncthreads();
-                for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; l_sub[h] = 0; l_subn[h] = G[h].sub_n; l_sec[h] = -1; }
+                for (int i = lane; i < m; i += 64) { const int h = ss->idx[i]; l_sub[h] = 0; l_subn[h] = G[h].sub_n; l_sec[h] = -1; }
                 if (lane == 0) l_z[0] = 0;
                 __syncthreads();
                 int nz = 1;
-                for (int i = 1; i < n; ++i) {
+                for (int i = 1; i < m; ++i) {
                     const int hi = ss->idx[i];
                     const int i_qb = ss->kb[hi], i_qe = ss->m_qe[hi], i_sc = ss->ka[hi];
                     int found = -1;
@@ -599,16 +574,98 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                             const int zi = l_z[found];
                             const int hj = ss->idx[zi];
                             if (l_sub[hj] == 0) l_sub[hj] = i_sc;
-                            if (ss->ka[hj] - i_sc <= tmp) ++l_subn[hj];
+                            if (ss->ka[hj] - i_sc <= tmp && (!l_alt || l_alt[hj] || !l_alt[hi])) ++l_subn[hj];
                             l_sec[hi] = zi;
                         }
                     } else { if (lane == 0) l_z[nz] = i; ++nz; }
                     __syncthreads();
                 }
-                for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; DReg &p = G[h]; p.sub = l_sub[h]; p.sub_n = l_subn[h]; p.secondary = l_sec[h]; }
+                for (int i = lane; i < m; i += 64) { const int h = ss->idx[i]; DReg &p = G[h]; p.sub = l_sub[h]; p.sub_n = l_subn[h]; p.secondary = l_sec[h]; }
                 __threadfence_block();
                 __syncthreads();
+            };
+            if (R.ann_alt && staged) {
+                // ALT-aware index, many regions: bwa's two-round marking (dev_mark_primary_alt has the serial statement) with the sorts
+                // and both rounds of the core on the wave.  l_alt / l_par (is_alt and the first round's parent, by handle) live in the
+                // two halves of m_rb, which nothing reads after the de-duplication.
+                const int lane = ss->lane;
+                int *l_alt = (int *)ss->m_rb, *l_par = (int *)ss->m_rb + ss->nmax, *par = (int *)w.srt;
+                __syncthreads();
+                int n_pri = 0;
+                for (int base = 0; base < n; base += 64) {
+                    const int i = base + lane;
+                    bool pri = false;
+                    if (i < n) {
+                        const int h = a[i];
+                        DReg &p = G[h];
+                        p.sub = 0; p.secondary = -1; p.hash = dev_hash_64(id + (uint64_t)i);
+                        const int al = ref_is_alt(R, p.rid);
+                        l_alt[h] = al;
+                        pri = !al;
+                    }
+                    n_pri += (int)__popcll(__ballot(pri));
+                }
+                __threadfence_block();
+                sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
+                             [&](int x, int y) {
+                                 const int sx = ss->ka[x], sy = ss->ka[y];
+                                 if (sx != sy) return sx > sy;
+                                 const int ax = l_alt[x], ay = l_alt[y];
+                                 return ax < ay || (ax == ay && (uint64_t)ss->k64[x] < (uint64_t)ss->k64[y]);
+                             },
+                             [&](int x, int y) { return false; });
+                core_staged(n, l_alt);
+                if (n_pri < n) {
+                    for (int i = lane; i < n; i += 64) { const int h = ss->idx[i], sidx = G[h].secondary; l_par[h] = sidx >= 0 ? ss->idx[sidx] : -1; }
+                    __syncthreads();
+                    if (n_pri > 0)
+                        sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
+                                     [&](int x, int y) {
+                                         const int ax = l_alt[x], ay = l_alt[y];
+                                         if (ax != ay) return ax < ay;
+                                         const int sx = ss->ka[x], sy = ss->ka[y];
+                                         return sx > sy || (sx == sy && (uint64_t)ss->k64[x] < (uint64_t)ss->k64[y]);
+                                     },
+                                     [&](int x, int y) { return false; });
+                    int *l_rank = (int *)ss->k64;                     // handle -> rank in the final order (the hashes are done with)
+                    __syncthreads();
+                    for (int i = lane; i < n; i += 64) l_rank[ss->idx[i]] = i;
+                    __syncthreads();
+                    for (int i = lane; i < n; i += 64) {
+                        const int h = ss->idx[i], ph = l_par[h];
+                        if (ph >= 0) { par[h] = l_rank[ph]; if (l_alt[h]) G[h].secondary = 0x7fffffff; }
+                        else par[h] = -1;
+                    }
+                    if (n_pri > 0) {
+                        __threadfence_block();
+                        core_staged(n_pri, l_alt);                    // (resets sub / secondary of the primary-assembly hits, carries sub_n)
+                    }
+                } else
+                    for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; par[h] = G[h].secondary; }
+                __threadfence_block();
+                __syncthreads();
+            } else if (R.ann_alt) {
+                dev_mark_primary_alt(R, opt, w, n, id);              // one region list per lane: the serial statement
             } else {
+            if (staged) {
+                for (int i = ss->lane; i < n; i += 64) { DReg &p = G[a[i]]; p.sub = 0; p.secondary = -1; p.hash = dev_hash_64(id + (uint64_t)i); }
+                __threadfence_block();
+            } else for (int i = 0; i < n; ++i) {
+                DReg &p = G[a[i]];
+                p.sub = 0; p.secondary = -1;
+                p.hash = dev_hash_64(id + (uint64_t)i);
+            }
+            sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
+                         [&](int x, int y) {
+                             const int sx = ss->ka[x], sy = ss->ka[y];
+                             return sx > sy || (sx == sy && (uint64_t)ss->k64[x] < (uint64_t)ss->k64[y]);
+                         },
+                         [&](int x, int y) {
+                             const DReg &X = G[x], &Y = G[y];
+                             return X.score > Y.score || (X.score == Y.score && X.hash < Y.hash);   // (no ALT contig in this index: is_alt is 0 for every region)
+                         });
+            if (staged) core_staged(n, nullptr);
+            else {
             int *z = w.ib, nz = 0;
             z[nz++] = 0;
             for (int i = 1; i < n; ++i) {

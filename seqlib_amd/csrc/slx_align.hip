@@ -8,7 +8,9 @@
 // fails with SLX_ENODEVICE.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <chrono>
 #include <cmath>
+#include <functional>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +129,7 @@ struct slx_aligner {
     // replicated on each), a batch sharded over them by contiguous read-ordinal ranges; nothing below is used then
     std::vector<slx_aligner *> subs;
     bool is_group = false;
+    int64_t merge_us = 0, call_us = 0;   // group: wall time of the last batch's copy-out phase / of the whole call (counters "group_merge_us", "group_call_us")
     int device = 0;
     hipStream_t stream = nullptr;
     // index in HBM
@@ -746,6 +749,8 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
 {   // what the last batch held (diagnostics and tests: "did that kernel see any work?"); -1 for an unknown key
     if (!al || !key) return -1;
     if (!strcmp(key, "workers")) return al->is_group ? al->subs[0]->n_workers : al->n_workers;     // (per device)
+    if (!strcmp(key, "group_merge_us")) return al->merge_us;
+    if (!strcmp(key, "group_call_us")) return al->call_us;
     static const char *const names[4] = {"heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads"};
     for (int i = 0; i < 4; ++i)
         if (!strcmp(key, names[i])) {
@@ -1710,13 +1715,19 @@ static void view_packed(slx_hits *out, uint8_t *blk, int64_t N, int64_t H, int64
     }
 }
 
+static int align_host_locked(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads, uint64_t rng_state,
+                             uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *dv);
+
 // A group handle (n_dev > 1): the batch is cut into contiguous read-ordinal ranges, one per device (read i keeps lrand48
-// draw first_ordinal + i wherever it runs), every device's aligner takes its range through the ordinary host entry on its own host
-// thread, and the per-device results are merged on the host into one packed block -- no data-path traffic between the GPUs.
+// draw first_ordinal + i wherever it runs).  Every device's aligner takes its range on its own host thread and leaves its result in
+// its own HBM; once the totals are known the merged host block is sized, every device shifts its two offset arrays by its hit /
+// cigar base in place and copies each of its arrays straight to its place in the block -- no host-side merge pass and no data-path
+// traffic between the GPUs.  grp->merge_ms: wall time of that second phase (test hook "group_merge_us").
 static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads, uint64_t rng_state,
                              uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
 {
     std::lock_guard<std::mutex> call(grp->call_mu);
+    const auto t_call = std::chrono::steady_clock::now();
     const int G = (int)grp->subs.size();
     std::vector<int64_t> lo((size_t)G + 1);
     for (int g = 0; g <= G; ++g) lo[(size_t)g] = n_reads * g / G;
@@ -1724,21 +1735,30 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
     std::vector<int> rcs((size_t)G, SLX_OK);
     std::vector<std::string> errs((size_t)G);
     for (auto &h : part) memset(&h, 0, sizeof h);
-    {
+    // one handle may be listed several times (a 1-GPU box standing in for several): each copy is its own aligner with its own
+    // buffers, so the per-device results stay valid until the copy-out below
+    auto on_all = [&](const std::function<int(int)> &fn) {
         std::vector<std::thread> th;
         for (int g = 0; g < G; ++g)
             th.emplace_back([&, g]() {
-                const int64_t a = lo[(size_t)g], b = lo[(size_t)g + 1];
-                if (b == a) return;
-                rcs[(size_t)g] = slx_align_batch(grp->subs[(size_t)g], opt, bases, offs + a, b - a, rng_state, first_ordinal + (uint64_t)a, hardclip, keepSecFrac,
-                                                 maxSecondary, &part[(size_t)g]);
+                if (lo[(size_t)g + 1] == lo[(size_t)g]) return;
+                slx_aligner *sub = grp->subs[(size_t)g];
+                std::lock_guard<std::mutex> lk(sub->call_mu);
+                rcs[(size_t)g] = fn(g);
                 if (rcs[(size_t)g] != SLX_OK) errs[(size_t)g] = slx_last_error();
             });
         for (auto &t : th) t.join();
-    }
-    auto drop_parts = [&]() { for (auto &h : part) slx_hits_free(&h); };
-    for (int g = 0; g < G; ++g)
-        if (rcs[(size_t)g] != SLX_OK) { slx_set_error("device %d: %s", grp->subs[(size_t)g]->device, errs[(size_t)g].c_str()); drop_parts(); return rcs[(size_t)g]; }
+        for (int g = 0; g < G; ++g)
+            if (rcs[(size_t)g] != SLX_OK) { slx_set_error("device %d: %s", grp->subs[(size_t)g]->device, errs[(size_t)g].c_str()); return rcs[(size_t)g]; }
+        return (int)SLX_OK;
+    };
+    int rc = on_all([&](int g) {
+        const int64_t a = lo[(size_t)g], b = lo[(size_t)g + 1];
+        return align_host_locked(grp->subs[(size_t)g], opt, bases, offs + a, b - a, rng_state, first_ordinal + (uint64_t)a, hardclip, keepSecFrac, maxSecondary,
+                                 &part[(size_t)g]);
+    });
+    if (rc != SLX_OK) return rc;
+    const auto t_merge = std::chrono::steady_clock::now();
     int64_t H = 0, C = 0;
     for (const auto &h : part) { H += h.n_hits; C += h.n_cigar; }
     const bool sam = (opt->flag & SLX_F_REG2SAM) != 0;
@@ -1748,45 +1768,44 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
     if (bytes >= (1u << 20)) blk = pin_acquire(bytes, &blk_cap);
     const bool is_pinned = blk != nullptr;
     if (!blk) blk = malloc(bytes);
-    if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); drop_parts(); return SLX_ENOMEM; }
+    if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); return SLX_ENOMEM; }
     int64_t hdr[4] = {n_reads, H, C, sam ? 1 : 0};
     memcpy(blk, hdr, 32);
     out->n_reads = n_reads; out->n_hits = H; out->n_cigar = C; out->on_device = 0;
     out->block = blk; out->block_pinned = is_pinned ? 1 : 0; out->block_bytes = is_pinned ? blk_cap : bytes;
     view_packed(out, (uint8_t *)blk, n_reads, H, C, sam);
-    {   // every device's slice lands at its hit / cigar base (one host thread per slice)
-        std::vector<int64_t> hb((size_t)G + 1, 0), cb((size_t)G + 1, 0);
-        for (int g = 0; g < G; ++g) { hb[(size_t)g + 1] = hb[(size_t)g] + part[(size_t)g].n_hits; cb[(size_t)g + 1] = cb[(size_t)g] + part[(size_t)g].n_cigar; }
-        std::vector<std::thread> th;
-        for (int g = 0; g < G; ++g)
-            th.emplace_back([&, g]() {
-                const slx_hits &p = part[(size_t)g];
-                const int64_t np = lo[(size_t)g + 1] - lo[(size_t)g], h = p.n_hits, c = p.n_cigar, h0 = hb[(size_t)g], c0 = cb[(size_t)g];
-                for (int64_t i = 0; i < np; ++i) out->hit_off[lo[(size_t)g] + i] = p.hit_off[i] + h0;
-                for (int64_t i = 0; i < h; ++i) out->cig_off[h0 + i] = p.cig_off[i] + c0;
-                if (h) {
-                    memcpy(out->rid + h0, p.rid, (size_t)h * 4); memcpy(out->pos + h0, p.pos, (size_t)h * 8); memcpy(out->flag + h0, p.flag, (size_t)h * 2);
-                    memcpy(out->mapq + h0, p.mapq, (size_t)h); memcpy(out->score + h0, p.score, (size_t)h * 4); memcpy(out->nm + h0, p.nm, (size_t)h * 4);
-                    memcpy(out->na + h0, p.na, (size_t)h * 4); memcpy(out->n_cigar_ops + h0, p.n_cigar_ops, (size_t)h * 4);
-                    if (sam && p.xa_parent) { memcpy(out->xa_parent + h0, p.xa_parent, (size_t)h * 4); memcpy(out->sub + h0, p.sub, (size_t)h * 4); }
-                }
-                if (c) memcpy(out->cigar + c0, p.cigar, (size_t)c * 4);
-            });
-        for (auto &t : th) t.join();
-        out->hit_off[n_reads] = H;
-        out->cig_off[H] = C;
-    }
-    drop_parts();
+    std::vector<int64_t> hb((size_t)G + 1, 0), cb((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) { hb[(size_t)g + 1] = hb[(size_t)g] + part[(size_t)g].n_hits; cb[(size_t)g + 1] = cb[(size_t)g] + part[(size_t)g].n_cigar; }
+    rc = on_all([&](int g) {
+        slx_aligner *sub = grp->subs[(size_t)g];
+        const slx_hits &p = part[(size_t)g];
+        const int64_t np = lo[(size_t)g + 1] - lo[(size_t)g], h = p.n_hits, c = p.n_cigar, h0 = hb[(size_t)g], c0 = cb[(size_t)g];
+        hipStream_t st = sub->stream;
+        HIPCHK(hipSetDevice(sub->device));
+        if (h0) hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, p.hit_off, p.hit_off, np, h0);
+        if (c0 && h) hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, st, p.cig_off, p.cig_off, h, c0);
+        HIPCHK(hipGetLastError());
+#define OUT(field, cnt, base) if ((cnt) > 0) HIPCHK(hipMemcpyAsync(out->field + (base), p.field, (size_t)(cnt) * sizeof *p.field, hipMemcpyDeviceToHost, st))
+        OUT(hit_off, np, lo[(size_t)g]); OUT(cig_off, h, h0); OUT(rid, h, h0); OUT(pos, h, h0); OUT(flag, h, h0); OUT(mapq, h, h0); OUT(score, h, h0);
+        OUT(nm, h, h0); OUT(na, h, h0); OUT(n_cigar_ops, h, h0); OUT(cigar, c, c0);
+        if (sam && p.xa_parent) { OUT(xa_parent, h, h0); OUT(sub, h, h0); }
+#undef OUT
+        HIPCHK(hipStreamSynchronize(st));
+        return (int)SLX_OK;
+    });
+    if (rc != SLX_OK) { slx_hits_free(out); return rc; }
+    out->hit_off[n_reads] = H;
+    out->cig_off[H] = C;
+    const auto t_end = std::chrono::steady_clock::now();
+    grp->merge_us = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_merge).count();
+    grp->call_us = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_call).count();
     return SLX_OK;
 }
 
-extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
-                               uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
+// host reads -> this device's result, left in HBM (*dv; valid until the aligner's next call); the caller holds al->call_mu
+static int align_host_locked(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads, uint64_t rng_state,
+                             uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *dv)
 {
-    if (!al || !opt || !out || n_reads < 0 || (n_reads > 0 && (!bases || !offs))) { slx_set_error("slx_align_batch: bad argument"); return SLX_EINVAL; }
-    memset(out, 0, sizeof *out);
-    if (al->is_group) return group_align_batch(al, opt, bases, offs, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, out);
-    std::lock_guard<std::mutex> call(al->call_mu);
     HIPCHK(hipSetDevice(al->device));
     if (n_reads && offs[n_reads] < offs[0]) { slx_set_error("read offsets are not monotonic"); return SLX_EINVAL; }
     const uint64_t first = n_reads ? offs[0] : 0, total = n_reads ? offs[n_reads] - first : 0;
@@ -1798,9 +1817,19 @@ extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *
     // bases [offs[0], offs[n]) go to the start of the staging buffer (the kernels subtract the chunk's first offset anyway); every
     // worker uploads its own part on its own stream (worker_run)
     if (!n_reads) HIPCHK(hipMemcpy(al->st_offs.p, &zero, 8, hipMemcpyHostToDevice));
+    return align_device_locked(al, opt, (const uint8_t *)al->st_bases.p - first, al->st_offs.p, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, dv,
+                               bases, offs);
+}
+
+extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *bases, const uint64_t *offs, int64_t n_reads,
+                               uint64_t rng_state, uint64_t first_ordinal, int hardclip, double keepSecFrac, int maxSecondary, slx_hits *out)
+{
+    if (!al || !opt || !out || n_reads < 0 || (n_reads > 0 && (!bases || !offs))) { slx_set_error("slx_align_batch: bad argument"); return SLX_EINVAL; }
+    memset(out, 0, sizeof *out);
+    if (al->is_group) return group_align_batch(al, opt, bases, offs, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, out);
+    std::lock_guard<std::mutex> call(al->call_mu);
     slx_hits dv;
-    rc = align_device_locked(al, opt, (const uint8_t *)al->st_bases.p - first, al->st_offs.p, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, &dv,
-                             bases, offs);
+    int rc = align_host_locked(al, opt, bases, offs, n_reads, rng_state, first_ordinal, hardclip, keepSecFrac, maxSecondary, &dv);
     if (rc != SLX_OK) return rc;
     // one packed image on the device, ONE device-to-host copy, and the result's arrays are views into it
     const bool sam = dv.xa_parent != nullptr;

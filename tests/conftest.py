@@ -35,3 +35,18 @@ def sim_reads(orc):
     n1, s1 = orc.read_fastq(os.path.join(GOLDEN, "sim1_bcr.head3000.fq"))
     n2, s2 = orc.read_fastq(os.path.join(GOLDEN, "sim2_bcr.head3000.fq"))
     return (n1, s1), (n2, s2)
+
+
+@pytest.fixture(scope="session")
+def sl():
+    import seqlib_amd
+    from seqlib_amd import _ffi
+    _ffi.lib()   # raises if the HIP extension is missing: there is no fallback
+    return seqlib_amd
+
+
+@pytest.fixture(scope="session")
+def tiny_gpu(sl, golden_dir):
+    idx = sl.BWAIndex()
+    idx.LoadIndex(os.path.join(golden_dir, "tiny.fa"))
+    return idx

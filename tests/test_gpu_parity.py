@@ -26,21 +26,6 @@ def assert_same(got, exp, what=""):
             raise AssertionError("%s: field %s differs" % (what, k))
 
 
-@pytest.fixture(scope="module")
-def sl():
-    import seqlib_amd
-    from seqlib_amd import _ffi
-    _ffi.lib()   # raises if the HIP extension is missing: there is no fallback
-    return seqlib_amd
-
-
-@pytest.fixture(scope="module")
-def tiny_gpu(sl, golden_dir):
-    idx = sl.BWAIndex()
-    idx.LoadIndex(os.path.join(golden_dir, "tiny.fa"))
-    return idx
-
-
 def test_fixture_reads_match_oracle_and_golden(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
     (_, s1), (_, s2) = sim_reads
     for seqs, fn in ((s1, "sim1_head3000.records.tsv"), (s2, "sim2_head3000.records.tsv")):
@@ -591,6 +576,55 @@ def test_alt_contigs_match_oracle(sl, orc, tmp_path):
     idx2 = sl.BWAIndex()
     idx2.LoadIndex(prefix)
     assert_same(sl.BWAAligner(idx2).alignSequences(reads), plain, "same files, no .alt")
+
+
+def test_alt_many_region_reads(sl, orc, tmp_path):
+    """reads of a repeat family whose ~250 copies sit on the primary assembly AND on ALT contigs: 30-170 regions survive per read, so the
+    wave-per-read region kernel runs bwa's two-round ALT marking (first round over all hits, re-sort with the primary-assembly hits
+    first, second round among them) on the wave -- bit-exact vs the oracle, record mode included"""
+    from seqlib_amd import synth
+    rng = np.random.default_rng(91)
+    E = rng.integers(0, 4, size=320, dtype=np.uint8)
+
+    def copy(rate):
+        e = E.copy()
+        m = rng.random(len(e)) < rate
+        e[m] = (e[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+        return e
+
+    def contig(length, n_copies, seed):
+        g = synth.make_genome(length, seed=seed).copy()
+        for p in np.sort(rng.choice(np.arange(1000, length - 1000, 700), size=n_copies, replace=False)):
+            g[p:p + 320] = copy(rng.uniform(0.004, 0.03))
+        return g
+
+    refs = [("chrP", contig(200000, 110, 801)), ("chrQ", contig(90000, 60, 802)), ("alt_a", contig(40000, 45, 803)), ("alt_b", contig(30000, 35, 804))]
+    prefix = str(tmp_path / "altm")
+    orc.Index.build([n for n, _ in refs], [synth.genome_ascii(g) for _, g in refs]).write(prefix)
+    open(prefix + ".alt", "w").write("alt_a\nalt_b\n")
+    oidx = orc.Index.load(prefix)
+    reads = []
+    for _ in range(120):
+        e = copy(rng.uniform(0.0, 0.03))
+        lo = int(rng.integers(0, 170))
+        reads.append(synth.genome_ascii(e[lo:lo + 150]))
+    for gi, (_, g) in enumerate(refs):                                  # and ordinary reads around them
+        blk, _, _ = synth.make_reads_block(g, gi, 300, 150, 5151)
+        reads += [bytes(r).decode() for r in blk]
+    exp = orc.align_batch(orc.default_opt(), oidx, reads, keep_sec_frac=0.0, max_secondary=1 << 20)
+    na = np.array([exp["na"][exp["hit_off"][i]] if exp["hit_off"][i + 1] > exp["hit_off"][i] else 0 for i in range(len(reads))])
+    assert (na >= 64).sum() >= 30 and na.max() >= 128
+    alt_hits = np.isin(exp["rid"], (2, 3))
+    assert alt_hits.sum() > 1000 and (~alt_hits).sum() > 1000
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+    for knobs in ((), (("regs_big", 2),), (("regs_big", 1 << 20),), (("split_min", 16), ("heavy_seeds", 8))):
+        al = sl.BWAAligner(idx)
+        for k, v in knobs:
+            al.set(k, v)
+        assert_same(al.alignSequences(reads, keepSecFrac=0.0, maxSecondary=1 << 20), exp, "many-region ALT reads %s" % (knobs,))
+    _check_sam_mode(sl, orc, idx, oidx, reads[:160], "many-region ALT reads, record mode")
+    _check_sam_mode(sl, orc, idx, oidx, reads[:160], "many-region ALT reads, record mode, lane kernel only", knobs=(("regs_big", 1 << 20),))
 
 
 def _sam_entries(res, i):
