@@ -406,6 +406,12 @@ def main():
     if cache and os.path.exists(cache) and os.path.getsize(cache) == n * read_len:
         reads = np.fromfile(cache, dtype=np.uint8).reshape(n, read_len)
     else:
+        # a profiler's preloaded library has initialised the GPU before main(): forking the block generators from here is exactly what the
+        # cache exists to avoid -- refuse instead of quietly regenerating
+        under_profiler = any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if cache and under_profiler:
+            raise SystemExit("bench.py: SLX_BENCH_READS_CACHE=%s is missing or has the wrong size and this process runs under a profiler; fill the "
+                             "cache with an un-profiled run of the same command first" % cache)
         reads = gen_reads(cfg, refs, n, first_block=rank * blocks_per_rank, share=world)
         if cache:
             np.ascontiguousarray(reads).tofile(cache)

@@ -11,6 +11,7 @@ BENCH="python3 $R/bench.py --config $CFG --no-cpu-baseline --no-extras --verify 
 # tool has initialised the GPU before main(), and a process in that state must not fork
 export SLX_BENCH_READS_CACHE=/tmp/slx_reads_cache
 timeout -s KILL 600 $BENCH > $OUT/bench_unprofiled.log 2>&1
+if [ $? -ne 0 ] || ! ls ${SLX_BENCH_READS_CACHE}.$CFG.* > /dev/null 2>&1; then echo "profile_round.sh: the un-profiled fill run failed"; tail -5 $OUT/bench_unprofiled.log; exit 1; fi
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv

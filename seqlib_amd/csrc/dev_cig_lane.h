@@ -14,9 +14,7 @@
 #include "dev_seed4.h"
 #include "dev_fin2.h"
 
-#define LANE_NEG (-16000)
-#define LANE_FIN_LIMIT 8000       // (lq + rlen) x the largest penalty + the gap opens must stay below this (host check)
-#define LANE_CIG_MAXQ 158         // ... and a query of at most this many bases
+// LANE_NEG, LANE_FIN_LIMIT, LANE_CIG_MAXQ, LANE_CIG_MAXT: dev_fin2.h, next to the routing that enforces them
 #define LANE_CIG_SLOTS (LANE_CIG_BAND + 1)   // LDS words per lane: the band (2 w + 2 columns; LANE_CIG_BAND = 2 w + 1 is defined in dev_fin2.h, where the jobs are routed)
 
 typedef uint32_t __attribute__((aligned(1))) z32u;

@@ -16,6 +16,15 @@
 #ifndef LANE_CIG_BAND
 #define LANE_CIG_BAND 33          // CIGAR jobs whose first band has at most this many columns (w <= 16) run one lane per job (dev_cig_lane.h)
 #endif
+// The lane kernel's cells are 16 bits wide: the routing here (dev_reg_emit), the host guard on the scores (slx_align.hip, launch_tail) and
+// the kernel (dev_cig_lane.h) must agree on the largest job, so the limits live in one place.
+#define LANE_CIG_MAXQ 158         // query bases of a lane job, at most
+#define LANE_CIG_MAXT 400         // target bases of a lane job, at most
+#define LANE_NEG (-16000)         // floor of a cell
+#define LANE_FIN_LIMIT 8000       // (lq + rlen) x the largest penalty + the gap opens must stay below this (host check), ...
+// ... and so must the largest match score x LANE_CIG_MAXQ (same check): an unreachable cell (the floor + at most a read's worth of match
+// scores) then stays below every reachable one (above -LANE_FIN_LIMIT), and both fit 16 bits
+static_assert(LANE_NEG + LANE_FIN_LIMIT <= -LANE_FIN_LIMIT && LANE_NEG >= -32768 && LANE_FIN_LIMIT <= 32767, "16-bit cells of k_cig_lanes");
 struct alignas(8) DJob {      // one pending bwa_gen_cigar2 sequence (mem_reg2aln's do/while)
     int64_t rb, re;
     int qb, qe;
@@ -269,7 +278,7 @@ __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt
     const bool fast = (qe - qb) == (int)(re - rb) && wc == 0;
     if (leader) {
         bool lanes = false;
-        if (!fast && fl.lane_list && qe - qb <= 158) {        // (LANE_CIG_MAXQ) the band bwa_gen_cigar2 starts with: at most LANE_CIG_BAND columns?
+        if (!fast && fl.lane_list && qe - qb <= LANE_CIG_MAXQ) {        // the band bwa_gen_cigar2 starts with: at most LANE_CIG_BAND columns?
             const int lq = qe - qb, rlen = (int)(re - rb);
             const int max_ins = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
             const int max_del = (int)((double)(((lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
@@ -279,7 +288,7 @@ __device__ __forceinline__ bool dev_reg_emit(const Chunk &ck, const slx_opt &opt
             int ww = (max_gap + dl + 1) >> 1;
             ww = ww < wc ? ww : wc;
             ww = ww > dl + 3 ? ww : dl + 3;
-            lanes = 2 * ww + 1 <= LANE_CIG_BAND && lq > 0 && rlen > 0 && rlen <= 400;
+            lanes = 2 * ww + 1 <= LANE_CIG_BAND && lq > 0 && rlen > 0 && rlen <= LANE_CIG_MAXT;
         }
         if (fast) fl.fast_list[wave_fetch_inc(fl.n_fast)] = (uint32_t)slot;
         else if (lanes) fl.lane_list[wave_fetch_inc(fl.n_lane)] = (uint32_t)slot;
@@ -723,7 +732,11 @@ __global__ void __launch_bounds__(128) k_hits_sam(DevRef R, Chunk ck, DevOpt dop
         const int *a = w.ia;
         const DReg *G = w.regs;
         int *hh = w.ic, *cnt = w.ib;               // output order; per region: XA alternatives it is the primary of (bit 30: one of them is ALT)
-        int *rec_of = (int *)w.srt + w.cap;        // per region: its ordinal among the records, or -1 (the lower half of srt holds secondary_all on an ALT index)
+        // srt[] (8 bytes per slot of the read: 2 * cap ints) has two tenants after the extension stage, its only other user (the seed order
+        // of a chain, dev_ext.h / dev_ext_reg.h): the lower half holds secondary_all by region handle, written by the region kernels on an
+        // ALT-aware index (dev_fin.h) and read here; the upper half is this kernel's rec_of.  The CIGAR kernels and the staged sorts between
+        // the two do not touch it (the sorts stage in LDS).
+        int *rec_of = (int *)w.srt + w.cap;        // per region: its ordinal among the records, or -1
         const int *sec_all = (const int *)w.srt;
         auto pri_of = [&](int i) {                 // get_pri_idx: the region this one would be an XA alternative of
             const int k = R.ann_alt ? sec_all[a[i]] : G[a[i]].secondary;

@@ -406,7 +406,7 @@ static int upload_fm(slx_aligner *al)
 }
 
 // the repeat filter of pass 2 of the seeding kernels: one bit per hashed rep_k-mer that occurs at least twice (8-16 bits per text symbol:
-// 128 MB for a 129 M-symbol index, 8 GB for GRCh38's 6.2 G)
+// 128 MB of HBM for a 129 M-symbol index, 8 GB for GRCh38's 6.2 G -- per aligner; knob "rep_k" = 0 turns it off)
 template <typename I>
 static int build_rep_filter(slx_aligner *al)
 {
@@ -414,8 +414,14 @@ static int build_rep_filter(slx_aligner *al)
     if (al->rep_k <= 0 || al->rep_k > 31 || !al->have_dense || al->host_idx->seq_len < 1024) return SLX_OK;
     uint64_t bits = 1ull << 20;
     while (bits < al->host_idx->seq_len * 8ull) bits <<= 1;
-    int rc;
-    if ((rc = al->d_rep.ensure(bits / 8)) != SLX_OK) return rc;
+    // The filter is an optimisation only (a false positive costs one pass-2 call that finds nothing new), and its bitset is the one
+    // large per-aligner allocation next to the index: when HBM is short -- several aligners on one device, a group listing a device
+    // twice -- take half the bits, down to one per symbol, and below that run without it rather than fail the aligner.
+    while (al->d_rep.ensure(bits / 8) != SLX_OK) {
+        (void)hipGetLastError();
+        bits >>= 1;
+        if (bits < al->host_idx->seq_len || bits < (1ull << 20)) { al->d_rep.release(); return SLX_OK; }
+    }
     HIPCHK(hipMemsetAsync(al->d_rep.p, 0, bits / 8, al->stream));
     DevFM<I> fm = fm_of<I>(al);
     fm.sa_dense = al->d_sa_dense.as<I>();
@@ -859,7 +865,7 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     {
         int pen = std::max(std::max(dopt.o.e_del, dopt.o.e_ins), 1), amax = 0;
         for (int i = 0; i < 25; ++i) { pen = std::max(pen, -(int)dopt.o.mat[i]); amax = std::max(amax, (int)dopt.o.mat[i]); }
-        if ((int64_t)(LANE_CIG_MAXQ + 400) * pen + dopt.o.o_del + dopt.o.o_ins >= LANE_FIN_LIMIT || (int64_t)amax * LANE_CIG_MAXQ >= LANE_FIN_LIMIT ||
+        if ((int64_t)(LANE_CIG_MAXQ + LANE_CIG_MAXT) * pen + dopt.o.o_del + dopt.o.o_ins >= LANE_FIN_LIMIT || (int64_t)amax * LANE_CIG_MAXQ >= LANE_FIN_LIMIT ||
             dopt.o.o_del < 0 || dopt.o.o_ins < 0 || dopt.o.e_del < 1 || dopt.o.e_ins < 1) cig_lanes = false;
     }
     fl.lane_list = cig_lanes ? wk->cig_lane_list.as<uint32_t>() : nullptr; fl.n_lane = q + 42;

@@ -682,6 +682,8 @@ def test_bwa_mem_record_mode(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_di
     aidx = sl.BWAIndex()
     aidx.LoadIndex(prefix)
     n_multi, n_xa = _check_sam_mode(sl, orc, aidx, orc.Index.load(prefix), areads[::3], "ALT index")
+    # secondary_all travels from the region kernels to the record kernel in the read's srt[] scratch: every region kernel must leave it there
+    _check_sam_mode(sl, orc, aidx, orc.Index.load(prefix), areads[1::7], "ALT index, wave region kernel + split schedule", knobs=(("regs_big", 2), ("split_min", 16), ("heavy_seeds", 3)))
     assert n_xa >= 10                                  # reads on the stretches the ALT contigs copy carry XA alternatives
 
 
