@@ -348,6 +348,7 @@ def main_c5(args):
             "step_split_ms": {"assemble (slx_fml_assemble_staged + contig strings)": split["assemble_s"] / max(args.steps, 1) * 1e3,
                               "realign (BWAAligner.alignSequences of the contigs)": split["realign_s"] / max(args.steps, 1) * 1e3,
                               "realign_stage_ms": {k: v / max(args.steps, 1) for k, v in split["realign_stage_ms"].items()}},
+            "realign_extension_rounds": {"rounds": al.counter("long_rounds"), "seed_jobs": al.counter("long_jobs")},
             "contigs_per_s_realign": len(fit) * args.steps / split["realign_s"] if split["realign_s"] > 0 else None,
             "contig_bit_match_rate": match, "verified_reads": min(args.verify, per_win) if args.verify > 0 else 0,
             "probe_ms_per_step": {k: v / steps for k, v in acc.items()},

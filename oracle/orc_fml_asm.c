@@ -21,7 +21,7 @@
  *   nsr, cov    strings merged into the unitig; per base the number of them covering it (33 + count, capped at 126).
  *
  * This file derives vertices and overlaps from a sorted array of all suffixes by binary search -- a different derivation from the
- * product's (a join of 32-mer seeds on the GPU), which is what the parity test is worth.
+ * product's (a join of 16-mer seeds on the GPU), which is what the parity test is worth.
  */
 #include <stdio.h>
 #include <stdlib.h>

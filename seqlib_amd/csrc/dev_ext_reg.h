@@ -383,7 +383,8 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
 template <int MAXQ>
 __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int *queue, const unsigned int *n_slots, int hi_prio,
                                                                    const int *first = nullptr, const unsigned int *n_first = nullptr,
-                                                                   const unsigned int *top_off = nullptr, unsigned int top_cap = 0, const DReg *top_tab = nullptr)
+                                                                   const unsigned int *top_off = nullptr, unsigned int top_cap = 0, const DReg *top_tab = nullptr,
+                                                                   ExtSpec sp = ExtSpec())
 {
     // top_tab (optional): the region of the top (longest) seed of every kept chain, extended ahead of time one wave per chain by
     // k_ext_first -- top_tab[top_off[r] + chain index] for the reads whose slots lie below top_cap.  What the extension of a seed
@@ -441,6 +442,11 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
             if (c == (unsigned int)n_chn && o + c <= top_cap) top_at = (int)o;
         }
         int n_av = 0;
+        [[maybe_unused]] int n_miss = 0;                      // rounds mode (ExtSpec): seeds whose region the memo does not hold yet
+        [[maybe_unused]] int64_t pend_diag = 0;               // lane i: diagonal (reference - query position) of the i-th of them
+        [[maybe_unused]] bool give_up = false;
+        [[maybe_unused]] const bool spec = MAXQ > 704 && sp.budget > 0;
+        [[maybe_unused]] const uint64_t slot0 = MAXQ > 704 ? rfl_u64(ck.seed_off[r]) : 0ull;
         unsigned long long t_sort = 0, t_test = 0, t_dp = 0, t_mark;
 #define DBG_T0() do { if (dbg) t_mark = __builtin_readcyclecounter(); } while (0)
 #define DBG_T1(acc) do { if (dbg) acc += __builtin_readcyclecounter() - t_mark; } while (0)
@@ -455,7 +461,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         uint32_t *const sd_ql = (uint32_t *)(hs + 28 * cap);
         int64_t *const sd_rb = (int64_t *)(hs + 32 * cap);
         int *const sd_s = w.ib;
-        for (int ci = 0; ci < n_chn; ++ci) {
+        for (int ci = 0; ci < n_chn && !give_up; ++ci) {
             const int c = __builtin_amdgcn_readfirstlane(w.ia[ci]);
             const int n = __builtin_amdgcn_readfirstlane(w.c_n[c]);
             const int *cs = w.c_w + __builtin_amdgcn_readfirstlane(w.c_first[c]);   // the chain's seeds, flattened by the chaining kernel
@@ -579,6 +585,13 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 // "has this seed been covered by an earlier region?": only whether ANY region passes the test matters, so lanes
                 // evaluate 64 regions each, four blocks of key loads in flight at a time
                 bool covered = false;
+                if constexpr (MAXQ > 704) {
+                    if (n_miss > 0) {          // a guess (this walk's result is discarded anyway): the pending seed's region will probably cover it
+                        const int64_t dd = (s_rbeg - s_qbeg) - pend_diag;
+                        const bool near = lane < (n_miss < 64 ? n_miss : 64) && dd < opt.w && -dd < opt.w;
+                        if (__ballot(near)) covered = true;
+                    }
+                }
                 for (int base = 0; base < n_av && !covered; base += 4 * WAVE) {
                     bool hit = false;
 #pragma unroll
@@ -633,6 +646,32 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 if (have_cand) a = ck.cand[cand_at + s];
                 else {
                     if (top_at >= 0 && k == n - 1) a = top_tab[top_at + ci];    // this chain's top seed: extended ahead of time (seedcov not filled in)
+                    else if constexpr (MAXQ > 704) {
+                        if (spec) {
+                            // rounds mode: the region comes from the memo, or the seed becomes a job of this round (see ExtSpec)
+                            const int mi = __builtin_amdgcn_readfirstlane(sp.memo_idx[slot0 + (uint64_t)s]);
+                            if (mi >= 0) a = sp.memo_tab[mi];                     // (every job of an earlier round has run)
+                            else {
+                                if (mi < 0) {
+                                    unsigned int j = 0;
+                                    if (lane == 0) {
+                                        j = atomicAdd(sp.n_jobs, 1u);
+                                        FirstJob fj;
+                                        fj.s_rbeg = s_rbeg; fj.rmax0 = rmax0; fj.rmax1 = rmax1; fj.q_off = q_off; fj.l_query = l_query;
+                                        fj.s_qbeg = s_qbeg; fj.s_len = s_len; fj.rid = w.c_rid[c]; fj.frac_rep = frac_rep; fj.pad = 0;
+                                        sp.memo_jobs[j] = fj;
+                                        sp.memo_idx[slot0 + (uint64_t)s] = (int)j;
+                                        sp.round_list[atomicAdd(sp.n_round, 1u)] = j;
+                                    }
+                                }
+                                if (lane == (n_miss & 63)) pend_diag = s_rbeg - s_qbeg;
+                                ++n_miss;
+                                if (k == n - 1) top_kept = true;
+                                if (n_miss >= sp.budget) { give_up = true; break; }
+                                continue;                                   // extended, region unknown: nothing joins the list
+                            }
+                        } else a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
+                    }
                     else a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
                     int cov = 0;
                     for (int i = lane; i < n; i += WAVE) {
@@ -650,6 +689,12 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = (uint32_t)a.qb << 16 | (uint32_t)a.qe; rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;
                 ++n_av;
                 DBG_T1(t_dp);
+            }
+        }
+        if constexpr (MAXQ > 704) {
+            if (n_miss > 0) {                                 // walked again next round, from the start
+                if (lane == 0) sp.todo_next[atomicAdd(sp.n_todo_next, 1u)] = r;
+                continue;
             }
         }
         ck.n_reg[r] = n_av;

@@ -61,6 +61,25 @@ struct alignas(8) FirstJob {   // one top-seed extension of a light read (k_firs
     int pad;
 };
 
+// Long reads (contigs), extension in rounds (k_extend_reg<MAXQ > 704>, slx_align.hip: launch_tail).  What extending a seed yields depends
+// on the seed and its chain only, never on the regions found before it -- only WHETHER mem_chain2aln extends it does.  So the per-read
+// walk does no dynamic programming itself: where it needs the region of a seed it takes it from the memo (memo_idx[seed slot] -> memo_tab),
+// and where the memo has none it emits a job (memo_jobs, round_list), treats the seed as extended-with-unknown-region and walks on to
+// find the other seeds it will probably need (at most `budget` per read and round; a seed close to the diagonal of a pending one is
+// taken to be covered by it).  The jobs of a round run one wave each (k_ext_first), then the reads that missed anything are walked again
+// from the start.  A walk that misses nothing has made every decision on real regions: it IS mem_chain2aln's, and only such a walk
+// writes the read's result.
+struct ExtSpec {
+    int *memo_idx = nullptr;           // per seed slot (ck.seed_off[r] + s): job index, or -1
+    FirstJob *memo_jobs = nullptr;     // job descriptors, one per emitted seed
+    const DReg *memo_tab = nullptr;    // their regions (seedcov not filled in)
+    unsigned int *n_jobs = nullptr;    // jobs emitted so far (all rounds)
+    unsigned int *round_list = nullptr, *n_round = nullptr;     // this round's jobs
+    int *todo_next = nullptr;          // reads that missed something this round
+    unsigned int *n_todo_next = nullptr;
+    int budget = 0;                    // 0: this mode is off
+};
+
 // one chunk of reads, all device pointers
 struct Chunk {
     int n_reads;

@@ -94,6 +94,8 @@ struct Worker {
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf memo_idx, memo_jobs, memo_tab, round_list, todo_a, todo_b, spec_cnt;     // long reads: extension in rounds (ExtSpec, dev_types.h)
+    int long_rounds_run = 0; unsigned int long_jobs_run = 0;                       // ... what the last long chunk took
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -119,6 +121,7 @@ struct Worker {
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
                &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
+               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -147,6 +150,8 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int cap_intv_long = 0;          // what chunks of long reads needed (kept apart from cap_intv)
+    int long_budget = 64;         // long reads (contigs): the extension stage runs in rounds (ExtSpec, dev_types.h); a walk emits at most this many
+                                  // seed jobs per read and round; 0 = the walk extends in place (one wave per read does every extension of its read)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
                                   // quadratic de-duplication scan 64 candidates at a time; 1 << 30 = off
     int coop_lim1 = 1 << 30, coop_lim2 = 1 << 30;   // test hooks: chains the two LDS tables of k_chain_coop take before giving a read up
@@ -669,6 +674,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "ext_split")) al->ext_split = (int)value;
     else if (!strcmp(key, "coop_lim1")) { if (value < 1) return SLX_EINVAL; al->coop_lim1 = (int)value; }
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
+    else if (!strcmp(key, "long_budget")) { if (value < 0 || value > 64) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
@@ -755,6 +761,13 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
 {   // what the last batch held (diagnostics and tests: "did that kernel see any work?"); -1 for an unknown key
     if (!al || !key) return -1;
     if (!strcmp(key, "workers")) return al->is_group ? al->subs[0]->n_workers : al->n_workers;     // (per device)
+    if (!strcmp(key, "long_rounds") || !strcmp(key, "long_jobs")) {       // extension rounds / seed jobs of the last long-read chunk (largest over the workers)
+        long long v = 0;
+        const bool rounds = key[5] == 'r';
+        auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v = std::max(v, rounds ? (long long)wk->long_rounds_run : (long long)wk->long_jobs_run); };
+        if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
+        return v;
+    }
     if (!strcmp(key, "group_merge_us")) return al->merge_us;
     if (!strcmp(key, "group_call_us")) return al->call_us;
     static const char *const names[4] = {"heavy_reads", "p2_calls", "p2_coop_calls", "p2_whole_reads"};
@@ -840,8 +853,52 @@ static void launch_tail(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
     const unsigned ext_smem = (MAXQ > 704 && !ck.huge_rows) ? (unsigned)(3 * ck.long_stride * 4) : 0u;
     if (ext_heavy) hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), ext_smem, st, al->ref, ck, dopt, ext_light, q + 1, ext_slots ? ext_slots : n_slots, 0,
                                       ext_heavy, n_heavy, top_off, top_cap, top_tab);
-    else hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), ext_smem, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
-                            (const unsigned int *)nullptr);
+    else {
+        bool in_rounds = false;
+        if constexpr (MAXQ > 704) {
+            // contigs: rounds of (walk every unfinished read, collecting the seeds whose regions it lacks) + (those seeds one wave each); a
+            // contig that ends in a tandem repeat needs dozens of full-length extensions that are serial only through the covered tests
+            const size_t S1 = wk->last_S1;
+            if (al->long_budget > 0 && top_tab && S1 > 0 && wk->memo_idx.ensure(S1 * 4) == SLX_OK && wk->memo_jobs.ensure(S1 * sizeof(FirstJob)) == SLX_OK &&
+                wk->memo_tab.ensure(S1 * sizeof(DReg)) == SLX_OK && wk->round_list.ensure(S1 * 4) == SLX_OK && wk->todo_a.ensure((size_t)n * 4 + 4) == SLX_OK &&
+                wk->todo_b.ensure((size_t)n * 4 + 4) == SLX_OK && wk->spec_cnt.ensure(64) == SLX_OK) {
+                in_rounds = true;
+                unsigned int *cnt = wk->spec_cnt.as<unsigned int>();          // [0] jobs so far, [1] jobs of this round, [2] reads for the next round, [3] queue, [4] reads of this round
+                (void)hipMemsetAsync(wk->memo_idx.p, 0xff, S1 * 4, st);
+                (void)hipMemsetAsync(cnt, 0, 64, st);
+                ExtSpec sp;
+                sp.memo_idx = wk->memo_idx.as<int>(); sp.memo_jobs = wk->memo_jobs.as<FirstJob>(); sp.memo_tab = wk->memo_tab.as<DReg>();
+                sp.n_jobs = cnt; sp.round_list = wk->round_list.as<unsigned int>(); sp.n_round = cnt + 1; sp.n_todo_next = cnt + 2; sp.budget = al->long_budget;
+                const int *todo = nullptr;
+                int n_todo = n, round = 0;
+                unsigned int jobs_total = 0;
+                for (;; ++round) {
+                    sp.todo_next = (round & 1 ? wk->todo_b : wk->todo_a).as<int>();
+                    (void)hipMemsetAsync(cnt + 1, 0, 12, st);
+                    const int gw = std::max(1, std::min(n_todo, g));
+                    hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(gw), dim3(64), ext_smem, st, al->ref, ck, dopt, todo, cnt + 3, round ? cnt + 4 : n_slots, 0, (const int *)nullptr,
+                                       (const unsigned int *)nullptr, top_off, top_cap, top_tab, sp);
+                    unsigned int h[3] = {0, 0, 0};
+                    if (hipMemcpyAsync(h, cnt, 12, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) break;   // (the caller's sync reports it)
+                    if (h[1]) {
+                        (void)hipMemsetAsync(cnt + 3, 0, 4, st);
+                        const unsigned first_smem = ck.huge_rows ? 0u : (unsigned)(2 * ck.long_stride * 4);
+                        const int gj = std::max(1, std::min((int)std::min<unsigned int>(h[1], 1u << 30), ck.huge_rows ? HUGE_BLOCKS : al->n_cu * 8));
+                        hipLaunchKernelGGL(k_ext_first<MAXQ>, dim3(gj), dim3(64), first_smem, st, al->ref, ck, dopt, n, top_off, top_cap, cnt + 3, wk->memo_jobs.as<FirstJob>(),
+                                           wk->memo_tab.as<DReg>(), wk->round_list.as<unsigned int>(), cnt + 1);
+                    }
+                    jobs_total = h[0];
+                    if (h[2] == 0) break;
+                    (void)hipMemcpyAsync(cnt + 4, cnt + 2, 4, hipMemcpyDeviceToDevice, st);
+                    todo = sp.todo_next; n_todo = (int)h[2];
+                }
+                wk->long_rounds_run = round + 1; wk->long_jobs_run = jobs_total;
+            }
+        }
+        if (!in_rounds)
+            hipLaunchKernelGGL(k_extend_reg<MAXQ>, dim3(g), dim3(64), ext_smem, st, al->ref, ck, dopt, (const int *)nullptr, q + 1, n_slots, 0, (const int *)nullptr,
+                               (const unsigned int *)nullptr, top_off, top_cap, top_tab);
+    }
 #ifdef EXT_STATS
     ext_stats_print(st, "extend_reg", n, nullptr);
 #endif

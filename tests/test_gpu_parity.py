@@ -267,6 +267,52 @@ def test_contig_length_reads_beyond_the_lds_row(sl, orc, tiny_gpu, tiny_index, g
     assert_same(al.alignSequences(mixed), exp, "contigs + short reads, u64 index")
 
 
+def test_contigs_that_end_in_tandem_repeats_extension_rounds(sl, orc, tmp_path):
+    """a contig whose end lies in a tandem repeat keeps seeds on dozens of shifted diagonals, and mem_chain2aln extends each of them across
+    the whole contig.  The long-read extension stage runs in rounds (walk -> the seeds whose regions are missing, one wave each -> walk
+    again): bit-exact vs the oracle for every budget per round, and equal to the in-place walk (long_budget = 0)"""
+    from seqlib_amd import synth
+    rng = np.random.default_rng(5)
+    g = synth.make_genome(90000, seed=911).copy()
+    tracts = ((30000, b"GTTAT", 40), (60000, b"AC", 90), (75000, b"GATTACA", 30))
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    for pos, unit, reps in tracts:
+        t = np.array([code[c] for c in unit * reps], dtype=np.uint8)
+        g[pos:pos + len(t)] = t
+    ref = synth.genome_ascii(g)
+    prefix = str(tmp_path / "tandem")
+    orc.Index.build(["chrT"], [ref]).write(prefix)
+    oidx = orc.Index.load(prefix)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+    seqs = []
+    for pos, unit, reps in tracts:
+        tl = len(unit) * reps
+        for L, inside in ((3000, tl // 2), (9000, tl - 7), (20000, tl // 3)):
+            seqs.append(ref[pos + inside - L:pos + inside])                        # ends inside the tract
+            seqs.append(orc_revcomp(ref[pos + tl - inside:pos + tl - inside + L]))  # starts inside it, other strand
+    s = list(ref[40000:52000])
+    for _ in range(30):
+        s[int(rng.integers(0, len(s)))] = "ACGT"[int(rng.integers(0, 4))]
+    seqs.append("".join(s))
+    exp = orc.align_batch(orc.default_opt(), oidx, seqs)
+    base = None
+    for budget in (64, 0, 1, 5):
+        al = sl.BWAAligner(idx)
+        al.set("long_budget", budget)
+        got = al.alignSequences(seqs)
+        assert_same(got, exp, "tandem-ended contigs, long_budget %d" % budget)
+        rounds, jobs = al.counter("long_rounds"), al.counter("long_jobs")
+        if budget == 64:
+            assert rounds >= 2 and jobs >= 10, (rounds, jobs)                      # the shifted-diagonal seeds were there, and ran as jobs
+            base = (rounds, jobs)
+        elif budget == 1:
+            assert rounds > base[0]                                                # one seed per read and round
+    short = [ref[100 + 151 * i:250 + 151 * i] for i in range(50)]
+    mixed = seqs[:4] + short + seqs[4:8]
+    assert_same(sl.BWAAligner(idx).alignSequences(mixed), orc.align_batch(orc.default_opt(), oidx, mixed), "tandem-ended contigs among short reads")
+
+
 def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
     """per-stage differential check (localises a mismatch): SMEM intervals after mem_collect_intv, kept chains with their seeds in
     extension order, and the region list as mem_chain2aln leaves it -- read by read against the oracle's stages, through the
