@@ -73,6 +73,161 @@ __device__ __forceinline__ int ext_tail_bound0(const slx_opt &o, int qlen, int h
 }
 __device__ __forceinline__ bool ext_tail_done(int b, int max, int gscore) { return b <= max && (b > 0 ? b : 0) < gscore; }
 
+// ---------------------------------------------------------------------------------------------- long extensions: the band in registers
+// A contig's extension runs for tens of thousands of rows inside a band of 2 w + 2 columns that slides one column per row.  Here the
+// band never leaves the registers: slot k of a 64 x CPB window holds column j = (i - w) + k of ksw_extend2's eh[] array (h, e) and its
+// query code, CPB consecutive slots per lane.  Per row: M / E / the insertion terms of all slots at once, F by a prefix maximum (within
+// the lane, then one DPP scan across the lanes), H(i, j) stored one slot up (eh[j + 1].h), and the whole window moved one slot down for
+// the next row -- two DPP moves per array -- with the column that enters at the top given its row -1 value (the insertion ramp) and
+// its query code.  Every cell of eh[] the scalar code can read is in the window: reads stay below end <= i + w + 1, writes at or below
+// end, beg never decreases, and a column that has been written stays in the window until it falls out at the bottom -- so cells that
+// leave the band and re-enter it keep their stale values exactly as in the array.  ~1 us less per row than the LDS-row form above.
+template <int CPB, typename QF, typename TF>
+__device__ ExtResult wave_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, int lane)
+{
+    constexpr int NB = WAVE * CPB;
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    auto ramp = [&](int j) { const int v = h0 - oe_ins - (j - 1) * e_ins; return j == 0 ? h0 : (v > 0 ? v : 0); };
+    int Sh[CPB], Se[CPB], Q[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) {
+        const int j = lane * CPB + c - w;
+        Sh[c] = (j >= 0 && j <= qlen) ? ramp(j) : 0;
+        Se[c] = 0;
+        Q[c] = (j >= 0 && j < qlen) ? qf(j) : 4;
+    }
+    const int tail_top = ext_tail_bound0(o, qlen, h0, amax);
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+    int tb_cur = lane < tlen ? tf(lane) : 0, tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    for (int i = 0; i < tlen; ++i) {
+        if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) break;
+        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = __builtin_amdgcn_readlane(tb_cur, __builtin_amdgcn_readfirstlane(i & (WAVE - 1)));
+        const uint32_t rowp = mr.packed[t];
+        const int row4 = mr.q4[t];
+        const int b = i - w;                                   // column of slot 0
+        // the column that enters the window for the next row, fetched now (only the last lane keeps it)
+        const int jt = b + NB;
+        int q_top = 4;
+        if (lane == WAVE - 1 && jt >= 0 && jt < qlen) q_top = qf(jt);
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1_init = 0;
+        if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+        int M[CPB], ex[CPB], run = NEG_BIG;
+        const int j0 = b + lane * CPB;
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int j = j0 + c;
+            const bool act = j >= beg && j < end;
+            const int q = Q[c];
+            const int sc = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
+            M[c] = Sh[c] ? Sh[c] + sc : 0;
+            int tins = M[c] - oe_ins; tins = tins > 0 ? tins : 0;
+            const int u = act ? tins + j * e_ins : NEG_BIG;
+            ex[c] = run;                                       // prefix maximum over this lane's earlier slots
+            run = run > u ? run : u;
+        }
+        const int incl = wave_incl_max_scan(run, lane);
+        const int left = xw_dpp<0x138, 0xf, 0xf>(NEG_BIG, incl);                 // wave_shr:1 -- prefix over the lanes to the left
+        int H[CPB], hkey = -1;
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int j = j0 + c;
+            const bool act = j >= beg && j < end;
+            const int pm = left > ex[c] ? left : ex[c];
+            const int f = j == beg ? 0 : pm - (j - 1) * e_ins;
+            const int e = Se[c];
+            int h = M[c] > e ? M[c] : e;
+            h = h > f ? h : f;
+            int tdel = M[c] - oe_del; tdel = tdel > 0 ? tdel : 0;
+            int en = e - e_del; en = en > tdel ? en : tdel;
+            H[c] = h;
+            if (act) { Se[c] = en; const int key = h << 9 | (lane * CPB + c); hkey = hkey > key ? hkey : key; }
+        }
+        // eh[j + 1].h = H(i, j) for the band's columns, eh[beg].h = h1, eh[end].e = 0 (an empty band still stores h1 into eh[end])
+        {
+            const int from_left = xw_dpp<0x138, 0xf, 0xf>(0, H[CPB - 1]);
+#pragma unroll
+            for (int c = CPB - 1; c >= 0; --c) {
+                const int j = j0 + c;
+                const int up = c > 0 ? H[c - 1] : from_left;
+                if (end > beg) {
+                    if (j > beg && j <= end) Sh[c] = up;
+                    else if (j == beg) Sh[c] = h1_init;
+                    if (j == end) Se[c] = 0;
+                } else if (j == end) { Sh[c] = h1_init; Se[c] = 0; }
+            }
+        }
+        // row maximum, ties -> the larger column (m starts at 0 and mj at -1: an empty band leaves them there)
+        const int mk = wave_max(hkey);
+        const int m = mk >= 0 ? mk >> 9 : 0;
+        const int mj = mk >= 0 ? b + (mk & 511) : -1;
+        const int jfin = end > beg ? end : beg;
+        if (jfin == qlen) {                                    // the row reached the end of the query: h1 = eh[end].h as just stored
+            int h1 = h1_init;
+            if (end > beg) {
+                int v = -1;
+#pragma unroll
+                for (int c = 0; c < CPB; ++c) if (j0 + c == end) v = Sh[c];
+                h1 = wave_max(v);
+            }
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            const int off = mj - i < 0 ? i - mj : mj - i;
+            max_off = max_off > off ? max_off : off;
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        // band for the next row: first / last column of [beg, end] whose h or e is non-zero
+        {
+            int lfirst = 0x7fffffff, llast = -1;
+            bool hole = false;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {
+                const int j = j0 + c;
+                const bool in = j >= beg && j <= end;
+                const bool nz = (Sh[c] | Se[c]) != 0;
+                if (in && nz) { if (lfirst == 0x7fffffff) lfirst = j; llast = j; }
+                hole |= in && !nz;
+            }
+            int first_nz = beg, last_nz = end;
+            if (__ballot(hole)) {
+                const unsigned long long bal = __ballot(llast >= 0);
+                first_nz = -1; last_nz = -1;
+                if (bal) {
+                    first_nz = __builtin_amdgcn_readlane(lfirst, __ffsll((long long)bal) - 1);
+                    last_nz = __builtin_amdgcn_readlane(llast, 63 - __clzll((long long)bal));
+                }
+            }
+            const int nbeg = (first_nz >= 0 && first_nz < end) ? first_nz : end;   // the first scan covers [beg, end) only
+            const int jl = last_nz >= nbeg ? last_nz : nbeg - 1;
+            beg = nbeg;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+        // the window moves one column up: every slot takes its upper neighbour's content, the top slot the entering column's
+        {
+            const int nh = xw_dpp<0x130, 0xf, 0xf>(0, Sh[0]), ne = xw_dpp<0x130, 0xf, 0xf>(0, Se[0]), nq = xw_dpp<0x130, 0xf, 0xf>(4, Q[0]);   // wave_shl:1 -- from the lane to the right
+#pragma unroll
+            for (int c = 0; c < CPB - 1; ++c) { Sh[c] = Sh[c + 1]; Se[c] = Se[c + 1]; Q[c] = Q[c + 1]; }
+            const bool top = lane == WAVE - 1;
+            Sh[CPB - 1] = top ? ((jt >= 0 && jt <= qlen) ? ramp(jt) : 0) : nh;
+            Se[CPB - 1] = top ? 0 : ne;
+            Q[CPB - 1] = top ? q_top : nq;
+        }
+    }
+    ExtResult r;
+    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    return r;
+}
+
 #define EXT_RING 1024         // LDS ring of the long-read extension row (ints per array): bands up to 2 w + 2 + 128 <= 1024 columns
 // wave-cooperative ksw_extend2; every lane returns the same result.  eh_h / eh_e are LDS rows of qlen+2 ints.
 template <int NCH, typename QF, typename TF>
@@ -99,6 +254,12 @@ __device__ ExtResult wave_ksw_extend2(int qlen, QF qf, int tlen, TF tf, const sl
     // within reach of the band -- `fresh` is the first column not yet set up, kept at least one past the band's upper end -- and by then the
     // column EXT_RING to its left has left the band for good (beg never decreases).  With the full-length row in HBM (a contig's row
     // does not fit LDS) every row paid several dependent round trips to memory: ~1.4 us per row, seconds for one contig.
+    if constexpr (NCH == 0) {          // long extensions whose band fits a register window (above); scores must fit the key of the row maximum
+        if ((long long)h0 + (long long)qlen * (max > 0 ? max : 0) < (1 << 21) && h0 >= 0 && e_ins > 0 && e_del > 0 && qlen > 2 * WAVE) {
+            if (2 * w + 2 <= 4 * WAVE) return wave_ksw_extend2_band<4>(qlen, qf, tlen, tf, o, mr, w, h0, max, lane);
+            if (2 * w + 2 <= 7 * WAVE) return wave_ksw_extend2_band<7>(qlen, qf, tlen, tf, o, mr, w, h0, max, lane);
+        }
+    }
     bool ring = false;
     int fresh = 0;
     if constexpr (NCH == 0) {

@@ -71,7 +71,30 @@ __device__ int dev_seed_sw(const DevRef &R, const slx_opt &o, const uint8_t *que
     return best;
 }
 
-// mem_flt_chained_seeds for the listed reads: one wave per read
+// mem_flt_chained_seeds for the listed reads, in two steps.  k_flt_score: the local alignment of every seed of every kept chain (the
+// flattened lists of a read are one contiguous slice of c_w), one seed per lane, FLT_PARTS blocks per read -- a contig has thousands
+// of short seeds, and on one wave per read a hundred contigs left the chip idle for 100 ms.  k_flt_seeds: the seeds below min_HSP_score
+// leave their chains (order kept), one wave per read.
+#define FLT_PARTS 64
+__global__ void __launch_bounds__(64) k_flt_score(DevRef R, Chunk ck, DevOpt dopt, const int *list, const unsigned int *n_list)
+{
+    const slx_opt &opt = dopt.o;
+    const unsigned int t = blockIdx.x / FLT_PARTS, part = blockIdx.x % FLT_PARTS;
+    if (t >= *n_list) return;
+    const int r = list[t];
+    ReadWS w = make_ws_uniform(ck, r);
+    const int n_chn = ck.n_chain[r];
+    if (n_chn <= 0) return;
+    const int c_last = w.ia[n_chn - 1];
+    const int total = w.c_first[c_last] + w.c_n[c_last];           // the kept chains' lists are laid out back to back from c_w[0]
+    const uint8_t *query = ck.codes + ck.offs[r];
+    const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
+    for (int i = (int)part * 64 + (int)threadIdx.x; i < total; i += FLT_PARTS * 64) {
+        const int s = w.c_w[i];
+        w.s_score[s] = dev_seed_sw(R, opt, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s]);
+    }
+}
+
 __global__ void __launch_bounds__(64) k_flt_seeds(DevRef R, Chunk ck, DevOpt dopt, const int *list, const unsigned int *n_list, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
@@ -84,30 +107,21 @@ __global__ void __launch_bounds__(64) k_flt_seeds(DevRef R, Chunk ck, DevOpt dop
         if (t >= n_todo) break;
         const int r = list[t];
         ReadWS w = make_ws_uniform(ck, r);
-        const uint8_t *query = ck.codes + ck.offs[r];
         const int l_query = (int)(ck.offs[r + 1] - ck.offs[r]);
         int min_hsp = 0;
         flt_live(opt, l_query, ck.log_lut[l_query], &min_hsp);
         const int n_chn = ck.n_chain[r];
-        for (int ci = 0; ci < n_chn; ++ci) {
+        for (int ci = lane; ci < n_chn; ci += 64) {              // a chain per lane
             const int c = w.ia[ci];
             const int n = w.c_n[c];
-            int *cs = w.c_w + w.c_first[c];                      // the chain's seeds, flattened by the chaining kernel
-            for (int i = lane; i < n; i += 64) {
-                const int s = cs[i];
-                w.s_score[s] = dev_seed_sw(R, opt, query, l_query, w.s_qbeg(s), w.s_len(s), w.s_rbeg[s]);
+            int *cs = w.c_w + w.c_first[c];
+            int k = 0;
+            for (int j = 0; j < n; ++j) {
+                const int s = cs[j];
+                const int sc = w.s_score[s];
+                if (sc < 0 || sc >= min_hsp) { w.s_score[s] = sc < 0 ? w.s_len(s) * opt.a : sc; cs[k++] = s; }
             }
-            __syncthreads();                                     // (one wave per block) scores of all lanes visible
-            if (lane == 0) {
-                int k = 0;
-                for (int j = 0; j < n; ++j) {
-                    const int s = cs[j];
-                    const int sc = w.s_score[s];
-                    if (sc < 0 || sc >= min_hsp) { w.s_score[s] = sc < 0 ? w.s_len(s) * opt.a : sc; cs[k++] = s; }
-                }
-                w.c_n[c] = k;
-            }
-            __syncthreads();
+            w.c_n[c] = k;
         }
     }
 }

@@ -150,6 +150,7 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int cap_intv_long = 0;          // what chunks of long reads needed (kept apart from cap_intv)
+    int long_coop = 1;            // contigs (reads beyond 704 bp): chaining one wave per read (k_chain_coop) for the reads with many seed occurrences; 0 = one lane per read
     int long_budget = 64;         // long reads (contigs): the extension stage runs in rounds (ExtSpec, dev_types.h); a walk emits at most this many
                                   // seed jobs per read and round; 0 = the walk extends in place (one wave per read does every extension of its read)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
@@ -674,6 +675,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "ext_split")) al->ext_split = (int)value;
     else if (!strcmp(key, "coop_lim1")) { if (value < 1) return SLX_EINVAL; al->coop_lim1 = (int)value; }
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
+    else if (!strcmp(key, "long_coop")) al->long_coop = value != 0;
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > 64) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
@@ -973,7 +975,7 @@ struct CvtI32U64 { __host__ __device__ unsigned long long operator()(int v) cons
 // wave-cooperative chaining of the heavy list, then (a few blocks, normally nothing to do) the reads whose chains outgrew the LDS table
 template <typename I>
 static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevOpt &dopt, const DevFM<I> &fm, hipStream_t st, unsigned int *q,
-                        unsigned int *counts, int n)
+                        unsigned int *counts, int n, bool both_tables = false)
 {
     // first table: COOP_N1 chains per wave in LDS (33 bytes each).  The kernel is bound by the serial merge steps of single reads, so what
     // counts is how many reads are in flight: the table size sets the waves per CU (1 536 chains = 50 KB: three; 512 = 17 KB: nine)
@@ -983,7 +985,7 @@ static void launch_coop(slx_aligner *al, Worker *wk, const Chunk &ck, const DevO
                        wk->order_out.as<int>(), q + 8, counts + 1, al->coop_lim1);
     // the 4 096-chain table only when a read can have more chains than the first table takes (chains <= seed occurrences): in the
     // pipeline an empty launch of it still waited ~20 ms for a CU with that much free LDS
-    if (std::min(N1, al->coop_lim1) < 512 || wk->max_seed_cnt > (unsigned int)std::min(N1, al->coop_lim1))     // (counts up to 512 are not tracked)
+    if (both_tables || std::min(N1, al->coop_lim1) < 512 || wk->max_seed_cnt > (unsigned int)std::min(N1, al->coop_lim1))     // (counts up to 512 are not tracked)
         hipLaunchKernelGGL((k_chain_coop<I, 4096, true>), dim3(std::max(1, std::min(n / 4096 + 1, N1 < 1536 ? al->n_cu : 16))), dim3(64), 0, st, fm, al->ref, ck, dopt,
                            wk->order_out.as<int>(), q + 10, counts + 1, al->coop_lim2);
 }
@@ -1181,10 +1183,26 @@ static int run_chunk(slx_aligner *al, Worker *wk, const slx_opt *opt, const uint
         if (!production) {
             // small batch (per-read calls) or a chunk with reads long enough for the seed filter: every read on the lane-per-read
             // chaining kernel, then the seed filter for the long ones, then every read on the wave-per-read extension kernel
+            if (max_len > 704 && al->long_coop) {
+                // contigs carry thousands of seed occurrences each: on one lane per read (k_chain) the chaining of a hundred contigs kept
+                // two waves busy for 200 ms.  They take the heavy reads' route -- one wave per read, the ordered chain set in LDS
+                // (k_chain_coop) -- and the short reads of the chunk stay on lanes
+                hipLaunchKernelGGL(k_part_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->seed_cnt.as<unsigned long long>(), n,
+                                   (unsigned int)al->heavy_seeds, wk->part_flag.as<unsigned int>());
+                size_t tb = wk->scan_tmp.cap;
+                HIPCHK(hipcub::DeviceScan::ExclusiveSum(wk->scan_tmp.p, tb, wk->part_flag.as<unsigned int>(), wk->part_pos.as<unsigned int>(), n, st));
+                hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wk->part_flag.as<unsigned int>(),
+                                   wk->part_pos.as<unsigned int>(), n, wk->order_in.as<int>(), wk->order_out.as<int>(), counts);
+                hipLaunchKernelGGL(k_chain<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, wk->order_in.as<int>(), q + 0, counts, 0);
+                launch_coop<I>(al, wk, ck, dopt, fm, st, q, counts, n, true);
+                hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);      // the stages below take every read in input order
+            } else {
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts, (unsigned int)n);
             hipLaunchKernelGGL(k_chain<I>, dim3(grid), dim3(bs), 0, st, fm, al->ref, ck, dopt, (const int *)nullptr, q + 0, counts, 0);
+            }
             if (has_long) {   // mem_flt_chained_seeds
                 hipLaunchKernelGGL(k_long_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, dopt, wk->long_list.as<int>(), q + 16);
+                hipLaunchKernelGGL(k_flt_score, dim3((unsigned)std::min<int64_t>((int64_t)n * FLT_PARTS, 0x7fffffff)), dim3(64), 0, st, al->ref, ck, dopt, wk->long_list.as<int>(), q + 16);
                 hipLaunchKernelGGL(k_flt_seeds, dim3(std::max(1, std::min(n, al->n_cu * 8))), dim3(64), 0, st, al->ref, ck, dopt, wk->long_list.as<int>(), q + 16, q + 17);
             }
             (void)hipEventRecord(wk->ev_probe[2], st);
