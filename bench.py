@@ -241,6 +241,9 @@ def main_c5(args):
     idx = seqlib_amd.BWAIndex()
     idx.ConstructIndex([(nm, synth.genome_ascii_bytes(g)) for nm, g in refs])
     al = seqlib_amd.BWAAligner(idx, device=local_rank)
+    for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=long_budget=16
+        k, v = kv.split("=")
+        al.set(k, int(v))
     ctx = fml.Context(local_rank)
     opt = fml.default_opt()
     ctx.stage(bases, quals, offs)

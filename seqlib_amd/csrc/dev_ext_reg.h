@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 // evaluate 64 regions each, four blocks of key loads in flight at a time
                 bool covered = false;
                 if constexpr (MAXQ > 704) {
-                    if (n_miss > 0) {          // a guess (this walk's result is discarded anyway): the pending seed's region will probably cover it
+                    if (n_miss > 0 && sp.guess) {          // a guess (this walk's result is discarded anyway): the pending seed's region will probably cover it
                         const int64_t dd = (s_rbeg - s_qbeg) - pend_diag;
                         const bool near = lane < (n_miss < 64 ? n_miss : 64) && dd < opt.w && -dd < opt.w;
                         if (__ballot(near)) covered = true;

@@ -100,6 +100,11 @@ __device__ ExtResult wave_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, con
     const int tail_top = ext_tail_bound0(o, qlen, h0, amax);
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     int tb_cur = lane < tlen ? tf(lane) : 0, tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    // query codes of the columns that enter the window, 64 per lane block, the next block in flight while this one is consumed (a load
+    // per row, needed by the end of the same row, was most of a row's time)
+    auto q_block = [&](int blk) { const int j = blk * WAVE + lane; return (j >= 0 && j < qlen) ? qf(j) : 4; };
+    int q_blk = (NB - w) >> 6;
+    int qb_cur = q_block(q_blk), qb_next = q_block(q_blk + 1);
     for (int i = 0; i < tlen; ++i) {
         if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) break;
         if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
@@ -107,10 +112,9 @@ __device__ ExtResult wave_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, con
         const uint32_t rowp = mr.packed[t];
         const int row4 = mr.q4[t];
         const int b = i - w;                                   // column of slot 0
-        // the column that enters the window for the next row, fetched now (only the last lane keeps it)
-        const int jt = b + NB;
-        int q_top = 4;
-        if (lane == WAVE - 1 && jt >= 0 && jt < qlen) q_top = qf(jt);
+        const int jt = b + NB;                                 // the column that enters the window for the next row (jt > 0: NB >= 2 w + 2)
+        if ((jt >> 6) != q_blk) { qb_cur = qb_next; ++q_blk; qb_next = q_block(q_blk + 1); }
+        const int q_top = __builtin_amdgcn_readlane(qb_cur, __builtin_amdgcn_readfirstlane(jt & (WAVE - 1)));
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;

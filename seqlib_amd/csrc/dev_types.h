@@ -78,6 +78,7 @@ struct ExtSpec {
     int *todo_next = nullptr;          // reads that missed something this round
     unsigned int *n_todo_next = nullptr;
     int budget = 0;                    // 0: this mode is off
+    int guess = 0;                     // 1: once a seed is pending, seeds within the band of its diagonal are taken to be covered by its region
 };
 
 // one chunk of reads, all device pointers

@@ -297,9 +297,10 @@ def test_contigs_that_end_in_tandem_repeats_extension_rounds(sl, orc, tmp_path):
     seqs.append("".join(s))
     exp = orc.align_batch(orc.default_opt(), oidx, seqs)
     base = None
-    for budget in (64, 0, 1, 5):
+    for budget in (64, 0, 1, 5, 1024):
         al = sl.BWAAligner(idx)
         al.set("long_budget", budget)
+        al.set("long_guess", 1 if budget in (64, 5) else 0)
         got = al.alignSequences(seqs)
         assert_same(got, exp, "tandem-ended contigs, long_budget %d" % budget)
         rounds, jobs = al.counter("long_rounds"), al.counter("long_jobs")
