@@ -88,6 +88,7 @@ extern "C" void slx_fml_free(slx_fml *f)
     if (!f) return;
     (void)hipSetDevice(f->device);
     for (FmlDevBuf *b : f->all_bufs()) b->release();
+    if (f->h_text_pin) (void)hipHostFree(f->h_text_pin);
     if (f->ev0) (void)hipEventDestroy(f->ev0);
     if (f->ev1) (void)hipEventDestroy(f->ev1);
     if (f->st) (void)hipStreamDestroy(f->st);

@@ -45,6 +45,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     const int n_win = f->n_win;
     if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
     std::vector<FmlStr> strs;
+    strs.reserve(2 * h_nl.size());
     std::vector<AsmWin> aw((size_t)n_win);
     unsigned long long text_len = 0;
     int kk = FML_SEED_MAX;
@@ -71,7 +72,20 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     const long long n_str = (long long)strs.size();
     // one min_match per batch on the device (the windows of a batch share the caller's options)
     const int min_match = n_win ? aw[0].min_match : 1;
-    std::vector<unsigned char> h_text((size_t)text_len + 1), h_cont((size_t)n_str + 1);
+    // the text comes back into a pinned buffer the context keeps (a fresh std::vector would be zero-filled and pageable: 240 MB of both for
+    // eight 100 000-read windows)
+    if (f->h_text_cap < (size_t)text_len + 1) {
+        if (f->h_text_pin) { (void)hipHostFree(f->h_text_pin); f->h_text_pin = nullptr; f->h_text_cap = 0; }
+        const size_t want = (size_t)text_len + (size_t)text_len / 8 + 4096;
+        if (hipHostMalloc((void **)&f->h_text_pin, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            slx_set_error("fml: out of pinned host memory (%llu bytes)", (unsigned long long)want);
+            return SLX_ENOMEM;
+        }
+        f->h_text_cap = want;
+    }
+    unsigned char *const h_text = f->h_text_pin;
+    std::vector<unsigned char> h_cont((size_t)n_str + 1);
     std::vector<int> h_rep((size_t)n_str + 1);
     std::vector<unsigned int> h_cnt((size_t)n_str + 1), h_nirr((size_t)n_str + 1);
     std::vector<unsigned long long> h_eoff((size_t)n_str + 2), h_stroff((size_t)n_str + 2), h_irroff((size_t)n_str + 1);
@@ -168,7 +182,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         FML_HIPCHK(hipMemcpyAsync(h_cont.data(), d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_nirr.data(), d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_irroff.data(), d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_text.data(), d_text.p, (size_t)text_len, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_text, d_text.p, (size_t)text_len, hipMemcpyDeviceToHost, f->st));
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
         h_out.resize((size_t)n_out + 1);
         if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
@@ -188,7 +202,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             std::vector<const unsigned char *> txt((size_t)n + 1);
             for (int t = 0; t < n; ++t) {
                 const FmlStr &s = strs[(size_t)(a.str0 + t)];
-                len[(size_t)t] = s.len; txt[(size_t)t] = h_text.data() + s.off;
+                len[(size_t)t] = s.len; txt[(size_t)t] = h_text + s.off;
                 rep[(size_t)t] = h_rep[(size_t)(a.str0 + t)] - (int)a.str0;
                 const unsigned long long o = h_irroff[(size_t)(a.str0 + t)];
                 for (unsigned int j = 0; j < h_nirr[(size_t)(a.str0 + t)]; ++j) { ev[(size_t)(o + j)] = h_out[(size_t)(o + j)].v - (int)a.str0; el[(size_t)(o + j)] = h_out[(size_t)(o + j)].len; }

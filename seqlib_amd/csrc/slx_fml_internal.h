@@ -47,6 +47,8 @@ struct slx_fml {
     bool has_qual = false;
     uint64_t n_slots = 0;
     std::vector<uint64_t> h_offs;          // rebased to 0
+    unsigned char *h_text_pin = nullptr;   // the assembly text on the host (pinned, kept between calls: 1 byte per base of both strands)
+    size_t h_text_cap = 0;
     std::vector<FmlWin> wins;
     std::vector<slx_fml_opt> wopt;         // per window: the caller's options after fml_opt_adjust on the window's reads
     std::vector<float> kcov;
