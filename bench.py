@@ -251,19 +251,42 @@ def main_c5(args):
 
     split = {"assemble_s": 0.0, "realign_s": 0.0, "realign_stage_ms": {}}
 
-    def step():
+    def assemble():
         t_a = time.time()
         wins = ctx.assemble_staged(opt, win_off)
         ms, ins, nb = ctx.probe_ms()
         contigs = [u["seq"] for w in wins for u in w]
         fit = [c for c in contigs if len(c) <= max_len]
+        split["assemble_s"] += time.time() - t_a
+        return wins, contigs, fit, ms, ins, nb
+
+    def realign(fit):
         t_b = time.time()
         hits = al.alignSequences(fit) if fit else None
-        t_c = time.time()
-        split["assemble_s"] += t_b - t_a; split["realign_s"] += t_c - t_b
+        split["realign_s"] += time.time() - t_b
         for k, v in al.stage_ms().items():
             split["realign_stage_ms"][k] = split["realign_stage_ms"].get(k, 0.0) + v
-        return wins, contigs, fit, hits, ms, ins, nb
+        return hits
+
+    def step():
+        wins, contigs, fit, ms, ins, nb = assemble()
+        return wins, contigs, fit, realign(fit), ms, ins, nb
+
+    def steps_pipelined(k_steps):
+        """the windows of step k + 1 are assembled (the context's stream + the host's graph threads) while the contigs of step k go through the
+        aligner (its workers' streams): two independent C-ABI objects driven from two host threads, as a pipeline over many batches of
+        windows would run them.  Every step's assembly and realignment still happen inside the timed region."""
+        from concurrent.futures import ThreadPoolExecutor
+        out = []
+        with ThreadPoolExecutor(1) as ex:
+            fut = ex.submit(assemble)
+            for k in range(k_steps):
+                wins, contigs, fit, ms, ins, nb = fut.result()
+                if k + 1 < k_steps:
+                    fut = ex.submit(assemble)
+                out.append((wins, contigs, fit, realign(fit), ms, ins, nb))
+                marks.append(time.time())
+        return out
 
     def fence():
         if world > 1:
@@ -278,9 +301,14 @@ def main_c5(args):
     fence()
     t0 = time.time()
     marks = [t0]
-    for _ in range(args.steps):
-        wins, contigs, fit, hits, ms, ins, nb = step()
-        marks.append(time.time())
+    if args.no_pipeline:
+        done = []
+        for _ in range(args.steps):
+            done.append(step())
+            marks.append(time.time())
+    else:
+        done = steps_pipelined(args.steps)
+    for wins, contigs, fit, hits, ms, ins, nb in done:
         for k, v in ms.items():
             acc[k] = acc.get(k, 0.0) + v
         ins_acc += ins; nb_acc += nb
@@ -348,6 +376,9 @@ def main_c5(args):
             "windows_per_s": n_win * world / (dt / args.steps),
             "contigs": {"n": len(contigs), "total_bp": sum(lens), "longest": lens[:5], "n50": n50, "realigned": len(fit), "realigned_bp": sum(len(c) for c in fit),
                         "skipped_longer_than_max_read_len": len(contigs) - len(fit), "records": int(hits["n_hits"]) if hits is not None else 0},
+            "pipelined": (not args.no_pipeline),
+            "pipelined_note": None if args.no_pipeline else "step k + 1's windows are assembled while step k's contigs are realigned (two host threads, separate streams); "
+                              "step_split_ms are the two halves' own wall times under that overlap; --no-pipeline runs them one after the other",
             "step_split_ms": {"assemble (slx_fml_assemble_staged + contig strings)": split["assemble_s"] / max(args.steps, 1) * 1e3,
                               "realign (BWAAligner.alignSequences of the contigs)": split["realign_s"] / max(args.steps, 1) * 1e3,
                               "realign_stage_ms": {k: v / max(args.steps, 1) for k, v in split["realign_stage_ms"].items()}},
@@ -376,6 +407,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / value_bamrecords")
     ap.add_argument("--verify", type=int, default=20000, help="reads of the timed batch checked bit-for-bit against the oracle")
     ap.add_argument("--windows", type=int, default=8, help="C5: windows per GPU and step")
+    ap.add_argument("--no-pipeline", action="store_true", help="C5: assemble and realign one after the other inside a step (default: step k + 1's assembly overlaps step k's realignment)")
     ap.add_argument("--coverage", type=float, default=30.0, help="C5: read coverage of a window")
     args = ap.parse_args()
 
@@ -585,6 +617,22 @@ def main():
                                "concurrently on the workers' streams (it can exceed the step time); the mean launch duration is what achieved uses",
                         algorithmic_bytes_per_read=seed_bytes, path_bytes_per_read=path_bytes,
                         path_achieved=path_bytes * n / (ms_per_step * 1e-3) / 1e9)
+            # the same launches against what the memory system gives DEPENDENT RANDOM reads at this index's footprint: one
+            # access per Occ block bwa's algorithm touches (the 8d count), ceiling from scripts/ubench/rand32.hip at the footprint
+            try:
+                ub = json.load(open(os.path.join(ROOT, "profiles", ROUND + "_ubench_rand32.json")))["table_mb"]
+                l_ref = sum(len(g) for _, g in refs)
+                foot_mb = (2 * l_ref / 4 * 2 + (128 << 20)) / 1e6          # occ planes (32 bytes per 64 symbols of the 2 x l_pac text, both strands) + the k-mer table
+                sizes = sorted(int(k) for k in ub)
+                at = next((m for m in sizes if m >= foot_mb), sizes[-1])
+                ceil_g = ub[str(at)]["g_reads_per_s"]
+                acc_g = per_read["n_occ_block"] * n / launches / (mean_launch_ms * 1e-3) / 1e9
+                roof["random_access"] = dict(accesses_per_read=per_read["n_occ_block"], achieved_g_per_s=acc_g, ceiling_from_ubench_g_per_s=ceil_g, frac=acc_g / ceil_g,
+                                             reads_per_s=n / launches / (mean_launch_ms * 1e-3), ceiling_reads_per_s=ceil_g * 1e9 / per_read["n_occ_block"],
+                                             footprint_mb=foot_mb, ubench_table_mb=at,
+                                             source="profiles/%s_ubench_rand32.json (scripts/ubench_rand32.sh; not measured in this run)" % ROUND)
+            except Exception:
+                roof["random_access"] = None
             cells = per_read.get("ext_cells", 0.0) + per_read.get("glb_cells", 0.0)
             if cells > 0 and ext_ms + cig_ms > 0:
                 ops = 14.0 * cells * n

@@ -41,10 +41,12 @@ static void run(const uint4 *tab, unsigned long long n_blocks, unsigned int *sin
     printf("table %7.0f MB  waves/SIMD %d  ILP %d : %7.2f G reads/s  %7.1f GB/s (32 B each)  %.0f ns per dependent step\n", mb, W, ILP, reads / ms / 1e6,
            reads * 32 / ms / 1e6, ms * 1e6 / steps);
 }
-int main()
+int main(int argc, char **argv)
 {
     unsigned int *sink; hipMalloc(&sink, 4);
-    for (double mb : {4.0, 64.0, 600.0, 4000.0}) {
+    std::vector<double> sizes = {4.0, 64.0, 600.0, 4000.0};
+    if (argc > 1) { sizes.clear(); for (int i = 1; i < argc; ++i) sizes.push_back(atof(argv[i])); }      // table sizes in MB
+    for (double mb : sizes) {
         const unsigned long long n_blocks = (unsigned long long)(mb * 1e6 / 32);
         uint4 *tab; hipMalloc(&tab, n_blocks * 32);
         std::vector<unsigned int> h(n_blocks * 8);

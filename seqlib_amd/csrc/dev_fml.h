@@ -22,6 +22,7 @@ struct FmlWin {                // per window, device-visible
     unsigned int tab_mask;              // slots - 1 (a power of two)
     int k, min_cov, mode;
     long long read0, read1;             // reads [read0, read1)
+    long long pos0;                     // first text position of the window (= offs[read0])
 };
 
 struct FmlPlanes { const unsigned long long *p0, *p1, *pn, *pq, *ps; };      // index = block + 1 (block -1 is a guard: all N)
@@ -127,9 +128,8 @@ static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long lon
     unsigned long long key = 0, inc = 1;
     FmlWin w;
     if (ok) {
-        const long long r = fml_upper(offs, n_reads + 1, (unsigned long long)p) - 1;          // the read holding position p
-        int lo = 0, hi = n_win;          // the window holding read r
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
+        int lo = 0, hi = n_win;          // the window holding position p (windows tile the text: no need to find the read -- that was a
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].pos0 <= p) lo = mid; else hi = mid; }   // 20-step search per lane)
         w = wins[lo];
         const int k = w.k;
         const uint32_t mask = (uint32_t)((1ULL << k) - 1);

@@ -75,6 +75,7 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     FML_HIPCHK(hipSetDevice(device));
     slx_fml *f = new slx_fml();
     f->device = device;
+    if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&f->ev0);
     if (e == hipSuccess) e = hipEventCreate(&f->ev1);
@@ -181,7 +182,7 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
         FmlWin &d = f->wins[(size_t)w];
         d.k = k > 0 ? k : 0;          // ec_k < 0: no table
         d.min_cov = o.min_cnt; d.mode = -1;
-        d.read0 = r0; d.read1 = r1;
+        d.read0 = r0; d.read1 = r1; d.pos0 = (long long)f->h_offs[(size_t)r0];
         // a table of (bases of the window) / tab_div slots: at 30x coverage a tenth of the k-mers are distinct, and a table that small
         // stays in the last-level cache, where the atomics are; fml_run_count enlarges it (x 4) when a window fills it past 70 %
         uint64_t cap = 1024;
@@ -480,7 +481,7 @@ extern "C" int slx_fml_error_correct(slx_fml *f, const slx_fml_opt *opt, char *b
     // the table stays; the reads to correct replace the reads it was counted from
     if ((rc = fml_upload(f, bases, quals, offs, n_reads))) return rc;
     f->wins.assign(1, f->count_win);
-    f->wins[0].read0 = 0; f->wins[0].read1 = n_reads;
+    f->wins[0].read0 = 0; f->wins[0].read1 = n_reads; f->wins[0].pos0 = 0;
     f->wopt.assign(1, *opt);
     f->n_win = 1;
     FML_HIPCHK(hipMemcpyAsync(f->d_wins.p, f->wins.data(), sizeof(FmlWin), hipMemcpyHostToDevice, f->st));
