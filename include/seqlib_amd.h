@@ -42,10 +42,11 @@ extern "C" {
 #define SLX_EUNSUPPORTED (-5)  /* read longer than the GPU path supports (SLX_MAX_READ_LEN) */
 #define SLX_EINTERNAL   (-6)
 
-/* Longest read the GPU path takes: query positions travel as 16-bit halves of one word through the seeding, chaining and
- * extension kernels.  Reads of ~727 bp and more (5.5*ln(L) <= 0.05*L) also run bwa's mem_flt_chained_seeds/ksw_align2 seed filter
- * and take the long-read kernels (dev_long.h); beyond 8 000 bp the extension kernel keeps its H/E row in HBM instead of LDS. */
-#define SLX_MAX_READ_LEN 65000
+/* Longest read the GPU path takes (the reference has no limit; this one is what the MAPQ log table and the tests cover, not a packing).
+ * Reads of ~727 bp and more (5.5*ln(L) <= 0.05*L) also run bwa's mem_flt_chained_seeds/ksw_align2 seed filter and take the long-read
+ * kernels (dev_long.h); beyond 8 000 bp the extension kernels keep their rows in HBM or registers instead of LDS; a chunk holding a read
+ * beyond 65 000 bp runs on the same pipeline compiled with 64-bit packed query positions (slx_align_wide.hip) instead of 16 + 16 bits. */
+#define SLX_MAX_READ_LEN 1000000
 
 /* mirrors bwa's mem_opt_t (fields the single-end path reads) */
 typedef struct {

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libseqlib_amd.so")
-SOURCES = ["slx_index.cpp", "slx_index_gpu.hip", "slx_index_gpu64.hip", "slx_align.hip", "slx_fml.hip", "slx_fml_asm.hip"]
+SOURCES = ["slx_index.cpp", "slx_index_gpu.hip", "slx_index_gpu64.hip", "slx_align.hip", "slx_align_wide.hip", "slx_fml.hip", "slx_fml_asm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -23,7 +23,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # two groups of translation units with their own headers: the BWAAligner path, and the FermiAssembler / BFC path (slx_fml*)
     is_fml = lambda f: "fml" in f
-    hdr_align = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") and not is_fml(f)] + [os.path.join(ROOT, "include", "seqlib_amd.h")]
+    hdr_align = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) and not is_fml(f)] + [os.path.join(ROOT, "include", "seqlib_amd.h")]
     hdr_fml = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") and is_fml(f)] + \
               [os.path.join(CSRC, "slx_internal.h"), os.path.join(ROOT, "include", "seqlib_amd.h"), os.path.join(ROOT, "include", "seqlib_amd_fml.h")]
     objs, procs = [], []

@@ -6,6 +6,7 @@
 #include "dev_fm.h"
 #include "dev_sort.h"
 #include "dev_types.h"
+#include "dev_pack.h"
 #include "dev_kbtree.h"
 
 // Reads are handed out 64 at a time (one per lane) from a device-wide queue, in heaviest-first order, so
@@ -23,13 +24,13 @@ __device__ __forceinline__ int next_slot(unsigned int *queue, int per_wave = 0)
 }
 
 struct ReadWS {               // views into the per-seed-slot arrays for one read
-    int64_t *s_rbeg; uint32_t *s_ql; int32_t *s_next; int32_t *s_score;
+    int64_t *s_rbeg; qp_t *s_ql; int32_t *s_next; int32_t *s_score;
     int64_t *c_pos; int32_t *c_head, *c_tail, *c_n, *c_rid, *c_w, *c_first; int8_t *c_kept;
     int32_t *ia, *ib, *ic; uint64_t *srt;
     DReg *regs; DHit *hits;
     int cap;
-    __device__ __forceinline__ int s_qbeg(int s) const { return (int)(s_ql[s] >> 16); }
-    __device__ __forceinline__ int s_len(int s) const { return (int)(s_ql[s] & 0xffff); }
+    __device__ __forceinline__ int s_qbeg(int s) const { return QP_HI(s_ql[s]); }
+    __device__ __forceinline__ int s_len(int s) const { return QP_LO(s_ql[s]); }
 };
 
 __device__ __forceinline__ uint64_t rfl_u64(uint64_t v)
@@ -45,7 +46,7 @@ __device__ __forceinline__ ReadWS make_ws_uniform(const Chunk &ck, int r)
 {
     const uint64_t o = rfl_u64(ck.seed_off[r]);
     ReadWS w;
-    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = (qp_t *)ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
     w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
     w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
     w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
@@ -58,7 +59,7 @@ __device__ __forceinline__ ReadWS make_ws(const Chunk &ck, int r)
 {
     const uint64_t o = ck.seed_off[r];
     ReadWS w;
-    w.s_rbeg = ck.s_rbeg + o; w.s_ql = ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
+    w.s_rbeg = ck.s_rbeg + o; w.s_ql = (qp_t *)ck.s_ql + o; w.s_next = ck.s_next + o; w.s_score = ck.s_score ? ck.s_score + o : nullptr;
     w.c_pos = ck.c_pos + o; w.c_head = ck.c_head + o; w.c_tail = ck.c_tail + o; w.c_n = ck.c_n + o;
     w.c_rid = ck.c_rid + o; w.c_w = ck.c_w + o; w.c_first = ck.c_first + o; w.c_kept = ck.c_kept + o;
     w.ia = ck.ia + o; w.ib = ck.ib + o; w.ic = ck.ic + o; w.srt = ck.srt + o;
@@ -96,7 +97,7 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         ReadWS w = make_ws(ck, r);
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_intv = (int)ck.intv_n[r];
-        const uint32_t *iinfo = ck.intv_info + (size_t)r * ck.cap_intv;
+        const qp_t *iinfo = (const qp_t *)ck.intv_info + (size_t)r * ck.cap_intv;
         const I *ix0 = (const I *)ck.intv_x0 + (size_t)r * ck.cap_intv;
         const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
         int ns = 0, nc = 0;                      // seeds stored, chains
@@ -106,10 +107,10 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
         // the chain touched last, in registers: a read from unique sequence has one chain that every seed is tested against, and each test
         // read c_head / c_tail and then the two seeds -- two dependent round trips per seed for values this lane wrote itself
         int cc = -1, cc_tail = 0, cc_n = 0, cc_rid = 0;
-        uint32_t cc_fql = 0, cc_lql = 0;
+        qp_t cc_fql = 0, cc_lql = 0;
         int64_t cc_frb = 0, cc_lrb = 0;
         for (int i = 0; i < n_intv; ++i) {
-            const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
+            const int qbeg = QP_HI(iinfo[i]), slen = QP_LO(iinfo[i]) - qbeg;
             const I x2 = ix2[i];
             const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
             I k = 0;
@@ -138,18 +139,18 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                             cc_lql = w.s_ql[cc_tail]; cc_lrb = w.s_rbeg[cc_tail];
                         }
                         const int last = cc_tail;
-                        const int l_qbeg = (int)(cc_lql >> 16), l_len = (int)(cc_lql & 0xffff);
+                        const int l_qbeg = QP_HI(cc_lql), l_len = QP_LO(cc_lql);
                         const int64_t l_rbeg = cc_lrb;
                         const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
                         int res;
                         if (rid != cc_rid) res = 0;
-                        else if (qbeg >= (int)(cc_fql >> 16) && qbeg + slen <= qend && rbeg >= cc_frb && rbeg + slen <= rend) res = 1; // contained
+                        else if (qbeg >= QP_HI(cc_fql) && qbeg + slen <= qend && rbeg >= cc_frb && rbeg + slen <= rend) res = 1; // contained
                         else if ((l_rbeg < R.l_pac || cc_frb < R.l_pac) && rbeg >= R.l_pac) res = 0;
                         else {
                             const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                             if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
                                 const int s = ns++;
-                                const uint32_t ql = ((uint32_t)qbeg << 16) | (uint32_t)slen;
+                                const qp_t ql = QP_PACK(qbeg, slen);
                                 w.s_rbeg[s] = rbeg; w.s_ql[s] = ql; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                                 w.s_next[last] = s; w.c_tail[c] = s; w.c_n[c] = ++cc_n;
                                 cc_tail = s; cc_lql = ql; cc_lrb = rbeg;
@@ -161,9 +162,9 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
                 }
                 if (to_add) {
                     const int s = ns++, c = nc;
-                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
+                    w.s_rbeg[s] = rbeg; w.s_ql[s] = QP_PACK(qbeg, slen); w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                     w.c_pos[c] = rbeg; w.c_head[c] = w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
-                    cc = c; cc_tail = s; cc_n = 1; cc_rid = rid; cc_fql = cc_lql = ((uint32_t)qbeg << 16) | (uint32_t)slen; cc_frb = cc_lrb = rbeg;
+                    cc = c; cc_tail = s; cc_n = 1; cc_rid = rid; cc_fql = cc_lql = QP_PACK(qbeg, slen); cc_frb = cc_lrb = rbeg;
                     if (!tree && nc == 2 * KB_T - 1) { kb.from_array((int *)w.regs, ord, w.c_pos, nc); tree = true; }   // the leaf is full: it splits now
                     if (tree) kb.put(rbeg, c);
                     else {

@@ -41,7 +41,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         // hands it to the launch with the bigger table, and past that one to a single lane on global memory.
         const int len = (int)(ck.offs[r + 1] - ck.offs[r]);
         const int n_intv = (int)ck.intv_n[r];
-        const uint32_t *iinfo = ck.intv_info + (size_t)r * ck.cap_intv;
+        const qp_t *iinfo = (const qp_t *)ck.intv_info + (size_t)r * ck.cap_intv;
         const I *ix0 = (const I *)ck.intv_x0 + (size_t)r * ck.cap_intv;
         const I *ix2 = (const I *)ck.intv_x2 + (size_t)r * ck.cap_intv;
         int ns = 0, nc = 0;
@@ -58,7 +58,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
         const bool cnt16 = ck.seed_off[r + 1] - ck.seed_off[r] < 65536;      // (the count fits 16 bits; else it is read back from c_n)
         // ---------------- mem_chain: seeds in interval order, occurrences in rank order
         for (int i = 0; i < n_intv; ++i) {
-            const int qbeg = (int)(iinfo[i] >> 16), slen = (int)(iinfo[i] & 0xffff) - qbeg;
+            const int qbeg = QP_HI(iinfo[i]), slen = QP_LO(iinfo[i]) - qbeg;
             const I x0 = ix0[i], x2 = ix2[i];
             const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
             I cm = (x2 + step - 1) / step;        // trips of `for (k = count = 0; k < x2 && count < max_occ; k += step, ++count)`
@@ -92,24 +92,35 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                         if (lower_c >= 0) {       // test_and_merge
                             const int c = lower_c;
                             const int last = l_tail[c];
+#ifdef SLX_WIDE                 // (positions beyond 16 bits: the summaries do not fit the LDS words; the seeds themselves are read)
+                            const qp_t lql = w.s_ql[last];
+                            const int f_qbeg = w.s_qbeg(w.c_head[c]);
+#else
                             const uint32_t lql = (uint32_t)l_lastql[c], fql = (uint32_t)l_firstql[c];
-                            const int l_qbeg = (int)(lql >> 16), l_len = (int)(lql & 0xffff);
+                            const int f_qbeg = (int)(fql >> 16);
+#endif
+                            const int l_qbeg = QP_HI(lql), l_len = QP_LO(lql);
                             const int64_t f_rbeg = tree ? w.c_pos[c] : s_pos[lo];          // a chain's position is its first seed's reference start
                             const int64_t l_rbeg = f_rbeg + l_lastoff[c];
                             const int64_t qend = l_qbeg + l_len, rend = l_rbeg + l_len;
                             int res;
                             if (rid != l_rid[c]) res = 0;
-                            else if (qbeg >= (int)(fql >> 16) && qbeg + slen <= qend && rbeg >= f_rbeg && rbeg + slen <= rend) res = 1;
+                            else if (qbeg >= f_qbeg && qbeg + slen <= qend && rbeg >= f_rbeg && rbeg + slen <= rend) res = 1;
                             else if ((l_rbeg < R.l_pac || f_rbeg < R.l_pac) && rbeg >= R.l_pac) res = 0;
                             else {
                                 const int64_t x = qbeg - l_qbeg, y = rbeg - l_rbeg;
                                 if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - l_len < opt.max_chain_gap && y - l_len < opt.max_chain_gap) {
                                     const int s = ns++;   // every lane stores the same bytes
-                                    w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
+                                    w.s_rbeg[s] = rbeg; w.s_ql[s] = QP_PACK(qbeg, slen); w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                                     w.s_next[last] = s; w.c_tail[c] = s;
+#ifdef SLX_WIDE
+                                    w.c_n[c] = w.c_n[c] + 1;
+                                    l_tail[c] = s; l_lastoff[c] = (int)(rbeg - f_rbeg);
+#else
                                     if (cnt16) { l_firstql[c] = (int)(fql + 1u); w.c_n[c] = (int)(fql & 0xffff) + 1; }     // the count rides in the low half
                                     else w.c_n[c] = w.c_n[c] + 1;
                                     l_tail[c] = s; l_lastql[c] = (int)(((uint32_t)qbeg << 16) | (uint32_t)slen); l_lastoff[c] = (int)(rbeg - f_rbeg);
+#endif
                                     res = 1;
                                 } else res = 0;
                             }
@@ -132,9 +143,13 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                     }
                     if (to_add) {
                         const int s = ns++, c = nc;
-                        w.s_rbeg[s] = rbeg; w.s_ql[s] = ((uint32_t)qbeg << 16) | (uint32_t)slen; w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
+                        w.s_rbeg[s] = rbeg; w.s_ql[s] = QP_PACK(qbeg, slen); w.s_next[s] = -1; if (w.s_score) w.s_score[s] = slen;
                         w.c_pos[c] = rbeg; w.c_head[c] = s; w.c_tail[c] = s; w.c_n[c] = 1; w.c_rid[c] = rid;
+#ifdef SLX_WIDE
+                        l_tail[c] = s; l_lastoff[c] = 0; l_rid[c] = rid;
+#else
                         l_tail[c] = s; l_lastql[c] = (int)(((uint32_t)qbeg << 16) | (uint32_t)slen); l_firstql[c] = (int)(((uint32_t)qbeg << 16) | 1u); l_lastoff[c] = 0; l_rid[c] = rid;
+#endif
                         if (tree) kb.put(rbeg, c);
                         else {
                             // ordered insert at rank lo+1: lanes shift the tail up by one, highest block first

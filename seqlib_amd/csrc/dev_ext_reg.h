@@ -456,9 +456,15 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
         uint8_t *const hs = (uint8_t *)w.hits;
         const size_t cap = (size_t)w.cap;
         int64_t *const rg_rb = (int64_t *)hs, *const rg_re = (int64_t *)(hs + 8 * cap);
+#ifdef SLX_WIDE         // 64-bit packed words: the regions' (qb, qe) take the seeds' place and the sorted seeds' words go to the chain positions (free after chaining)
+        qp_t *const rg_q = (qp_t *)(hs + 16 * cap);
+        int *const rg_w = (int *)(hs + 24 * cap), *const rg_sl0 = (int *)(hs + 28 * cap);
+        qp_t *const sd_ql = (qp_t *)w.c_pos;
+#else
         uint32_t *const rg_q = (uint32_t *)(hs + 16 * cap);
         int *const rg_w = (int *)(hs + 20 * cap), *const rg_sl0 = (int *)(hs + 24 * cap);
         uint32_t *const sd_ql = (uint32_t *)(hs + 28 * cap);
+#endif
         int64_t *const sd_rb = (int64_t *)(hs + 32 * cap);
         int *const sd_s = w.ib;
         for (int ci = 0; ci < n_chn && !give_up; ++ci) {
@@ -496,13 +502,13 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
             // ---- the chain's seeds in the order mem_chain2aln takes them (ascending (length, list index), walked from the top):
             // ranks by an all-pairs count on registers (keys are distinct), records scattered to a sorted SoA scratch
             DBG_T0();
-            uint32_t my_ql = 0; int64_t my_rb = 0; int my_rank = -1;   // n <= 64: this lane's seed and its rank, for the batch test below
+            qp_t my_ql = 0; int64_t my_rb = 0; int my_rank = -1;   // n <= 64: this lane's seed and its rank, for the batch test below
             if (n <= WAVE) {                                       // the common case: keys never leave the registers
                 const bool mine = lane < n;
                 const int sid = mine ? cs[lane] : 0;
-                const uint32_t ql = mine ? w.s_ql[sid] : 0u;
+                const qp_t ql = mine ? w.s_ql[sid] : (qp_t)0;
                 const int64_t rb = mine ? w.s_rbeg[sid] : 0;
-                const uint32_t sc = w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (ql & 0xffffu);    // mem_seed_t::score (= length unless the seed filter ran)
+                const uint32_t sc = w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (uint32_t)QP_LO(ql);    // mem_seed_t::score (= length unless the seed filter ran)
                 const uint64_t key = mine ? ((uint64_t)sc << 32 | (uint64_t)(uint32_t)lane) : ~0ull;
                 int rank = 0;
                 for (int j = 0; j < n; ++j) {
@@ -518,9 +524,9 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     const int i = i0 + lane;
                     const bool mine = i < n;
                     const int sid = mine ? cs[i] : 0;
-                    const uint32_t ql = mine ? w.s_ql[sid] : 0u;
+                    const qp_t ql = mine ? w.s_ql[sid] : (qp_t)0;
                     const int64_t rb = mine ? w.s_rbeg[sid] : 0;
-                    const uint64_t key = (uint64_t)(w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (ql & 0xffffu)) << 32 | (uint64_t)(uint32_t)i;
+                    const uint64_t key = (uint64_t)(w.s_score ? (mine ? (uint32_t)w.s_score[sid] : 0u) : (uint32_t)QP_LO(ql)) << 32 | (uint64_t)(uint32_t)i;
                     int rank = 0;
                     for (int b0 = 0; b0 < n; b0 += WAVE) {
                         const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
@@ -544,17 +550,17 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     // so far and no extended seed of the chain crosses it on another diagonal, so each is dropped in turn.  By induction
                     // over that order only the top seed can be "extended" for the other-diagonal test, so all of them can be judged at
                     // once, one seed per lane; if any lane disagrees the scalar order below takes over unchanged.
-                    const uint32_t f_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd_ql[n - 1]);
+                    const qp_t f_ql = qp_uniform(sd_ql[n - 1]);
                     const int64_t f_rb = (int64_t)rfl_u64((uint64_t)sd_rb[n - 1]);
                     bool fail = false;
                     if (my_rank >= 0 && my_rank <= n - 2) {
-                        const int q0 = (int)(my_ql >> 16), l0 = (int)(my_ql & 0xffffu);
+                        const int q0 = QP_HI(my_ql), l0 = QP_LO(my_ql);
                         bool cov = false;
                         for (int ri = 0; ri < n_av; ++ri) {
                             const int64_t prb = rg_rb[ri], pre_ = rg_re[ri];
-                            const uint32_t pq = rg_q[ri];
+                            const qp_t pq = rg_q[ri];
                             const int pw = rg_w[ri], psl0 = rg_sl0[ri];
-                            const int pqb = (int)(pq >> 16), pqe = (int)(pq & 0xffffu);
+                            const int pqb = QP_HI(pq), pqe = QP_LO(pq);
                             if (!(my_rb < prb || my_rb + l0 > pre_ || q0 < pqb || q0 + l0 > pqe) && !((double)(l0 - psl0) > .1 * l_query)) {
                                 int qd = q0 - pqb; int64_t rd = my_rb - prb;
                                 int mg = max_gap_of(qd < rd ? qd : (int)rd);
@@ -568,7 +574,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                         }
                         bool cross = false;
                         if (top_kept) {
-                            const int t_qbeg = (int)(f_ql >> 16), t_len = (int)(f_ql & 0xffffu);
+                            const int t_qbeg = QP_HI(f_ql), t_len = QP_LO(f_ql);
                             if (!((double)t_len < l0 * .95)) {
                                 if (q0 <= t_qbeg && q0 + l0 - t_qbeg >= l0 >> 2 && t_qbeg - q0 != f_rb - my_rb) cross = true;
                                 if (t_qbeg <= q0 && t_qbeg + t_len - q0 >= l0 >> 2 && q0 - t_qbeg != my_rb - f_rb) cross = true;
@@ -578,9 +584,9 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     }
                     if (__ballot(fail) == 0) { DBG_T1(t_test); break; }
                 }
-                const uint32_t s_ql = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd_ql[k]);
+                const qp_t s_ql = qp_uniform(sd_ql[k]);
                 const int s = __builtin_amdgcn_readfirstlane(sd_s[k]);
-                const int s_qbeg = (int)(s_ql >> 16), s_len = (int)(s_ql & 0xffffu);
+                const int s_qbeg = QP_HI(s_ql), s_len = QP_LO(s_ql);
                 const int64_t s_rbeg = (int64_t)rfl_u64((uint64_t)sd_rb[k]);
                 // "has this seed been covered by an earlier region?": only whether ANY region passes the test matters, so lanes
                 // evaluate 64 regions each, four blocks of key loads in flight at a time
@@ -600,9 +606,9 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                         const bool valid = ri0 < n_av;
                         const int ri = valid ? ri0 : n_av - 1;
                         const int64_t prb = rg_rb[ri], pre_ = rg_re[ri];
-                        const uint32_t pq = rg_q[ri];
+                        const qp_t pq = rg_q[ri];
                         const int pw = rg_w[ri], psl0 = rg_sl0[ri];
-                        const int pqb = (int)(pq >> 16), pqe = (int)(pq & 0xffffu);
+                        const int pqb = QP_HI(pq), pqe = QP_LO(pq);
                         if (valid && !(s_rbeg < prb || s_rbeg + s_len > pre_ || s_qbeg < pqb || s_qbeg + s_len > pqe) &&
                             !((double)(s_len - psl0) > .1 * l_query)) {
                             int qd = s_qbeg - pqb; int64_t rd = s_rbeg - prb;
@@ -627,9 +633,9 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                             const int ti0 = base + u * WAVE + lane;
                             const bool valid = ti0 < n;
                             const int ti = valid ? ti0 : n - 1;
-                            const uint32_t tq = sd_ql[ti];
+                            const qp_t tq = sd_ql[ti];
                             const int64_t t_rbeg = sd_rb[ti];
-                            const int t_qbeg = (int)(tq >> 16), t_len = (int)(tq & 0xffffu);       // a dropped seed has length 0 here
+                            const int t_qbeg = QP_HI(tq), t_len = QP_LO(tq);       // a dropped seed has length 0 here
                             if (valid && !((double)t_len < s_len * .95)) {
                                 if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) hit = true;
                                 if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) hit = true;
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                         }
                         if (__ballot(hit)) other_diag = true;
                     }
-                    if (!other_diag) { sd_ql[k] = s_ql & 0xffff0000u; DBG_T1(t_test); continue; }      // every lane stores the same word
+                    if (!other_diag) { sd_ql[k] = QP_KEEP_HI(s_ql); DBG_T1(t_test); continue; }      // every lane stores the same word
                 }
                 DBG_T1(t_test);
                 DBG_T0();
@@ -675,8 +681,8 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     else a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
                     int cov = 0;
                     for (int i = lane; i < n; i += WAVE) {
-                        const uint32_t tq = w.s_ql[cs[i]];
-                        const int t_qbeg = (int)(tq >> 16), t_len = (int)(tq & 0xffffu);
+                        const qp_t tq = w.s_ql[cs[i]];
+                        const int t_qbeg = QP_HI(tq), t_len = QP_LO(tq);
                         const int64_t t_rbeg = w.s_rbeg[cs[i]];
                         if (t_qbeg >= a.qb && t_qbeg + t_len <= a.qe && t_rbeg >= a.rb && t_rbeg + t_len <= a.re) cov += t_len;
                     }
@@ -686,7 +692,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 if (k == n - 1) top_kept = true;
                 // every lane stores the same bytes (region + its keys for the covered test), so every lane may read them back
                 w.regs[n_av] = a;
-                rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = (uint32_t)a.qb << 16 | (uint32_t)a.qe; rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;
+                rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = QP_PACK(a.qb, a.qe); rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;
                 ++n_av;
                 DBG_T1(t_dp);
             }

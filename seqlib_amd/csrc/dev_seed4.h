@@ -24,6 +24,7 @@
 // load issued up front: 59 ms against 55).
 #pragma once
 #include "dev_occ.h"
+#include "dev_pack.h"
 
 // one rank block in flight.  Plain scalar members on purpose: selecting a vector element or an array slot by the per-lane symbol makes
 // the compiler park the struct in scratch memory.
@@ -200,9 +201,9 @@ __global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, Dev
         const uint64_t kmask = kf < 32 ? (1ull << (2 * kf)) - 1 : ~0ull;
         for (int k = 0; k < n; ++k) {
             const size_t o = (size_t)r * ck.cap_intv + k;
-            const uint32_t inf = ck.intv_info[o];
+            const qp_t inf = ((const qp_t *)ck.intv_info)[o];
             const I s = ((const I *)ck.intv_x2)[o];
-            const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+            const int start = QP_HI(inf), end = QP_LO(inf);
             if (end - start < split_len || s > (I)opt.split_width) continue;
             if (k >= 63) { mask |= 1ull << 63; break; }
             const int mid = (start + end) >> 1;
@@ -424,11 +425,11 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
             const uint32_t slot = atomicAdd(ck.intv_n + r, 1u);
             if (slot < (uint32_t)ck.cap_intv) {
                 const size_t o = (size_t)r * ck.cap_intv + slot;
-                ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
+                ((qp_t *)ck.intv_info)[o] = QP_PACK(start, end); ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
             } else { atomicSub(ck.intv_n + r, 1u); out_ovf = true; }   // (the count never stays above the capacity: later kernels index with it)
         } else if (n_out < ck.cap_intv) {
             const size_t o = (size_t)r * ck.cap_intv + n_out;
-            ck.intv_info[o] = ((uint32_t)start << 16) | (uint32_t)end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
+            ((qp_t *)ck.intv_info)[o] = QP_PACK(start, end); ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = s;
             ++n_out;
         } else out_ovf = true;
     };
@@ -528,9 +529,9 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
                         if (k < 63 && !((p2m >> k) & 1ull)) continue;           // k_seed2_select: not a candidate, or the repeat filter rules a result out
                         if (k >= 63 && !(p2m >> 63)) { k2 = old_n; break; }
                         const size_t o = (size_t)r * ck.cap_intv + k;
-                        const uint32_t inf = ck.intv_info[o];
+                        const qp_t inf = ((const qp_t *)ck.intv_info)[o];
                         const I s = ((const I *)ck.intv_x2)[o];
-                        const int start = (int)(inf >> 16), end = (int)(inf & 0xffff);
+                        const int start = QP_HI(inf), end = QP_LO(inf);
                         const int mid = (start + end) >> 1;
                         if (k >= 63) {                  // beyond the mask: bwa's own conditions here
                             if (end - start < split_len || s > (I)opt.split_width) continue;
@@ -744,8 +745,8 @@ __global__ void __launch_bounds__(64) k_seed2_coop(DevFM<I> fm, DevRef R, Chunk 
         const uint64_t qoff = ck.offs[r];
         const int len = (int)(ck.offs[r + 1] - qoff);
         const size_t po = (size_t)r * ck.cap_intv + (it & 63u);
-        const uint32_t pinf0 = ck.intv_info[po];
-        const int sx = ((int)(pinf0 >> 16) + (int)(pinf0 & 0xffff)) >> 1;
+        const qp_t pinf0 = ((const qp_t *)ck.intv_info)[po];
+        const int sx = (QP_HI(pinf0) + QP_LO(pinf0)) >> 1;
         const I min_intv = ((const I *)ck.intv_x2)[po] + 1;
         QWin win; win.bits = 0; win.chunk = 0xffffffffu;
         auto qb = [&](int p) { return q_at(ck.codes, qoff + (uint64_t)p, win); };
@@ -787,7 +788,7 @@ __global__ void __launch_bounds__(64) k_seed2_coop(DevFM<I> fm, DevRef R, Chunk 
                     const uint32_t slot = atomicAdd(ck.intv_n + r, 1u);
                     if (slot < (uint32_t)ck.cap_intv) {
                         const size_t o = (size_t)r * ck.cap_intv + slot;
-                        ck.intv_info[o] = ((uint32_t)(bi + 1) << 16) | end; ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = sz;
+                        ((qp_t *)ck.intv_info)[o] = QP_PACK(bi + 1, end); ((I *)ck.intv_x0)[o] = a; ((I *)ck.intv_x2)[o] = sz;
                     } else { atomicSub(ck.intv_n + r, 1u); out_ovf = true; }
                 }
             }
@@ -871,7 +872,7 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
     const uint64_t qoff = live ? ck.offs[r] : 0;
     const int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
     const size_t ob = (size_t)(live ? r : 0) * ck.cap_intv;
-    uint32_t *oinfo = ck.intv_info + ob;
+    qp_t *oinfo = (qp_t *)ck.intv_info + ob;
     I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
     int n_out = live ? (int)ck.intv_n[r] : 0;
     bool out_ovf = false;
@@ -914,7 +915,7 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
                     } else if (k2 != 0) fwd_step<I>(fm, k0, k1, k2, cq, o0, o1, o2);      // (an empty interval stays empty: bwa walks on to min_seed_len)
                     if (o2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
                         if (o2 > 0) {
-                            if (n_out < ck.cap_intv) { oinfo[n_out] = ((uint32_t)x << 16) | (uint32_t)(i + 1); ox0[n_out] = o0; ox2[n_out] = o2; ++n_out; }
+                            if (n_out < ck.cap_intv) { oinfo[n_out] = QP_PACK(x, i + 1); ox0[n_out] = o0; ox2[n_out] = o2; ++n_out; }
                             else out_ovf = true;
                         }
                         x = i + 1; fresh = true; dir = false;
@@ -944,20 +945,20 @@ template <typename I>
 __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned int *max_cnt, unsigned int heavy_thr, unsigned int *n_heavy)
 {
     const slx_opt &opt = dopt.o;
-    __shared__ uint32_t s_info[SEED_EPI_N * 64];
+    __shared__ qp_t s_info[SEED_EPI_N * 64];
     __shared__ I s_x0[SEED_EPI_N * 64], s_x2[SEED_EPI_N * 64];
     const int lane = threadIdx.x;
     const int r = blockIdx.x * 64 + lane;
     if (r >= ck.n_reads) return;
     const size_t ob = (size_t)r * ck.cap_intv;
-    uint32_t *oinfo = ck.intv_info + ob;
+    qp_t *oinfo = (qp_t *)ck.intv_info + ob;
     I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
     const int n_out = (int)ck.intv_n[r];
     int b = 0, e = 0, l_rep = 0;
     uint32_t cnt = 0;
-    auto account = [&](uint32_t inf, I s) {          // mem_chain prologue, entries in sorted order
+    auto account = [&](qp_t inf, I s) {          // mem_chain prologue, entries in sorted order
         if (s > (I)opt.max_occ) {
-            const int sb = (int)(inf >> 16), se = (int)(inf & 0xffff);
+            const int sb = QP_HI(inf), se = QP_LO(inf);
             if (sb > e) { l_rep += e - b; b = sb; e = se; }
             else e = e > se ? e : se;
             const I step = s / (I)opt.max_occ;
@@ -967,7 +968,7 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned
     };
     if (n_out <= SEED_EPI_N) {
         for (int a = 0; a < n_out; a += 4) {         // four entries' loads in flight at a time
-            uint32_t ki[4]; I v0[4], v2[4];
+            qp_t ki[4]; I v0[4], v2[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (a + u < n_out) { ki[u] = oinfo[a + u]; v0[u] = ox0[a + u]; v2[u] = ox2[a + u]; }
 #pragma unroll
@@ -975,7 +976,7 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned
         }
         bool moved = false;
         for (int a = 1; a < n_out; ++a) {
-            const uint32_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
+            const qp_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
             int p = a - 1;
             while (p >= 0 && s_info[p * 64 + lane] > ki) {
                 s_info[(p + 1) * 64 + lane] = s_info[p * 64 + lane]; s_x0[(p + 1) * 64 + lane] = s_x0[p * 64 + lane]; s_x2[(p + 1) * 64 + lane] = s_x2[p * 64 + lane];
@@ -984,13 +985,13 @@ __global__ void __launch_bounds__(64) k_seed_epi(Chunk ck, DevOpt dopt, unsigned
             if (p + 1 != a) { s_info[(p + 1) * 64 + lane] = ki; s_x0[(p + 1) * 64 + lane] = k0; s_x2[(p + 1) * 64 + lane] = k2; moved = true; }
         }
         for (int a = 0; a < n_out; ++a) {
-            const uint32_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
+            const qp_t ki = s_info[a * 64 + lane]; const I k0 = s_x0[a * 64 + lane], k2 = s_x2[a * 64 + lane];
             if (moved) { oinfo[a] = ki; ox0[a] = k0; ox2[a] = k2; }
             account(ki, k2);
         }
     } else {
         for (int a = 1; a < n_out; ++a) {
-            const uint32_t ki = oinfo[a]; const I s0 = ox0[a], s2 = ox2[a];
+            const qp_t ki = oinfo[a]; const I s0 = ox0[a], s2 = ox2[a];
             int p = a - 1;
             while (p >= 0 && oinfo[p] > ki) { oinfo[p + 1] = oinfo[p]; ox0[p + 1] = ox0[p]; ox2[p + 1] = ox2[p]; --p; }
             oinfo[p + 1] = ki; ox0[p + 1] = s0; ox2[p + 1] = s2;

@@ -314,6 +314,59 @@ def test_contigs_that_end_in_tandem_repeats_extension_rounds(sl, orc, tmp_path):
     assert_same(sl.BWAAligner(idx).alignSequences(mixed), orc.align_batch(orc.default_opt(), oidx, mixed), "tandem-ended contigs among short reads")
 
 
+def test_reads_beyond_the_16_bit_packings(sl, orc, tmp_path):
+    """reads of 65 001 bp and more -- the contigs of 100 000-read assembly windows reach hundreds of kilobases (src/seqtools/seqtools.cpp:198-210
+    realigns them) -- run on the pipeline compiled with 64-bit packed query positions (slx_align_wide.hip): bit-exact vs the oracle, alone,
+    next to short reads, ending in a tandem repeat, on both index widths; the old limit's neighbourhood on both sides of the switch"""
+    from seqlib_amd import synth, _ffi
+    rng = np.random.default_rng(17)
+    g = synth.make_genome(700000, seed=933).copy()
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    g[400000:400200] = np.array([code[c] for c in b"GTTAT" * 40], dtype=np.uint8)
+    ref = synth.genome_ascii(g)
+    prefix = str(tmp_path / "wide")
+    orc.Index.build(["chrW"], [ref]).write(prefix)
+    oidx = orc.Index.load(prefix)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+
+    def mut(t, n_sub, indel):
+        t = list(t)
+        for _ in range(n_sub):
+            t[int(rng.integers(0, len(t)))] = "ACGT"[int(rng.integers(0, 4))]
+        if indel:
+            q = len(t) // 3
+            t[q:q] = list("ACGTTGCAACGT")
+            del t[2 * q:2 * q + 9]
+        return "".join(t)
+
+    seqs = [mut(ref[1000:66001], 30, False),                       # 65 001 bp: the first length on the wide pipeline
+            ref[2000:67000],                                       # 65 000 bp: the last on the narrow one
+            orc_revcomp(mut(ref[100000:231000], 100, True)),       # 131 kb
+            mut(ref[300000:600000], 200, True),                    # 300 kb, through the tandem tract
+            ref[320100:400100],                                    # 80 kb ending inside the tract
+            mut(ref[10000:90000], 800, False) + ref[500000:520000]]   # a diverged 80 kb stretch joined to another locus
+    exp = orc.align_batch(orc.default_opt(), oidx, seqs)
+    al = sl.BWAAligner(idx)
+    assert_same(al.alignSequences(seqs), exp, "reads beyond 65 kb")
+    assert max(len(t) for t in seqs) > 4 * _ffi.SLX_MAX_READ_LEN // 16
+    short = [ref[100 + 151 * i:250 + 151 * i] for i in range(60)] + [ref[5000:7000]]
+    mixed = seqs[:1] + short + seqs[2:4]
+    expm = orc.align_batch(orc.default_opt(), oidx, mixed)
+    assert_same(sl.BWAAligner(idx).alignSequences(mixed), expm, "long contigs among short reads")
+    al = sl.BWAAligner(idx)
+    al.set("wide_index", 1)
+    assert_same(al.alignSequences(mixed), expm, "long contigs among short reads, u64 index")
+    for knobs in ((("long_budget", 0),), (("long_coop", 0),)):
+        al = sl.BWAAligner(idx)
+        for k, v in knobs:
+            al.set(k, v)
+        assert_same(al.alignSequences(seqs[2:5]), orc.align_batch(orc.default_opt(), oidx, seqs[2:5]), "reads beyond 65 kb %s" % (knobs,))
+    with pytest.raises(_ffi.SlxError) as e:
+        sl.BWAAligner(idx).alignSequences(["ACGT" * (_ffi.SLX_MAX_READ_LEN // 4 + 1)])
+    assert e.value.code == _ffi.SLX_EUNSUPPORTED
+
+
 def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
     """per-stage differential check (localises a mismatch): SMEM intervals after mem_collect_intv, kept chains with their seeds in
     extension order, and the region list as mem_chain2aln leaves it -- read by read against the oracle's stages, through the
