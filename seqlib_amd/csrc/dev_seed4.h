@@ -864,13 +864,14 @@ __global__ void __launch_bounds__(64) k_seed2_coop(DevFM<I> fm, DevRef R, Chunk 
 // in lock step for reads of equal length, with the forward step of this file (two masked popcounts per block instead of all four
 // symbol counts).
 template <typename I>
-__global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt)
+__global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, int par_min_len = 0x7fffffff)
 {
     const slx_opt &opt = dopt.o;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r < ck.n_reads;
+    bool live = r < ck.n_reads;
     const uint64_t qoff = live ? ck.offs[r] : 0;
-    const int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
+    int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
+    if (len >= par_min_len) { live = false; len = 0; }          // a contig: k_seed3_next + k_seed3_chase below
     const size_t ob = (size_t)(live ? r : 0) * ck.cap_intv;
     qp_t *oinfo = (qp_t *)ck.intv_info + ob;
     I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
@@ -928,6 +929,98 @@ __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck,
         }
     }
     if (!live) return;
+    ck.intv_n[r] = (uint32_t)n_out;
+    if (out_ovf) atomicOr(ck.flags, OVF_INTV);
+}
+
+// Pass 3 for contigs.  bwt_seed_strategy1 is restarted where the previous seed ended, so the walk over a read is a chain x -> next(x) --
+// ten thousand dependent walks for a 300 kb contig on its one lane (240 ms).  But what a walk from x does (where it ends, what it reports)
+// depends on x alone: k_seed3_next runs the walk from EVERY position of the long reads, one lane per position (the same state machine as
+// k_seed3m, started fresh at x), and k_seed3_chase follows the chain from 0 through the stored results, one lane per read, appending the
+// seeds of the positions it visits.  ~25 x the rank queries, all of them independent.  (The order the seeds are appended in does not
+// matter: k_seed_epi sorts them.)
+template <typename I>
+struct Seed3Next { int next, end; I x0, x2; };      // x2 = 0: nothing reported from this start
+
+template <typename I>
+__global__ void __launch_bounds__(256) k_seed3_next(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, int par_min_len, uint64_t n_bases, Seed3Next<I> *out)
+{
+    const slx_opt &opt = dopt.o;
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_bases || opt.max_mem_intv <= 0) return;
+    int lo = 0, hi = ck.n_reads;                        // the read holding base p
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ck.offs[mid] <= p) lo = mid; else hi = mid; }
+    const int r = lo;
+    const uint64_t qoff = ck.offs[r];
+    const int len = (int)(ck.offs[r + 1] - qoff);
+    if (len < par_min_len) return;
+    const int x0s = (int)(p - qoff);
+    QWin win; win.bits = 0; win.chunk = 0xffffffffu;
+    auto qb = [&](int q) { return q_at(ck.codes, qoff + (uint64_t)q, win); };
+    RWin rwin; rwin.bits = 0; rwin.chunk = -1;
+    const bool direct_ok = fm.sa_dense != nullptr;
+    const int K = (fm.lut && fm.lut_k <= opt.min_seed_len) ? fm.lut_k : 0;
+    const LutE<I> *lut = (const LutE<I> *)fm.lut;
+    Seed3Next<I> res; res.next = len; res.end = 0; res.x0 = 0; res.x2 = 0;
+    // ---- the entry of a fresh walk at x (k_seed3m's `fresh` block, one position only: where it moves x, that is this start's next)
+    int x = x0s, i = 0;
+    I k0 = 0, k1 = 0, k2 = 0;
+    bool started = false;
+    if (qb(x) > 3) res.next = x + 1;
+    else if (!K) { set_intv4<I>(fm, qb(x), k0, k1, k2); i = x + 1; started = true; }
+    else if (x + K > len) res.next = len;
+    else {
+        uint32_t fw, rc;
+        const int bad = kmer_codes(qb, x, K, fw, rc);
+        if (bad >= 0) res.next = x + bad + 1;
+        else { const LutE<I> e = lut[fw]; k0 = e.lo; k2 = e.sz; k1 = lut[rc].lo; i = x + K; started = true; }
+    }
+    // ---- the walk
+    bool dir = false;
+    int64_t dpos = 0;
+    while (started) {
+        if (i >= len) { res.next = len; break; }            // the read ends inside the walk: nothing reported
+        const int cq = qb(i);
+        if (cq > 3) { res.next = i + 1; break; }
+        I o0 = k0, o1 = k1, o2 = 0;
+        if (dir) {
+            const int64_t tp = dpos + (int64_t)(i - x);
+            o2 = (k2 != 0 && tp < (R.l_pac << 1) && text_at(R, tp, rwin) == cq) ? (I)1 : (I)0;
+        } else if (k2 != 0) fwd_step<I>(fm, k0, k1, k2, cq, o0, o1, o2);
+        if (o2 < (I)opt.max_mem_intv && i - x >= opt.min_seed_len) {
+            if (o2 > 0) { res.end = i + 1; res.x0 = o0; res.x2 = o2; }
+            res.next = i + 1;
+            break;
+        }
+        k0 = o0; k1 = o1; k2 = o2; ++i;
+        if (!dir && direct_ok && k2 == 1 && x + opt.min_seed_len - i >= 2) { dpos = fm_sa<I>(fm, k0); dir = true; }
+    }
+    out[p] = res;
+}
+
+template <typename I>
+__global__ void __launch_bounds__(64) k_seed3_chase(Chunk ck, DevOpt dopt, int par_min_len, const Seed3Next<I> *nx)
+{
+    const slx_opt &opt = dopt.o;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ck.n_reads || opt.max_mem_intv <= 0) return;
+    const uint64_t qoff = ck.offs[r];
+    const int len = (int)(ck.offs[r + 1] - qoff);
+    if (len < par_min_len) return;
+    const size_t ob = (size_t)r * ck.cap_intv;
+    qp_t *oinfo = (qp_t *)ck.intv_info + ob;
+    I *ox0 = (I *)ck.intv_x0 + ob, *ox2 = (I *)ck.intv_x2 + ob;
+    int n_out = (int)ck.intv_n[r];
+    bool out_ovf = false;
+    int x = len >= opt.min_seed_len ? 0 : len;
+    while (x < len) {
+        const Seed3Next<I> e = nx[qoff + (uint64_t)x];
+        if (e.x2 > 0) {
+            if (n_out < ck.cap_intv) { oinfo[n_out] = QP_PACK(x, e.end); ox0[n_out] = e.x0; ox2[n_out] = e.x2; ++n_out; }
+            else out_ovf = true;
+        }
+        x = e.next;
+    }
     ck.intv_n[r] = (uint32_t)n_out;
     if (out_ovf) atomicOr(ck.flags, OVF_INTV);
 }
