@@ -10,7 +10,9 @@
 #pragma once
 #include "dev_ext_reg.h"
 
+#ifndef XB_THREADS
 #define XB_THREADS 256
+#endif
 #define XB_WAVES (XB_THREADS / WAVE)
 
 struct XbShared {
@@ -217,6 +219,7 @@ __device__ ExtResult block_extend_side(int qlen, QF qf, int tlen, TF tf, const s
     const bool fits = (long long)h0 + (long long)qlen * (amax > 0 ? amax : 0) < (1 << 21) && h0 >= 0 && o.e_ins > 0 && o.e_del > 0 && qlen > 2 * WAVE && tlen >= 1;
     if (fits && 2 * w + 2 <= XB_THREADS) return block_ksw_extend2_band<1>(qlen, qf, tlen, tf, o, mr, w, h0, amax, S);
     if (fits && 2 * w + 2 <= 2 * XB_THREADS) return block_ksw_extend2_band<2>(qlen, qf, tlen, tf, o, mr, w, h0, amax, S);
+    if (fits && XB_THREADS < 256 && 2 * w + 2 <= 4 * XB_THREADS) return block_ksw_extend2_band<4>(qlen, qf, tlen, tf, o, mr, w, h0, amax, S);
     __syncthreads();
     if (threadIdx.x < WAVE) {
         const ExtResult r = reg_ksw_extend2_auto<0>(qlen, qf, tlen, tf, o, mr, w_in, end_bonus, h0, eh_h, eh_e, (int)threadIdx.x);
