@@ -22,6 +22,7 @@ it: `value_host_to_host` (pinned host reads -> host SoA hits through slx_align_b
 import argparse
 import ctypes as C
 import json
+import math
 import mmap
 import multiprocessing as mp
 import os
@@ -624,7 +625,7 @@ def main():
                 l_ref = sum(len(g) for _, g in refs)
                 foot_mb = (2 * l_ref / 4 * 2 + (128 << 20)) / 1e6          # occ planes (32 bytes per 64 symbols of the 2 x l_pac text, both strands) + the k-mer table
                 sizes = sorted(int(k) for k in ub)
-                at = next((m for m in sizes if m >= foot_mb), sizes[-1])
+                at = min(sizes, key=lambda m: abs(math.log(m / foot_mb)))          # the measured table size closest to the footprint
                 ceil_g = ub[str(at)]["g_reads_per_s"]
                 acc_g = per_read["n_occ_block"] * n / launches / (mean_launch_ms * 1e-3) / 1e9
                 roof["random_access"] = dict(accesses_per_read=per_read["n_occ_block"], achieved_g_per_s=acc_g, ceiling_from_ubench_g_per_s=ceil_g, frac=acc_g / ceil_g,
