@@ -377,6 +377,14 @@ __device__ DReg dev_extend_core(const DevRef &R, const slx_opt &opt, const MatRo
 #define EXT_JOB_WAVES 5       // waves/SIMD of the job kernels (k_ext_first, k_extend_cand): DP only, no per-read bookkeeping.  At 6 the DP loop spills
                               // (80 VGPRs + 580 B of scratch): k_ext_first 25.4 ms alone; at 5: 23.6 ms; at 4: 24.0; at 8: 34.1
 #endif
+// the counting sort of k_extend_reg's long-read walk: only the long instantiations own its LDS histogram
+template <int MAXQ> __device__ __forceinline__ bool dev_long_sort(int n) { return MAXQ > 704 && n > 4 * WAVE; }
+template <int MAXQ> __device__ __forceinline__ int *dev_long_sort_hist()
+{
+    if constexpr (MAXQ > 704) { __shared__ int s_hist[1024]; return s_hist; }
+    else return nullptr;
+}
+
 #ifndef EXT_MIN_WAVES
 #define EXT_MIN_WAVES 4
 #endif
@@ -517,6 +525,77 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     rank += kj < key ? 1 : 0;
                 }
                 if (mine) { sd_ql[rank] = ql; sd_rb[rank] = rb; sd_s[rank] = sid; my_ql = ql; my_rb = rb; my_rank = rank; }
+            } else if (dev_long_sort<MAXQ>(n)) {
+                // contigs: a chain of thousands of seeds.  The all-pairs count below is quadratic (a third of the walk's time for a 7 000-seed
+                // chain); the keys are (score, list index) and the scores of all but a few seeds are small integers, so: a counting sort by
+                // score -- histogram in LDS, exclusive scan, placement in index order (stable: the position among the equal scores of a block of
+                // 64 by a lane-by-lane comparison, among earlier blocks by a running count) -- and the all-pairs count only among the seeds
+                // whose score passes the last bucket.
+                constexpr int CS_CAP = 1024;
+                int *const s_hist = dev_long_sort_hist<MAXQ>();
+                auto score_of = [&](int sid, qp_t ql) { return w.s_score ? w.s_score[sid] : QP_LO(ql); };
+                for (int b = lane; b < CS_CAP; b += WAVE) s_hist[b] = 0;
+                __syncthreads();
+                for (int i = lane; i < n; i += WAVE) {
+                    const int sid = cs[i];
+                    const int sc = score_of(sid, w.s_ql[sid]);
+                    atomicAdd(&s_hist[sc < CS_CAP - 1 ? (sc > 0 ? sc : 0) : CS_CAP - 1], 1);
+                }
+                __syncthreads();
+                {   // exclusive scan over the buckets, 16 per lane
+                    int loc[CS_CAP / WAVE], sum = 0;
+#pragma unroll
+                    for (int u = 0; u < CS_CAP / WAVE; ++u) { loc[u] = s_hist[lane * (CS_CAP / WAVE) + u]; sum += loc[u]; }
+                    int run = dpp_incl_add_scan(sum) - sum;
+#pragma unroll
+                    for (int u = 0; u < CS_CAP / WAVE; ++u) { s_hist[lane * (CS_CAP / WAVE) + u] = run; run += loc[u]; }
+                }
+                __syncthreads();
+                const int big0 = __builtin_amdgcn_readfirstlane(s_hist[CS_CAP - 1]);          // first position of the seeds beyond the last bucket
+                for (int i0 = 0; i0 < n; i0 += WAVE) {
+                    const int i = i0 + lane;
+                    const bool mine = i < n;
+                    const int sid = mine ? cs[i] : 0;
+                    const qp_t ql = mine ? w.s_ql[sid] : (qp_t)0;
+                    const int64_t rb = mine ? w.s_rbeg[sid] : 0;
+                    const int sc = mine ? score_of(sid, ql) : 0;
+                    const int b = mine ? (sc < CS_CAP - 1 ? (sc > 0 ? sc : 0) : CS_CAP - 1) : -1;
+                    int lower = 0, same = 0;
+                    for (int j = 0; j < WAVE; ++j) {
+                        const int bj = __builtin_amdgcn_readlane(b, j);
+                        same += bj == b ? 1 : 0;
+                        lower += (bj == b && j < lane) ? 1 : 0;
+                    }
+                    const int base = mine ? s_hist[b] : 0;
+                    __syncthreads();
+                    if (mine && lower == same - 1) s_hist[b] = base + same;
+                    __syncthreads();
+                    const int pos = base + lower;
+                    if (mine) {
+                        if (b < CS_CAP - 1) { sd_ql[pos] = ql; sd_rb[pos] = rb; sd_s[pos] = sid; }
+                        else w.srt[pos] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(uint32_t)i;      // placed below, by (score, index)
+                    }
+                }
+                __threadfence_block();
+                for (int p0 = big0; p0 < n; p0 += WAVE) {
+                    const int p = p0 + lane;
+                    const bool mine = p < n;
+                    const uint64_t key = mine ? w.srt[p] : ~0ull;
+                    int rank = big0;
+                    for (int b0 = big0; b0 < n; b0 += WAVE) {
+                        const uint64_t kb = b0 + lane < n ? w.srt[b0 + lane] : ~0ull;
+                        const int nb = n - b0 < WAVE ? n - b0 : WAVE;
+                        for (int j = 0; j < nb; ++j) {
+                            const uint64_t kj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kb >> 32), j) << 32 |
+                                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kb, j);
+                            rank += kj < key ? 1 : 0;
+                        }
+                    }
+                    if (mine) {
+                        const int sid = cs[(int)(uint32_t)key];
+                        sd_ql[rank] = w.s_ql[sid]; sd_rb[rank] = w.s_rbeg[sid]; sd_s[rank] = sid;
+                    }
+                }
             } else {
                 for (int i = lane; i < n; i += WAVE) w.srt[i] = (uint64_t)(uint32_t)(w.s_score ? w.s_score[cs[i]] : w.s_len(cs[i])) << 32 | (uint64_t)i;
                 __threadfence_block();                                 // other lanes read these keys below
@@ -543,6 +622,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
             __threadfence_block();
             DBG_T1(t_sort);
             bool top_kept = false;                                 // was the chain's first (longest) seed extended?
+            [[maybe_unused]] int n_ext = 0;                        // contigs: sorted positions of the seeds of this chain taken so far, in w.ic[]
             for (int k = n - 1; k >= 0; --k) {
                 DBG_T0();
                 if (k == n - 2 && n <= WAVE && n_av <= 4) {
@@ -626,13 +706,17 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                 if (covered) {
                     // extend anyway only if a long overlapping seed of this chain (one taken before and not dropped) sits on another diagonal
                     bool other_diag = false;
-                    for (int base = k + 1; base < n && !other_diag; base += 4 * WAVE) {
+                    // (contigs: a chain has thousands of seeds, nearly all dropped -- and a dropped seed can never pass the test below -- so the scan
+                    // runs over the list of the seeds of this chain taken so far, w.ic[0 .. n_ext), instead of over every seed above k)
+                    const int scan_lo = MAXQ > 704 ? 0 : k + 1, scan_hi = MAXQ > 704 ? n_ext : n;
+                    for (int base = scan_lo; base < scan_hi && !other_diag; base += 4 * WAVE) {
                         bool hit = false;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int ti0 = base + u * WAVE + lane;
-                            const bool valid = ti0 < n;
-                            const int ti = valid ? ti0 : n - 1;
+                            const bool valid = ti0 < scan_hi;
+                            int ti = valid ? ti0 : scan_hi - 1;
+                            if constexpr (MAXQ > 704) ti = w.ic[ti];
                             const qp_t tq = sd_ql[ti];
                             const int64_t t_rbeg = sd_rb[ti];
                             const int t_qbeg = QP_HI(tq), t_len = QP_LO(tq);       // a dropped seed has length 0 here
@@ -672,6 +756,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                                 }
                                 if (lane == (n_miss & 63)) pend_diag = s_rbeg - s_qbeg;
                                 ++n_miss;
+                                w.ic[n_ext++] = k;                            // taken (its length stays): every lane stores the same word
                                 if (k == n - 1) top_kept = true;
                                 if (n_miss >= sp.budget) { give_up = true; break; }
                                 continue;                                   // extended, region unknown: nothing joins the list
@@ -690,6 +775,7 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                     a.seedcov = cov;
                 }
                 if (k == n - 1) top_kept = true;
+                if constexpr (MAXQ > 704) w.ic[n_ext++] = k;
                 // every lane stores the same bytes (region + its keys for the covered test), so every lane may read them back
                 w.regs[n_av] = a;
                 rg_rb[n_av] = a.rb; rg_re[n_av] = a.re; rg_q[n_av] = QP_PACK(a.qb, a.qe); rg_w[n_av] = a.w; rg_sl0[n_av] = a.seedlen0;
