@@ -318,6 +318,9 @@ def test_cpp_record_blobs_match_oracle(exe, golden_dir, tmp_path, hardclip):
     reads.append(refs[2][100:250][:75] + "acgtn" + refs[2][100:250][80:])     # mixed case inside
     reads.append(refs[3][300:340])                                             # short
     reads.append("ACGTACGTAC")                                                 # no alignment: no record
+    contig = list(refs[1][2000:72000])                                         # a 70 kb contig (the pipeline with 64-bit packed positions) with an insertion and
+    contig[30000:30000] = list("ACGTTGCATT")                                   # a junction to another locus: a long CIGAR, a supplementary-like second record
+    reads.append("".join(contig) + refs[0][90000:93000])
     names_r = ["q%d" % i for i in range(len(reads))]
     path = tmp_path / "reads.tsv"
     path.write_text("".join("%s\t%s\n" % (n, r) for n, r in zip(names_r, reads)))

@@ -828,6 +828,66 @@ def test_option_fuzz_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_
         assert_same(al.alignSequences(base), orc.align_batch(o, tiny_index, base), what)
 
 
+def test_option_fuzz_on_contig_length_reads(sl, orc, tmp_path):
+    """the long-read forms of the extension (band in registers on a wave and on a block, LDS-ring and HBM rows beyond them), of the CIGAR
+    and of the region stage under other band widths (3 .. 300: the register window holds 2 w + 2 <= 448 columns, wider bands fall back),
+    z-drop on and off, clipping and gap penalties, scores scaled by a = 3 -- on contigs of 3 kb .. 140 kb with substitutions, indels of
+    1 .. 60 bp, a chimeric junction and a tandem-repeat end; bit-exact vs the oracle, narrow and wide pipeline in one batch"""
+    from seqlib_amd import synth
+    rng = np.random.default_rng(4242)
+    g = synth.make_genome(400000, seed=977).copy()
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    g[250000:250180] = np.array([code[c] for c in b"GATTAC" * 30], dtype=np.uint8)
+    ref = synth.genome_ascii(g)
+    prefix = str(tmp_path / "fuzzlong")
+    orc.Index.build(["chrF"], [ref]).write(prefix)
+    oidx = orc.Index.load(prefix)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+
+    def edit(t, n_sub, indels):
+        t = list(t)
+        for _ in range(n_sub):
+            t[int(rng.integers(0, len(t)))] = "ACGT"[int(rng.integers(0, 4))]
+        for L in indels:
+            p = int(rng.integers(200, len(t) - 200))
+            if L > 0:
+                t[p:p] = list("".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=L)))
+            else:
+                del t[p:p - L]
+        return "".join(t)
+
+    seqs = [edit(ref[1000:4000], 6, (3,)), edit(ref[10000:19500], 40, (-1, 12, -25)), orc_revcomp(edit(ref[30000:62000], 100, (60, -60, 5))),
+            edit(ref[100000:180000], 300, (-8, 30)), edit(ref[200000:250090], 50, (2,)),
+            edit(ref[260000:330000], 150, ()) + edit(ref[50000:120000], 150, (-3,)),          # 140 kb chimera
+            ref[340000:352000]]
+    for trial in range(6):
+        o = orc.default_opt()
+        al = sl.BWAAligner(idx)
+
+        def put(name, v):
+            setattr(o, name, v); setattr(al.opt, name, v)
+        put("w", (100, 3, 25, 150, 300, 60)[trial])
+        put("zdrop", (100, 0, 40, 200, 100, 10)[trial])
+        put("a", (1, 1, 3, 1, 2, 1)[trial])
+        put("b", int(rng.integers(2, 9)))
+        for f in ("o_del", "o_ins"):
+            put(f, int(rng.integers(2, 13)))
+        for f in ("e_del", "e_ins"):
+            put(f, int(rng.integers(1, 4)))
+        put("pen_clip5", int(rng.integers(0, 11))); put("pen_clip3", int(rng.integers(0, 11)))
+        put("max_chain_gap", int(rng.choice([1000, 10000])))
+        orc.lib().orc_fill_scmat(o.a, o.b, o.mat)
+        for i in range(25):
+            al.opt.mat[i] = o.mat[i]
+        if trial == 3:
+            al.set("long_block", 0)
+        if trial == 4:
+            al.set("long_budget", 3)
+        what = "long fuzz %d: " % trial + " ".join("%s=%s" % (f, getattr(o, f)) for f in ("w", "zdrop", "a", "b", "o_del", "o_ins", "e_del", "e_ins", "pen_clip5", "pen_clip3"))
+        assert_same(al.alignSequences(seqs), orc.align_batch(o, oidx, seqs), what)
+
+
 def test_option_fuzz_and_record_mode_on_a_repeat_rich_block(sl, orc, tmp_path):
     """The option space and bwa's own record rules on data that reaches the repeat / heavy-read / big-table kernels: a chr20_syn
     (C3) block thinned to 20 000 reads -- every read of a 131 072-read block with two or more hits, low-complexity reads, the rest at
