@@ -756,10 +756,20 @@ __global__ void __launch_bounds__(64, EXT_MIN_WAVES) k_extend_reg(DevRef R, Chun
                                 }
                                 if (lane == (n_miss & 63)) pend_diag = s_rbeg - s_qbeg;
                                 ++n_miss;
-                                w.ic[n_ext++] = k;                            // taken (its length stays): every lane stores the same word
                                 if (k == n - 1) top_kept = true;
                                 if (n_miss >= sp.budget) { give_up = true; break; }
-                                continue;                                   // extended, region unknown: nothing joins the list
+                                if (!(sp.predict && k == n - 1)) {
+                                    w.ic[n_ext++] = k;                        // taken (its length stays): every lane stores the same word
+                                    continue;                               // extended, region unknown: nothing joins the list
+                                }
+                                // first round, the chain's top seed: its region is GUESSED to run along its diagonal over the whole read (what the
+                                // main alignment of a contig does), so that this walk already finds the seeds on other diagonals that will
+                                // need their own extension -- their jobs then run in the same launch as the top seeds'.  The walk's result is
+                                // discarded either way (n_miss > 0); the next one sees the real regions.
+                                a.rb = s_rbeg - s_qbeg; a.re = s_rbeg + (l_query - s_qbeg); a.qb = 0; a.qe = l_query;
+                                a.rb = a.rb > rmax0 ? a.rb : rmax0; a.re = a.re < rmax1 ? a.re : rmax1;
+                                a.w = opt.w; a.seedlen0 = s_len; a.score = a.truesc = 0; a.rid = w.c_rid[c];
+                                a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0; a.n_comp = 0; a.hash = 0; a.frac_rep = frac_rep;
                             }
                         } else a = dev_extend_core<NCH>(R, opt, mr, query, l_query, s_qbeg, s_len, s_rbeg, rmax0, rmax1, w.c_rid[c], frac_rep, eh_h, eh_e, lane);
                     }

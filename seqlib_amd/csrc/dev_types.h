@@ -78,6 +78,7 @@ struct ExtSpec {
     int *todo_next = nullptr;          // reads that missed something this round
     unsigned int *n_todo_next = nullptr;
     int budget = 0;                    // 0: this mode is off
+    int predict = 0;                   // 1 (the first round): the top seed of a chain, not extended yet, is given a guessed region (its diagonal, the whole read)
     int guess = 0;                     // 1: once a seed is pending, seeds within the band of its diagonal are taken to be covered by its region
 };
 

@@ -425,6 +425,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "coop_lim2")) { if (value < 1) return SLX_EINVAL; al->coop_lim2 = (int)value; }
     else if (!strcmp(key, "long_coop")) al->long_coop = value != 0;
     else if (!strcmp(key, "long_seed3")) al->long_seed3 = value != 0;
+    else if (!strcmp(key, "long_predict")) al->long_predict = value != 0;
     else if (!strcmp(key, "long_block")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->long_block = (int)value; }
     else if (!strcmp(key, "long_guess")) al->long_guess = value != 0;
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }

@@ -125,6 +125,9 @@ struct slx_aligner {
     int64_t chunk_reads = 1 << 24;  // one chunk per worker for a 10 M-read batch: the heavy-tail reads are then paid for once
     int cap_intv = 40;
     int cap_intv_long = 0;          // what chunks of long reads needed (kept apart from cap_intv)
+    int long_predict = 0;         // 1 = contigs: the first extension round guesses the regions of the chains' top seeds instead of waiting for them
+                                  // (ExtSpec::predict).  Measured on C5's contigs: 4 rounds / 2 444 jobs / 693 ms of extension against 2 rounds / 1 468 jobs /
+                                  // 697 ms -- where the guess is wrong a full-length job shows up a round later all the same: off
     int long_block = 4096;        // contigs: a round of at most this many extension jobs runs four waves per job (k_ext_block); 0 = always one wave per job
     int long_seed3 = 1;           // contigs: pass 3 of seeding one lane per position + a chase per read (k_seed3_next / k_seed3_chase); 0 = one lane per read
     int long_coop = 1;            // contigs (reads beyond 704 bp): chaining one wave per read (k_chain_coop) for the reads with many seed occurrences; 0 = one lane per read

@@ -357,7 +357,7 @@ def test_reads_beyond_the_16_bit_packings(sl, orc, tmp_path):
     al = sl.BWAAligner(idx)
     al.set("wide_index", 1)
     assert_same(al.alignSequences(mixed), expm, "long contigs among short reads, u64 index")
-    for knobs in ((("long_budget", 0),), (("long_coop", 0),), (("long_seed3", 0),), (("long_block", 0),)):
+    for knobs in ((("long_budget", 0),), (("long_coop", 0),), (("long_seed3", 0),), (("long_block", 0),), (("long_predict", 0),)):
         al = sl.BWAAligner(idx)
         for k, v in knobs:
             al.set(k, v)
