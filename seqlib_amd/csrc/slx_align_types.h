@@ -68,6 +68,7 @@ struct Worker {
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
+    DevBuf job_key_in, job_key_out, job_val_in, job_val_out, job_sort_tmp;         // contigs: extension jobs ordered longest first
     DevBuf seed3_buf;                                                              // contigs: pass 3 of seeding from every position (k_seed3_next)
     DevBuf memo_idx, memo_jobs, memo_tab, round_list, todo_a, todo_b, spec_cnt;     // long reads: extension in rounds (ExtSpec, dev_types.h)
     int long_rounds_run = 0; unsigned int long_jobs_run = 0;                       // ... what the last long chunk took
@@ -96,7 +97,7 @@ struct Worker {
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
                &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
-               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf,
+               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -128,7 +129,7 @@ struct slx_aligner {
     int long_predict = 0;         // 1 = contigs: the first extension round guesses the regions of the chains' top seeds instead of waiting for them
                                   // (ExtSpec::predict).  Measured on C5's contigs: 4 rounds / 2 444 jobs / 693 ms of extension against 2 rounds / 1 468 jobs /
                                   // 697 ms -- where the guess is wrong a full-length job shows up a round later all the same: off
-    int long_block = 4096;        // contigs: a round of at most this many extension jobs runs four waves per job (k_ext_block); 0 = always one wave per job
+    int long_block = 32768;       // contigs: a round of at most this many extension jobs runs four waves per job (k_ext_block); 0 = always one wave per job
     int long_seed3 = 1;           // contigs: pass 3 of seeding one lane per position + a chase per read (k_seed3_next / k_seed3_chase); 0 = one lane per read
     int long_coop = 1;            // contigs (reads beyond 704 bp): chaining one wave per read (k_chain_coop) for the reads with many seed occurrences; 0 = one lane per read
     int long_guess = 0;           // (see ExtSpec::guess; measured on C5's contigs: 254 ms of extension without the guess, 370 with it)
