@@ -407,8 +407,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_to_host / value_bamrecords")
     ap.add_argument("--verify", type=int, default=20000, help="reads of the timed batch checked bit-for-bit against the oracle")
-    ap.add_argument("--windows", type=int, default=32, help="C5: windows per GPU and step (the stages of the longest contig are single-wave long poles: more windows per "
-                                                            "step fill the chip under them -- 8: 0.48 M reads/s, 16: 0.71 M, 32: 1.2 M, 64: 1.65 M on one MI355X)")
+    ap.add_argument("--windows", type=int, default=64, help="C5: windows per GPU and step (the stages of the longest contig are single-wave long poles: more windows per "
+                                                            "step fill the chip under them -- 8: 0.51 M reads/s, 32: 1.34 M, 64: 2.05 M on one MI355X)")
     ap.add_argument("--no-pipeline", action="store_true", help="C5: assemble and realign one after the other inside a step (default: step k + 1's assembly overlaps step k's realignment)")
     ap.add_argument("--coverage", type=float, default=30.0, help="C5: read coverage of a window")
     args = ap.parse_args()
