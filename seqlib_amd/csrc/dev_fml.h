@@ -23,6 +23,7 @@ struct FmlWin {                // per window, device-visible
     int k, min_cov, mode;
     long long read0, read1;             // reads [read0, read1)
     long long pos0;                     // first text position of the window (= offs[read0])
+    unsigned int part0, part_mask;      // partitioned counting (k_fml_bin / k_fml_part): first partition of the window, partitions - 1 (a power of two)
 };
 
 struct FmlPlanes { const unsigned long long *p0, *p1, *pn, *pq, *ps; };      // index = block + 1 (block -1 is a guard: all N)
@@ -152,6 +153,129 @@ static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long lon
     }
     const unsigned long long m = __ballot(ok);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&stats[0], (unsigned long long)__popcll(m));
+}
+
+// ---- fml_count in two passes, without the contended global atomics of k_fml_count.  At 30x coverage a k-mer is inserted ~25 times, and
+// each insert of k_fml_count is a device-scope read-modify-write on a 16-byte slot somewhere in a table of hundreds of megabytes: the
+// memory side serves ~4.3 G of them per second, whatever the table's size.  Here the k-mers are first BINNED by the high bits of their
+// hash into partitions of ~8-16 K k-mers (k_fml_bin: a block counts its tile's k-mers per partition in LDS, reserves a stretch of each
+// partition with ONE global atomic, and writes the 8-byte items there), then each partition is counted by one block in an LDS hash table
+// (k_fml_part: LDS atomics), and every distinct k-mer is inserted into the window's table once, uncontended.  A partition or an LDS table
+// that overflows raises a flag and the host counts the batch again with k_fml_count.
+#define FML_BIN_TILE 16384          // text positions per block of k_fml_bin
+#define FML_PART_CAP 20736          // items a partition holds (1.25 x the 16 K mean at most + slack)
+#define FML_PART_SLOTS 4096         // LDS table of k_fml_part
+#define FML_PART_MAX 4096           // partitions per window at most (LDS counters of k_fml_bin)
+
+__device__ __forceinline__ bool fml_kmer_at(const FmlPlanes &pl, long long p, const FmlWin &w, unsigned long long &key, bool &hq)
+{
+    const int k = w.k;
+    const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+    if (!(k > 0 && fml_extract(pl.pn, p, mask) == 0 && (fml_extract(pl.ps, p, mask) & (mask >> 1)) == 0)) return false;
+    key = fml_key(k, fml_extract(pl.p0, p, mask), fml_extract(pl.p1, p, mask), mask);
+    hq = fml_extract(pl.pq, p, mask) == mask;
+    return true;
+}
+
+static __global__ void __launch_bounds__(256) k_fml_bin(FmlPlanes pl, long long total, const FmlWin *wins, int n_win, unsigned int *cursor, unsigned long long *items,
+                                                 unsigned long long *stats)
+{
+    __shared__ unsigned int s_cnt[FML_PART_MAX], s_base[FML_PART_MAX];
+    __shared__ unsigned int s_valid;
+    const long long t0 = (long long)blockIdx.x * FML_BIN_TILE;
+    int lo = 0, hi = n_win;                                     // the window of the tile's first position: its partitions are counted in LDS
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].pos0 <= t0) lo = mid; else hi = mid; }
+    const FmlWin w0 = wins[lo];
+    const long long w0_end = lo + 1 < n_win ? wins[lo + 1].pos0 : total;
+    for (unsigned int i = threadIdx.x; i <= w0.part_mask; i += 256) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    unsigned int n_valid = 0;
+    for (int it = 0; it < FML_BIN_TILE / 256; ++it) {
+        const long long p = t0 + it * 256 + threadIdx.x;
+        if (p >= total || p >= w0_end) continue;                // (positions of later windows: second pass)
+        unsigned long long key; bool hq;
+        if (!fml_kmer_at(pl, p, w0, key, hq)) continue;
+        ++n_valid;
+        atomicAdd(&s_cnt[(unsigned int)(fml_mix64(key) >> 40) & w0.part_mask], 1u);
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i <= w0.part_mask; i += 256) {
+        const unsigned int c = s_cnt[i];
+        s_base[i] = c ? atomicAdd(&cursor[w0.part0 + i], c) : 0u;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < FML_BIN_TILE / 256; ++it) {
+        const long long p = t0 + it * 256 + threadIdx.x;
+        if (p >= total) continue;
+        if (p < w0_end) {
+            unsigned long long key; bool hq;
+            if (!fml_kmer_at(pl, p, w0, key, hq)) continue;
+            const unsigned int lp = (unsigned int)(fml_mix64(key) >> 40) & w0.part_mask;
+            const unsigned int at = s_base[lp] + atomicAdd(&s_cnt[lp], 1u);
+            if (at < FML_PART_CAP) items[(unsigned long long)(w0.part0 + lp) * FML_PART_CAP + at] = key | (hq ? 1ULL << 63 : 0ULL);
+            else stats[2] = 1;
+        } else {                                                // a tile that runs into the next window(s): those k-mers one global atomic each
+            int l2 = lo, h2 = n_win;
+            while (h2 - l2 > 1) { const int mid = (l2 + h2) >> 1; if (wins[mid].pos0 <= p) l2 = mid; else h2 = mid; }
+            const FmlWin w = wins[l2];
+            unsigned long long key; bool hq;
+            if (!fml_kmer_at(pl, p, w, key, hq)) continue;
+            ++n_valid;
+            const unsigned int gp = w.part0 + ((unsigned int)(fml_mix64(key) >> 40) & w.part_mask);
+            const unsigned int at = atomicAdd(&cursor[gp], 1u);
+            if (at < FML_PART_CAP) items[(unsigned long long)gp * FML_PART_CAP + at] = key | (hq ? 1ULL << 63 : 0ULL);
+            else stats[2] = 1;
+        }
+    }
+    atomicAdd(&s_valid, n_valid);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&stats[0], (unsigned long long)s_valid);
+}
+
+static __global__ void __launch_bounds__(256) k_fml_part(const unsigned int *cursor, const unsigned long long *items, const FmlWin *wins, int n_win, FmlSlot *tab,
+                                                  unsigned long long *stats)
+{
+    __shared__ unsigned long long s_key[FML_PART_SLOTS];
+    __shared__ unsigned int s_val[FML_PART_SLOTS];              // occurrences | high-quality occurrences << 16 (a partition holds < 2^16 items)
+    const unsigned int gp = blockIdx.x;
+    unsigned int n = cursor[gp];
+    if (n == 0) return;
+    if (n > FML_PART_CAP) n = FML_PART_CAP;                     // (the overflow is flagged by k_fml_bin)
+    int lo = 0, hi = n_win;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].part0 <= gp) lo = mid; else hi = mid; }
+    const FmlWin w = wins[lo];
+    for (int i = threadIdx.x; i < FML_PART_SLOTS; i += 256) { s_key[i] = 0; s_val[i] = 0; }
+    __syncthreads();
+    const unsigned long long *src = items + (unsigned long long)gp * FML_PART_CAP;
+    for (unsigned int i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long it = src[i];
+        const unsigned long long key = it & ~(1ULL << 63);
+        const unsigned int inc = 1u | (unsigned int)(it >> 63) << 16;
+        unsigned int s = (unsigned int)(fml_mix64(key) >> 20) & (FML_PART_SLOTS - 1), probes = 0;
+        while (true) {
+            unsigned long long old = s_key[s];
+            if (old == 0) old = atomicCAS(&s_key[s], 0ULL, key + 1);
+            if (old == 0 || old == key + 1) { atomicAdd(&s_val[s], inc); break; }
+            s = (s + 1) & (FML_PART_SLOTS - 1);
+            if (++probes >= FML_PART_SLOTS) { stats[2] = 1; break; }
+        }
+    }
+    __syncthreads();
+    FmlSlot *t = tab + w.tab_off;
+    for (int i = threadIdx.x; i < FML_PART_SLOTS; i += 256) {
+        const unsigned long long k1 = s_key[i];
+        if (!k1) continue;
+        const unsigned int v = s_val[i];
+        unsigned int j = (unsigned int)fml_mix64(k1 - 1) & w.tab_mask, probes = 0;
+        while (true) {                                          // every k-mer lives in ONE partition: the slot is claimed once, its count stored plainly
+            const unsigned long long old = atomicCAS(&t[j].key, 0ULL, k1);
+            if (old == 0) { t[j].cnt = (unsigned long long)(v & 0xffffu) | (unsigned long long)(v >> 16) << 32; break; }
+            j = (j + 1) & w.tab_mask;
+            if (++probes > w.tab_mask) { stats[1] = 1; break; }
+        }
+    }
 }
 
 // bfc_ch_hist: blocks of 1024 slots never straddle two windows (tables are powers of two >= 1024, laid end to end)

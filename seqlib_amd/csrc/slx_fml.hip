@@ -75,6 +75,7 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     FML_HIPCHK(hipSetDevice(device));
     slx_fml *f = new slx_fml();
     f->device = device;
+    if (const char *e = getenv("SLX_FML_PART")) f->use_part = atoi(e) != 0;           // experiment / test hook: 0 = fml_count with one atomic per k-mer only
     if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&f->ev0);
@@ -120,6 +121,8 @@ extern "C" int64_t slx_fml_counter(const slx_fml *f, const char *key)
     if (k == "big_vertices") return f->n_big_vertices;
     if (k == "huge_vertices") return f->n_huge_vertices;
     if (k == "host_threads") return fml_host_cpus();
+    if (k == "count_partitions") return (int64_t)f->n_parts;
+    if (k == "count_fallbacks") return f->n_part_fallbacks;
     return -1;
 }
 
@@ -168,6 +171,8 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
     f->wins.assign((size_t)std::max(n_win, 1), FmlWin());
     f->wopt.assign((size_t)std::max(n_win, 1), *opt);
     uint64_t slots = 0;
+    unsigned int parts = 0;
+    f->part_ok = f->use_part;
     for (int w = 0; w < n_win; ++w) {
         const int64_t r0 = win_off[w], r1 = win_off[w + 1];
         if (r0 < 0 || r1 < r0 || r1 > f->n_reads || (w == 0 && r0 != 0) || (w == n_win - 1 && r1 != f->n_reads)) {
@@ -183,6 +188,13 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
         d.k = k > 0 ? k : 0;          // ec_k < 0: no table
         d.min_cov = o.min_cnt; d.mode = -1;
         d.read0 = r0; d.read1 = r1; d.pos0 = (long long)f->h_offs[(size_t)r0];
+        {   // partitions of the two-pass count: a power of two, ~8-16 K k-mers each
+            unsigned int pw = 1;
+            while ((uint64_t)pw * 16384u < tot && pw < FML_PART_MAX) pw <<= 1;
+            if ((uint64_t)pw * 16384u < tot) f->part_ok = false;          // a window beyond 64 M bases: k_fml_count
+            d.part0 = parts; d.part_mask = pw - 1;
+            parts += pw;
+        }
         // a table of (bases of the window) / tab_div slots: at 30x coverage a tenth of the k-mers are distinct, and a table that small
         // stays in the last-level cache, where the atomics are; fml_run_count enlarges it (x 4) when a window fills it past 70 %
         uint64_t cap = 1024;
@@ -191,7 +203,7 @@ int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off
         d.tab_off = slots; d.tab_mask = (unsigned int)(cap - 1);
         slots += cap;
     }
-    f->n_win = n_win; f->n_slots = slots;
+    f->n_win = n_win; f->n_slots = slots; f->n_parts = parts;
     int rc;
     if ((rc = f->d_tab.ensure((size_t)std::max<uint64_t>(slots, 1) * sizeof(FmlSlot))) || (rc = f->d_wins.ensure(f->wins.size() * sizeof(FmlWin)))) return rc;
     FML_HIPCHK(hipMemcpyAsync(f->d_wins.p, f->wins.data(), f->wins.size() * sizeof(FmlWin), hipMemcpyHostToDevice, f->st));
@@ -234,6 +246,28 @@ static int run_count_once(slx_fml *f, int q, bool *too_small)
         hipLaunchKernelGGL(k_fml_pack, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr,
                            (long long)total, q, p0, p1, pn, pq);
         FmlPlanes P{p0, p1, pn, pq, ps};
+        // large batches: bin the k-mers into partitions, count each partition in LDS, insert every distinct k-mer once (dev_fml.h); else, and when
+        // a partition overflows, one contended atomic per k-mer
+        bool by_parts = f->part_ok && f->n_parts > 0 && total >= (1 << 20) &&
+                        f->d_cursor.ensure((size_t)f->n_parts * 4 + 64) == SLX_OK && f->d_items.ensure((size_t)f->n_parts * FML_PART_CAP * 8 + 64) == SLX_OK;
+        if (by_parts) {
+            FML_HIPCHK(hipMemsetAsync(f->d_cursor.p, 0, (size_t)f->n_parts * 4 + 64, f->st));
+            hipLaunchKernelGGL(k_fml_bin, dim3((unsigned)((total + FML_BIN_TILE - 1) / FML_BIN_TILE)), dim3(256), 0, f->st, P, (long long)total, f->d_wins.as<FmlWin>(), f->n_win,
+                               f->d_cursor.as<unsigned int>(), f->d_items.as<unsigned long long>(), f->d_stats.as<unsigned long long>());
+            hipLaunchKernelGGL(k_fml_part, dim3(f->n_parts), dim3(256), 0, f->st, (const unsigned int *)f->d_cursor.as<unsigned int>(), (const unsigned long long *)f->d_items.as<unsigned long long>(),
+                               f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
+            FML_HIPCHK(hipGetLastError());
+            unsigned long long st3[3] = {0, 0, 0};
+            FML_HIPCHK(hipMemcpyAsync(st3, f->d_stats.p, 24, hipMemcpyDeviceToHost, f->st));
+            FML_HIPCHK(hipStreamSynchronize(f->st));
+            if (st3[2]) {                                     // a partition or its LDS table overflowed (low coverage, one k-mer thousands of times): count again the plain way
+                by_parts = false;
+                ++f->n_part_fallbacks;
+                FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
+                FML_HIPCHK(hipMemsetAsync(f->d_stats.p, 0, 256, f->st));
+            }
+        }
+        if (!by_parts)
         hipLaunchKernelGGL(k_fml_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, f->st, P, (long long)total, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
                            f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
         FML_HIPCHK(hipGetLastError());

@@ -56,15 +56,19 @@ struct slx_fml {
     // BFC::Train's table, kept between calls
     bool have_count = false, staged = false;
     FmlWin count_win;
-    FmlDevBuf d_bases0, d_quals0, d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_stats, d_tri, d_index, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+    FmlDevBuf d_bases0, d_quals0, d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_stats, d_tri, d_index, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5, d_cursor, d_items;
     float probe[SLX_FML_N_PROBES] = {0, 0, 0, 0, 0, 0};
     int64_t n_inserted = 0, n_bases = 0, n_distinct = 0;
+    bool use_part = true;                   // fml_count by partitions (k_fml_bin + k_fml_part) when the batch is large enough; SLX_FML_PART=0 turns it off
+    bool part_ok = false;                   // ... and the windows of this batch fit the partition limits
+    unsigned int n_parts = 0;
+    int64_t n_part_fallbacks = 0;
     int tab_div = 8, tab_grow = 1;          // table slots = 2 x bases x tab_grow / tab_div, a power of two (adapts when a table fills up)
     int64_t n_overlaps = 0, n_irreducible = 0, asm_text_len = 0, n_big_vertices = 0, n_huge_vertices = 0, n_strings = 0;
     unsigned long long tri_per_str = 40;          // of the last assemble call
     std::vector<FmlDevBuf *> all_bufs()
     {
-        return {&d_bases0, &d_quals0, &d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_stats, &d_tri, &d_index, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5};
+        return {&d_bases0, &d_quals0, &d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_stats, &d_tri, &d_index, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5, &d_cursor, &d_items};
     }
     void reset_probes() { for (float &p : probe) p = 0; n_inserted = 0; n_bases = 0; }
 };
