@@ -344,8 +344,8 @@ def main_c5(args):
             match = float(len(got) == len(exp) and all(a["seq"] == e["seq"] and a["cov"] == e["cov"] and a["ovlp"] == e["ovlp"] for a, e in zip(got, exp)))
             ctx.stage(bases, quals, offs)
         cpu = None if args.no_cpu_baseline else c5_cpu_baseline(args.coverage, read_len, 20000)
-        # the k-mer counting kernel against the HBM roofline: per inserted k-mer one 16-byte table slot read and written back, per base
-        # the ASCII base and quality read once by the plane kernel
+        # the k-mer counting kernels against the HBM roofline: per inserted k-mer one 16-byte table slot read and written back (what fml_count's
+        # hash table does per k-mer: the algorithmic figure), per base the ASCII base and quality read once by the plane kernel
         steps = max(args.steps, 1)
         count_ms = acc.get("count", 0.0) / steps / 2.0          # two launches per step: before the correction and before the filter
         alg = (32.0 * ins_acc + 2.0 * nb_acc) / steps / 2.0
@@ -356,8 +356,9 @@ def main_c5(args):
         except Exception:
             pass
         traffic = pmc.get("count_fetch_plus_write_bytes_per_launch") if pmc and pmc.get("reads_per_launch") == n_reads else None
-        roof = dict(bound="hbm", kernel="k_fml_count (+ k_fml_pack, k_fml_starts): k-mer counting of the FermiAssembler pipeline, one lane per text position, "
-                                         "atomic insert into per-window open-addressing tables", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+        roof = dict(bound="hbm", kernel="k-mer counting of the FermiAssembler pipeline (k_fml_starts, k_fml_pack, k_fml_bin, k_fml_part): one lane per text position; k-mers binned "
+                                         "by hash into partitions, each partition counted in an LDS table, every distinct k-mer inserted once into its window's table",
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS if achieved else None, traffic=traffic,
                     traffic_source=("profiles/%s_c5_pmc_summary.json (separate rocprofv3 --pmc passes of this command)" % ROUND) if traffic else None,
                     achieved_basis="ALGORITHMIC bytes per launch (32 B per inserted k-mer: its 16-byte slot read and written; 2 B per base: ASCII base + quality) / "

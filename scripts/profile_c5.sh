@@ -29,13 +29,16 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
 bench = json.loads(open(out + "/c5_bench_under_rocprof.json").read().strip().splitlines()[-1])
 kern = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 launches = {k: max(len(v) for v in d.values()) for k, d in acc.items()}
-cnt = kern.get("k_fml_count", {})
+cnt = collections.defaultdict(float)          # the counting kernels together (k_fml_count is the fallback for small batches)
+for name in ("k_fml_bin", "k_fml_part", "k_fml_count", "k_fml_pack", "k_fml_starts"):
+    for c, v in kern.get(name, {}).items():
+        cnt[c] += v
 n_reads = bench["config"]["windows_per_gpu"] * bench["config"]["reads_per_window"]
 res = {
     "command": "bench.py --config C5 --steps 2 --warmup 1 (separate rocprofv3 --pmc passes, --kernel-trace only)",
     "reads_per_launch": n_reads,
     "units": "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them, x 1024 here; FETCH_SIZE is known to under-report wide coalesced streams 2x on gfx950 "
-             "(MI355X_MICROARCH.md) -- k_fml_count's table traffic is 16-byte atomics at random slots, for which no calibration exists, so the raw value is given",
+             "(MI355X_MICROARCH.md) -- the counting kernels' traffic is 8-byte scattered item writes and uncontended slot inserts, for which no calibration exists, so the raw value is given",
     "count_fetch_bytes_per_launch": cnt.get("FETCH_SIZE", 0.0) * 1024.0 or None,
     "count_write_bytes_per_launch": cnt.get("WRITE_SIZE", 0.0) * 1024.0 or None,
     "count_fetch_plus_write_bytes_per_launch": (cnt.get("FETCH_SIZE", 0.0) + cnt.get("WRITE_SIZE", 0.0)) * 1024.0 or None,

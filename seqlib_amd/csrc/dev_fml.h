@@ -167,6 +167,19 @@ static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long lon
 #define FML_PART_SLOTS 4096         // LDS table of k_fml_part
 #define FML_PART_MAX 4096           // partitions per window at most (LDS counters of k_fml_bin)
 
+// one insert into a window's table (what k_fml_count does per k-mer); false = the table is full
+__device__ __forceinline__ bool fml_insert(FmlSlot *t, unsigned int tab_mask, unsigned long long key, unsigned long long inc)
+{
+    unsigned int i = (unsigned int)fml_mix64(key) & tab_mask, probes = 0;
+    while (true) {
+        unsigned long long old = t[i].key;
+        if (old == 0) old = atomicCAS(&t[i].key, 0ULL, key + 1);
+        if (old == 0 || old == key + 1) { atomicAdd(&t[i].cnt, inc); return true; }
+        i = (i + 1) & tab_mask;
+        if (++probes > tab_mask) return false;
+    }
+}
+
 __device__ __forceinline__ bool fml_kmer_at(const FmlPlanes &pl, long long p, const FmlWin &w, unsigned long long &key, bool &hq)
 {
     const int k = w.k;
@@ -178,7 +191,7 @@ __device__ __forceinline__ bool fml_kmer_at(const FmlPlanes &pl, long long p, co
 }
 
 static __global__ void __launch_bounds__(256) k_fml_bin(FmlPlanes pl, long long total, const FmlWin *wins, int n_win, unsigned int *cursor, unsigned long long *items,
-                                                 unsigned long long *stats)
+                                                 FmlSlot *tab, unsigned long long *stats)
 {
     __shared__ unsigned int s_cnt[FML_PART_MAX], s_base[FML_PART_MAX];
     __shared__ unsigned int s_valid;
@@ -215,7 +228,7 @@ static __global__ void __launch_bounds__(256) k_fml_bin(FmlPlanes pl, long long 
             const unsigned int lp = (unsigned int)(fml_mix64(key) >> 40) & w0.part_mask;
             const unsigned int at = s_base[lp] + atomicAdd(&s_cnt[lp], 1u);
             if (at < FML_PART_CAP) items[(unsigned long long)(w0.part0 + lp) * FML_PART_CAP + at] = key | (hq ? 1ULL << 63 : 0ULL);
-            else stats[2] = 1;
+            else if (!fml_insert(tab + w0.tab_off, w0.tab_mask, key, hq ? (1ULL | 1ULL << 32) : 1ULL)) stats[1] = 1;      // a full partition (one k-mer thousands of times): straight into the table
         } else {                                                // a tile that runs into the next window(s): those k-mers one global atomic each
             int l2 = lo, h2 = n_win;
             while (h2 - l2 > 1) { const int mid = (l2 + h2) >> 1; if (wins[mid].pos0 <= p) l2 = mid; else h2 = mid; }
@@ -226,7 +239,7 @@ static __global__ void __launch_bounds__(256) k_fml_bin(FmlPlanes pl, long long 
             const unsigned int gp = w.part0 + ((unsigned int)(fml_mix64(key) >> 40) & w.part_mask);
             const unsigned int at = atomicAdd(&cursor[gp], 1u);
             if (at < FML_PART_CAP) items[(unsigned long long)gp * FML_PART_CAP + at] = key | (hq ? 1ULL << 63 : 0ULL);
-            else stats[2] = 1;
+            else if (!fml_insert(tab + w.tab_off, w.tab_mask, key, hq ? (1ULL | 1ULL << 32) : 1ULL)) stats[1] = 1;
         }
     }
     atomicAdd(&s_valid, n_valid);
@@ -259,7 +272,10 @@ static __global__ void __launch_bounds__(256) k_fml_part(const unsigned int *cur
             if (old == 0) old = atomicCAS(&s_key[s], 0ULL, key + 1);
             if (old == 0 || old == key + 1) { atomicAdd(&s_val[s], inc); break; }
             s = (s + 1) & (FML_PART_SLOTS - 1);
-            if (++probes >= FML_PART_SLOTS) { stats[2] = 1; break; }
+            if (++probes >= FML_PART_SLOTS) {                      // the LDS table is full (a partition of mostly distinct k-mers): this one goes straight into the table
+                if (!fml_insert(tab + w.tab_off, w.tab_mask, key, (unsigned long long)(inc & 0xffffu) | (unsigned long long)(inc >> 16) << 32)) stats[1] = 1;
+                break;
+            }
         }
     }
     __syncthreads();
@@ -269,9 +285,10 @@ static __global__ void __launch_bounds__(256) k_fml_part(const unsigned int *cur
         if (!k1) continue;
         const unsigned int v = s_val[i];
         unsigned int j = (unsigned int)fml_mix64(k1 - 1) & w.tab_mask, probes = 0;
-        while (true) {                                          // every k-mer lives in ONE partition: the slot is claimed once, its count stored plainly
-            const unsigned long long old = atomicCAS(&t[j].key, 0ULL, k1);
-            if (old == 0) { t[j].cnt = (unsigned long long)(v & 0xffffu) | (unsigned long long)(v >> 16) << 32; break; }
+        while (true) {                                          // every k-mer lives in ONE partition: its slot is claimed once (the overflow paths may have been there first)
+            unsigned long long old = t[j].key;
+            if (old == 0) old = atomicCAS(&t[j].key, 0ULL, k1);
+            if (old == 0 || old == k1) { atomicAdd(&t[j].cnt, (unsigned long long)(v & 0xffffu) | (unsigned long long)(v >> 16) << 32); break; }
             j = (j + 1) & w.tab_mask;
             if (++probes > w.tab_mask) { stats[1] = 1; break; }
         }

@@ -75,6 +75,7 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     FML_HIPCHK(hipSetDevice(device));
     slx_fml *f = new slx_fml();
     f->device = device;
+    if (const char *e = getenv("SLX_FML_PART_MIN")) f->part_min_bases = atoll(e);       // test hook: batches of at least this many bases count by partitions
     if (const char *e = getenv("SLX_FML_PART")) f->use_part = atoi(e) != 0;           // experiment / test hook: 0 = fml_count with one atomic per k-mer only
     if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
@@ -248,12 +249,12 @@ static int run_count_once(slx_fml *f, int q, bool *too_small)
         FmlPlanes P{p0, p1, pn, pq, ps};
         // large batches: bin the k-mers into partitions, count each partition in LDS, insert every distinct k-mer once (dev_fml.h); else, and when
         // a partition overflows, one contended atomic per k-mer
-        bool by_parts = f->part_ok && f->n_parts > 0 && total >= (1 << 20) &&
+        bool by_parts = f->part_ok && f->n_parts > 0 && total >= f->part_min_bases &&
                         f->d_cursor.ensure((size_t)f->n_parts * 4 + 64) == SLX_OK && f->d_items.ensure((size_t)f->n_parts * FML_PART_CAP * 8 + 64) == SLX_OK;
         if (by_parts) {
             FML_HIPCHK(hipMemsetAsync(f->d_cursor.p, 0, (size_t)f->n_parts * 4 + 64, f->st));
             hipLaunchKernelGGL(k_fml_bin, dim3((unsigned)((total + FML_BIN_TILE - 1) / FML_BIN_TILE)), dim3(256), 0, f->st, P, (long long)total, f->d_wins.as<FmlWin>(), f->n_win,
-                               f->d_cursor.as<unsigned int>(), f->d_items.as<unsigned long long>(), f->d_stats.as<unsigned long long>());
+                               f->d_cursor.as<unsigned int>(), f->d_items.as<unsigned long long>(), f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
             hipLaunchKernelGGL(k_fml_part, dim3(f->n_parts), dim3(256), 0, f->st, (const unsigned int *)f->d_cursor.as<unsigned int>(), (const unsigned long long *)f->d_items.as<unsigned long long>(),
                                f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
             FML_HIPCHK(hipGetLastError());

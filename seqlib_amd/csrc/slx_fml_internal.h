@@ -62,6 +62,7 @@ struct slx_fml {
     bool use_part = true;                   // fml_count by partitions (k_fml_bin + k_fml_part) when the batch is large enough; SLX_FML_PART=0 turns it off
     bool part_ok = false;                   // ... and the windows of this batch fit the partition limits
     unsigned int n_parts = 0;
+    int64_t part_min_bases = 1 << 20;       // smaller batches: one atomic per k-mer (k_fml_count)
     int64_t n_part_fallbacks = 0;
     int tab_div = 8, tab_grow = 1;          // table slots = 2 x bases x tab_grow / tab_div, a power of two (adapts when a table fills up)
     int64_t n_overlaps = 0, n_irreducible = 0, asm_text_len = 0, n_big_vertices = 0, n_huge_vertices = 0, n_strings = 0;

@@ -86,6 +86,42 @@ def test_count_edge_cases(F, G, ctx):
         ctx.count(*G.flatten(seqs, quals), 32)
 
 
+def test_count_by_partitions(F, G, genome, monkeypatch):
+    """fml_count as bin -> count-in-LDS -> insert-once (k_fml_bin / k_fml_part), forced on for small batches: tables equal to the oracle's for windows
+    of very different sizes in one batch (tiles that run across window borders), for a window with one k-mer tens of thousands of times (a full partition:
+    the overflow goes straight into the table) and for a low-coverage window whose partitions are almost all distinct k-mers (a full LDS table)"""
+    monkeypatch.setenv("SLX_FML_PART_MIN", "1")
+    c = G.Context()
+    try:
+        wins = _windows(genome)
+        polya = ([b"A" * 150] * 400 + [b"ACGT" * 37] * 300 + wins[1][0][:500], [b"I" * 150] * 400 + [b"I" * 148] * 300 + wins[1][1][:500])
+        thin = U.sim_window(genome["abl"][0:170000], 2500, seed=31, err=0.0)          # 2x: nearly every k-mer once
+        groups = [wins[0][:2], wins[1][:2], (wins[2][0][:40], wins[2][1][:40]), polya, thin[:2], (wins[2][0][40:], wins[2][1][40:])]
+        seqs = [s for g in groups for s in g[0]]
+        quals = [q for g in groups for q in g[1]]
+        win_off = np.cumsum([0] + [len(g[0]) for g in groups])
+        b, q, o = G.flatten(seqs, quals)
+        kcov, eck, ns, nl = c.correct(G.default_opt(), b, q, o, win_off, flt_uniq=0)
+        assert c.counter("count_partitions") >= len(groups) and c.counter("count_fallbacks") == 0
+        got_s = G.unflatten(b, o)
+        for gi, g in enumerate(groups):
+            ek, ekcov, es, eq = _oracle_window(F, g[0], g[1], 0)
+            assert eck[gi] == ek and kcov[gi] == np.float32(ekcov), (gi, eck[gi], ek, kcov[gi], ekcov)
+            assert got_s[win_off[gi]:win_off[gi + 1]] == es, "window %d: corrected reads differ" % gi
+        for g, k in ((polya, 19), (thin[:2], 21), (wins[0][:2], 17)):      # and the tables themselves, one window at a time
+            R = F.Reads(g[0], g[1])
+            oc = F.Count(R, k)
+            ek, ev = oc.dump()
+            bb, qq, oo = G.flatten(g[0], g[1])
+            c.count(bb, qq, oo, k)
+            gk, gv = c.count_dump()
+            assert np.array_equal(ek, gk) and np.array_equal(ev, gv), "k-mer table differs at k = %d" % k
+            assert c.count_hist() == oc.hist()
+            R.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("flt", [0, 1])
 def test_correct_windows_match_oracle(F, G, ctx, genome, flt):
     wins = _windows(genome)
