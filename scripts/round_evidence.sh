@@ -14,7 +14,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json
 timeout 600 python bench.py --config C2 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 300 $OUT/bench_c2.json
 case " $SKIP " in *" c5 "*) ;; *)
-timeout 900 python bench.py --config C5 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 400 $OUT/bench_c5.json
+timeout 900 python bench.py --config C5 --steps 6 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 400 $OUT/bench_c5.json
 bash scripts/profile_c5.sh $OUT/c5 > $OUT/profile_c5.log 2>&1 ;; esac
 bash scripts/profile_round.sh $OUT/c3 C3 > $OUT/profile_c3.log 2>&1
 bash scripts/profile_alone.sh $OUT/alone_C3 C3 8333333 > $OUT/alone_C3.txt 2>&1
