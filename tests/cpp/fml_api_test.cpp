@@ -3,12 +3,14 @@
 // /root/reference/src/seqtools/seqtools.cpp:106-212) and prints what tests/test_cpp_fml.py compares with the CPU checker.
 //   fml_api_test cpu
 //   fml_api_test gpu <fastq> <n_reads>
+//   fml_api_test pipeline <index prefix> <fastq> <n_reads>      reads -> FermiAssembler -> contigs -> BWAAligner::alignSequence (seqtools' fml mode)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include "SeqLib/BFC.h"
+#include "SeqLib/BWAAligner.h"
 #include "SeqLib/FastqReader.h"
 #include "SeqLib/FermiAssembler.h"
 
@@ -94,9 +96,35 @@ static int gpu(const char *fq, long n)
     return 0;
 }
 
+// src/seqtools/seqtools.cpp:106-212 (the "fml" mode with realignment): every read into one FermiAssembler, CorrectReads, PerformAssembly,
+// every contig through BWAAligner::alignSequence(contig, "contigN", brv, false, 0.9, 10)
+static int pipeline(const char *prefix, const char *fq, long n)
+{
+    FastqReader r(fq);
+    FermiAssembler f;
+    UnalignedSequence u;
+    long got = 0;
+    while (got < n && r.GetNextSequence(u)) { f.AddRead(u); ++got; }
+    f.CorrectReads();
+    f.PerformAssembly();
+    std::vector<std::string> contigs = f.GetContigs();
+    BWAIndexPtr idx(new BWAIndex());
+    idx->LoadIndex(prefix);
+    BWAAligner bwa(idx);
+    for (size_t i = 0; i < contigs.size(); ++i) {
+        BamRecordPtrVector brv;
+        bwa.alignSequence(contigs[i], "contig" + std::to_string(i), brv, false, 0.9, 10);
+        std::printf("CTG\t%zu\t%zu\t%zu\n", i, contigs[i].size(), brv.size());
+        for (size_t k = 0; k < brv.size(); ++k)
+            std::printf("REC\t%zu\t%d\t%d\t%d\t%d\t%s\n", i, brv[k]->ChrID(), brv[k]->Position(), brv[k]->AlignmentFlag(), brv[k]->MapQuality(), brv[k]->CigarString().c_str());
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
+        if (argc >= 5 && std::string(argv[1]) == "pipeline") return pipeline(argv[2], argv[3], std::atol(argv[4]));
         if (argc >= 2 && std::string(argv[1]) == "cpu") return cpu();
         if (argc >= 4 && std::string(argv[1]) == "gpu") return gpu(argv[2], std::atol(argv[3]));
     } catch (const std::exception &e) {

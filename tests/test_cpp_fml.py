@@ -77,3 +77,35 @@ def test_cpp_fml_pipeline_matches_oracle(exe, golden_dir):
     F.fltuniq(o, R)
     fs, _ = R.get()
     assert out["FLT"] == [s.decode() for s in fs]
+
+
+@pytest.mark.gpu
+def test_cpp_assemble_then_realign_like_seqtools(exe, golden_dir):
+    """the whole of BASELINE config 5 through the reference's own classes (src/seqtools/seqtools.cpp:106-212): reads into one FermiAssembler,
+    CorrectReads, PerformAssembly, every contig through BWAAligner::alignSequence -- contigs and records equal to what the two CPU checkers
+    give for the same calls (the i-th alignSequence call of the process takes lrand48 draw i)"""
+    from oracle import orc, orc_fml as F
+    n = 3000
+    fq = os.path.join(golden_dir, "sim2_bcr.head3000.fq")
+    prefix = os.path.join(golden_dir, "tiny.fa")
+    r = subprocess.run([exe, "pipeline", prefix, fq, str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    L = open(fq).read().split("\n")
+    seqs = [L[i + 1].encode() for i in range(0, 4 * n, 4)]
+    quals = [L[i + 3].encode() for i in range(0, 4 * n, 4)]
+    R = F.Reads(seqs, quals)
+    o = F.default_opt()
+    F.opt_adjust(o, R)
+    F.correct(o, R)
+    cs, cq = R.get()
+    contigs = [u["seq"].decode() for u in F.assemble(F.default_opt(), F.Reads(cs, cq))]
+    oidx = orc.Index.load(prefix)
+    opt = orc.default_opt()
+    exp = []
+    for i, c in enumerate(contigs):
+        recs = orc.align_sequence(opt, oidx, c, name="contig%d" % i, ordinal=i)
+        exp.append("CTG\t%d\t%d\t%d" % (i, len(c), len(recs)))
+        exp += ["REC\t%d\t%d\t%d\t%d\t%d\t%s" % (i, x["rid"], x["pos"], x["flag"], x["mapq"], orc.cigar_str(x["cigar"])) for x in recs]
+    got = [ln for ln in r.stdout.split("\n") if ln]
+    assert got == exp
+    assert len(contigs) > 5 and max(len(c) for c in contigs) > 1000 and sum(ln.startswith("REC") for ln in got) >= len(contigs) // 2
