@@ -112,12 +112,127 @@ __device__ int wave_ksw_global2_bandn(int qlen_, QF qf, int tlen_, TF tf, const 
     return lane_read(pick, src);
 }
 
+// The same alignment with the band's offsets spread over the 256 threads of a block (CPB offsets per thread): a CIGAR job of a contig with a
+// few dozen mismatches has a band of several hundred columns, 8-13 offsets per lane on one wave and ~200 dependent instructions per row.
+// H stays in place, the prefix maximum behind F crosses the waves through LDS (the one barrier of a row), E moves one offset down -- across a
+// wave's upper edge through LDS too, read after the NEXT row's barrier -- and every wave fetches the query code that enters at its own top
+// offset itself.  LDS words are double-buffered by row parity.
+#define GB_THREADS 256
+#define GB_WAVES (GB_THREADS / WAVE)
+struct GbShared { int scan[2][GB_WAVES], edge[2][GB_WAVES]; int result; };
+
+template <int CPB, typename QF, typename TF>
+__device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, uint8_t *z, int n_col, GbShared &S)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const MatCols mc = make_matcols(o.mat);
+    auto pack_of = [&](int j) -> uint32_t {
+        const int q = j >= 0 && j < qlen ? qf(j) : 4;
+        return q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
+    };
+    const int b0 = tid * CPB;                     // this thread holds band offsets b0 .. b0 + CPB - 1; offset b of row i is column j = i - w + b
+    int H[CPB], E[CPB];
+    uint32_t P[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) {
+        const int j = b0 + c - w;
+        P[c] = pack_of(j);
+        H[c] = j == 0 ? 0 : (j > 0 && j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
+        E[c] = DEV_MINUS_INF;
+    }
+    // the query code entering at this wave's top offset in row i + 1: column i - w + top, top = first offset of the next wave
+    const int top = (wv + 1) * WAVE * CPB;
+    int q_blk = (top - w) >> 6;
+    uint32_t q_cur = pack_of(q_blk * WAVE + lane), q_next = pack_of((q_blk + 1) * WAVE + lane);
+    int tb_cur = lane < tlen ? tf(lane) : 0;
+    int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    __syncthreads();                              // (S may still be read by the previous alignment)
+#pragma unroll 1
+    for (int i = 0; i < tlen; ++i) {
+        const int par = i & 1;
+        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        const int t = lane_read(tb_cur, i & (WAVE - 1));
+        const uint32_t sh = (uint32_t)t << 3;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int b_lo = beg - (i - w), b_hi = end - (i - w);
+        int m[CPB], exl[CPB];
+        bool act[CPB];
+        int run = G_NEG;
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int b = b0 + c;
+            act[c] = b >= b_lo && b < b_hi;
+            m[c] = H[c] + __builtin_amdgcn_sbfe((int)P[c], sh, 8u);
+            exl[c] = run;
+            const int u = act[c] ? m[c] - oe_ins + b * e_ins : G_NEG;
+            run = imax(run, u);
+        }
+        const int incl = dpp_incl_max_scan_g(run);
+        int lane_ex = dpp_get<0x138, 0xf, 0xf>(G_NEG, incl);
+        if (lane == WAVE - 1) S.scan[par][wv] = incl;
+        __syncthreads();                          // ---------------- the row's barrier
+        if (i > 0 && lane == WAVE - 1 && wv < GB_WAVES - 1) E[CPB - 1] = S.edge[par ^ 1][wv + 1];      // E'(i, .) of the next wave's lowest offset, stored in row i - 1
+#pragma unroll
+        for (int k = 0; k < GB_WAVES - 1; ++k) { const int v = S.scan[par][k]; if (k < wv) lane_ex = imax(lane_ex, v); }
+        int e2v[CPB];
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            const int b = b0 + c;
+            const int ex = imax(lane_ex, exl[c]);
+            int f = DEV_MINUS_INF - (b - b_lo) * e_ins;
+            if (b > b_lo) f = imax(f, ex - (b - 1) * e_ins);
+            const int e = E[c];
+            int d = m[c] >= e ? 0 : 1;
+            int hh = m[c] >= e ? m[c] : e;
+            d = hh >= f ? d : 2;
+            hh = hh >= f ? hh : f;
+            int tt = m[c] - oe_del;
+            int e2 = e - e_del;
+            d |= e2 > tt ? 1 << 2 : 0;
+            e2 = e2 > tt ? e2 : tt;
+            tt = m[c] - oe_ins;
+            const int f2 = f - e_ins;
+            d |= f2 > tt ? 2 << 4 : 0;
+            if (act[c] && z) z[(size_t)i * n_col + (b - b_lo)] = (uint8_t)d;
+            if (act[c]) H[c] = hh;
+            if (b == w - (i + 1)) H[c] = -(o_del + e_del * (i + 1));
+            e2v[c] = act[c] ? e2 : DEV_MINUS_INF;
+        }
+        if (lane == 0) S.edge[par][wv] = e2v[0];
+        // E'(i+1, j) and the query codes move one offset down: inside the thread a register move, across lanes one wave_shl, across waves see above
+        const int e_in = dpp_get<0x130, 0xf, 0xf>(DEV_MINUS_INF, e2v[0]);
+        const uint32_t p_in = (uint32_t)dpp_get<0x130, 0xf, 0xf>(0, (int)P[0]);
+        const int jn = i - w + top;                                                   // column of the wave's top offset in row i + 1
+        if ((jn >> 6) != q_blk) { q_blk = jn >> 6; q_cur = q_next; q_next = pack_of((q_blk + 1) * WAVE + lane); }
+        const uint32_t p_top = (uint32_t)lane_read((int)q_cur, jn & (WAVE - 1));
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            E[c] = c + 1 < CPB ? e2v[c + 1 < CPB ? c + 1 : c] : e_in;
+            const uint32_t p_up = c + 1 < CPB ? P[c + 1 < CPB ? c + 1 : c] : p_in;
+            P[c] = (c == CPB - 1 && lane == WAVE - 1) ? p_top : p_up;
+        }
+    }
+    // H(tlen-1, qlen-1) sits at offset qlen-1 - (tlen-1-w)
+    const int bf = qlen - 1 - (tlen - 1 - w);
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) if (b0 + c == bf) S.result = H[c];
+    __syncthreads();
+    return S.result;
+}
+
 #define CIG_BAND_MAX_COLS (13 * WAVE)          // widest band the wave kernel takes (2 w + 1 columns)
 
 // One CIGAR job of a long read on one wave: mem_reg2aln's bwa_gen_cigar2 sequence (up to three band widths), traceback, NM, position.
 // Mirrors dev_cig_dp_job (dev_fin2.h) with the band kernel above in place of the register-per-column ones.
-static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, uint32_t slot, int lane)
+// BLOCK: the same job on a 256-thread block -- the alignment on all four waves (block_ksw_global2_bandn), everything else on wave 0.
+struct CigBlockShared { GbShared gb; unsigned long long off; int n_ops_dummy; };
+template <bool BLOCK>
+static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, uint32_t slot, int lane, CigBlockShared *SB = nullptr)
 {
+    [[maybe_unused]] const bool wave0 = !BLOCK || threadIdx.x < WAVE;
     const DJob j = fl.jobs[slot];
     DHit h = ck.hits[slot];
     const uint8_t *query = ck.codes + ck.offs[j.r];
@@ -150,12 +265,24 @@ static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chun
             if (2 * ww + 1 > CIG_BAND_MAX_COLS) return false;          // a band this wide (a long gap between the region's ends): left to k_cig_long
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
             unsigned long long off = 0;
+            if constexpr (BLOCK) {
+                __syncthreads();
+                if (threadIdx.x == 0) SB->off = atomicAdd(ck.zused, need);
+                __syncthreads();
+                off = SB->off;
+            } else {
             if (lane == 0) off = atomicAdd(ck.zused, need);
             off = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                   (unsigned int)__builtin_amdgcn_readfirstlane((int)(off & 0xffffffffull));
-            if (off + need > ck.zcap) { if (lane == 0) atomicOr(ck.flags, OVF_ZARENA); return true; }
+            }
+            if (off + need > ck.zcap) { if (lane == 0 && wave0) atomicOr(ck.flags, OVF_ZARENA); return true; }
             z = ck.zarena + off;
             const int cols = 2 * ww + 1;
+            if constexpr (BLOCK) {
+                if (cols <= GB_THREADS) score = block_ksw_global2_bandn<1>(lq, qf, rlen, tf, opt, ww, z, n_col, SB->gb);
+                else if (cols <= 2 * GB_THREADS) score = block_ksw_global2_bandn<2>(lq, qf, rlen, tf, opt, ww, z, n_col, SB->gb);
+                else score = block_ksw_global2_bandn<4>(lq, qf, rlen, tf, opt, ww, z, n_col, SB->gb);
+            } else
             if (cols <= WAVE) score = wave_ksw_global2_bandn<1>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
             else if (cols <= 2 * WAVE) score = wave_ksw_global2_bandn<2>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
             else if (cols <= 4 * WAVE) score = wave_ksw_global2_bandn<4>(lq, qf, rlen, tf, opt, ww, z, n_col, lane);
@@ -166,6 +293,11 @@ static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chun
             w2 <<= 1;
             if (!(score < j.truesc - opt.a)) break;
         }
+    }
+    if constexpr (BLOCK) {
+        __threadfence();
+        __syncthreads();                          // the direction bytes of all four waves are written
+        if (!wave0) return true;                  // the traceback and the record: wave 0
     }
     int n_ops = 0;
     if (valid) {
@@ -212,7 +344,24 @@ __global__ void __launch_bounds__(64) k_cig_band(DevRef R, Chunk ck, DevOpt dopt
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= n_jobs) break;
         const uint32_t slot = fl.dp_list[t];
-        if (!dev_cig_band_job(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+        if (!dev_cig_band_job<false>(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+    }
+}
+
+// the largest jobs of the list (`n_block` of them: the list is sorted largest first) one BLOCK per job; k_cig_band then starts behind them
+__global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, unsigned int *queue, uint32_t *rest, unsigned int *n_rest)
+{
+    __shared__ CigBlockShared SB;
+    __shared__ unsigned int s_t;
+    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_t = atomicAdd(queue, 1u);
+        __syncthreads();
+        const unsigned int t = s_t;
+        if (t >= n_jobs) break;
+        const uint32_t slot = fl.dp_list[t];
+        if (!dev_cig_band_job<true>(R, ck, dopt.o, fl, slot, (int)(threadIdx.x & (WAVE - 1)), &SB) && threadIdx.x == 0) rest[atomicAdd(n_rest, 1u)] = slot;
     }
 }
 
