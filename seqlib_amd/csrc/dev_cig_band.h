@@ -367,8 +367,32 @@ __global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk c
 
 // bwa_gen_cigar2 (score only) for mem_patch_reg on a long read, one wave: the band kernel above without direction bytes; a band beyond
 // its 832 columns falls back to the scalar loops on one lane (rows in this wave's stretch of the per-thread scratch).
+// what wave 0 hands the three helper waves of k_regs_wave_long for one of mem_patch_reg's alignments (RegsBlockShared::cmd: 1 = run, 0 = leave)
+struct RegsBlockShared {
+    GbShared gb;
+    int cmd, w, l_query, rlen, rev;
+    const uint8_t *qseg;
+    int64_t rb, re;
+};
+
+// the alignment itself, run by all four waves after the barrier that publishes S
+__device__ __noinline__ int regs_block_dp(const DevRef &R, const slx_opt &o, RegsBlockShared &S)
+{
+    const int w = S.w, l_query = S.l_query, rlen = S.rlen;
+    const bool rev = S.rev != 0;
+    const uint8_t *qseg = S.qseg;
+    const int64_t rb = S.rb, re = S.re;
+    auto qf = [&](int x) { return (int)(rev ? qseg[l_query - 1 - x] : qseg[x]); };
+    auto tf = [&](int y) { return rev ? ref_base(R, re - 1 - y) : ref_base(R, rb + y); };
+    const int cols = 2 * w + 1;
+    if (cols <= GB_THREADS) return block_ksw_global2_bandn<1>(l_query, qf, rlen, tf, o, w, nullptr, 0, S.gb);
+    if (cols <= 2 * GB_THREADS) return block_ksw_global2_bandn<2>(l_query, qf, rlen, tf, o, w, nullptr, 0, S.gb);
+    return block_ksw_global2_bandn<4>(l_query, qf, rlen, tf, o, w, nullptr, 0, S.gb);
+}
+
 struct WaveScorerLong {
     const DevRef &R; const slx_opt &o; const Chunk &ck; int lane; int *eh_h, *eh_e;
+    RegsBlockShared *SB;          // non-null: three helper waves wait at a block barrier for work (k_regs_wave_long)
     __device__ int operator()(int w_, int l_query, const uint8_t *qseg, int64_t rb, int64_t re) const
     {
         if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return 0;
@@ -392,6 +416,11 @@ struct WaveScorerLong {
         const int min_w = dl + 3;
         w = w > min_w ? w : min_w;
         const int cols = 2 * w + 1;
+        if (SB && cols > 2 * WAVE && cols <= 4 * GB_THREADS && rlen >= 2048) {          // a wide band over thousands of rows: all four waves of the block
+            if (lane == 0) { SB->w = w; SB->l_query = l_query; SB->rlen = rlen; SB->rev = rev ? 1 : 0; SB->qseg = qseg; SB->rb = rb; SB->re = re; SB->cmd = 1; }
+            __syncthreads();                                                                // releases the helpers (they wait at this barrier)
+            return regs_block_dp(R, o, *SB);
+        }
         if (cols <= WAVE) return wave_ksw_global2_bandn<1>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
         if (cols <= 2 * WAVE) return wave_ksw_global2_bandn<2>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
         if (cols <= 4 * WAVE) return wave_ksw_global2_bandn<4>(l_query, qf, rlen, tf, o, w, nullptr, 0, lane);
@@ -405,18 +434,29 @@ struct WaveScorerLong {
 
 // mem_sort_dedup_patch .. hit emission for the multi-region reads of a long-read chunk: one wave per read (k_regs would run
 // mem_patch_reg's contig-long global alignment on a single lane)
+// -- inside a 256-thread block: wave 0 runs the read, waves 1-3 wait at a block barrier and join it for the wide-band alignments of
+// mem_patch_reg (regs_block_dp); the barriers of the region code itself are wave-local in this instantiation (fin_sync, dev_fin.h)
 template <int MAXQ, int NB>
-__global__ void __launch_bounds__(64) k_regs_wave_long(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
+__global__ void __launch_bounds__(GB_THREADS) k_regs_wave_long(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
 {
     __shared__ int s_idx[NB], s_ka[NB], s_kb[NB], s_qe[NB], s_rid[NB], s_w[NB];
     __shared__ int64_t s_k64[NB], s_rb[NB];
+    __shared__ RegsBlockShared SB;
+    if ((int)blockIdx.x * WAVE >= ck.long_threads) return;          // (this block's stretch of the per-thread rows: threads blockIdx.x * 64 ..)
+    if (threadIdx.x >= WAVE) {                                       // helpers
+        for (;;) {
+            __syncthreads();
+            if (SB.cmd == 0) break;
+            regs_block_dp(R, dopt.o, SB);
+        }
+        return;
+    }
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x * WAVE >= ck.long_threads) return;          // (this wave's stretch of the per-thread rows: threads blockIdx.x * 64 ..)
     SortStage ss;
     ss.idx = s_idx; ss.k64 = s_k64; ss.ka = s_ka; ss.kb = s_kb; ss.m_rb = s_rb; ss.m_qe = s_qe; ss.m_rid = s_rid; ss.m_w = s_w;
     ss.nmax = NB; ss.lane = lane;
     int *eh_h = ck.long_scratch + (size_t)blockIdx.x * WAVE * 2 * ck.long_stride, *eh_e = eh_h + ck.long_stride;
-    WaveScorerLong sc{R, dopt.o, ck, lane, eh_h, eh_e};
+    WaveScorerLong sc{R, dopt.o, ck, lane, eh_h, eh_e, &SB};
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     for (;;) {
         int slot = 0;
@@ -426,4 +466,6 @@ __global__ void __launch_bounds__(64) k_regs_wave_long(DevRef R, Chunk ck, DevOp
         const int r = order ? order[slot] : slot;
         dev_regs_read<MAXQ>(R, ck, dopt.o, fl, r, sc, lane == 0, &ss);
     }
+    if (lane == 0) SB.cmd = 0;
+    __syncthreads();                                                 // the helpers leave
 }

@@ -320,6 +320,16 @@ struct SortStage {
     int lane;
 };
 
+// The barriers of dev_fin_regs order the LDS traffic of ONE wave (the staged path runs one read per wave).  The contig-length region kernel
+// (k_regs_wave_long, dev_cig_band.h) runs that wave inside a 256-thread block whose other waves only help with mem_patch_reg's alignments,
+// so there the ordering must not be a block barrier: a workgroup fence + wave barrier does for a single wave what s_barrier did.
+template <int MAXQ>
+__device__ __forceinline__ void fin_sync()
+{
+    if constexpr (MAXQ > 704) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
 template <int MAXQ, typename SC>
 __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query, SC &sc,
                             const SortStage *ss = nullptr)
@@ -335,7 +345,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             if (!staged) { ks_introsort_idx(m, a, less_glb); return; }
             __threadfence_block();                                   // a[] and G[] were last written by other lanes' stores
             for (int i = ss->lane; i < m; i += 64) { const int h = a[i]; ss->idx[i] = h; fill(h); }
-            __syncthreads();
+            fin_sync<MAXQ>();
             // When no two keys are equal every correct sort gives klib's order, so the wave counts ranks (64 elements at a time against
             // all m, keys broadcast from LDS): ~m * m / 64 comparisons per lane instead of one lane's m log m at LDS latency.  With a tie
             // anywhere the tie order of ks_introsort shows in the output: then the serial algorithm itself runs, on one lane as before.
@@ -352,17 +362,17 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 ss->m_w[e] = rank;                                   // (m_w / m_rid are free during the three sorts)
             }
             if (!__any(tie)) {
-                __syncthreads();
+                fin_sync<MAXQ>();
                 for (int e = ss->lane; e < m; e += 64) ss->m_rid[ss->m_w[e]] = ss->idx[e];
-                __syncthreads();
+                fin_sync<MAXQ>();
                 for (int e = ss->lane; e < m; e += 64) { const int h = ss->m_rid[e]; ss->idx[e] = h; a[e] = h; }
             } else {
-                __syncthreads();
+                fin_sync<MAXQ>();
                 if (ss->lane == 0) ks_introsort_idx(m, ss->idx, less_lds);
-                __syncthreads();
+                fin_sync<MAXQ>();
                 for (int i = ss->lane; i < m; i += 64) a[i] = ss->idx[i];
             }
-            __syncthreads();
+            fin_sync<MAXQ>();
             __threadfence_block();
         };
         if (staged) { for (int i = ss->lane; i < n; i += 64) a[i] = i; __threadfence_block(); }
@@ -387,7 +397,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                     const DReg &g = G[h];
                     ss->m_rb[h] = g.rb; m_re[h] = g.re; m_qb[h] = g.qb; ss->m_qe[h] = g.qe; ss->m_rid[h] = g.rid; m_sc[h] = g.score; ss->m_w[h] = g.w;
                 }
-                __syncthreads();
+                fin_sync<MAXQ>();
                 for (int i = 1; i < n; ++i) {
                     const int ph = ss->idx[i], prevh = ss->idx[i - 1];
                     if (ss->m_rid[ph] != ss->m_rid[prevh] || ss->m_rb[ph] >= m_re[prevh] + opt.max_chain_gap) continue;
@@ -416,7 +426,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                         const unsigned long long evm = __ballot(cat >= 2);
                         const int first_ev = evm ? (int)__ffsll((long long)evm) - 1 : 64;
                         if (cat == 1 && lane < first_ev) { ss->m_qe[qh] = q_qb; G[qh].qe = q_qb; }        // q.qe = q.qb
-                        __syncthreads();
+                        fin_sync<MAXQ>();
                         if (first_ev == 64) {                // no p-changing event among the live lanes
                             if (first_stop < 64) break;
                             jtop -= 64;
@@ -426,7 +436,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                         const int ev_q = __builtin_amdgcn_readlane(qh, first_ev);
                         if (ev_cat == 2) {                   // p.qe = p.qb; break
                             if (lane == 0) { ss->m_qe[ph] = p_qb; G[ph].qe = p_qb; }
-                            __syncthreads();
+                            fin_sync<MAXQ>();
                             break;
                         }
                         {                                    // patch attempt with q = ev_q
@@ -447,7 +457,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                                     m_qb[ph] = m_qb[ev_q]; ss->m_rb[ph] = ss->m_rb[ev_q]; m_sc[ph] = score; ss->m_w[ph] = ww;
                                     m_qb[ev_q] = ss->m_qe[ev_q];
                                 }
-                                __syncthreads();
+                                fin_sync<MAXQ>();
                             }
                         }
                         jtop -= first_ev + 1;                // resume just below the event with the (possibly new) p
@@ -517,7 +527,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                     const int h = ss->idx[i], hp = ss->idx[i - 1];
                     if (ss->ka[h] == ss->ka[hp] && ss->k64[h] == ss->k64[hp] && ss->kb[h] == ss->kb[hp]) { G[h].qe = ss->kb[h]; ss->m_qe[h] = ss->kb[h]; }
                 }
-                __syncthreads();
+                fin_sync<MAXQ>();
                 n = compact_staged(n, 1);
             } else {
                 for (int i = 1; i < n; ++i)
@@ -544,10 +554,10 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
             auto core_staged = [&](int m, const int *l_alt) {
                 const int lane = ss->lane;
                 int *l_sub = ss->m_rid, *l_subn = ss->m_w, *l_sec = (int *)ss->k64, *l_z = (int *)ss->k64 + ss->nmax;
-                __syncthreads();
+                fin_sync<MAXQ>();
                 for (int i = lane; i < m; i += 64) { const int h = ss->idx[i]; l_sub[h] = 0; l_subn[h] = G[h].sub_n; l_sec[h] = -1; }
                 if (lane == 0) l_z[0] = 0;
-                __syncthreads();
+                fin_sync<MAXQ>();
                 int nz = 1;
                 for (int i = 1; i < m; ++i) {
                     const int hi = ss->idx[i];
@@ -578,11 +588,11 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                             l_sec[hi] = zi;
                         }
                     } else { if (lane == 0) l_z[nz] = i; ++nz; }
-                    __syncthreads();
+                    fin_sync<MAXQ>();
                 }
                 for (int i = lane; i < m; i += 64) { const int h = ss->idx[i]; DReg &p = G[h]; p.sub = l_sub[h]; p.sub_n = l_subn[h]; p.secondary = l_sec[h]; }
                 __threadfence_block();
-                __syncthreads();
+                fin_sync<MAXQ>();
             };
             if (R.ann_alt && staged) {
                 // ALT-aware index, many regions: bwa's two-round marking (dev_mark_primary_alt has the serial statement) with the sorts
@@ -590,7 +600,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 // two halves of m_rb, which nothing reads after the de-duplication.
                 const int lane = ss->lane;
                 int *l_alt = (int *)ss->m_rb, *l_par = (int *)ss->m_rb + ss->nmax, *par = (int *)w.srt;
-                __syncthreads();
+                fin_sync<MAXQ>();
                 int n_pri = 0;
                 for (int base = 0; base < n; base += 64) {
                     const int i = base + lane;
@@ -617,7 +627,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 core_staged(n, l_alt);
                 if (n_pri < n) {
                     for (int i = lane; i < n; i += 64) { const int h = ss->idx[i], sidx = G[h].secondary; l_par[h] = sidx >= 0 ? ss->idx[sidx] : -1; }
-                    __syncthreads();
+                    fin_sync<MAXQ>();
                     if (n_pri > 0)
                         sort_handles(n, [&](int h) { ss->ka[h] = G[h].score; ss->k64[h] = (int64_t)G[h].hash; },
                                      [&](int x, int y) {
@@ -628,9 +638,9 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                                      },
                                      [&](int x, int y) { return false; });
                     int *l_rank = (int *)ss->k64;                     // handle -> rank in the final order (the hashes are done with)
-                    __syncthreads();
+                    fin_sync<MAXQ>();
                     for (int i = lane; i < n; i += 64) l_rank[ss->idx[i]] = i;
-                    __syncthreads();
+                    fin_sync<MAXQ>();
                     for (int i = lane; i < n; i += 64) {
                         const int h = ss->idx[i], ph = l_par[h];
                         if (ph >= 0) { par[h] = l_rank[ph]; if (l_alt[h]) G[h].secondary = 0x7fffffff; }
@@ -643,7 +653,7 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                 } else
                     for (int i = lane; i < n; i += 64) { const int h = ss->idx[i]; par[h] = G[h].secondary; }
                 __threadfence_block();
-                __syncthreads();
+                fin_sync<MAXQ>();
             } else if (R.ann_alt) {
                 dev_mark_primary_alt(R, opt, w, n, id);              // one region list per lane: the serial statement
             } else {
