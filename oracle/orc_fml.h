@@ -75,6 +75,8 @@ float orc_fml_fltuniq(const orc_fml_opt *opt, int n, orc_fseq *seqs);           
 orc_fml_utg *orc_fml_assemble(const orc_fml_opt *opt, int n, orc_fseq *seqs, int *n_utg);   /* fml_assemble (:142); consumes the reads */
 orc_fml_utg *orc_fml_direct_assemble(orc_fml_opt *opt, float kcov, int n, orc_fseq *seqs, int *n_utg);   /* FermiAssembler::DirectAssemble (:26-44) */
 void  orc_fml_utg_destroy(int n_utg, orc_fml_utg *utg);                           /* fml_utg_destroy (:103) */
+/* test hook (orc_fml_asm.c): the next assemble call of this thread writes its overlap graph and cleaning options to `path` */
+void  orc_fml_set_overlap_dump(const char *path);
 
 /* the BFC class's split of the same work (src/BFC.cpp): Train = opt_adjust + l_pre + fml_count; ErrorCorrect = hist, kcov, min_cov, kmer_correct */
 typedef struct orc_bfc_ch orc_bfc_ch;

@@ -81,6 +81,7 @@ def lib():
         L.orc_fml_reads_total.restype = C.c_uint64
         L.orc_fml_reads_to_flat.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_fml_counters_get.argtypes = [C.POINTER(Counters)]
+        L.orc_fml_set_overlap_dump.argtypes = [C.c_char_p]
         _LIB = L
     return _LIB
 
@@ -157,16 +158,21 @@ def _utgs(p, n):
     return out
 
 
-def assemble(opt, reads):
-    """fml_assemble: correct + filter + assemble; consumes the reads (as fermi-lite frees them)"""
+def assemble(opt, reads, dump=None):
+    """fml_assemble: correct + filter + assemble; consumes the reads (as fermi-lite frees them).  dump: a path that receives the overlap graph
+    and the cleaning options of this call (input of tests/cpp/fml_graph_test.cpp)"""
     n = C.c_int(0)
+    keep = dump.encode() if dump else None
+    lib().orc_fml_set_overlap_dump(keep)
     p = lib().orc_fml_assemble(C.byref(opt), reads.n, reads.p, C.byref(n))
     reads.p = None
     return _utgs(p, n.value)
 
 
-def direct_assemble(opt, kcov, reads):
+def direct_assemble(opt, kcov, reads, dump=None):
     n = C.c_int(0)
+    keep = dump.encode() if dump else None
+    lib().orc_fml_set_overlap_dump(keep)
     p = lib().orc_fml_direct_assemble(C.byref(opt), kcov, reads.n, reads.p, C.byref(n))
     reads.p = None
     return _utgs(p, n.value)

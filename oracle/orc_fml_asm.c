@@ -494,27 +494,6 @@ static void mag_g_rm_edge(mag_t *g, int min_ovlp, double min_ratio, int min_len,
     free(a);
 }
 
-/* unit-cost edit distance; free_tail: the cheapest alignment of all of a against a PREFIX of b */
-static int edit_dist(const char *a, int la, const char *b, int lb, int free_tail)
-{
-    int *row = (int*)malloc(sizeof(int) * (lb + 1)), i, j, best;
-    for (j = 0; j <= lb; ++j) row[j] = j;
-    for (i = 1; i <= la; ++i) {
-        int diag = row[0];
-        row[0] = i;
-        for (j = 1; j <= lb; ++j) {
-            int t = row[j], d = diag + (a[i - 1] != b[j - 1]);
-            if (row[j] + 1 < d) d = row[j] + 1;
-            if (row[j - 1] + 1 < d) d = row[j - 1] + 1;
-            row[j] = d; diag = t;
-        }
-    }
-    best = row[lb];
-    if (free_tail) for (j = 0; j <= lb; ++j) if (row[j] < best) best = row[j];
-    free(row);
-    return best;
-}
-
 /* the l bases of vertex q that follow its overlap when it is entered through side `side` (side 1: read backwards, complemented) */
 static void branch_seq(const magv_t *q, int side, int ovlp, int l, char *seq, float *avg)
 {
@@ -528,46 +507,100 @@ static void branch_seq(const magv_t *q, int side, int ovlp, int l, char *seq, fl
     *avg = l > 0 ? (float)(s / l) : 0.0f;
 }
 
-#define MAX_N_DIFF 2.01
-#define MAX_R_DIFF 0.1
+/* ksw.c: ksw_align(qlen, query, tlen, target, 4, mat, gapo, gape, xtra = 0).score.  With xtra = 0 the query profile is built for 16-bit cells and
+ * ksw_i16 runs: the exact Smith-Waterman optimum of a local alignment in which a gap of length k costs gapo + k * gape; the kernel's adds saturate,
+ * so no score exceeds 32767.  Codes 0..3 = ACGT.  [CHOICE] a base that is not ACGT arrives as code 4 and makes the striped kernel index past its
+ * 4 x 4 matrix (undefined behaviour upstream); here it scores as a mismatch against everything. */
+static int ksw_align_score(int qlen, const char *query, int tlen, const char *target, int match, int mismatch, int gapo, int gape)
+{
+    int i, j, best = 0;
+    int *H = (int*)calloc((size_t)qlen + 1, sizeof(int)), *E = (int*)calloc((size_t)qlen + 1, sizeof(int));
+    for (i = 0; i < tlen; ++i) {
+        int f = 0, hdiag = 0;
+        for (j = 1; j <= qlen; ++j) {
+            const int s = (target[i] == query[j - 1] && target[i] < 4) ? match : mismatch;
+            int h = hdiag + s, e = E[j], x;
+            hdiag = H[j];
+            if (h < e) h = e;
+            if (h < f) h = f;
+            if (h < 0) h = 0;
+            if (h > 32767) h = 32767;
+            H[j] = h;
+            if (h > best) best = h;
+            x = h - gapo - gape;
+            e -= gape; if (e < x) e = x; if (e < 0) e = 0; E[j] = e;
+            f -= gape; if (f < x) f = x; if (f < 0) f = 0;
+        }
+    }
+    free(H); free(E);
+    return best;
+}
 
-/* mag_vh_pop_simple: a fork into two single-path vertices that meet again at one end.  [CHOICE] fermi-lite measures the difference of the two
- * branches with its striped Smith-Waterman; here it is their unit-cost edit distance. */
+#define MAX_N_DIFF 2.01          /* bubble.c */
+#define MAX_R_DIFF 0.1
+#define L_DIFF_COEF 0.2          /* n_diff = |l_0 - l_1| * L_DIFF_COEF when a branch has nothing between its two overlaps */
+
+/* bubble.c: mag_vh_pop_simple -- a fork at end idd into two single-path vertices that meet again at one end.  The two branches (what lies
+ * between their two overlaps, read in the direction away from p) are compared by ksw_align with 5 / -4 and gap 5, 2:
+ * n_diff = (min(l0, l1) * 5 - score) / 9, r_diff = n_diff / mean length; the branch of lower mean coverage goes when the branches are that
+ * close and (aggressive, or its coverage is below max_bfrac of the sum and below max_bcov). */
 static void mag_vh_pop_simple(mag_t *g, int64_t idd, float max_cov, float max_frac, int aggressive)
 {
     magv_t *p = &g->a[idd >> 1], *q[2];
     ku128_v *r;
-    int j, dir = (int)(idd & 1), l[2], side[2];
-    char *seq[2] = {0, 0};
-    float avg[2], n_diff, r_diff;
+    int i, j, dir[2], l[2];
+    char *seq[2], *cov[2];
+    float n_diff, r_diff, avg[2];
     const float max_n_diff = aggressive ? MAX_N_DIFF * 2. : MAX_N_DIFF, max_r_diff = aggressive ? MAX_R_DIFF * 2. : MAX_R_DIFF;
-    if (p->len < 0 || p->nei[dir].n != 2) return;
-    r = &p->nei[dir];
+    if (p->len < 0 || p->nei[idd & 1].n != 2) return;          /* deleted, or no fork */
+    r = &p->nei[idd & 1];
     for (j = 0; j < 2; ++j) {
         int64_t x;
-        if ((int64_t)r->a[j].x < 0 || edge_is_del(r->a[j])) return;
+        if ((int64_t)r->a[j].x < 0) return;
         x = tid2idd(g, r->a[j].x);
-        side[j] = (int)(x & 1); q[j] = &g->a[x >> 1];
-        if (q[j] == p || q[j]->nei[0].n != 1 || q[j]->nei[1].n != 1) return;
-        if (edge_is_del(q[j]->nei[side[j] ^ 1].a[0])) return;
-        l[j] = q[j]->len - (int)r->a[j].y - (int)q[j]->nei[side[j] ^ 1].a[0].y;          /* between the two overlaps */
+        dir[j] = (int)(x & 1);
+        q[j] = &g->a[x >> 1];
+        if (q[j]->nei[0].n != 1 || q[j]->nei[1].n != 1) return;          /* no bubble */
+        l[j] = q[j]->len - (int)(q[j]->nei[0].a->y + q[j]->nei[1].a->y);
     }
-    if (q[0] == q[1]) return;
-    if (q[0]->nei[side[0] ^ 1].a[0].x != q[1]->nei[side[1] ^ 1].a[0].x) return;          /* they do not meet again */
-    for (j = 0; j < 2; ++j) {
-        if (l[j] < 0) l[j] = 0;
-        seq[j] = (char*)malloc(l[j] + 1);
-        branch_seq(q[j], side[j], (int)r->a[j].y, l[j], seq[j], &avg[j]);
-        if (l[j] == 0) {          /* nothing between the overlaps: the coverage of the whole vertex */
-            double s = 0; int i;
-            for (i = 0; i < q[j]->len; ++i) s += q[j]->cov[i] - 33;
-            avg[j] = (float)(s / q[j]->len);
+    if (q[0]->nei[dir[0] ^ 1].a->x != q[1]->nei[dir[1] ^ 1].a->x) return;          /* the branches do not meet again */
+    for (j = 0; j < 2; ++j) {          /* seq[], cov[] and the mean coverage avg[] */
+        if (l[j] > 0) {
+            const int b0 = (int)q[j]->nei[0].a->y;
+            seq[j] = (char*)malloc((size_t)l[j] << 1);
+            cov[j] = seq[j] + l[j];
+            for (i = 0; i < l[j]; ++i) seq[j][i] = q[j]->seq[i + b0], cov[j][i] = q[j]->cov[i + b0];
+            if (dir[j]) {          /* seq_revcomp6 + seq_reverse */
+                for (i = 0; i < l[j] >> 1; ++i) {
+                    char a = seq[j][i], b = seq[j][l[j] - 1 - i], c;
+                    seq[j][i] = b < 5 ? 5 - b : 5; seq[j][l[j] - 1 - i] = a < 5 ? 5 - a : 5;
+                    c = cov[j][i]; cov[j][i] = cov[j][l[j] - 1 - i]; cov[j][l[j] - 1 - i] = c;
+                }
+                if (l[j] & 1) seq[j][l[j] >> 1] = seq[j][l[j] >> 1] < 5 ? 5 - seq[j][l[j] >> 1] : 5;
+            }
+            for (i = 0, avg[j] = 0.; i < l[j]; ++i) {
+                --seq[j][i];          /* codes 1..5 -> 0..4 for the alignment */
+                avg[j] += cov[j][i] - 33;
+            }
+            avg[j] /= l[j];
+        } else {          /* nothing between the overlaps (around a tandem repeat) */
+            int beg = (int)q[j]->nei[0].a->y, end = q[j]->len - (int)q[j]->nei[1].a->y;
+            seq[j] = cov[j] = 0;
+            if (beg > end) { int t = beg; beg = end; end = t; }
+            if (beg < end) {
+                for (i = beg, avg[j] = 0.; i < end; ++i) avg[j] += q[j]->cov[i] - 33;
+                avg[j] /= end - beg;
+            } else avg[j] = q[j]->cov[beg] - 33;
         }
     }
     if (l[0] > 0 && l[1] > 0) {
-        n_diff = (float)edit_dist(seq[0], l[0], seq[1], l[1], 0);
-        r_diff = n_diff / (float)(l[0] < l[1] ? l[0] : l[1]);
-    } else n_diff = (float)abs(l[0] - l[1]), r_diff = 1.f;
+        const int score = ksw_align_score(l[0], seq[0], l[1], seq[1], 5, -4, 5, 2);
+        n_diff = ((l[0] < l[1] ? l[0] : l[1]) * 5. - score) / (5. + 4.);
+        r_diff = n_diff / ((l[0] + l[1]) / 2.);
+    } else {
+        n_diff = abs(l[0] - l[1]) * L_DIFF_COEF;
+        r_diff = 1.;
+    }
     if (n_diff < max_n_diff || r_diff < max_r_diff) {
         j = avg[0] < avg[1] ? 0 : 1;
         if (aggressive || (avg[j] / (avg[j ^ 1] + avg[j]) < max_frac && avg[j] < max_cov)) mag_v_del(g, q[j]);
@@ -585,52 +618,111 @@ static void mag_g_pop_simple(mag_t *g, float max_cov, float max_frac, int min_me
     mag_g_merge(g, 0, min_merge_len);
 }
 
-/* mag_v_pop_open: a short dead-end branch that repeats what a sibling branch at the same fork says.  [CHOICE] fermi-lite extends the tip
- * against each sibling with ksw_extend; here the tip's own bases (beyond the overlap) are compared with the start of the sibling's by unit-cost
- * edit distance with a free end in the sibling: gone when some sibling is within max(2, 10 % of the tip's own length). */
+/* ksw.c: ksw_extend(qlen, query, tlen, target, m = 5, mat, gapo, gape, w, h0, &qle, &tle) -- fermi-lite carries the first form of bwa's extension
+ * (one gap cost for both kinds, no z-drop, no end bonus): the row loop, the band, its shrinking over zero cells and the arg-max are those of
+ * ksw_extend2 with o_del = o_ins, e_del = e_ins, zdrop = 0, end_bonus = 0. */
+static int ksw_extend_old(int qlen, const char *query, int tlen, const char *target, const int8_t *mat /* 5 x 5 */, int gapo, int gape, int w, int h0,
+                          int *_qle, int *_tle)
+{
+    typedef struct { int32_t h, e; } eh_t;
+    eh_t *eh = (eh_t*)calloc((size_t)qlen + 1, 8);
+    int i, j, k, gapoe = gapo + gape, beg, end, max, max_i, max_j, max_gap;
+    eh[0].h = h0; eh[1].h = h0 > gapoe ? h0 - gapoe : 0;
+    for (j = 2; j <= qlen && eh[j - 1].h > gape; ++j) eh[j].h = eh[j - 1].h - gape;
+    for (i = 0, max = 0, k = 25; i < k; ++i) max = max > mat[i] ? max : mat[i];
+    max_gap = (int)((double)(qlen * max - gapo) / gape + 1.);
+    max_gap = max_gap > 1 ? max_gap : 1;
+    w = w < max_gap ? w : max_gap;
+    max = h0; max_i = max_j = -1;
+    beg = 0; end = qlen;
+    for (i = 0; i < tlen; ++i) {
+        int f = 0, h1, m = 0, mj = -1, t;
+        const int8_t *q = &mat[target[i] * 5];
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1 = h0 - (gapo + gape * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
+        for (j = beg; j < end; ++j) {
+            eh_t *p = &eh[j];
+            int h, M = p->h, e = p->e;
+            p->h = h1;
+            M = M ? M + q[(int)query[j]] : 0;
+            h = M > e ? M : e;
+            h = h > f ? h : f;
+            h1 = h;
+            mj = m > h ? mj : j;
+            m = m > h ? m : h;
+            t = M - gapoe; t = t > 0 ? t : 0;
+            e -= gape; e = e > t ? e : t; p->e = e;
+            f -= gape; f = f > t ? f : t;
+        }
+        eh[end].h = h1; eh[end].e = 0;
+        if (m == 0) break;
+        if (m > max) max = m, max_i = i, max_j = mj;
+        for (j = beg; j < end && eh[j].h == 0 && eh[j].e == 0; ++j) {}
+        beg = j;
+        for (j = end; j >= beg && eh[j].h == 0 && eh[j].e == 0; --j) {}
+        end = j + 2 < qlen ? j + 2 : qlen;
+    }
+    free(eh);
+    if (_qle) *_qle = max_j + 1;
+    if (_tle) *_tle = max_i + 1;
+    return max;
+}
+
+/* mag.c: mag_v_pop_open -- a short dead-end vertex p (shorter than min_elen, one neighbour in all) whose bases repeat what a sibling branch at the
+ * same fork says.  As in fermi-lite the tip is EXTENDED against every sibling with ksw_extend (5 / -4, gap 5, 2, h0 = 5 x the tip's overlap with
+ * the fork vertex): query = the tip's bases beyond its overlap, read away from the fork; target = the sibling's bases beyond ITS overlap.
+ * [CHOICE -- the one rule of this function that could not be recovered without the source] the tip goes when for some sibling the extension
+ * reaches the tip's far end (qle == the tip's own length) with at most one difference per ten bases: score - h0 >= 5 * l_qry - 9 * max(1, l_qry / 10).
+ * Band: w = 50. */
 static void mag_v_pop_open(mag_t *g, magv_t *p, int min_elen)
 {
-    int dir, i, lp, side_p;
+    int dir, i, j, k, l_qry, kill = 0;
     int64_t x;
     magv_t *q;
     ku128_v *r;
-    char *ps;
+    char *qry;
     float dummy;
-    int kill = 0;
+    int8_t mat[25];
     if (p->len < 0 || p->len >= min_elen) return;
     if (p->nei[0].n + p->nei[1].n != 1) return;
     dir = p->nei[0].n ? 0 : 1;
-    if ((int64_t)p->nei[dir].a[0].x < 0 || edge_is_del(p->nei[dir].a[0])) return;
+    for (i = k = 0; i < 4; ++i) {
+        for (j = 0; j < 4; ++j) mat[k++] = i == j ? 5 : -4;
+        mat[k++] = 0;
+    }
+    for (j = 0; j < 5; ++j) mat[k++] = 0;
+    if ((int64_t)p->nei[dir].a[0].x < 0) return;
     x = tid2idd(g, p->nei[dir].a[0].x);
     q = &g->a[x >> 1];
     if (q == p) return;
     r = &q->nei[x & 1];
-    if (r->n < 2) return;
-    lp = p->len - (int)p->nei[dir].a[0].y;
-    if (lp <= 0) return;
-    side_p = dir;          /* p is left through the end that touches q: read away from it */
-    ps = (char*)malloc(lp + 1);
-    branch_seq(p, side_p, (int)p->nei[dir].a[0].y, lp, ps, &dummy);
+    l_qry = p->len - (int)p->nei[dir].a[0].y;
+    if (l_qry <= 0) return;
+    qry = (char*)malloc(l_qry + 1);
+    branch_seq(p, dir, (int)p->nei[dir].a[0].y, l_qry, qry, &dummy);
+    for (i = 0; i < l_qry; ++i) --qry[i];
     for (i = 0; i < r->n && !kill; ++i) {
         int64_t y;
         magv_t *t;
-        int lt, d, thr;
+        int l, sc, qle, tle;
+        const int h0 = (int)p->nei[dir].a[0].y * 5;
         char *ts;
-        if ((int64_t)r->a[i].x < 0 || edge_is_del(r->a[i])) continue;
+        if ((int64_t)r->a[i].x < 0) continue;
         y = tid2idd(g, r->a[i].x);
         t = &g->a[y >> 1];
         if (t == p || t == q || t->len < 0) continue;
-        lt = t->len - (int)r->a[i].y;
-        if (lt < lp) continue;          /* only a branch that goes at least as far can stand for the tip */
-        if (lt > lp + lp / 4 + 8) lt = lp + lp / 4 + 8;
-        ts = (char*)malloc(lt + 1);
-        branch_seq(t, (int)(y & 1), (int)r->a[i].y, lt, ts, &dummy);
-        d = edit_dist(ps, lp, ts, lt, 1);
-        thr = lp / 10 > 2 ? lp / 10 : 2;
-        if (d <= thr) kill = 1;
+        l = t->len - (int)r->a[i].y;
+        if (l <= 0) continue;
+        ts = (char*)malloc(l + 1);
+        branch_seq(t, (int)(y & 1), (int)r->a[i].y, l, ts, &dummy);
+        for (j = 0; j < l; ++j) --ts[j];
+        sc = ksw_extend_old(l_qry, qry, l, ts, mat, 5, 2, 50, h0, &qle, &tle);
+        if (qle == l_qry && sc - h0 >= 5 * l_qry - 9 * (l_qry / 10 > 1 ? l_qry / 10 : 1)) kill = 1;
         free(ts);
     }
-    free(ps);
+    free(qry);
     if (kill) mag_v_del(g, p);
 }
 
@@ -809,6 +901,31 @@ static orc_fml_utg *mag2utg(mag_t *g, int *n_utg)          /* misc.c: fml_mag2ut
 
 /* ------------------------------------------------------------------------------------------------ entry points (misc.c) */
 
+/* test hook: the next assemble call on this thread also writes its overlap graph (strings, representatives, containment, irreducible edges) and the
+ * graph-cleaning options it runs with to `path`, so that the product's host-side graph stage (seqlib_amd/csrc/fml_graph.h) can be run on the same
+ * overlaps without a GPU (tests/cpp/fml_graph_test.cpp).  NULL switches it off. */
+static __thread const char *g_dump_path;
+void orc_fml_set_overlap_dump(const char *path) { g_dump_path = path; }
+
+static void overlap_dump(const char *path, const strset_t *S, const ograph_t *G, const orc_magopt *mo)
+{
+    FILE *fp = fopen(path, "wb");
+    int32_t t, j, hdr[2];
+    if (!fp) return;
+    hdr[0] = S->n; hdr[1] = S->min_match;
+    fwrite(hdr, 4, 2, fp);
+    fwrite(mo, sizeof(*mo), 1, fp);
+    for (t = 0; t < S->n; ++t) { int32_t l = S->len[t]; fwrite(&l, 4, 1, fp); fwrite(S->s[t], 1, (size_t)l, fp); }
+    for (t = 0; t < S->n; ++t) { int32_t r = G->rep[t]; fwrite(&r, 4, 1, fp); }
+    fwrite(G->contained, 1, (size_t)S->n, fp);
+    for (t = 0; t < S->n; ++t) {
+        int32_t k = G->out[t].n;
+        fwrite(&k, 4, 1, fp);
+        for (j = 0; j < k; ++j) { int32_t e[2]; e[0] = G->out[t].a[j].v; e[1] = G->out[t].a[j].len; fwrite(e, 4, 2, fp); }
+    }
+    fclose(fp);
+}
+
 static orc_fml_utg *assemble_core(const orc_fml_opt *opt, int n, const orc_fseq *seqs, int *n_utg)          /* fml_seq2fmi + fml_fmi2mag + fml_mag_clean + fml_mag2utg */
 {
     strset_t *S = strset_build(n, seqs, opt->min_asm_ovlp);
@@ -817,6 +934,7 @@ static orc_fml_utg *assemble_core(const orc_fml_opt *opt, int n, const orc_fseq 
     orc_magopt mo = opt->mag_opt;
     orc_fml_utg *utg;
     mo.min_merge_len = opt->min_merge_len;          /* misc.c: fml_mag_clean */
+    if (g_dump_path) { overlap_dump(g_dump_path, S, G, &mo); g_dump_path = 0; }
     mag_g_clean(g, &mo);
     utg = mag2utg(g, n_utg);
     mag_destroy(g);

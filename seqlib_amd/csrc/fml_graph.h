@@ -250,77 +250,127 @@ struct Graph {
         }
     }
 
-    static int edit_dist(const std::string &a, const std::string &b, bool free_tail)
+    // ksw_align(..., 4, mat(5 / -4), gapo, gape, xtra = 0).score: the local-alignment optimum, a gap of k bases costing gapo + k * gape, cells capped at
+    // 32767 as the 16-bit striped kernel's saturating adds cap them.  Codes 0..3 = ACGT, anything else never matches.
+    // Computed column by column of the query (the checker walks rows of the target): same cells, same values.
+    static int sw_local(const std::string &qry, const std::string &tgt, int match, int mismatch, int gapo, int gape)
     {
-        const int la = (int)a.size(), lb = (int)b.size();
-        std::vector<int> row((size_t)lb + 1);
-        for (int j = 0; j <= lb; ++j) row[(size_t)j] = j;
-        for (int i = 1; i <= la; ++i) {
-            int diag = row[0];
-            row[0] = i;
-            for (int j = 1; j <= lb; ++j) {
-                const int t = row[(size_t)j];
-                int d = diag + (a[(size_t)i - 1] != b[(size_t)j - 1]);
-                d = std::min(d, std::min(row[(size_t)j] + 1, row[(size_t)j - 1] + 1));
-                row[(size_t)j] = d; diag = t;
+        const size_t n = tgt.size();
+        std::vector<int> H(n + 1, 0), F(n + 1, 0);          // H of the previous query column; F = best score ending in a gap that consumes query bases
+        int best = 0;
+        for (size_t j = 0; j < qry.size(); ++j) {
+            int diag = 0, e = 0;          // e = best score ending in a gap that consumes target bases, within this column
+            const char cq = qry[j];
+            for (size_t i = 1; i <= n; ++i) {
+                const int up = H[i];
+                int h = diag + ((tgt[i - 1] == cq && cq < 4) ? match : mismatch);
+                h = std::max(std::max(h, F[i]), std::max(e, 0));
+                h = std::min(h, 32767);
+                diag = up;
+                H[i] = h;
+                best = std::max(best, h);
+                const int open = h - gapo - gape;
+                F[i] = std::max(std::max(F[i] - gape, open), 0);
+                e = std::max(std::max(e - gape, open), 0);
             }
         }
-        int best = row[(size_t)lb];
-        if (free_tail) for (int j = 0; j <= lb; ++j) best = std::min(best, row[(size_t)j]);
         return best;
     }
 
-    // the l bases of q that follow its overlap when it is entered through `side`
-    static std::string branch(const Vtx &q, int side, int ovlp, int l, float *avg)
+    // ksw_extend (fermi-lite's ksw.c: one gap cost, no z-drop, no end bonus), as called by mag_v_pop_open: 5 x 5 matrix, 5 / -4, code 4 scores 0
+    static int extend(const std::string &qry, const std::string &tgt, int gapo, int gape, int w, int h0, int *qle)
+    {
+        const int qlen = (int)qry.size(), tlen = (int)tgt.size(), gapoe = gapo + gape;
+        struct Cell { int h = 0, e = 0; };
+        std::vector<Cell> eh((size_t)qlen + 2);
+        auto sc = [](char a, char b) { return (a > 3 || b > 3) ? 0 : (a == b ? 5 : -4); };
+        eh[0].h = h0;
+        if (qlen >= 1) eh[1].h = h0 > gapoe ? h0 - gapoe : 0;
+        for (int j = 2; j <= qlen && eh[(size_t)j - 1].h > gape; ++j) eh[(size_t)j].h = eh[(size_t)j - 1].h - gape;
+        int max_gap = (int)((double)(qlen * 5 - gapo) / gape + 1.);
+        max_gap = std::max(max_gap, 1);
+        w = std::min(w, max_gap);
+        int best = h0, best_j = -1, beg = 0, end = qlen;
+        for (int i = 0; i < tlen; ++i) {
+            int f = 0, row_max = 0, row_j = -1;
+            beg = std::max(beg, i - w);
+            end = std::min(std::min(end, i + w + 1), qlen);
+            int h1 = beg == 0 ? std::max(h0 - (gapo + gape * (i + 1)), 0) : 0;
+            int j = beg;
+            for (; j < end; ++j) {
+                Cell &c = eh[(size_t)j];
+                int M = c.h, e = c.e;
+                c.h = h1;
+                M = M ? M + sc(tgt[(size_t)i], qry[(size_t)j]) : 0;
+                const int h = std::max(std::max(M, e), f);
+                h1 = h;
+                if (!(row_max > h)) row_j = j;
+                row_max = std::max(row_max, h);
+                const int t = std::max(M - gapoe, 0);
+                c.e = std::max(e - gape, t);
+                f = std::max(f - gape, t);
+            }
+            eh[(size_t)end].h = h1; eh[(size_t)end].e = 0;
+            if (row_max == 0) break;
+            if (row_max > best) best = row_max, best_j = row_j;
+            for (j = beg; j < end && eh[(size_t)j].h == 0 && eh[(size_t)j].e == 0; ++j) {}
+            beg = j;
+            for (j = end; j >= beg && eh[(size_t)j].h == 0 && eh[(size_t)j].e == 0; --j) {}
+            end = std::min(j + 2, qlen);
+        }
+        *qle = best_j + 1;
+        return best;
+    }
+
+    // the l bases of q that follow its overlap when it is entered through `side`, as codes 0..4
+    static std::string branch(const Vtx &q, int side, int ovlp, int l)
     {
         std::string s((size_t)std::max(l, 0), 0);
-        double sum = 0;
         for (int i = 0; i < l; ++i) {
             const int at = side == 0 ? ovlp + i : q.len - 1 - ovlp - i;
             const char c = q.seq[(size_t)at];
-            s[(size_t)i] = side == 0 ? c : (c < 5 ? (char)(5 - c) : (char)5);
-            sum += q.cov[(size_t)at] - 33;
+            s[(size_t)i] = (char)((side == 0 ? c : (c < 5 ? (char)(5 - c) : (char)5)) - 1);
         }
-        if (avg) *avg = l > 0 ? (float)(sum / l) : 0.0f;
         return s;
     }
 
+    // bubble.c: mag_vh_pop_simple
     void pop_simple_at(int64_t x0, float max_cov, float max_frac, bool aggressive)
     {
         const int pi = (int)(x0 >> 1), dir = (int)(x0 & 1);
-        Vtx &p = v[(size_t)pi];
+        const Vtx &p = v[(size_t)pi];
         const float max_n_diff = aggressive ? 2.01 * 2. : 2.01, max_r_diff = aggressive ? 0.1 * 2. : 0.1;
         if (p.len < 0 || p.nei[dir].size() != 2) return;
         int qi[2], side[2], l[2];
         float avg[2];
         for (int j = 0; j < 2; ++j) {
             const Nei &e = p.nei[dir][(size_t)j];
-            if ((int64_t)e.x < 0 || is_del(e)) return;
+            if ((int64_t)e.x < 0) return;
             const int64_t x = tid2idd(e.x);
             side[j] = (int)(x & 1); qi[j] = (int)(x >> 1);
             const Vtx &q = v[(size_t)qi[j]];
-            if (qi[j] == pi || q.nei[0].size() != 1 || q.nei[1].size() != 1) return;
-            if (is_del(q.nei[side[j] ^ 1][0])) return;
-            l[j] = q.len - (int)e.y - (int)q.nei[side[j] ^ 1][0].y;
+            if (q.nei[0].size() != 1 || q.nei[1].size() != 1) return;
+            l[j] = q.len - (int)(q.nei[0][0].y + q.nei[1][0].y);
         }
-        if (qi[0] == qi[1]) return;
         if (v[(size_t)qi[0]].nei[side[0] ^ 1][0].x != v[(size_t)qi[1]].nei[side[1] ^ 1][0].x) return;
         std::string seq[2];
         for (int j = 0; j < 2; ++j) {
             const Vtx &q = v[(size_t)qi[j]];
-            if (l[j] < 0) l[j] = 0;
-            seq[j] = branch(q, side[j], (int)p.nei[dir][(size_t)j].y, l[j], &avg[j]);
-            if (l[j] == 0) {
-                double s = 0;
-                for (int i = 0; i < q.len; ++i) s += q.cov[(size_t)i] - 33;
-                avg[j] = (float)(s / q.len);
-            }
+            int beg = (int)q.nei[0][0].y, end = q.len - (int)q.nei[1][0].y;
+            if (l[j] > 0) seq[j] = branch(q, side[j], (int)q.nei[side[j]][0].y, l[j]);
+            else if (beg > end) std::swap(beg, end);
+            if (beg < end) {          // l > 0: exactly the stretch between the overlaps; the sum of small integers is exact in float whatever its order
+                int s = 0;
+                for (int i = beg; i < end; ++i) s += q.cov[(size_t)i] - 33;
+                avg[j] = (float)s / (float)(end - beg);
+            } else avg[j] = (float)(q.cov[(size_t)beg] - 33);
         }
         float n_diff, r_diff;
         if (l[0] > 0 && l[1] > 0) {
-            n_diff = (float)edit_dist(seq[0], seq[1], false);
-            r_diff = n_diff / (float)std::min(l[0], l[1]);
-        } else n_diff = (float)std::abs(l[0] - l[1]), r_diff = 1.f;
+            const int score = sw_local(seq[0], seq[1], 5, -4, 5, 2);
+            n_diff = (float)((std::min(l[0], l[1]) * 5. - score) / (5. + 4.));
+            r_diff = (float)(n_diff / ((l[0] + l[1]) / 2.));
+        } else n_diff = (float)(std::abs(l[0] - l[1]) * 0.2), r_diff = 1.f;
         if (n_diff < max_n_diff || r_diff < max_r_diff) {
             const int j = avg[0] < avg[1] ? 0 : 1;
             if (aggressive || (avg[j] / (avg[j ^ 1] + avg[j]) < max_frac && avg[j] < max_cov)) v_del(qi[j]);
@@ -336,34 +386,35 @@ struct Graph {
         merge(false, min_merge_len);
     }
 
+    // mag.c: mag_v_pop_open (the tip is extended against every sibling with ksw_extend)
     void pop_open_at(int pi, int min_elen)
     {
-        Vtx &p = v[(size_t)pi];
+        const Vtx &p = v[(size_t)pi];
         if (p.len < 0 || p.len >= min_elen) return;
         if (p.nei[0].size() + p.nei[1].size() != 1) return;
         const int dir = p.nei[0].empty() ? 1 : 0;
         const Nei e0 = p.nei[dir][0];
-        if ((int64_t)e0.x < 0 || is_del(e0)) return;
+        if ((int64_t)e0.x < 0) return;
         const int64_t x = tid2idd(e0.x);
         const int qi = (int)(x >> 1);
         if (qi == pi) return;
         const std::vector<Nei> &r = v[(size_t)qi].nei[x & 1];
-        if (r.size() < 2) return;
-        const int lp = p.len - (int)e0.y;
-        if (lp <= 0) return;
-        const std::string ps = branch(p, dir, (int)e0.y, lp, nullptr);
+        const int lq = p.len - (int)e0.y;
+        if (lq <= 0) return;
+        const std::string qs = branch(p, dir, (int)e0.y, lq);
+        const int h0 = (int)e0.y * 5;
         bool kill = false;
         for (size_t i = 0; i < r.size() && !kill; ++i) {
-            if ((int64_t)r[i].x < 0 || is_del(r[i])) continue;
+            if ((int64_t)r[i].x < 0) continue;
             const int64_t y = tid2idd(r[i].x);
             const int ti = (int)(y >> 1);
             const Vtx &t = v[(size_t)ti];
             if (ti == pi || ti == qi || t.len < 0) continue;
-            int lt = t.len - (int)r[i].y;
-            if (lt < lp) continue;
-            lt = std::min(lt, lp + lp / 4 + 8);
-            const std::string ts = branch(t, (int)(y & 1), (int)r[i].y, lt, nullptr);
-            if (edit_dist(ps, ts, true) <= std::max(lp / 10, 2)) kill = true;
+            const int lt = t.len - (int)r[i].y;
+            if (lt <= 0) continue;
+            int qle = 0;
+            const int sc = extend(qs, branch(t, (int)(y & 1), (int)r[i].y, lt), 5, 2, 50, h0, &qle);
+            if (qle == lq && sc - h0 >= 5 * lq - 9 * std::max(lq / 10, 1)) kill = true;
         }
         if (kill) v_del(pi);
     }

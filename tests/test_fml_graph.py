@@ -1,0 +1,101 @@
+"""The product's host-side graph stage (seqlib_amd/csrc/fml_graph.h: unitig chaining, mag_g_clean with fermi-lite's Smith-Waterman bubble tests,
+fml_mag2utg) against the CPU checker's (oracle/orc_fml_asm.c) on the SAME overlap graphs, without a GPU: the checker dumps the overlap graph of a
+window, tests/cpp/fml_graph_test.cpp runs the product's code on it.  Windows with two haplotypes (bubbles: SNPs and small indels), repeats, the
+reference's own fixture reads; every flag of mag_g_clean the reference's setters and fml_opt_t constructor can reach except MAG_F_NO_SIMPL cleared."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import fml_util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "fml_graph_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "fml_graph_test.cpp"), "-o", out])
+    return out
+
+
+def _run(exe, dump):
+    r = subprocess.run([exe, dump], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = []
+    for line in r.stdout.split("\n"):
+        if not line:
+            continue
+        f = line.split("\t")
+        ov = [tuple(int(x) for x in o.split(":")) for o in f[7:]]
+        out.append(dict(len=int(f[1]), nsr=int(f[2]), seq=f[3].encode(), cov=f[4].encode(), n_ovlp=(int(f[5]), int(f[6])),
+                        ovlp=[{"len": a, "from": b, "id": c, "to": d} for a, b, c, d in ov]))
+    return out
+
+
+def _same(got, exp, tag):
+    assert len(got) == len(exp), "%s: %d unitigs, checker %d" % (tag, len(got), len(exp))
+    for i, (a, b) in enumerate(zip(got, exp)):
+        for k in ("len", "nsr", "seq", "cov", "n_ovlp", "ovlp"):
+            assert a[k] == b[k], "%s: unitig %d differs in %s" % (tag, i, k)
+
+
+def _het_windows(genome):
+    w = []
+    for seed, (name, a, b), cov_reads, err in ((1, ("abl", 50000, 60000), 1600, 0.01), (2, ("bcr", 30000, 38000), 1300, 0.005), (3, ("tp53", 2000, 9000), 1200, 0.01),
+                                                (4, ("myc", 0, 7000), 1000, 0.002)):
+        g = genome[name][a:b]
+        x = U.sim_window(g, cov_reads, seed=100 + seed, err=err)
+        y = U.sim_window(U.het_genome(g, seed), cov_reads, seed=200 + seed, err=err)
+        w.append((x[0] + y[0], x[1] + y[1]))
+    # a minor haplotype at a tenth of the reads: the bubbles mag_vh_pop_simple pops under the DEFAULT thresholds (coverage < max_bcov, < max_bfrac of the sum)
+    for seed, (name, a, b) in ((5, ("abl", 80000, 92000)), (6, ("bcr", 90000, 100000))):
+        g = genome[name][a:b]
+        x = U.sim_window(g, (b - a) // 5, seed=300 + seed, err=0.005)
+        y = U.sim_window(U.het_genome(g, seed), (b - a) // 40, seed=400 + seed, err=0.005)
+        w.append((x[0] + y[0], x[1] + y[1]))
+    return w
+
+
+@pytest.mark.parametrize("flags", [0, 0x20, 0x40, 0x60])
+def test_graph_stage_matches_checker(exe, tmp_path, flags):
+    from oracle import orc_fml as F
+    genome = U.fixture_genome()
+    wins = _het_windows(genome) + U.asm_windows(genome)[1:4]
+    n_bubbles_gone = 0
+    for wi, w in enumerate(wins):
+        o = F.default_opt()
+        o.mag_opt.flag |= flags
+        dump = str(tmp_path / ("w%d.bin" % wi))
+        exp = F.assemble(o, F.Reads(w[0], w[1]), dump=dump)
+        got = _run(exe, dump)
+        _same(got, exp, "window %d flags %#x" % (wi, flags))
+        assert exp
+        n_bubbles_gone += len(exp)
+    assert n_bubbles_gone > 0
+
+
+def test_bubble_pass_is_live(exe, tmp_path):
+    """the Smith-Waterman test of mag_vh_pop_simple decides something on these windows: with the pass unable to delete (max_bcov = max_bfrac = 0, not
+    aggressive) the unitigs of the minor-haplotype windows change, and the aggressive flag changes those of the balanced ones"""
+    from oracle import orc_fml as F
+    genome = U.fixture_genome()
+    wins = _het_windows(genome)
+    changed = 0
+    for w in wins[4:]:
+        a = F.assemble(F.default_opt(), F.Reads(w[0], w[1]))
+        o = F.default_opt()
+        o.mag_opt.max_bcov = 0.0
+        o.mag_opt.max_bfrac = 0.0
+        b = F.assemble(o, F.Reads(w[0], w[1]))
+        changed += [u["seq"] for u in a] != [u["seq"] for u in b]
+    assert changed > 0
+    changed = 0
+    for w in wins[:2]:
+        a = F.assemble(F.default_opt(), F.Reads(w[0], w[1]))
+        o = F.default_opt()
+        o.mag_opt.flag |= 0x20
+        b = F.assemble(o, F.Reads(w[0], w[1]))
+        changed += [u["seq"] for u in a] != [u["seq"] for u in b]
+    assert changed > 0
