@@ -77,6 +77,10 @@ def _gen_block(job):
     return m
 
 
+def under_profiler():
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def gen_reads(cfg, refs, n_reads, first_block, share=1):
     """n_reads reads of the config's read set from block first_block on, generated block-parallel by forked workers that
     write straight into one anonymous shared mapping.  Runs BEFORE this process touches the GPU."""
@@ -89,6 +93,8 @@ def gen_reads(cfg, refs, n_reads, first_block, share=1):
     nb = (n_reads + synth.BLOCK - 1) // synth.BLOCK
     jobs = [(first_block + b, b * synth.BLOCK, min(synth.BLOCK, n_reads - b * synth.BLOCK)) for b in range(nb)]
     procs = max(1, min(nb, effective_cpus() // max(1, share), 48))
+    if under_profiler():
+        procs = 1          # a profiler's preloaded library has initialised the GPU before main(): never fork from such a process (slow but safe)
     _G.update(cfg=cfg, refs=refs, out=out)
     if procs > 1:
         with mp.get_context("fork").Pool(procs) as pool:
@@ -447,8 +453,7 @@ def main():
     else:
         # a profiler's preloaded library has initialised the GPU before main(): forking the block generators from here is exactly what the
         # cache exists to avoid -- refuse instead of quietly regenerating
-        under_profiler = any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        if cache and under_profiler:
+        if cache and under_profiler():
             raise SystemExit("bench.py: SLX_BENCH_READS_CACHE=%s is missing or has the wrong size and this process runs under a profiler; fill the "
                              "cache with an un-profiled run of the same command first" % cache)
         reads = gen_reads(cfg, refs, n, first_block=rank * blocks_per_rank, share=world)

@@ -1,6 +1,6 @@
 // BFC.h -- MI355X-native mirror of SeqLib::BFC (/root/reference/SeqLib/BFC.h:22-116, /root/reference/src/BFC.cpp): k-mer-spectrum error
 // correction split the way the reference splits it -- Train() counts the k-mers of the stored reads (fml_count, src/BFC.cpp:208-286) and
-// keeps the table (here: in HBM, slx_fml_count), ErrorCorrect() derives kcov / min_cov from its histogram and corrects the stored reads in
+// keeps the table (here: in HBM, in a device context this object owns -- slx_fml_count), ErrorCorrect() derives kcov / min_cov from its histogram and corrects the stored reads in
 // place (src/BFC.cpp:289-362, slx_fml_error_correct).  Header-only over include/seqlib_amd_fml.h.
 #pragma once
 #include <algorithm>
@@ -15,7 +15,9 @@ namespace SeqLib {
 class BFC {
 public:
     BFC() { fml_opt_init(&fml_opt); }
-    ~BFC() {}
+    ~BFC() { if (own) slx_fml_free(own); }
+    BFC(const BFC &) = delete;          // the object owns its k-mer table (the reference's BFC owns its bfc_ch_t, src/BFC.cpp:208-286)
+    BFC &operator=(const BFC &) = delete;
 
     /** Add a sequence for training or correction (src/BFC.cpp:59-86: refuses an empty sequence or a quality string of another length) */
     bool AddSequence(std::string_view seq, std::string_view qual, std::string_view name)
@@ -39,7 +41,8 @@ public:
             kmer = fml_opt.ec_k;
         }
         detail::FlatReads f = flat();
-        detail::fml_check(slx_fml_count(detail::FmlContext::get(), f.bases.data(), f.has_qual ? f.quals.data() : nullptr, f.offs.data(), (int64_t)m_seq.size(), kmer, 20));
+        if (!own && slx_fml_create(-1, &own) != SLX_OK) throw std::runtime_error(std::string("seqlib_amd: ") + slx_last_error());
+        detail::fml_check(slx_fml_count(own, f.bases.data(), f.has_qual ? f.quals.data() : nullptr, f.offs.data(), (int64_t)m_seq.size(), kmer, 20));
         trained = true;
     }
 
@@ -50,11 +53,11 @@ public:
         if (!trained) throw std::runtime_error("BFC::ErrorCorrect: Train() first");
         detail::FlatReads f = flat();
         int min_cov = 0;
-        detail::fml_check(slx_fml_error_correct(detail::FmlContext::get(), &fml_opt, f.bases.data(), f.has_qual ? f.quals.data() : nullptr, f.offs.data(), (int64_t)m_seq.size(),
+        detail::fml_check(slx_fml_error_correct(own, &fml_opt, f.bases.data(), f.has_qual ? f.quals.data() : nullptr, f.offs.data(), (int64_t)m_seq.size(),
                                                 0, nullptr, nullptr, &kcov, &min_cov));
         for (size_t i = 0; i < m_seq.size(); ++i) {
             m_seq[i].assign(f.bases, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
-            if (f.has_qual) m_qual[i].assign(f.quals, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
+            if (f.has_qual && m_qual[i].size() == m_seq[i].size()) m_qual[i].assign(f.quals, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
         }
     }
 
@@ -78,24 +81,14 @@ public:
     void ResetGetSequence() { m_idx = 0; }
 
 private:
-    detail::FlatReads flat() const
-    {
-        detail::FlatReads f;
-        f.offs.push_back(0);
-        for (size_t i = 0; i < m_seq.size(); ++i) {
-            f.bases += m_seq[i];
-            if (m_qual[i].size() == m_seq[i].size()) f.quals += m_qual[i]; else f.has_qual = false;
-            f.offs.push_back(f.bases.size());
-        }
-        if (!f.has_qual) f.quals.clear();
-        return f;
-    }
+    detail::FlatReads flat() const { return detail::flat_reads(m_seq, m_qual, nullptr); }
     size_t m_idx = 0;
     std::vector<std::string> m_seq, m_qual, m_names;
     fml_opt_t fml_opt;
     int kmer = 0;
     float kcov = 0;
     bool trained = false;
+    slx_fml *own = nullptr;          // this object's device context: its count table lives there from Train() to the next Train()
 };
 
 }  // namespace SeqLib

@@ -148,27 +148,32 @@ public:
 
     void SetGapOpen(int gap_open)
     {
+        Flush();
         if (gap_open < 0) throw std::invalid_argument{"SetGapOpen: gap_open must be >= 0"};
         memopt_.o_ins = memopt_.o_del = gap_open;
     }
     void SetGapExtension(int gap_ext)
     {
+        Flush();
         if (gap_ext < 0) throw std::invalid_argument{"SetGapExtension: gap_ext must be >= 0"};
         memopt_.e_ins = memopt_.e_del = gap_ext;
     }
     void SetMismatchPenalty(int mismatch)
     {
+        Flush();
         if (mismatch < 0) throw std::invalid_argument{"SetMismatchPenalty: mismatch must be >= 0"};
         memopt_.b = mismatch;
         slx_fill_scmat(memopt_.a, memopt_.b, memopt_.mat);
     }
     void SetZDropoff(int zdrop)
     {
+        Flush();
         if (zdrop < 0) throw std::invalid_argument{"SetZDropoff: zdrop must be >= 0"};
         memopt_.zdrop = zdrop;
     }
     void SetAScore(int a)
-    {   // scales the penalties but leaves the score matrix as it was (reference behaviour, src/BWAAligner.cpp:43-59)
+    {
+        Flush();   // scales the penalties but leaves the score matrix as it was (reference behaviour, src/BWAAligner.cpp:43-59)
         if (a < 0) throw std::invalid_argument{"SetAScore: a must be >= 0"};
         memopt_.a = a;
         memopt_.b *= a; memopt_.T *= a; memopt_.o_ins *= a; memopt_.o_del *= a; memopt_.e_ins *= a; memopt_.e_del *= a;
@@ -176,21 +181,25 @@ public:
     }
     void Set3primeClippingPenalty(int penalty)
     {
+        Flush();
         if (penalty < 0) throw std::invalid_argument{"Set3primeClippingPenalty: penalty must be >= 0"};
         memopt_.pen_clip3 = penalty;
     }
     void Set5primeClippingPenalty(int penalty)
     {
+        Flush();
         if (penalty < 0) throw std::invalid_argument{"Set5primeClippingPenalty: penalty must be >= 0"};
         memopt_.pen_clip5 = penalty;
     }
     void SetBandwidth(int bw)
     {
+        Flush();
         if (bw < 0) throw std::invalid_argument{"SetBandwidth: bandwidth must be >= 0"};
         memopt_.w = bw;
     }
     void SetReseedTrigger(float trigger)
     {
+        Flush();
         if (trigger < 0.0f) throw std::invalid_argument{"SetReseedTrigger: trigger must be >= 0"};
         memopt_.split_factor = trigger;
     }
@@ -201,9 +210,10 @@ public:
     // scoring >= T in bwa's order (0x800 on all but the first, mapq capped at the first's), XA:Z from mem_gen_alt through the
     // branch of :240, MD:Z, XS:i and SA:Z; a read without such a record yields one unmapped record (flag 4).  keepSecFrac and
     // maxSecondary are not used then.
-    void UseBwaMemRecords(bool on = true) { if (on) memopt_.flag |= SLX_F_REG2SAM; else memopt_.flag &= ~SLX_F_REG2SAM; }
+    void UseBwaMemRecords(bool on = true) { Flush(); if (on) memopt_.flag |= SLX_F_REG2SAM; else memopt_.flag &= ~SLX_F_REG2SAM; }
     void SetOutputScoreThreshold(int T)
     {
+        Flush();
         if (T < 0) throw std::invalid_argument{"SetOutputScoreThreshold: T must be >= 0"};
         memopt_.T = T;
     }
@@ -213,6 +223,7 @@ public:
                        int maxSecondary) const
     {
         if (index_->IsEmpty()) return;                       // nothing to do if no index (src/BWAAligner.cpp:101)
+        Flush();                                             // queued calls came first: they keep the earlier lrand48 draws
         const uint64_t offs[2] = {0, (uint64_t)seq.size()};
         const char *names[1] = {name.c_str()};
         run(seq.data(), offs, 1, names, nullptr, hardclip, keepSecFrac, maxSecondary, &out, nullptr);
@@ -232,6 +243,7 @@ public:
         out.clear();
         out.resize(reads.size());
         if (index_->IsEmpty() || reads.empty()) return;
+        Flush();
         run_batch(reads, out, hardclip, keepSecFrac, maxSecondary);
     }
     // ---- deferred per-read calls (new): the reference's calling convention at batch speed ----------------
@@ -239,8 +251,10 @@ public:
     // call is one GPU round trip (~1 ms: dozens of launches for one read), so a loop over 10^6 reads is slower than the CPU library.
     // alignSequenceAsync queues the call instead -- same arguments, the caller's own output vector -- and Flush() runs everything queued
     // as ONE batch: the i-th queued read is the i-th successive alignSequence call (same lrand48 draw, records appended to its vector in
-    // call order).  Queued calls flush by themselves when the arguments after the name change, when 2 M reads are waiting, and in the
-    // destructor.  The output vectors must stay alive until then.  Not thread-safe (one queue per aligner).
+    // call order).  Queued calls flush by themselves when the arguments after the name change, when 2 M reads are waiting, before any
+    // synchronous alignSequence / alignSequences call and before any option setter takes effect (so a queued read is aligned with the
+    // options and the draw it would have had as a plain call), and in the destructor.  The output vectors must stay alive until then.
+    // If the batch throws, the queue is put back.  Not thread-safe (one queue per aligner).
     void alignSequenceAsync(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double keepSecFrac, int maxSecondary)
     {
         if (index_->IsEmpty()) return;
@@ -250,14 +264,15 @@ public:
         q_outs_.push_back(&out);
         if (q_reads_.size() >= (size_t)2 << 20) Flush();
     }
-    void Flush()
+    void Flush() const
     {
         if (q_reads_.empty()) return;
         std::vector<BamRecordPtrVector> res;
         UnalignedSequenceVector reads;
         std::vector<BamRecordPtrVector *> outs;
-        reads.swap(q_reads_); outs.swap(q_outs_);
-        alignSequences(reads, res, q_hardclip_, q_ksf_, q_maxsec_);
+        reads.swap(q_reads_); outs.swap(q_outs_);          // (the batch below finds the queue empty)
+        try { alignSequences(reads, res, q_hardclip_, q_ksf_, q_maxsec_); }
+        catch (...) { reads.swap(q_reads_); outs.swap(q_outs_); throw; }          // nothing was delivered: the calls stay queued
         for (size_t i = 0; i < res.size(); ++i)
             for (auto &r : res[i]) outs[i]->push_back(std::move(r));
     }
@@ -278,8 +293,8 @@ public:
     }
 
 private:
-    UnalignedSequenceVector q_reads_;               // alignSequenceAsync's queue
-    std::vector<BamRecordPtrVector *> q_outs_;
+    mutable UnalignedSequenceVector q_reads_;       // alignSequenceAsync's queue (mutable: the const entry points flush it first)
+    mutable std::vector<BamRecordPtrVector *> q_outs_;
     bool q_hardclip_ = false; double q_ksf_ = 0; int q_maxsec_ = 0;
     BWAIndexPtr index_;
     slx_opt memopt_;

@@ -36,8 +36,25 @@ inline void fml_check(int rc) { if (rc != SLX_OK) throw std::runtime_error(std::
 struct FlatReads {
     std::string bases, quals;
     std::vector<uint64_t> offs;
-    bool has_qual = true;
+    bool has_qual = false;
 };
+// The reads as flat text.  Qualities are kept PER READ as the reference keeps them (fseq1_t::qual is NULL for a read without, src/FermiAssembler.cpp:52-62,
+// and fermi-lite then counts every base of that read as high quality): a read without a quality string of its sequence's length gets a stretch of 'I'
+// (Phred 40, above every threshold of bfc) in the flat buffer, and its own quality string is never written back.  No read with qualities: no buffer.
+inline FlatReads flat_reads(const std::vector<std::string> &seq, const std::vector<std::string> &qual, const std::vector<char> *hasq)
+{
+    FlatReads f;
+    f.offs.push_back(0);
+    for (size_t i = 0; i < seq.size(); ++i) if ((!hasq || (*hasq)[i]) && !seq[i].empty() && qual[i].size() == seq[i].size()) { f.has_qual = true; break; }
+    for (size_t i = 0; i < seq.size(); ++i) {
+        f.bases += seq[i];
+        if (f.has_qual) {
+            if ((!hasq || (*hasq)[i]) && qual[i].size() == seq[i].size()) f.quals += qual[i]; else f.quals.append(seq[i].size(), 'I');
+        }
+        f.offs.push_back(f.bases.size());
+    }
+    return f;
+}
 }  // namespace detail
 
 class FermiAssembler {
@@ -154,13 +171,10 @@ public:
         const int n_win = (int)win_off.size() - 1;
         contigs.assign((size_t)std::max(n_win, 0), std::vector<std::string>());
         if (n_win <= 0) return;
-        detail::FlatReads f;
-        f.offs.push_back(0);
-        for (const UnalignedSequence &r : reads) {
-            f.bases += r.Seq;
-            if (r.Qual.size() == r.Seq.size()) f.quals += r.Qual; else f.has_qual = false;
-            f.offs.push_back(f.bases.size());
-        }
+        std::vector<std::string> sq, ql;
+        sq.reserve(reads.size()); ql.reserve(reads.size());
+        for (const UnalignedSequence &r : reads) { sq.push_back(r.Seq); ql.push_back(r.Qual); }
+        detail::FlatReads f = detail::flat_reads(sq, ql, nullptr);
         std::vector<fml_utg_t *> utgs((size_t)n_win, nullptr);
         std::vector<int> n_utg((size_t)n_win, 0);
         detail::fml_check(slx_fml_assemble(detail::FmlContext::get(), &o, f.bases.data(), f.has_qual ? f.quals.data() : nullptr, f.offs.data(), (int64_t)reads.size(),
@@ -176,20 +190,7 @@ private:
     {
         m_names.push_back(name); m_seq.push_back(seq); m_qual.push_back(qual); m_hasq.push_back(has_qual ? 1 : 0);
     }
-    // the reads as flat text; a quality string is passed on only when every read has one of its sequence's length
-    // (fermi-lite reads qual[i] for every base of a read whose qual pointer is not NULL)
-    detail::FlatReads flat() const
-    {
-        detail::FlatReads f;
-        f.offs.push_back(0);
-        for (size_t i = 0; i < m_seq.size(); ++i) {
-            f.bases += m_seq[i];
-            if (m_hasq[i] && m_qual[i].size() == m_seq[i].size()) f.quals += m_qual[i]; else f.has_qual = false;
-            f.offs.push_back(f.bases.size());
-        }
-        if (!f.has_qual) f.quals.clear();
-        return f;
-    }
+    detail::FlatReads flat() const { return detail::flat_reads(m_seq, m_qual, &m_hasq); }
     void run_correct(int flt_uniq)
     {
         detail::FlatReads f = flat();
@@ -204,7 +205,7 @@ private:
                 if (m_hasq[i] && m_qual[i].size() >= (size_t)(ns[i] + nl[i])) m_qual[i] = m_qual[i].substr((size_t)ns[i], (size_t)nl[i]);
             } else {
                 m_seq[i].assign(f.bases, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
-                if (f.has_qual) m_qual[i].assign(f.quals, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
+                if (f.has_qual && m_hasq[i] && m_qual[i].size() == m_seq[i].size()) m_qual[i].assign(f.quals, (size_t)f.offs[i], (size_t)(f.offs[i + 1] - f.offs[i]));
             }
         }
     }

@@ -49,7 +49,8 @@ typedef struct {           /* mirrors fermi-lite's magopt_t */
 
 typedef struct {           /* mirrors fermi-lite's fml_opt_t */
     int n_threads;
-    int ec_k;              /* 0 = chosen from the window's total length (fml_opt_adjust); < 0 = fml_assemble skips the correction */
+    int ec_k;              /* 0 = chosen from the window's total length (fml_opt_adjust); < 0 is refused (SLX_EINVAL): fermi-lite would skip the
+                            * correction but still run fml_fltuniq -> fml_count with the negative k, which is undefined there */
     int min_cnt, max_cnt;
     int min_asm_ovlp;
     int min_merge_len;

@@ -637,7 +637,8 @@ static void kmer_correct(const bfc_opt_t *o, int mode, const orc_bfc_ch *ch, int
     free(e.heap); free(e.stack); free(e.seq.a); free(e.ec[0].a); free(e.ec[1].a);
 }
 
-float orc_bfc_error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch *ch, int n, orc_fseq *seqs, int flt_uniq, int *min_cov_out)
+/* bfc_class = 1: BFC::ErrorCorrect (src/BFC.cpp:289-362), whose min_cov adds the FLOAT constant 0.499f (:339); 0: bfc.c's fml_correct_core (.499) */
+static float error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch *ch, int n, orc_fseq *seqs, int flt_uniq, int *min_cov_out, int bfc_class)
 {
     bfc_opt_t o;
     uint64_t hist[256], hist_high[64], sum_k = 0, tot_k = 0;
@@ -648,7 +649,7 @@ float orc_bfc_error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch 
     mode = orc_bfc_ch_hist(ch, hist, hist_high);
     for (i = fml_opt->min_cnt; i < 256; ++i) sum_k += hist[i], tot_k += hist[i] * i;
     kcov = sum_k ? (float)tot_k / sum_k : 0.0f;          /* src/BFC.cpp:346 guards the empty case; fermi-lite divides */
-    o.min_cov = (int)(BFC_EC_MIN_COV_COEF * kcov + .499);
+    o.min_cov = bfc_class ? (int)(BFC_EC_MIN_COV_COEF * kcov + 0.499f) : (int)(BFC_EC_MIN_COV_COEF * kcov + .499);
     o.min_cov = o.min_cov < fml_opt->max_cnt ? o.min_cov : fml_opt->max_cnt;
     o.min_cov = o.min_cov > fml_opt->min_cnt ? o.min_cov : fml_opt->min_cnt;
     if (min_cov_out) *min_cov_out = o.min_cov;
@@ -656,12 +657,17 @@ float orc_bfc_error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch 
     return kcov;
 }
 
+float orc_bfc_error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch *ch, int n, orc_fseq *seqs, int flt_uniq, int *min_cov_out)
+{
+    return error_correct(fml_opt, k, ch, n, seqs, flt_uniq, min_cov_out, 1);
+}
+
 static float fml_correct_core(const orc_fml_opt *opt, int flt_uniq, int n, orc_fseq *seqs)          /* bfc.c: fml_correct_core */
 {
     orc_bfc_ch *ch = orc_fml_count(n, seqs, opt->ec_k, 20);
     float kcov;
     if (!ch) return 0.0f;
-    kcov = orc_bfc_error_correct(opt, opt->ec_k, ch, n, seqs, flt_uniq, 0);
+    kcov = error_correct(opt, opt->ec_k, ch, n, seqs, flt_uniq, 0, 0);
     orc_bfc_ch_destroy(ch);
     return kcov;
 }
@@ -684,6 +690,9 @@ orc_fseq *orc_fml_reads_from_flat(const char *bases, const char *quals, const ui
     }
     return s;
 }
+
+/* a read without a quality string among reads that have one (fseq1_t::qual == NULL, /root/reference/src/FermiAssembler.cpp:52-62) */
+void orc_fml_reads_drop_qual(orc_fseq *seqs, int i) { free(seqs[i].qual); seqs[i].qual = 0; }
 
 void orc_fml_reads_free(int n, orc_fseq *seqs)
 {

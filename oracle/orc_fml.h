@@ -45,7 +45,8 @@ typedef struct {           /* fermi-lite magopt_t */
 
 typedef struct {           /* fermi-lite fml_opt_t */
     int n_threads;
-    int ec_k;              /* 0 = by total length (fml_opt_adjust); < 0 = no correction inside fml_assemble */
+    int ec_k;              /* 0 = by total length (fml_opt_adjust); < 0 = no correction inside fml_assemble (fml_fltuniq then counts with a negative k:
+                            * undefined in fermi-lite; the product refuses it) */
     int min_cnt, max_cnt;
     int min_asm_ovlp;
     int min_merge_len;
@@ -92,6 +93,7 @@ float orc_bfc_error_correct(const orc_fml_opt *fml_opt, int k, const orc_bfc_ch 
 /* flat helpers for ctypes: reads as concatenated text + offsets */
 orc_fseq *orc_fml_reads_from_flat(const char *bases, const char *quals /* or NULL */, const uint64_t *offs, int n);
 void  orc_fml_reads_free(int n, orc_fseq *seqs);
+void  orc_fml_reads_drop_qual(orc_fseq *seqs, int i);                            /* read i loses its quality string (qual = NULL) */
 uint64_t orc_fml_reads_total(int n, const orc_fseq *seqs);
 void  orc_fml_reads_to_flat(int n, const orc_fseq *seqs, char *bases, char *quals /* or NULL */, uint64_t *offs /* n + 1 */);
 

@@ -77,6 +77,7 @@ def lib():
         L.orc_fml_reads_from_flat.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
         L.orc_fml_reads_from_flat.restype = C.c_void_p
         L.orc_fml_reads_free.argtypes = [C.c_int, C.c_void_p]
+        L.orc_fml_reads_drop_qual.argtypes = [C.c_void_p, C.c_int]
         L.orc_fml_reads_total.argtypes = [C.c_int, C.c_void_p]
         L.orc_fml_reads_total.restype = C.c_uint64
         L.orc_fml_reads_to_flat.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -112,6 +113,10 @@ class Reads:
             assert len(q) == int(offs[-1])
         self.p = lib().orc_fml_reads_from_flat(b"".join(b), q, offs.ctypes.data, self.n)
         self.has_qual = quals is not None
+
+    def drop_qual(self, i):
+        """read i loses its quality string (fseq1_t::qual = NULL); get() reports zero bytes for it"""
+        lib().orc_fml_reads_drop_qual(self.p, i)
 
     def get(self):
         """(seqs, quals) as lists of bytes; a dropped read is b''"""

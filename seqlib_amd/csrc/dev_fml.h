@@ -160,12 +160,13 @@ static __global__ void __launch_bounds__(256) k_fml_count(FmlPlanes pl, long lon
 // memory side serves ~4.3 G of them per second, whatever the table's size.  Here the k-mers are first BINNED by the high bits of their
 // hash into partitions of ~8-16 K k-mers (k_fml_bin: a block counts its tile's k-mers per partition in LDS, reserves a stretch of each
 // partition with ONE global atomic, and writes the 8-byte items there), then each partition is counted by one block in an LDS hash table
-// (k_fml_part: LDS atomics), and every distinct k-mer is inserted into the window's table once, uncontended.  A partition or an LDS table
-// that overflows raises a flag and the host counts the batch again with k_fml_count.
+// (k_fml_part: LDS atomics), and every distinct k-mer is inserted into the window's table once, uncontended.  The items a full partition or a
+// full LDS table cannot take go straight into the window's table (one global atomic each, as k_fml_count would): no flag, no recount.
 #define FML_BIN_TILE 16384          // text positions per block of k_fml_bin
 #define FML_PART_CAP 20736          // items a partition holds (1.25 x the 16 K mean at most + slack)
 #define FML_PART_SLOTS 4096         // LDS table of k_fml_part
 #define FML_PART_MAX 4096           // partitions per window at most (LDS counters of k_fml_bin)
+#define FML_PART_PROBES 64          // LDS probes before an item of k_fml_part spills into the window's table (a full LDS table must not cost 4096 probes per item)
 
 // one insert into a window's table (what k_fml_count does per k-mer); false = the table is full
 __device__ __forceinline__ bool fml_insert(FmlSlot *t, unsigned int tab_mask, unsigned long long key, unsigned long long inc)
@@ -272,7 +273,7 @@ static __global__ void __launch_bounds__(256) k_fml_part(const unsigned int *cur
             if (old == 0) old = atomicCAS(&s_key[s], 0ULL, key + 1);
             if (old == 0 || old == key + 1) { atomicAdd(&s_val[s], inc); break; }
             s = (s + 1) & (FML_PART_SLOTS - 1);
-            if (++probes >= FML_PART_SLOTS) {                      // the LDS table is full (a partition of mostly distinct k-mers): this one goes straight into the table
+            if (++probes >= FML_PART_PROBES) {                     // the LDS table is (nearly) full around here -- a partition of mostly distinct k-mers: this one goes straight into the table
                 if (!fml_insert(tab + w.tab_off, w.tab_mask, key, (unsigned long long)(inc & 0xffffu) | (unsigned long long)(inc >> 16) << 32)) stats[1] = 1;
                 break;
             }

@@ -123,7 +123,6 @@ extern "C" int64_t slx_fml_counter(const slx_fml *f, const char *key)
     if (k == "huge_vertices") return f->n_huge_vertices;
     if (k == "host_threads") return fml_host_cpus();
     if (k == "count_partitions") return (int64_t)f->n_parts;
-    if (k == "count_fallbacks") return f->n_part_fallbacks;
     return -1;
 }
 
@@ -247,8 +246,8 @@ static int run_count_once(slx_fml *f, int q, bool *too_small)
         hipLaunchKernelGGL(k_fml_pack, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr,
                            (long long)total, q, p0, p1, pn, pq);
         FmlPlanes P{p0, p1, pn, pq, ps};
-        // large batches: bin the k-mers into partitions, count each partition in LDS, insert every distinct k-mer once (dev_fml.h); else, and when
-        // a partition overflows, one contended atomic per k-mer
+        // large batches: bin the k-mers into partitions, count each partition in LDS, insert every distinct k-mer once (dev_fml.h: overflowing items spill
+        // straight into the table); small batches: one contended atomic per k-mer
         bool by_parts = f->part_ok && f->n_parts > 0 && total >= f->part_min_bases &&
                         f->d_cursor.ensure((size_t)f->n_parts * 4 + 64) == SLX_OK && f->d_items.ensure((size_t)f->n_parts * FML_PART_CAP * 8 + 64) == SLX_OK;
         if (by_parts) {
@@ -258,15 +257,6 @@ static int run_count_once(slx_fml *f, int q, bool *too_small)
             hipLaunchKernelGGL(k_fml_part, dim3(f->n_parts), dim3(256), 0, f->st, (const unsigned int *)f->d_cursor.as<unsigned int>(), (const unsigned long long *)f->d_items.as<unsigned long long>(),
                                f->d_wins.as<FmlWin>(), f->n_win, f->d_tab.as<FmlSlot>(), f->d_stats.as<unsigned long long>());
             FML_HIPCHK(hipGetLastError());
-            unsigned long long st3[3] = {0, 0, 0};
-            FML_HIPCHK(hipMemcpyAsync(st3, f->d_stats.p, 24, hipMemcpyDeviceToHost, f->st));
-            FML_HIPCHK(hipStreamSynchronize(f->st));
-            if (st3[2]) {                                     // a partition or its LDS table overflowed (low coverage, one k-mer thousands of times): count again the plain way
-                by_parts = false;
-                ++f->n_part_fallbacks;
-                FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
-                FML_HIPCHK(hipMemsetAsync(f->d_stats.p, 0, 256, f->st));
-            }
         }
         if (!by_parts)
         hipLaunchKernelGGL(k_fml_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, f->st, P, (long long)total, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
@@ -320,7 +310,8 @@ int fml_run_count(slx_fml *f, int q)
 }
 
 // what fml_correct_core derives from bfc_ch_hist (the histograms are in f->h_hist since the count): mode, kcov, min_cov (src/BFC.cpp:315-348)
-int fml_run_hist(slx_fml *f)
+// bfc_class: the rounding constant of BFC::ErrorCorrect (src/BFC.cpp:339 adds the FLOAT 0.499f, fml_correct_core the double .499)
+int fml_run_hist(slx_fml *f, bool bfc_class)
 {
     const int nw = std::max(f->n_win, 1);
     if (f->h_hist.size() < (size_t)nw * 320) { int rc = launch_hist(f); if (rc) return rc; }
@@ -335,7 +326,7 @@ int fml_run_hist(slx_fml *f)
         for (int i = o.min_cnt; i < 256; ++i)
             if (i >= 0) sum_k += hist[i], tot_k += hist[i] * (uint64_t)i;
         const float kcov = sum_k ? (float)tot_k / (float)sum_k : 0.0f;
-        int min_cov = (int)(.1 * kcov + .499);
+        int min_cov = bfc_class ? (int)(.1 * kcov + 0.499f) : (int)(.1 * kcov + .499);
         min_cov = min_cov < o.max_cnt ? min_cov : o.max_cnt;
         min_cov = min_cov > o.min_cnt ? min_cov : o.min_cnt;
         f->wins[(size_t)w].mode = mode; f->wins[(size_t)w].min_cov = min_cov;
@@ -520,7 +511,7 @@ extern "C" int slx_fml_error_correct(slx_fml *f, const slx_fml_opt *opt, char *b
     f->wopt.assign(1, *opt);
     f->n_win = 1;
     FML_HIPCHK(hipMemcpyAsync(f->d_wins.p, f->wins.data(), sizeof(FmlWin), hipMemcpyHostToDevice, f->st));
-    if ((rc = fml_run_hist(f))) return rc;
+    if ((rc = fml_run_hist(f, true))) return rc;
     f->count_win.mode = f->wins[0].mode; f->count_win.min_cov = f->wins[0].min_cov;
     if ((rc = flt_uniq ? fml_run_streak(f) : fml_run_ec(f))) return rc;
     if (flt_uniq) { if ((rc = download_trim(f, new_start, new_len))) return rc; }

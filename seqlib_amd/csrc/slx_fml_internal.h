@@ -63,7 +63,6 @@ struct slx_fml {
     bool part_ok = false;                   // ... and the windows of this batch fit the partition limits
     unsigned int n_parts = 0;
     int64_t part_min_bases = 1 << 20;       // smaller batches: one atomic per k-mer (k_fml_count)
-    int64_t n_part_fallbacks = 0;
     int tab_div = 8, tab_grow = 1;          // table slots = 2 x bases x tab_grow / tab_div, a power of two (adapts when a table fills up)
     int64_t n_overlaps = 0, n_irreducible = 0, asm_text_len = 0, n_big_vertices = 0, n_huge_vertices = 0, n_strings = 0;
     unsigned long long tri_per_str = 40;          // of the last assemble call
@@ -79,7 +78,7 @@ int fml_probe_end(slx_fml *f, int which);
 int fml_upload(slx_fml *f, const char *bases, const char *quals, const uint64_t *offs, int64_t n_reads);
 int fml_setup_windows(slx_fml *f, const slx_fml_opt *opt, const int64_t *win_off, int n_win, int k_fixed);
 int fml_run_count(slx_fml *f, int q);
-int fml_run_hist(slx_fml *f);
+int fml_run_hist(slx_fml *f, bool bfc_class = false);
 int fml_run_ec(slx_fml *f);
 int fml_run_streak(slx_fml *f);
 int fml_correct_core_device(slx_fml *f, int flt_uniq);

@@ -45,6 +45,13 @@ static int cpu()
     CHECK(b.GetSequence(s, q) && s == "ACGT" && q == "x" && b.GetSequence(s, q) && !b.GetSequence(s, q));
     b.ResetGetSequence(); CHECK(b.GetSequence(s, q));
     b.ClearReads(); CHECK(b.NumSequences() == 0);
+    {   // qualities are kept per read: a read without gets a stretch of 'I' in the flat buffer, and no buffer at all when no read has qualities
+        std::vector<std::string> sq = {"ACGT", "GG", "TTT"}, ql = {"#I#I", "", "II"};
+        detail::FlatReads fr = detail::flat_reads(sq, ql, nullptr);
+        CHECK(fr.has_qual && fr.bases == "ACGTGGTTT" && fr.quals == "#I#IIIIII" && fr.offs.size() == 4 && fr.offs[3] == 9);
+        std::vector<char> hq = {0, 0, 0};
+        CHECK(!detail::flat_reads(sq, ql, &hq).has_qual && detail::flat_reads(sq, ql, &hq).quals.empty());
+    }
     bool threw = false;
     try { f.AddRead(UnalignedSequence("a", "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT", "")); f.CorrectReads(); } catch (const std::runtime_error &) { threw = true; }
     std::printf("no-GPU call %s\n", threw ? "throws" : "runs");
@@ -93,6 +100,32 @@ static int gpu(const char *fq, long n)
     size_t kept = 0;
     for (const UnalignedSequence &x : g2.GetSequences()) { kept += !x.Seq.empty(); std::cout << "FLT\t" << x.Seq << "\n"; }
     std::cerr << "kept " << kept << " of " << reads.size() << "\n";
+    // 5. two BFC objects own a table each (src/BFC.cpp:208-286: the object's own bfc_ch_t): A trains on the first half, B on the second with another k,
+    //    a FermiAssembler runs in between, then A corrects against ITS table
+    {
+        BFC A, B;
+        const size_t half = reads.size() / 2;
+        for (size_t i = 0; i < half; ++i) A.AddSequence(reads[i].Seq, reads[i].Qual, reads[i].Name);
+        for (size_t i = half; i < reads.size(); ++i) B.AddSequence(reads[i].Seq, reads[i].Qual, reads[i].Name);
+        A.SetKmer(17); B.SetKmer(21);
+        A.Train(); B.Train();
+        FermiAssembler between;
+        for (size_t i = 0; i < 200 && i < reads.size(); ++i) between.AddRead(reads[i]);
+        between.CorrectReads();
+        A.ErrorCorrect();
+        B.ErrorCorrect();
+        std::cout << "BF2\t" << A.GetKMer() << "\t" << A.GetKCov() << "\t" << B.GetKMer() << "\t" << B.GetKCov() << "\n";
+        std::string sa, na;
+        while (A.GetSequence(sa, na)) std::cout << "BFA\t" << sa << "\n";
+        while (B.GetSequence(sa, na)) std::cout << "BFB\t" << sa << "\n";
+    }
+    // 6. a mixed read set: every third read has no quality string (AddRead keeps qual = NULL for it, src/FermiAssembler.cpp:52-62)
+    {
+        FermiAssembler m;
+        for (size_t i = 0; i < reads.size(); ++i) m.AddRead(i % 3 == 1 ? UnalignedSequence(reads[i].Name, reads[i].Seq, "") : reads[i]);
+        m.CorrectReads();
+        for (const UnalignedSequence &x : m.GetSequences()) std::cout << "MIX\t" << x.Seq << "\n";
+    }
     return 0;
 }
 

@@ -77,6 +77,26 @@ def test_cpp_fml_pipeline_matches_oracle(exe, golden_dir):
     F.fltuniq(o, R)
     fs, _ = R.get()
     assert out["FLT"] == [s.decode() for s in fs]
+    # 5. two BFC objects, each correcting against its own table, with a FermiAssembler call in between (the table is the object's)
+    half = n // 2
+    got_k = out["BF2"][0].split("\t")
+    for tag, (a, b), k, gk, gkcov in (("BFA", (0, half), 17, got_k[0], got_k[1]), ("BFB", (half, n), 21, got_k[2], got_k[3])):
+        R = F.Reads(seqs[a:b], quals[a:b])
+        c = F.Count(R, k)
+        kcov, _ = c.error_correct(F.default_opt(), R)
+        es, _ = R.get()
+        assert int(gk) == k and abs(float(gkcov) - kcov) < 1e-3 * kcov
+        assert out[tag] == [s.decode().upper() for s in es], tag
+    # 6. every third read without a quality string: those reads count as all-high-quality, the others keep their own qualities
+    R = F.Reads(seqs, quals)
+    for i in range(1, n, 3):
+        R.drop_qual(i)
+    o = F.default_opt(); F.opt_adjust(o, R)
+    F.correct(o, R)
+    ms, _ = R.get()
+    assert out["MIX"] == [s.decode() for s in ms]
+    R2 = F.Reads(seqs, quals); o = F.default_opt(); F.opt_adjust(o, R2); F.correct(o, R2)
+    assert R2.get()[0] != ms          # (and the missing qualities do change the corrections)
 
 
 @pytest.mark.gpu
