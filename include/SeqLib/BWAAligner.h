@@ -44,7 +44,7 @@
 namespace SeqLib {
 
 namespace detail {
-// CPUs this process may actually use: hardware threads, cut down to the CPU affinity mask and to the cgroup's CPU quota (a container
+// CPUs this process may actually use: hardware threads, cut down to the CPU affinity mask, to the cgroup's CPU quota and to this rank's share (a container
 // that shows 256 hardware threads with a quota of 16 CPUs runs 256 busy threads at a sixteenth of their speed each).
 inline unsigned effective_cpus()
 {
@@ -66,6 +66,12 @@ inline unsigned effective_cpus()
     double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                         // cgroup v2: "<quota> <period>" or "max <period>"
     if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // cgroup v1
     if (q > 0) n = std::min(n, (unsigned)std::max(1.0, std::ceil(q)));
+    // one process per GPU on a shared node: every rank takes its share of the CPUs, not all of them (LOCAL_WORLD_SIZE is what
+    // torch.distributed.run / torchrun export; SEQLIB_AMD_LOCAL_RANKS for any other launcher)
+    for (const char *name : {"SEQLIB_AMD_LOCAL_RANKS", "LOCAL_WORLD_SIZE"}) {
+        const char *e = std::getenv(name);
+        if (e && std::atoi(e) > 1) { n = std::max(1u, n / (unsigned)std::atoi(e)); break; }
+    }
     return n;
 }
 

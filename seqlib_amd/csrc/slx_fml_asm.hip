@@ -18,7 +18,7 @@
 #include "dev_fml_asm.h"
 #include "fml_graph.h"
 
-// CPUs this process may use: hardware threads cut down to the cgroup CPU quota (the GPU boxes show 256 under a quota of 16)
+// CPUs this process may use: hardware threads cut down to the cgroup CPU quota (the GPU boxes show 256 under a quota of 16) and to this rank's share
 int fml_host_cpus()
 {
     static int cached = 0;
@@ -29,6 +29,9 @@ int fml_host_cpus()
     std::ifstream f("/sys/fs/cgroup/cpu.max");
     std::string q; long long per = 0;
     if (f >> q >> per) { if (q != "max" && per > 0) { const long long c = (atoll(q.c_str()) + per - 1) / per; if (c >= 1 && c < n) n = (long)c; } }
+    // one process per GPU on a shared node: this rank's share of the CPUs (LOCAL_WORLD_SIZE from torch.distributed.run; SEQLIB_AMD_LOCAL_RANKS otherwise)
+    for (const char *name : {"SEQLIB_AMD_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+        if (const char *e = getenv(name)) { if (atoi(e) > 1) { n = std::max<long>(1, n / atoi(e)); break; } }
     cached = (int)n;
     return cached;
 }

@@ -63,6 +63,56 @@ def test_pack_unpack_roundtrip(orc, tiny_index, sim_reads):
     assert gather.unpack(gather.pack_numpy(empty))["n_hits"] == 0
 
 
+def _c5_worker(rank, world, port, n_win, per_win, out_path):
+    """one rank of `bench.py --config C5 --gpus N`'s sharding: rank r owns windows [r * W, (r + 1) * W) of the job (bench.c5_workload); the windows
+    are assembled by the CPU checker here (no GPU in this container), the contigs gathered to rank 0"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from oracle import orc_fml
+    _, _, bases, quals, offs, win_off, span = bench.c5_workload(rank, n_win, per_win, 30.0, 150)
+    mine = []
+    for w in range(n_win):
+        a, b = int(win_off[w]), int(win_off[w + 1])
+        rb, rq = bases[a * 150:b * 150].tobytes(), quals[a * 150:b * 150].tobytes()
+        seqs = [rb[i * 150:(i + 1) * 150] for i in range(b - a)]
+        qs = [rq[i * 150:(i + 1) * 150] for i in range(b - a)]
+        mine.append([u["seq"] for u in orc_fml.assemble(orc_fml.default_opt(), orc_fml.Reads(seqs, qs))])
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    if rank == 0:
+        import pickle
+        pickle.dump([w for p in parts for w in p], open(out_path, "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_c5_window_sharding_equals_single_process(tmp_path):
+    """C5's multi-GPU partitioning (windows are independent objects: no data-path collective): the union of two ranks' windows, in rank order, is the
+    single-process job -- same reads, same contigs"""
+    import pickle
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import orc_fml
+    W, per_win = 2, 1500
+    out = str(tmp_path / "c5.pkl")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_c5_worker, args=(2, port, W, per_win, out), nprocs=2, join=True)
+    got = pickle.load(open(out, "rb"))
+    _, _, bases, quals, offs, win_off, span = bench.c5_workload(0, 2 * W, per_win, 30.0, 150)
+    exp = []
+    for w in range(2 * W):
+        a, b = int(win_off[w]), int(win_off[w + 1])
+        rb, rq = bases[a * 150:b * 150].tobytes(), quals[a * 150:b * 150].tobytes()
+        seqs = [rb[i * 150:(i + 1) * 150] for i in range(b - a)]
+        qs = [rq[i * 150:(i + 1) * 150] for i in range(b - a)]
+        exp.append([u["seq"] for u in orc_fml.assemble(orc_fml.default_opt(), orc_fml.Reads(seqs, qs))])
+    assert got == exp and sum(len(w) for w in exp) > 0
+
+
 def _gpu_worker(rank, world, port, n, out_path):
     """one rank of the device path: shard aligned on the GPU, slx_hits_pack into a device buffer, that image gathered to rank 0"""
     sys.path.insert(0, ROOT)

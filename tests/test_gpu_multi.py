@@ -43,6 +43,25 @@ def test_bench_two_ranks_under_rccl():
     assert line["cigar_bit_match_rate"] in (None, 1.0)
 
 
+def test_bench_c5_two_ranks():
+    """`bench.py --gpus 2 --config C5` as the driver would launch it: windows sharded over the ranks with no data-path collective, one JSON line,
+    the spot-checked window identical to the CPU checker's, the per-rank host thread count in the line"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5", "--windows", "4", "--reads", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["contig_bit_match_rate"] in (None, 1.0)
+    assert line["host_threads_per_rank"] >= 1
+
+
 def test_group_of_eight_copy_out_share(sl, orc, tiny_gpu, tiny_index, sim_reads):
     """the group handle with eight entries (device 0 x 8): results equal the oracle's, and the second phase of the call -- sizing the
     merged block and copying every device's arrays to their place in it -- is a small part of the call"""
