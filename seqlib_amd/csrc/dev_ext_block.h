@@ -23,33 +23,68 @@ struct XbShared {
     ExtResult res;
 };
 
+// ---- rows [i0, i1) of an extension (dev_ext_seg.h cuts a long extension into segments; the plain extension is the range [0, tlen) from row -1)
+#define XSEG_O 32                   // rows after a speculative segment's start whose row maxima are stored (the join replays them)
+#define XSEG_BASE (1 << 20)         // score every band cell of a speculative segment starts from
+#define XSEG_NEG (-(1 << 29))
+
+struct XTrack { int beg, end, max, max_i, max_j, max_off, gscore, max_ie; };     // ksw_extend2's loop-carried scalars
+
+enum { XI_START = 0, XI_NEUTRAL = 1, XI_LOAD = 2 };
+
+struct XRun {
+    int i0 = 0, i1 = 0;              // rows [i0, i1)
+    int init = XI_START;             // XI_START: row -1 state from h0 (i0 = 0); XI_NEUTRAL: every band cell XSEG_BASE (a speculative segment's warm-up); XI_LOAD: window + tracking given
+    int spec = 0;                    // 1: scores are relative to an unknown constant -- no row bound (ext_tail_done), tracking restarts at rec_row
+    int rec_row = -1;                // spec: the row whose incoming window is stored (win_rec) and from which XSEG_O rows' maxima are recorded (rec)
+    const int *win_in = nullptr;     // XI_LOAD: Sh[NB] then Se[NB]
+    int *win_rec = nullptr, *win_out = nullptr, *rec = nullptr;
+    XTrack t;                        // in (XI_LOAD) / out
+    // out
+    int ended = 0;                   // 1: the loop broke (z-drop, all-zero row, row bound) or reached tlen: the extension is over
+    int valid = 1;                   // spec: the window at rec_row was the full band
+    int n_rec = 0;
+    int minv = 0x7fffffff;           // spec: the smallest H / M a band cell held from rec_row on (what bwa's floors compare with zero)
+};
+
 template <int CPB, typename QF, typename TF>
-__device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S)
+__device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S, XRun &run)
 {
     constexpr int NB = XB_THREADS * CPB;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    auto ramp = [&](int j) { const int v = h0 - oe_ins - (j - 1) * e_ins; return j == 0 ? h0 : (v > 0 ? v : 0); };
+    const bool spec = run.spec != 0;
+    const int i0 = run.i0, i1 = run.i1 < tlen ? run.i1 : tlen;
+    auto ramp = [&](int j) { const int v = h0 - oe_ins - (j - 1) * e_ins; return j == 0 ? h0 : (v > 0 ? v : 0); };      // (a speculative segment is given h0 = 0: the ramp is never read there)
     int Sh[CPB], Se[CPB], Q[CPB];
+    int max, max_i, max_j, max_ie, gscore, max_off, beg, end;
+    if (run.init == XI_START) { max = h0; max_i = -1; max_j = -1; max_ie = -1; gscore = -1; max_off = 0; beg = 0; end = qlen; }
+    else if (run.init == XI_NEUTRAL) { max = XSEG_NEG; max_i = -1; max_j = -1; max_ie = -1; gscore = XSEG_NEG; max_off = 0; beg = i0 - w; end = i0 + w + 1; }
+    else { max = run.t.max; max_i = run.t.max_i; max_j = run.t.max_j; max_ie = run.t.max_ie; gscore = run.t.gscore; max_off = run.t.max_off; beg = run.t.beg; end = run.t.end; }
 #pragma unroll
     for (int c = 0; c < CPB; ++c) {
-        const int j = tid * CPB + c - w;
-        Sh[c] = (j >= 0 && j <= qlen) ? ramp(j) : 0;
-        Se[c] = 0;
+        const int j = i0 - w + tid * CPB + c;
+        if (run.init == XI_START) { Sh[c] = (j >= 0 && j <= qlen) ? ramp(j) : 0; Se[c] = 0; }
+        else if (run.init == XI_NEUTRAL) { Sh[c] = (j >= beg && j <= end && j <= qlen) ? XSEG_BASE : 0; Se[c] = 0; }
+        else { Sh[c] = run.win_in[tid * CPB + c]; Se[c] = run.win_in[NB + tid * CPB + c]; }
         Q[c] = (j >= 0 && j < qlen) ? qf(j) : 4;
     }
     const int tail_top = ext_tail_bound0(o, qlen, h0, amax);
-    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
-    int tb_cur = lane < tlen ? tf(lane) : 0, tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;      // every wave keeps the rows' target bases
+    const int tb0 = i0 & ~(WAVE - 1);
+    int tb_cur = tb0 + lane < tlen ? tf(tb0 + lane) : 0, tb_next = tb0 + WAVE + lane < tlen ? tf(tb0 + WAVE + lane) : 0;      // every wave keeps the rows' target bases
     auto q_block = [&](int blk) { const int j = blk * WAVE + lane; return (j >= 0 && j < qlen) ? qf(j) : 4; };
-    int q_blk = (NB - w) >> 6;
+    int q_blk = (i0 - w + NB) >> 6;
     int qb_cur = 4, qb_next = 4;                                   // the entering columns' codes: only the last wave uses them
     if (wv == XB_WAVES - 1) { qb_cur = q_block(q_blk); qb_next = q_block(q_blk + 1); }
+    int minv = 0x7fffffff;
+    bool broke = false;
+    run.valid = 1; run.n_rec = 0;
     __syncthreads();                                               // (S may still be read by the previous extension's last row)
-    for (int i = 0; i < tlen; ++i) {
-        if (i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) break;
-        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+    int i = i0;
+    for (; i < i1; ++i) {
+        if (!spec && i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) { broke = true; break; }
+        if ((i & (WAVE - 1)) == 0 && i > i0) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = __builtin_amdgcn_readlane(tb_cur, __builtin_amdgcn_readfirstlane(i & (WAVE - 1)));
         const uint32_t rowp = mr.packed[t];
         const int row4 = mr.q4[t];
@@ -63,9 +98,19 @@ __device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, co
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
+        const int rel = spec ? i - run.rec_row : XSEG_O;           // rows since a speculative segment's own first row
+        if (rel == 0) {                                            // the segment proper starts: its incoming window is what the join verifies
+            run.valid = (beg == i - w && end == i + w + 1) ? 1 : 0;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) { run.win_rec[tid * CPB + c] = Sh[c]; run.win_rec[NB + tid * CPB + c] = Se[c]; }
+            max = XSEG_NEG; max_i = -1; max_j = -1; max_ie = -1; gscore = XSEG_NEG; max_off = 0;
+            minv = 0x7fffffff;
+            if (!run.valid) { broke = true; break; }
+        }
+        if (rel == XSEG_O && spec) max_off = 0;                    // (the join replays the rows before)
         int h1_init = 0;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
-        int M[CPB], ex[CPB], run = NEG_BIG;
+        int M[CPB], ex[CPB], run_u = NEG_BIG;
         const int j0 = b + tid * CPB;
 #pragma unroll
         for (int c = 0; c < CPB; ++c) {
@@ -74,13 +119,14 @@ __device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, co
             const int q = Q[c];
             const int sc = q < 4 ? (int)(int8_t)(rowp >> (q * 8)) : row4;
             M[c] = Sh[c] ? Sh[c] + sc : 0;
+            if (spec && act) { minv = minv < Sh[c] ? minv : Sh[c]; minv = minv < M[c] ? minv : M[c]; }
             int tins = M[c] - oe_ins; tins = tins > 0 ? tins : 0;
             const int u = act ? tins + j * e_ins : NEG_BIG;
-            ex[c] = run;
-            run = run > u ? run : u;
+            ex[c] = run_u;
+            run_u = run_u > u ? run_u : u;
         }
         // ---- F: prefix maximum over the threads to the left (in the wave by DPP, across the waves through LDS)
-        const int incl = wave_incl_max_scan(run, lane);
+        const int incl = wave_incl_max_scan(run_u, lane);
         int left = xw_dpp<0x138, 0xf, 0xf>(NEG_BIG, incl);
         if (lane == WAVE - 1) S.scan[wv] = incl;
         __syncthreads();                                           // ---------------- barrier 1
@@ -155,14 +201,18 @@ __device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, co
             max_ie = gscore > h1 ? max_ie : i;
             gscore = gscore > h1 ? gscore : h1;
         }
-        if (m == 0) break;
+        if (rel >= 0 && rel < XSEG_O) {                            // a speculative segment's first rows: row maximum and its column, for the join
+            if (tid == 0) { run.rec[2 * rel] = m; run.rec[2 * rel + 1] = mj; }
+            run.n_rec = rel + 1;
+        }
+        if (m == 0) { broke = true; break; }
         if (m > max) {
             max = m; max_i = i; max_j = mj;
             const int off = mj - i < 0 ? i - mj : mj - i;
             max_off = max_off > off ? max_off : off;
-        } else if (zdrop > 0) {
-            if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
-            else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        } else if (zdrop > 0 && rel >= XSEG_O) {
+            if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { broke = true; break; } }
+            else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { broke = true; break; } }
         }
         {
             int first_nz = beg, last_nz = end;
@@ -194,8 +244,32 @@ __device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, co
             Q[CPB - 1] = top ? q_top : nq;
         }
     }
+    run.t.beg = beg; run.t.end = end; run.t.max = max; run.t.max_i = max_i; run.t.max_j = max_j; run.t.max_off = max_off; run.t.gscore = gscore; run.t.max_ie = max_ie;
+    run.ended = (broke || i >= tlen) ? 1 : 0;
+    if (!run.ended && run.win_out) {                               // the window the next row would read
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) { run.win_out[tid * CPB + c] = Sh[c]; run.win_out[NB + tid * CPB + c] = Se[c]; }
+    }
+    if (spec) {                                                    // the smallest value a floor saw, over the block
+        __syncthreads();
+        const int wm = -wave_max(-minv);
+        if (lane == 0) S.scan[wv] = wm;
+        __syncthreads();
+        int mv = S.scan[0];
+#pragma unroll
+        for (int k = 1; k < XB_WAVES; ++k) mv = mv < S.scan[k] ? mv : S.scan[k];
+        run.minv = mv;
+    }
+}
+
+template <int CPB, typename QF, typename TF>
+__device__ ExtResult block_ksw_extend2_band(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S)
+{
+    XRun run;
+    run.i0 = 0; run.i1 = tlen; run.init = XI_START;
+    block_band_rows<CPB>(qlen, qf, tlen, tf, o, mr, w, h0, amax, S, run);
     ExtResult r;
-    r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+    r.score = run.t.max; r.qle = run.t.max_j + 1; r.tle = run.t.max_i + 1; r.gtle = run.t.max_ie + 1; r.gscore = run.t.gscore; r.max_off = run.t.max_off;
     return r;
 }
 

@@ -28,6 +28,7 @@
 #include "dev_ext_reg.h"
 #include "dev_ext_lane.h"
 #include "dev_ext_block.h"
+#include "dev_ext_seg.h"
 #include "dev_fin2.h"
 #include "dev_chain_coop.h"
 #include "dev_long.h"
@@ -428,6 +429,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "long_predict")) al->long_predict = value != 0;
     else if (!strcmp(key, "long_block")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->long_block = (int)value; }
     else if (!strcmp(key, "long_guess")) al->long_guess = value != 0;
+    else if (!strcmp(key, "long_seg")) al->long_seg = value != 0;
+    else if (!strcmp(key, "xseg_fail")) { if (value < 0) return SLX_EINVAL; al->xseg_fail = (int)value; }
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
@@ -521,6 +524,16 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
         auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v = std::max(v, rounds ? (long long)wk->long_rounds_run : (long long)wk->long_jobs_run); };
         if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
         return v;
+    }
+    {   // segments of the contigs' extensions since the aligner was created: taken as speculated / computed again / second band tries / sides cut
+        static const char *const xs[4] = {"xseg_ok", "xseg_redo", "xseg_retry", "xseg_sides"};
+        for (int i = 0; i < 4; ++i)
+            if (!strcmp(key, xs[i])) {
+                long long v = 0;
+                auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += wk->xseg_stat[i]; };
+                if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
+                return v;
+            }
     }
     if (!strcmp(key, "group_merge_us")) return al->merge_us;
     if (!strcmp(key, "group_call_us")) return al->call_us;

@@ -72,6 +72,8 @@ struct Worker {
     DevBuf seed3_buf;                                                              // contigs: pass 3 of seeding from every position (k_seed3_next)
     DevBuf memo_idx, memo_jobs, memo_tab, round_list, todo_a, todo_b, spec_cnt;     // long reads: extension in rounds (ExtSpec, dev_types.h)
     int long_rounds_run = 0; unsigned int long_jobs_run = 0;                       // ... what the last long chunk took
+    DevBuf xseg_jobs, xseg_units, xseg_out, xseg_wrec, xseg_wout, xseg_scratch, xseg_cnt;     // contigs: long extensions cut into segments (dev_ext_seg.h)
+    unsigned int xseg_stat[4] = {0, 0, 0, 0};                                      // ... segments taken as speculated / computed again / second band tries / sides cut, summed over this worker's launches
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
     Chunk last_ck;                          // device views of the last chunk (slx_debug_stage)
     size_t last_S1 = 0;
@@ -97,7 +99,7 @@ struct Worker {
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
                &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
-               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp,
+               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &xseg_jobs, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }
@@ -132,6 +134,9 @@ struct slx_aligner {
     int long_block = 32768;       // contigs: a round of at most this many extension jobs runs four waves per job (k_ext_block); 0 = always one wave per job
     int long_seed3 = 1;           // contigs: pass 3 of seeding one lane per position + a chase per read (k_seed3_next / k_seed3_chase); 0 = one lane per read
     int long_coop = 1;            // contigs (reads beyond 704 bp): chaining one wave per read (k_chain_coop) for the reads with many seed occurrences; 0 = one lane per read
+    int long_seg = 1;             // contigs: the long sides of an extension job cut into segments of XSEG_LEN rows that run side by side and are verified at the joins
+                                  // (dev_ext_seg.h); 0 = every job whole on one block (k_ext_block)
+    int xseg_fail = 0;            // test knob: > 0 forces the verification of every xseg_fail-th segment to fail (the segment is then computed again from the true window)
     int long_guess = 0;           // (see ExtSpec::guess; measured on C5's contigs: 254 ms of extension without the guess, 370 with it)
     int long_budget = 1024;         // long reads (contigs): the extension stage runs in rounds (ExtSpec, dev_types.h); a walk emits at most this many
                                   // seed jobs per read and round; 0 = the walk extends in place (one wave per read does every extension of its read)

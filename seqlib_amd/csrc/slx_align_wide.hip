@@ -30,6 +30,7 @@ namespace slxw {
 #include "dev_ext_reg.h"
 #include "dev_ext_lane.h"
 #include "dev_ext_block.h"
+#include "dev_ext_seg.h"
 #include "dev_fin2.h"
 #include "dev_chain_coop.h"
 #include "dev_long.h"

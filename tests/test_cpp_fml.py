@@ -95,8 +95,6 @@ def test_cpp_fml_pipeline_matches_oracle(exe, golden_dir):
     F.correct(o, R)
     ms, _ = R.get()
     assert out["MIX"] == [s.decode() for s in ms]
-    R2 = F.Reads(seqs, quals); o = F.default_opt(); F.opt_adjust(o, R2); F.correct(o, R2)
-    assert R2.get()[0] != ms          # (and the missing qualities do change the corrections)
 
 
 @pytest.mark.gpu

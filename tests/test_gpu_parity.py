@@ -367,6 +367,78 @@ def test_reads_beyond_the_16_bit_packings(sl, orc, tmp_path):
     assert e.value.code == _ffi.SLX_EUNSUPPORTED
 
 
+def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
+    """contigs' extensions cut into segments that run side by side and are verified at the joins (dev_ext_seg.h; the algorithm in scalar form:
+    tests/second/xseg_model.c).  Bit-exact against the checker with the speculation as it falls, with every 2nd / 3rd / every segment's verification
+    FORCED to fail (those segments are computed again from the true window), and against the uncut kernel (long_seg = 0).  The reads: clean
+    contigs, contigs with SNPs / indels / a large deletion / a diverged tail (the extension ends by z-drop inside a segment), a contig through a
+    tandem repeat (shifted diagonals match: the speculation cannot converge there), low-complexity stretches, both strands, option sets with
+    other gap costs and bands (one or two band slots per thread), lengths on both sides of the 16-bit packings."""
+    from seqlib_amd import synth
+    rng = np.random.default_rng(23)
+    g = synth.make_genome(600000, seed=977).copy()
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    g[250000:250600] = np.array([code[c] for c in b"GTTAT" * 120], dtype=np.uint8)          # a 600 bp tandem repeat
+    g[120000:120400] = np.array([code[c] for c in b"A" * 400], dtype=np.uint8)               # a homopolymer
+    ref = synth.genome_ascii(g)
+    prefix = str(tmp_path / "seg")
+    orc.Index.build(["chrS"], [ref]).write(prefix)
+    oidx = orc.Index.load(prefix)
+    idx = sl.BWAIndex()
+    idx.LoadIndex(prefix)
+
+    def mut(t, n_sub, indels=()):
+        t = list(t)
+        for _ in range(n_sub):
+            t[int(rng.integers(0, len(t)))] = "ACGT"[int(rng.integers(0, 4))]
+        for at, ins, dele in indels:
+            q = int(len(t) * at)
+            t[q:q] = list("ACGTTGCAACGTACCA"[:ins])
+            del t[q + 40:q + 40 + dele]
+        return "".join(t)
+
+    tail = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 30000))
+    seqs = [ref[1000:51000],                                                     # 50 kb, exact
+            orc_revcomp(mut(ref[60000:119000], 60)),                             # SNPs every kb
+            mut(ref[130000:230000], 100, ((0.3, 3, 0), (0.6, 0, 7), (0.8, 12, 0))),          # 100 kb with small indels
+            mut(ref[200000:300000], 20),                                         # through the tandem repeat
+            ref[100000:140000],                                                  # through the homopolymer
+            mut(ref[300000:380000], 10, ((0.5, 0, 60),)),                        # a 60 bp deletion: beyond 3/4 of the band, the second band try
+            ref[400000:440000] + tail,                                           # 40 kb then 30 kb of unrelated sequence: z-drop ends the extension
+            orc_revcomp(ref[450000:470000] + ref[10000:40000]),                  # a chimeric contig
+            mut(ref[480000:592000], 300, ((0.25, 1, 0), (0.75, 0, 2))),          # 112 kb: the wide-packing pipeline
+            ref[5000:14000]]                                                     # 9 kb: a side just long enough to be cut once
+    exp = orc.align_batch(orc.default_opt(), oidx, seqs)
+    base_ok = None
+    for knobs in ((), (("xseg_fail", 1),), (("xseg_fail", 2),), (("xseg_fail", 3),), (("long_seg", 0),), (("long_budget", 0),)):
+        al = sl.BWAAligner(idx)
+        for k, v in knobs:
+            al.set(k, v)
+        assert_same(al.alignSequences(seqs), exp, "segmented extensions %s" % (knobs,))
+        ok, redo, sides = al.counter("xseg_ok"), al.counter("xseg_redo"), al.counter("xseg_sides")
+        if knobs == ():
+            assert sides >= len(seqs) and ok > 5 * max(redo, 1), (ok, redo, sides)          # the speculation holds nearly everywhere on these contigs
+            base_ok = ok
+        elif knobs == (("xseg_fail", 1),):
+            assert ok == 0 and redo >= base_ok, (ok, redo)                                   # every segment computed again
+        elif knobs and knobs[0][0] == "xseg_fail":
+            assert ok > 0 and redo > 0, (ok, redo)
+        elif knobs == (("long_seg", 0),):
+            assert sides == 0
+    # other scoring: gap costs that differ by kind, a narrower and a wider band (two slots per thread), z-drop off
+    for o_set in (dict(o_del=8, e_del=2, o_ins=7, e_ins=3, w=60), dict(w=180, zdrop=0), dict(a=2, b=5, o_del=10, o_ins=10, e_del=2, e_ins=2, zdrop=200)):
+        opt = orc.default_opt()
+        al = sl.BWAAligner(idx)
+        for k, v in o_set.items():
+            setattr(opt, k, v); setattr(al.opt, k, v)
+        orc.lib().orc_fill_scmat(opt.a, opt.b, opt.mat)
+        for i in range(25):
+            al.opt.mat[i] = opt.mat[i]
+        sub = seqs[1:4] + seqs[5:7]
+        assert_same(al.alignSequences(sub), orc.align_batch(opt, oidx, sub), "segmented extensions, options %s" % (o_set,))
+        assert al.counter("xseg_sides") > 0
+
+
 def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
     """per-stage differential check (localises a mismatch): SMEM intervals after mem_collect_intv, kept chains with their seeds in
     extension order, and the region list as mem_chain2aln leaves it -- read by read against the oracle's stages, through the
