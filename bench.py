@@ -464,7 +464,9 @@ def main_c5(args):
             "step_split_ms": {"assemble (slx_fml_assemble_staged + contig strings)": split["assemble_s"] / max(args.steps, 1) * 1e3,
                               "realign (BWAAligner.alignSequences of the contigs)": split["realign_s"] / max(args.steps, 1) * 1e3,
                               "realign_stage_ms": {k: v / max(args.steps, 1) for k, v in split["realign_stage_ms"].items()}},
-            "realign_extension_rounds": {"rounds": al.counter("long_rounds"), "seed_jobs": al.counter("long_jobs")},
+            "realign_extension_rounds": {"rounds": al.counter("long_rounds"), "seed_jobs": al.counter("long_jobs"),
+                                         "segments": {"sides_cut": al.counter("xseg_sides"), "taken_as_speculated": al.counter("xseg_ok"), "computed_again": al.counter("xseg_redo"),
+                                                      "second_band_tries_whole": al.counter("xseg_retry"), "note": "since the aligner was created (warm-up, timed steps, verification)"}},
             "contigs_per_s_realign": len(fit) * args.steps / split["realign_s"] if split["realign_s"] > 0 else None,
             "contig_bit_match_rate": match, "realigned_contig_bit_match_rate": match_realign, "verified": verify_desc,
             "probe_ms_per_step": {k: v / steps for k, v in acc.items()},

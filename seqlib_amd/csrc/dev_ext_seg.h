@@ -17,8 +17,11 @@
 //     speculation -- tests/second/xseg_model.c is the same algorithm in scalar C against the CPU checker's ksw_extend2 on thousands of
 //     seeded cases, tests/test_gpu_parity.py runs this file against the checker with the speculation forced to fail (knob "xseg_fail").
 //     The right side's segment 0 needs the left side's score as h0 and runs on the join's block; its other segments do not (they are
-//     speculative anyway) and run in k_xseg_run beside the left side's.  The second band try of mem_chain2aln (w doubled when max_off is
-//     large) is rare and runs whole on the join's block.
+//     speculative anyway) and run in k_xseg_run beside the left side's.
+//   * mem_chain2aln's second band try (w doubled when the first try's max_off reaches 3/4 of the band: a contig that differs from the
+//     reference by a 75 bp indel, as assemblies of low-complexity tracts do) is a whole new extension of the side.  The join of a job whose
+//     cut side needs it stops there and keeps the job's state (XState); the host then runs a second PASS -- plan, segments and join of
+//     just those sides with the doubled band, two band slots per thread -- and a third for a right side that needs it after its left side did.
 // Behaviour: bwa's ksw_extend2 as reached from mem_chain2aln, /root/reference/src/BWAAligner.cpp:104-109.
 #pragma once
 #include "dev_ext_block.h"
@@ -32,14 +35,17 @@
 #define XSEG_NBMAX (XB_THREADS * 2)
 #define XSEG_WIN (2 * XSEG_NBMAX)   // ints of one stored window: Sh[NB] then Se[NB]
 
-struct XJob { int seg_base[2]; int n_seg[2]; unsigned int unit_base; int pad; };          // per job of the launch, [0] = left, [1] = right; n_seg < 2: that side is not cut
-struct XUnit { unsigned int job_k; int side, k; };                                          // one block's work in k_xseg_run
+struct XJob { int seg_base[2][2]; int n_seg[2][2]; unsigned int unit_base; int pad; };    // per job of the launch, [side][band try]: side 0 = left, 1 = right; n_seg < 2: not cut
+struct XUnit { unsigned int job_k; int side, k, btry; };                                    // one block's work in k_xseg_run
 struct XSegOut { XTrack t; int valid, ended, n_rec, minv; int rec[2 * XSEG_O]; };
+struct XState { DReg a; int stage, aw0; };     // a job between passes: 0 = not started, 1 = waits for the left side's second try, 2 = for the right side's (a, aw0 kept), 9 = done
 
 struct XPlan {
-    XJob *xjobs; XUnit *units; XSegOut *out; int *wrec, *wout, *scratch;
-    unsigned int *cnt;              // [0] segment slots, [1] units, [2] unit queue, [3] job queue, [4] segments taken as speculated, [5] computed again, [6] second band tries, [7] sides cut
+    XJob *xjobs; XState *state; XUnit *units; XSegOut *out; int *wrec, *wout, *scratch;
+    unsigned int *cnt;              // [0] segment slots (all passes), [1] units of this pass, [2] unit queue, [3] job queue, [4] segments taken as speculated, [5] computed again,
+                                    // [6] second band tries, [7] sides cut, [8] jobs waiting for another pass
     int fail_mod;                   // test knob: > 0 forces the verification of every fail_mod-th segment to fail
+    int pass;                       // 0: every job, first band tries; 1, 2: the jobs that wait for a second try
 };
 
 // one side of a seed's extension as ksw_extend2 sees it
@@ -53,13 +59,13 @@ struct XT { const DevRef *R; int64_t t0; int dir; __device__ __forceinline__ int
 
 __device__ inline int xseg_amax(const slx_opt &o) { int m = 0; for (int i = 0; i < 25; ++i) m = m > o.mat[i] ? m : o.mat[i]; return m; }
 
-__device__ inline XSide xside_of(const FirstJob &j, const uint8_t *query, int side, const slx_opt &o, int amax)
+__device__ inline XSide xside_of(const FirstJob &j, const uint8_t *query, int side, const slx_opt &o, int amax, int btry)
 {
     XSide s;
     const int qe = j.s_qbeg + j.s_len;
     if (side == 0) { s.present = j.s_qbeg > 0; s.qlen = j.s_qbeg; s.tlen = (int)(j.s_rbeg - j.rmax0); s.q = query + j.s_qbeg - 1; s.q_dir = -1; s.t0 = j.s_rbeg - 1; s.t_dir = -1; s.end_bonus = o.pen_clip5; }
     else { s.present = qe != j.l_query; s.qlen = j.l_query - qe; s.tlen = (int)(j.rmax1 - (j.s_rbeg + j.s_len)); s.q = query + qe; s.q_dir = 1; s.t0 = j.s_rbeg + j.s_len; s.t_dir = 1; s.end_bonus = o.pen_clip3; }
-    int w = o.w;                                                   // ksw_extend2's own narrowing of the band (first try: w = opt.w)
+    int w = o.w << btry;                                           // ksw_extend2's own narrowing of the band mem_chain2aln gives it (opt.w, then twice that)
     bool ok = s.present && o.e_ins > 0 && o.e_del > 0;
     if (ok) {
         int max_ins = (int)((double)(s.qlen * amax + s.end_bonus - o.o_ins) / o.e_ins + 1.);
@@ -95,18 +101,33 @@ __global__ void k_xseg_plan(Chunk ck, DevOpt dopt, const FirstJob *jobs, const u
     const uint8_t *query = ck.codes + j.q_off;
     XJob x;
     int slots = 0, units = 0;
-    for (int side = 0; side < 2; ++side) {
-        const XSide s = xside_of(j, query, side, opt, amax);
-        x.n_seg[side] = s.n_seg >= 2 ? s.n_seg : 0;
-        x.seg_base[side] = slots;
-        slots += x.n_seg[side];
-        units += x.n_seg[side] ? (side == 0 ? s.n_seg : s.n_seg - 1) : 0;
+    if (P.pass == 0) {
+        for (int side = 0; side < 2; ++side) {
+            const XSide s = xside_of(j, query, side, opt, amax, 0);
+            x.n_seg[side][0] = s.n_seg >= 2 ? s.n_seg : 0; x.n_seg[side][1] = 0;
+            x.seg_base[side][0] = slots; x.seg_base[side][1] = 0;
+            slots += x.n_seg[side][0];
+            units += x.n_seg[side][0] ? (side == 0 ? s.n_seg : s.n_seg - 1) : 0;
+        }
+        x.pad = 0;
+        P.state[k].stage = 0;
+    } else {
+        x = P.xjobs[k];
+        const int stage = P.state[k].stage;
+        if (stage != 1 && stage != 2) { x.unit_base = 0; x.pad = 0; P.xjobs[k] = x; return; }
+        const int side = stage - 1;
+        const XSide s = xside_of(j, query, side, opt, amax, 1);          // (the join only waits for a second try that is cut)
+        x.n_seg[side][1] = s.n_seg >= 2 ? s.n_seg : 0;
+        x.seg_base[side][1] = 0;
+        slots = x.n_seg[side][1];
+        units = x.n_seg[side][1] ? (side == 0 ? s.n_seg : s.n_seg - 1) : 0;
+        x.pad = 1;                                                   // this pass has units of this job
     }
-    x.pad = 0;
     const unsigned int sb = slots ? atomicAdd(&P.cnt[0], (unsigned int)slots) : 0u;
     x.unit_base = units ? atomicAdd(&P.cnt[1], (unsigned int)units) : 0u;
-    x.seg_base[0] += (int)sb; x.seg_base[1] += (int)sb;
-    if (slots) atomicAdd(&P.cnt[7], (unsigned int)((x.n_seg[0] ? 1 : 0) + (x.n_seg[1] ? 1 : 0)));
+    if (P.pass == 0) { x.seg_base[0][0] += (int)sb; x.seg_base[1][0] += (int)sb; }
+    else x.seg_base[P.state[k].stage - 1][1] = (int)sb;
+    if (slots) atomicAdd(&P.cnt[7], P.pass == 0 ? (unsigned int)((x.n_seg[0][0] ? 1 : 0) + (x.n_seg[1][0] ? 1 : 0)) : 1u);
     P.xjobs[k] = x;
 }
 
@@ -116,8 +137,13 @@ __global__ void k_xseg_units(unsigned int n_jobs, XPlan P)
     if (k >= n_jobs) return;
     const XJob x = P.xjobs[k];
     unsigned int u = x.unit_base;
-    for (int side = 0; side < 2; ++side)
-        for (int s = side == 0 ? 0 : 1; s < x.n_seg[side]; ++s) { XUnit v; v.job_k = k; v.side = side; v.k = s; P.units[u++] = v; }
+    if (P.pass == 0) {
+        for (int side = 0; side < 2; ++side)
+            for (int s = side == 0 ? 0 : 1; s < x.n_seg[side][0]; ++s) { XUnit v; v.job_k = k; v.side = side; v.k = s; v.btry = 0; P.units[u++] = v; }
+    } else if (x.pad) {
+        const int side = P.state[k].stage - 1;
+        for (int s = side == 0 ? 0 : 1; s < x.n_seg[side][1]; ++s) { XUnit v; v.job_k = k; v.side = side; v.k = s; v.btry = 1; P.units[u++] = v; }
+    }
 }
 
 // ---- the segments, one block each
@@ -154,8 +180,8 @@ __global__ void __launch_bounds__(XB_THREADS) k_xseg_run(DevRef R, Chunk ck, Dev
         const XUnit v = P.units[u];
         const XJob x = P.xjobs[v.job_k];
         const FirstJob j = jobs[job_list ? job_list[v.job_k] : v.job_k];
-        const XSide sd = xside_of(j, ck.codes + j.q_off, v.side, opt, amax);
-        const int slot = x.seg_base[v.side] + v.k;
+        const XSide sd = xside_of(j, ck.codes + j.q_off, v.side, opt, amax, v.btry);
+        const int slot = x.seg_base[v.side][v.btry] + v.k;
         if (sd.cpb == 1) xseg_run_unit<1>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
         else xseg_run_unit<2>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
     }
@@ -275,29 +301,21 @@ __device__ ExtResult xseg_join_side(const DevRef &R, const slx_opt &o, const Mat
     return r;
 }
 
-// one side: its first band try from the segments where the side was cut (else whole, as k_ext_block runs it), the second try whole
-__device__ ExtResult xseg_side(const DevRef &R, const slx_opt &opt, const MatRows &mr, int amax, const FirstJob &j, const uint8_t *query, int side, int h0, int prev,
-                               const XJob &x, unsigned int job_k, const XPlan &P, int *scratch, int *eh_h, int *eh_e, XbShared &S, int *aw_out)
+// one band try of one side: from its segments where it was cut, else whole on this block (as k_ext_block runs it)
+__device__ ExtResult xseg_try(const DevRef &R, const slx_opt &opt, const MatRows &mr, int amax, const FirstJob &j, const uint8_t *query, int side, int btry, int h0,
+                              const XJob &x, unsigned int job_k, const XPlan &P, int *scratch, int *eh_h, int *eh_e, XbShared &S)
 {
-    const XSide sd = xside_of(j, query, side, opt, amax);
+    const XSide sd = xside_of(j, query, side, opt, amax, btry);
+    if (x.n_seg[side][btry] >= 2) {
+        if (sd.cpb == 1) return xseg_join_side<1>(R, opt, mr, amax, sd, h0, side == 0, P, x.seg_base[side][btry], job_k, scratch, S);
+        return xseg_join_side<2>(R, opt, mr, amax, sd, h0, side == 0, P, x.seg_base[side][btry], job_k, scratch, S);
+    }
     const XQ qf{sd.q, sd.q_dir};
     const XT tf{&R, sd.t0, sd.t_dir};
-    int aw = opt.w;
-    ExtResult er;
-    if (x.n_seg[side] >= 2) {
-        if (sd.cpb == 1) er = xseg_join_side<1>(R, opt, mr, amax, sd, h0, side == 0, P, x.seg_base[side], job_k, scratch, S);
-        else er = xseg_join_side<2>(R, opt, mr, amax, sd, h0, side == 0, P, x.seg_base[side], job_k, scratch, S);
-    } else er = block_extend_side(sd.qlen, qf, sd.tlen, tf, opt, mr, aw, sd.end_bonus, h0, eh_h, eh_e, S);
-    if (!(er.score == prev || er.max_off < (aw >> 1) + (aw >> 2))) {          // mem_chain2aln's second try with twice the band
-        aw = opt.w << 1;
-        if (threadIdx.x == 0) atomicAdd(&P.cnt[6], 1u);
-        er = block_extend_side(sd.qlen, qf, sd.tlen, tf, opt, mr, aw, sd.end_bonus, h0, eh_h, eh_e, S);
-    }
-    *aw_out = aw;
-    return er;
+    return block_extend_side(sd.qlen, qf, sd.tlen, tf, opt, mr, opt.w << btry, sd.end_bonus, h0, eh_h, eh_e, S);
 }
 
-// block_extend_core (dev_ext_block.h) with the sides' first tries taken from their segments
+// block_extend_core (dev_ext_block.h) with the sides' band tries taken from their segments; a job whose cut side needs the second try waits for the next pass
 __global__ void __launch_bounds__(XB_THREADS) k_xseg_join(DevRef R, Chunk ck, DevOpt dopt, const FirstJob *jobs, DReg *out, const unsigned int *job_list, unsigned int n_jobs, XPlan P)
 {
     const slx_opt &opt = dopt.o;
@@ -316,25 +334,51 @@ __global__ void __launch_bounds__(XB_THREADS) k_xseg_join(DevRef R, Chunk ck, De
         __syncthreads();
         const unsigned int k = s_job;
         if (k >= n_jobs) break;
+        const int stage = P.state[k].stage;
+        if (stage == 9) continue;
         const unsigned int job = job_list ? job_list[k] : k;
         const FirstJob j = jobs[job];
         const XJob x = P.xjobs[k];
         const uint8_t *query = ck.codes + j.q_off;
+        const int w1 = opt.w, thr1 = (w1 >> 1) + (w1 >> 2);
         DReg a;
-        a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
-        a.n_comp = 0; a.hash = 0;
         int aw0 = opt.w, aw1 = opt.w;
-        a.w = opt.w; a.score = a.truesc = -1; a.rid = j.rid;
-        if (j.s_qbeg) {
-            const ExtResult er = xseg_side(R, opt, mr, amax, j, query, 0, j.s_len * opt.a, -1, x, k, P, scratch, eh_h, eh_e, S, &aw0);
-            a.score = er.score;
-            if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = j.s_qbeg - er.qle; a.rb = j.s_rbeg - er.tle; a.truesc = a.score; }
-            else { a.qb = 0; a.rb = j.s_rbeg - er.gtle; a.truesc = er.gscore; }
-        } else { a.score = a.truesc = j.s_len * opt.a; a.qb = 0; a.rb = j.s_rbeg; }
+        bool wait = false;
+        if (stage == 2) { a = P.state[k].a; aw0 = P.state[k].aw0; }
+        else {
+            a.rb = a.re = 0; a.qb = a.qe = 0; a.sub = a.csub = a.sub_n = 0; a.seedcov = 0; a.secondary = 0;
+            a.n_comp = 0; a.hash = 0;
+            a.w = opt.w; a.score = a.truesc = -1; a.rid = j.rid;
+            if (j.s_qbeg) {
+                const int h0 = j.s_len * opt.a;
+                ExtResult er;
+                if (stage == 0) {
+                    er = xseg_try(R, opt, mr, amax, j, query, 0, 0, h0, x, k, P, scratch, eh_h, eh_e, S);
+                    if (!(er.score == -1 || er.max_off < thr1)) {          // mem_chain2aln's second try with twice the band
+                        if (threadIdx.x == 0) atomicAdd(&P.cnt[6], 1u);
+                        if (xside_of(j, query, 0, opt, amax, 1).n_seg >= 2) wait = true;
+                        else { er = xseg_try(R, opt, mr, amax, j, query, 0, 1, h0, x, k, P, scratch, eh_h, eh_e, S); aw0 = opt.w << 1; }
+                    }
+                    if (wait) { if (threadIdx.x == 0) { P.state[k].stage = 1; atomicAdd(&P.cnt[8], 1u); } continue; }
+                } else { er = xseg_try(R, opt, mr, amax, j, query, 0, 1, h0, x, k, P, scratch, eh_h, eh_e, S); aw0 = opt.w << 1; }
+                a.score = er.score;
+                if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip5) { a.qb = j.s_qbeg - er.qle; a.rb = j.s_rbeg - er.tle; a.truesc = a.score; }
+                else { a.qb = 0; a.rb = j.s_rbeg - er.gtle; a.truesc = er.gscore; }
+            } else { a.score = a.truesc = j.s_len * opt.a; a.qb = 0; a.rb = j.s_rbeg; }
+        }
         if (j.s_qbeg + j.s_len != j.l_query) {
             const int sc0 = a.score, qe = j.s_qbeg + j.s_len;
             const int64_t re0 = j.s_rbeg + j.s_len;
-            const ExtResult er = xseg_side(R, opt, mr, amax, j, query, 1, sc0, sc0, x, k, P, scratch, eh_h, eh_e, S, &aw1);
+            ExtResult er;
+            if (stage != 2) {
+                er = xseg_try(R, opt, mr, amax, j, query, 1, 0, sc0, x, k, P, scratch, eh_h, eh_e, S);
+                if (!(er.score == sc0 || er.max_off < thr1)) {
+                    if (threadIdx.x == 0) atomicAdd(&P.cnt[6], 1u);
+                    if (xside_of(j, query, 1, opt, amax, 1).n_seg >= 2) wait = true;
+                    else { er = xseg_try(R, opt, mr, amax, j, query, 1, 1, sc0, x, k, P, scratch, eh_h, eh_e, S); aw1 = opt.w << 1; }
+                }
+                if (wait) { if (threadIdx.x == 0) { P.state[k].a = a; P.state[k].aw0 = aw0; P.state[k].stage = 2; atomicAdd(&P.cnt[8], 1u); } continue; }
+            } else { er = xseg_try(R, opt, mr, amax, j, query, 1, 1, sc0, x, k, P, scratch, eh_h, eh_e, S); aw1 = opt.w << 1; }
             a.score = er.score;
             if (er.gscore <= 0 || er.gscore <= a.score - opt.pen_clip3) { a.qe = qe + er.qle; a.re = re0 + er.tle; a.truesc += a.score - sc0; }
             else { a.qe = j.l_query; a.re = re0 + er.gtle; a.truesc += er.gscore - sc0; }
@@ -342,6 +386,6 @@ __global__ void __launch_bounds__(XB_THREADS) k_xseg_join(DevRef R, Chunk ck, De
         a.w = aw0 > aw1 ? aw0 : aw1;
         a.seedlen0 = j.s_len;
         a.frac_rep = j.frac_rep;
-        if (threadIdx.x == 0) out[job] = a;
+        if (threadIdx.x == 0) { out[job] = a; P.state[k].stage = 9; }
     }
 }
