@@ -46,6 +46,11 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                        slx_fml_utg **utgs, int *n_utg)
 {
     const int n_win = f->n_win;
+    const bool times = getenv("SLX_FML_TIMES") != nullptr;          // debug: host-side wall time of this call's parts, on stderr
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    const auto tm0 = now();
+    float tm_strs = 0, tm_gpu = 0, tm_down = 0;
     if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
     std::vector<FmlStr> strs;
     strs.reserve(2 * h_nl.size());
@@ -73,6 +78,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         aw[(size_t)w].str1 = (int64_t)strs.size();
     }
     const long long n_str = (long long)strs.size();
+    tm_strs = ms_since(tm0);
     // one min_match per batch on the device (the windows of a batch share the caller's options)
     const int min_match = n_win ? aw[0].min_match : 1;
     // the text comes back into a pinned buffer the context keeps (a fresh std::vector would be zero-filled and pageable: 240 MB of both for
@@ -180,6 +186,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             }
         }
         unsigned long long n_out = 0;
+        if (times) { (void)hipStreamSynchronize(f->st); tm_gpu = ms_since(tm0); }
         FML_HIPCHK(hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_rep.data(), d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_cont.data(), d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
@@ -191,6 +198,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
         f->n_strings = (int64_t)n_str; f->n_overlaps = (int64_t)n_tri; f->n_irreducible = (int64_t)n_out; f->asm_text_len = (int64_t)text_len; f->n_big_vertices = (int64_t)n_big; f->n_huge_vertices = (int64_t)n_huge;
     }
+    tm_down = ms_since(tm0);
     // ---- per window on the host: chains, cleaning, records -- the windows are independent, so they go over the host's CPUs
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> ev(h_out.size()), el(h_out.size());
@@ -227,6 +235,8 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         for (std::thread &t : pool) t.join();
     }
     f->probe[5] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (times) fprintf(stderr, "[fml times] build_and_assemble: strings on the host %.1f ms, + uploads and overlap kernels %.1f, + downloads %.1f, + graph on the host %.1f (cumulative), %lld strings\n",
+                       tm_strs, tm_gpu, tm_down, ms_since(tm0), n_str);
     return SLX_OK;
 }
 
@@ -246,8 +256,10 @@ static int assemble_resident(slx_fml *f, const slx_fml_opt *opt, const int64_t *
 {
     const int64_t n_reads = f->n_reads;
     int rc;
+    const auto tm0 = std::chrono::steady_clock::now();
     if ((rc = fml_setup_windows(f, opt, win_off, n_win, 0))) return rc;
     if ((rc = fml_correct_core_device(f, 0)) || (rc = fml_correct_core_device(f, 1))) return rc;
+    if (getenv("SLX_FML_TIMES")) { (void)hipStreamSynchronize(f->st); fprintf(stderr, "[fml times] correct + filter on the device: %.1f ms wall\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tm0).count()); }
     std::vector<int> ns((size_t)n_reads + 1), nl((size_t)n_reads + 1);
     if (n_reads) {
         FML_HIPCHK(hipMemcpyAsync(ns.data(), f->d_ns.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, f->st));
