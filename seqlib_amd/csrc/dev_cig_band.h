@@ -348,20 +348,36 @@ __global__ void __launch_bounds__(64) k_cig_band(DevRef R, Chunk ck, DevOpt dopt
     }
 }
 
-// the largest jobs of the list (`n_block` of them: the list is sorted largest first) one BLOCK per job; k_cig_band then starts behind them
-__global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, unsigned int *queue, uint32_t *rest, unsigned int *n_rest)
+// The largest jobs of the list (`n_block` of them: the list is sorted largest first, wide-band jobs before the others) one BLOCK per job, and IN THE SAME
+// LAUNCH the other jobs one WAVE per job (fl.q_dp starts at n_block): a contig's narrow-band CIGAR is as many rows as its wide-band ones -- one full-length
+// alignment on one wave -- and behind the block jobs it would start when they end.  Blocks below n_block_blocks take block jobs first and then turn their
+// four waves to the wave jobs; the blocks above go to the wave jobs at once, so the longest of those starts with the launch.
+__global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, unsigned int n_block_blocks, unsigned int *queue,
+                                                               uint32_t *rest, unsigned int *n_rest)
 {
     __shared__ CigBlockShared SB;
     __shared__ unsigned int s_t;
     const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    if (blockIdx.x < n_block_blocks)
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_t = atomicAdd(queue, 1u);
+            __syncthreads();
+            const unsigned int t = s_t;
+            if (t >= n_jobs) break;
+            const uint32_t slot = fl.dp_list[t];
+            if (!dev_cig_band_job<true>(R, ck, dopt.o, fl, slot, (int)(threadIdx.x & (WAVE - 1)), &SB) && threadIdx.x == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+        }
+    // wave jobs (k_cig_band's loop; fl.q_dp was set to n_block before the launch)
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned int n_all = *fl.n_dp;
     for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_t = atomicAdd(queue, 1u);
-        __syncthreads();
-        const unsigned int t = s_t;
-        if (t >= n_jobs) break;
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_all) break;
         const uint32_t slot = fl.dp_list[t];
-        if (!dev_cig_band_job<true>(R, ck, dopt.o, fl, slot, (int)(threadIdx.x & (WAVE - 1)), &SB) && threadIdx.x == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+        if (!dev_cig_band_job<false>(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
     }
 }
 
