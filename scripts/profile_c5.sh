@@ -53,7 +53,7 @@ res = {
     "count_fetch_bytes_per_launch": cnt.get("FETCH_SIZE", 0.0) * 1024.0 or None,
     "count_write_bytes_per_launch": cnt.get("WRITE_SIZE", 0.0) * 1024.0 or None,
     "count_fetch_plus_write_bytes_per_launch": (cnt.get("FETCH_SIZE", 0.0) + cnt.get("WRITE_SIZE", 0.0)) * 1024.0 or None,
-    "count_algorithmic_bytes_per_launch": 32.0 * bench["roofline"]["kmers_per_launch"] + 2.0 * bench["roofline"]["bases_per_launch"],
+    "count_algorithmic_bytes_per_launch": 32.0 * (bench.get("roofline_count") or bench["roofline"])["kmers_per_launch"] + 2.0 * (bench.get("roofline_count") or bench["roofline"])["bases_per_launch"],
     "ext_kernels": sorted(ext),
     "ext_valu_busy": busy(ext), "ext_valu_lane_utilisation": lanes(ext),
     "ext_valu_busy_by_kernel": {k: busy([k]) for k in sorted(ext)},
