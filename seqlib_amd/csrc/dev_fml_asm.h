@@ -124,13 +124,16 @@ __device__ __forceinline__ bool fml_same(const unsigned char *x, const unsigned 
 // search in the sorted keys and are verified against u[p ..).  A string that ends inside u is contained (over the whole of u at p = 0: a
 // duplicate, the smaller index stands for both); one that runs past the end of u overlaps it by |u| - p bases.  Overlaps leave as
 // (u, v, length) triples, a wave reserving room for its lanes' finds with one atomic; cnt[u] counts them per source.
+#define FML_TRI_CHUNK 1024          // triples a wave reserves at a time: one atomic on the shared counter per chunk, not per round (12.7 M strings x 2 rounds of
+                                    // same-address atomics serialise in one L2 channel at ~10 ns each: that, not the probing, was 3/4 of this kernel's time)
 static __global__ void __launch_bounds__(256) k_asm_join(const unsigned char *text, const FmlStr *strs, long long n_str, int kk, int min_match,
                                                          const unsigned long long *keys, const unsigned int *vals, const unsigned long long *hkey, const unsigned int *hval, unsigned int hmask,
                                                          int *rep, unsigned char *contained, unsigned int *cnt, FmlTriple *tri, unsigned long long tri_cap, unsigned long long *tri_n)
 {
-    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (u >= n_str) return;
+    unsigned long long my_base = 0;          // this wave's stretch of tri[] (wave-uniform)
+    unsigned int my_left = 0;
+    for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < n_str; u += (long long)gridDim.x * 4) {
     const FmlStr su = strs[u];
     const unsigned char *ut = text + su.off;
     unsigned int n_mine = 0;
@@ -157,21 +160,29 @@ static __global__ void __launch_bounds__(256) k_asm_join(const unsigned char *te
                 }
             }
         }
-        // the wave's finds of this round (at most four per lane; the rare rest went out one by one above)
+        // the wave's finds of this round (at most four per lane; the rare rest went out one by one above) into the wave's own stretch
         const int mine = nf < 4 ? nf : 4;
         int incl = mine;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int total = __shfl(incl, 63);
         if (total) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(tri_n, (unsigned long long)total);
-            base = __shfl(base, 0) + (unsigned long long)(incl - mine);
+            if ((unsigned int)total > my_left) {          // a new stretch; what is left of the old one is marked empty (u = -1: k_asm_scatter skips it)
+                for (unsigned int i = (unsigned int)lane; i < my_left; i += 64) if (my_base + i < tri_cap) tri[my_base + i] = FmlTriple{-1, 0, 0};
+                unsigned long long nb = 0;
+                const unsigned int want = total > FML_TRI_CHUNK ? (unsigned int)total : FML_TRI_CHUNK;
+                if (lane == 0) nb = atomicAdd(tri_n, (unsigned long long)want);
+                my_base = __shfl(nb, 0); my_left = want;
+            }
+            const unsigned long long base = my_base + (unsigned long long)(incl - mine);
             for (int j = 0; j < mine; ++j) if (base + j < tri_cap) tri[base + j] = found[j];
+            my_base += (unsigned long long)total; my_left -= (unsigned int)total;
         }
         n_mine += (unsigned int)nf;
     }
     for (int o = 32; o > 0; o >>= 1) n_mine += __shfl_xor(n_mine, o);
     if (lane == 0 && n_mine) cnt[u] = n_mine;
+    }
+    for (unsigned int i = (unsigned int)lane; i < my_left; i += 64) if (my_base + i < tri_cap) tri[my_base + i] = FmlTriple{-1, 0, 0};
 }
 
 // the overlaps between vertices, grouped by source (eoff = exclusive scan of cnt)
@@ -181,6 +192,7 @@ static __global__ void __launch_bounds__(256) k_asm_scatter(const FmlTriple *tri
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tri) return;
     const FmlTriple t = tri[i];
+    if (t.u < 0) return;          // (the unused end of a wave's stretch)
     if (rep[t.u] != t.u || contained[t.u] || rep[t.v] != t.v || contained[t.v]) return;
     const unsigned int slot = atomicAdd(&cur[t.u], 1u);
     edges[eoff[t.u] + slot] = FmlEdge{t.v, t.len};
@@ -191,16 +203,18 @@ static __global__ void __launch_bounds__(256) k_asm_scatter(const FmlTriple *tri
 // u.  Up to 64 edges (the rule: ~coverage x (1 - min_overlap / read length)) live one per lane in registers -- ranks by 64 shuffles, the
 // sort as one cross-lane push, the witnesses' descriptors by shuffle; more go through memory (k_asm_reduce_big).  The irreducible edges of
 // u go to out[] at an offset reserved with one atomic per wave; n_irr / irr_off say where.
+#define FML_OUT_CHUNK 128           // irreducible edges a wave reserves at a time (as FML_TRI_CHUNK: one same-address atomic per chunk instead of one per vertex)
 static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *text, const FmlStr *strs, long long n_str, const unsigned long long *eoff, const unsigned int *cur,
                                                            const FmlEdge *edges, unsigned int *n_irr, unsigned long long *irr_off, FmlEdge *out, unsigned long long *out_n,
                                                            int *big_list, unsigned int *n_big)
 {
-    const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (u >= n_str) return;
+    unsigned long long my_base = 0;
+    unsigned int my_left = 0;
+    for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < n_str; u += (long long)gridDim.x * 4) {
     const int d = (int)cur[u];
-    if (d == 0) { if (lane == 0) { n_irr[u] = 0; irr_off[u] = 0; } return; }
-    if (d > 64) { if (lane == 0) big_list[atomicAdd(n_big, 1u)] = (int)u; return; }
+    if (d == 0) { if (lane == 0) { n_irr[u] = 0; irr_off[u] = 0; } continue; }
+    if (d > 64) { if (lane == 0) big_list[atomicAdd(n_big, 1u)] = (int)u; continue; }
     const FmlEdge me = lane < d ? edges[eoff[u] + (unsigned long long)lane] : FmlEdge{0x7fffffff, -1};
     int r = 0;
     for (int j = 0; j < d; ++j) {
@@ -231,10 +245,15 @@ static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *
     const bool keep = lane < d && !dup && !drop;
     const unsigned long long m = __ballot(keep);
     const int n_keep = __popcll(m);
-    unsigned long long at = 0;
-    if (lane == 0) { at = atomicAdd(out_n, (unsigned long long)n_keep); n_irr[u] = (unsigned int)n_keep; irr_off[u] = at; }
-    at = __shfl(at, 0);
-    if (keep) out[at + __popcll(m & ((1ULL << lane) - 1))] = FmlEdge{sv, sl};
+    if ((unsigned int)n_keep > my_left) {
+        unsigned long long nb = 0;
+        if (lane == 0) nb = atomicAdd(out_n, (unsigned long long)FML_OUT_CHUNK);
+        my_base = __shfl(nb, 0); my_left = FML_OUT_CHUNK;
+    }
+    if (lane == 0) { n_irr[u] = (unsigned int)n_keep; irr_off[u] = my_base; }
+    if (keep) out[my_base + __popcll(m & ((1ULL << lane) - 1))] = FmlEdge{sv, sl};
+    my_base += (unsigned long long)n_keep; my_left -= (unsigned int)n_keep;
+    }
 }
 
 // The same for the vertices with more than 64 overlaps (reads inside repeats and low-complexity tracts: hundreds to thousands of

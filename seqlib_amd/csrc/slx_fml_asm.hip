@@ -138,7 +138,9 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         FML_HIPCHK(hipMemsetAsync(d_hkey, 0, ((size_t)hmask + 1) * 8, f->st));
         hipLaunchKernelGGL(k_asm_index, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, f->st, (const unsigned long long *)keys_out, n_str, d_hkey, d_hval, hmask);
         unsigned long long tri_cap = std::max<unsigned long long>(f->tri_per_str * (unsigned long long)n_str + (1u << 20), 1u << 20), n_tri = 0;
-        const unsigned grid_str = (unsigned)((n_str + 3) / 4);
+        int asm_cus = 256;
+        (void)hipDeviceGetAttribute(&asm_cus, hipDeviceAttributeMultiprocessorCount, f->device);
+        const unsigned grid_str = (unsigned)std::min<long long>((n_str + 3) / 4, (long long)asm_cus * 16);          // persistent waves: each keeps its own stretch of the output (dev_fml_asm.h)
         while (true) {
             if ((rc = f->d_tri.ensure((size_t)tri_cap * sizeof(FmlTriple)))) return rc;
             FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
@@ -157,9 +159,11 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         h_eoff[(size_t)n_str] = n_edges;
         // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
         FmlDevBuf &d_edges = f->d_scratch;
-        if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 3 + 1) + ns * 8 + 256))) return rc;
+        // (e_out: every wave of k_asm_reduce may leave most of one FML_OUT_CHUNK unused)
+        const unsigned long long out_cap = n_edges + 1 + (unsigned long long)grid_str * 4 * FML_OUT_CHUNK;
+        if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 2 + 1) + (size_t)out_cap * sizeof(FmlEdge) + ns * 8 + 256))) return rc;
         FmlEdge *e_raw = d_edges.as<FmlEdge>(), *e_sorted = e_raw + n_edges + 1, *e_out = e_sorted + n_edges + 1;
-        unsigned char *e_flags = (unsigned char *)(e_out + n_edges + 1);
+        unsigned char *e_flags = (unsigned char *)(e_out + out_cap);
         int *big_list = (int *)(((uintptr_t)(e_flags + n_edges + 1) + 15) & ~(uintptr_t)15), *huge_list = big_list + ns;
         FML_HIPCHK(hipMemcpyAsync(d_eoff, h_eoff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
         if (n_tri)
@@ -196,7 +200,9 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
         h_out.resize((size_t)n_out + 1);
         if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
-        f->n_strings = (int64_t)n_str; f->n_overlaps = (int64_t)n_tri; f->n_irreducible = (int64_t)n_out; f->asm_text_len = (int64_t)text_len; f->n_big_vertices = (int64_t)n_big; f->n_huge_vertices = (int64_t)n_huge;
+        { unsigned long long fo = 0, fi = 0; for (long long t = 0; t < n_str; ++t) { fo += h_cnt[(size_t)t]; fi += h_nirr[(size_t)t]; }          // (n_tri and n_out count reserved slots, some unused)
+          f->n_overlaps = (int64_t)fo; f->n_irreducible = (int64_t)fi; }
+        f->n_strings = (int64_t)n_str; f->asm_text_len = (int64_t)text_len; f->n_big_vertices = (int64_t)n_big; f->n_huge_vertices = (int64_t)n_huge;
     }
     tm_down = ms_since(tm0);
     // ---- per window on the host: chains, cleaning, records -- the windows are independent, so they go over the host's CPUs
