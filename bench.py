@@ -30,6 +30,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -270,28 +271,45 @@ def main_c5(args):
     for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):      # experiment hook, e.g. SLX_KNOBS=long_budget=16
         k, v = kv.split("=")
         al.set(k, int(v))
+    aligners = [al]
+    for _ in range(0 if args.no_pipeline else max(0, args.realign_workers - 1)):          # the pipelined steps realign several batches at a time (steps_pipelined)
+        al2 = seqlib_amd.BWAAligner(idx, device=local_rank)
+        for kv in filter(None, os.environ.get("SLX_KNOBS", "").split(",")):
+            k, v = kv.split("=")
+            al2.set(k, int(v))
+        aligners.append(al2)
     ctx = fml.Context(local_rank)
     opt = fml.default_opt()
     ctx.stage(bases, quals, offs)
+    ctxs = [ctx]
+    for _ in range(0 if args.no_pipeline else max(0, args.asm_workers - 1)):
+        ctx2 = fml.Context(local_rank)
+        ctx2.stage(bases, quals, offs)
+        ctxs.append(ctx2)
     max_len = seqlib_amd._ffi.SLX_MAX_READ_LEN
 
     split = {"assemble_s": 0.0, "realign_s": 0.0, "realign_stage_ms": {}}
+    split_lock = threading.Lock()
 
-    def assemble():
+    def assemble(c=None):
+        c = c or ctx
         t_a = time.time()
-        wins = ctx.assemble_staged(opt, win_off)
-        ms, ins, nb = ctx.probe_ms()
+        wins = c.assemble_staged(opt, win_off)
+        ms, ins, nb = c.probe_ms()
         contigs = [u["seq"] for w in wins for u in w]
         fit = [c for c in contigs if len(c) <= max_len]
-        split["assemble_s"] += time.time() - t_a
+        with split_lock:
+            split["assemble_s"] += time.time() - t_a
         return wins, contigs, fit, ms, ins, nb
 
-    def realign(fit):
+    def realign(fit, a=None):
+        a = a or al
         t_b = time.time()
-        hits = al.alignSequences(fit) if fit else None
-        split["realign_s"] += time.time() - t_b
-        for k, v in al.stage_ms().items():
-            split["realign_stage_ms"][k] = split["realign_stage_ms"].get(k, 0.0) + v
+        hits = a.alignSequences(fit) if fit else None
+        with split_lock:
+            split["realign_s"] += time.time() - t_b
+            for k, v in a.stage_ms().items():
+                split["realign_stage_ms"][k] = split["realign_stage_ms"].get(k, 0.0) + v
         return hits
 
     def step():
@@ -299,19 +317,29 @@ def main_c5(args):
         return wins, contigs, fit, realign(fit), ms, ins, nb
 
     def steps_pipelined(k_steps):
-        """the windows of step k + 1 are assembled (the context's stream + the host's graph threads) while the contigs of step k go through the
-        aligner (its workers' streams): two independent C-ABI objects driven from two host threads, as a pipeline over many batches of
-        windows would run them.  Every step's assembly and realignment still happen inside the timed region."""
+        """a pipeline over the steps' batches of windows, as a job of many batches would run: TWO assembly threads, each with an fml context of its own (its stream + the
+        host's graph threads), take the steps alternately -- one batch's graph cleaning on the host runs under the other's kernels --; the contigs of a finished assembly
+        go to one of TWO realignment threads, each with an aligner of its own (the workers' streams): the realignment of a batch is mostly the latency of its longest
+        contig through single-block stages, and two batches' poles overlap.  Four independent C-ABI objects driven from four host threads; every step's assembly and
+        realignment happen inside the timed region."""
         from concurrent.futures import ThreadPoolExecutor
-        out = []
-        with ThreadPoolExecutor(1) as ex:
-            fut = ex.submit(assemble)
+        out = [None] * k_steps
+        with ThreadPoolExecutor(len(ctxs)) as ex_a, ThreadPoolExecutor(len(aligners)) as ex_r:
+            fa = [ex_a.submit(assemble, ctxs[k % len(ctxs)]) for k in range(k_steps)]          # (a context runs its assemblies one after another)
+            fr = []
+
+            def realign_timed(fit, a):
+                h = realign(fit, a)
+                return h, time.time()
             for k in range(k_steps):
-                wins, contigs, fit, ms, ins, nb = fut.result()
-                if k + 1 < k_steps:
-                    fut = ex.submit(assemble)
-                out.append((wins, contigs, fit, realign(fit), ms, ins, nb))
-                marks.append(time.time())
+                wins, contigs, fit, ms, ins, nb = fa[k].result()
+                fr.append((k, wins, contigs, fit, ms, ins, nb, ex_r.submit(realign_timed, fit, aligners[k % len(aligners)])))
+            ends = []
+            for k, wins, contigs, fit, ms, ins, nb, f in fr:
+                h, t_done = f.result()
+                out[k] = (wins, contigs, fit, h, ms, ins, nb)
+                ends.append(t_done)
+            marks.extend(sorted(ends))          # when each step's realignment ended
         return out
 
     def fence():
@@ -320,7 +348,11 @@ def main_c5(args):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        w_ = step()
+        for a2 in aligners[1:]:          # the second realignment thread's aligner and the second assembly context size their work areas too
+            realign(w_[2], a2)
+        for c2 in ctxs[1:]:
+            assemble(c2)
     acc = {}
     ins_acc = nb_acc = 0
     split.update(assemble_s=0.0, realign_s=0.0, realign_stage_ms={})
@@ -458,9 +490,10 @@ def main_c5(args):
             "windows_per_s": n_win * world / (dt / args.steps),
             "contigs": {"n": len(contigs), "total_bp": sum(lens), "longest": lens[:5], "n50": n50, "realigned": len(fit), "realigned_bp": sum(len(c) for c in fit),
                         "skipped_longer_than_max_read_len": len(contigs) - len(fit), "records": int(hits["n_hits"]) if hits is not None else 0},
-            "pipelined": (not args.no_pipeline),
-            "pipelined_note": None if args.no_pipeline else "step k + 1's windows are assembled while step k's contigs are realigned (two host threads, separate streams); "
-                              "step_split_ms are the two halves' own wall times under that overlap; --no-pipeline runs them one after the other",
+            "pipelined": (not args.no_pipeline), "asm_workers": len(ctxs), "realign_workers": len(aligners),
+            "pipelined_note": None if args.no_pipeline else "two assembly threads (an fml context each) take the steps alternately; finished contigs go to one of two realignment threads, each with its own aligner "
+                              "(four C-ABI objects, separate streams): neighbouring steps' assemblies and realignments overlap; "
+                              "step_split_ms are the halves' own wall times under that overlap (realign: summed over the two threads / steps); --no-pipeline runs everything one after the other",
             "step_split_ms": {"assemble (slx_fml_assemble_staged + contig strings)": split["assemble_s"] / max(args.steps, 1) * 1e3,
                               "realign (BWAAligner.alignSequences of the contigs)": split["realign_s"] / max(args.steps, 1) * 1e3,
                               "realign_stage_ms": {k: v / max(args.steps, 1) for k, v in split["realign_stage_ms"].items()}},
@@ -494,6 +527,8 @@ def main():
                                                             "step fill the chip under them -- 8: 0.51 M reads/s, 32: 1.34 M, 64: 2.05 M on one MI355X)")
     ap.add_argument("--no-pipeline", action="store_true", help="C5: assemble and realign one after the other inside a step (default: step k + 1's assembly overlaps step k's realignment)")
     ap.add_argument("--coverage", type=float, default=30.0, help="C5: read coverage of a window")
+    ap.add_argument("--asm-workers", type=int, default=2, help="C5, pipelined: assembly threads, each with an fml context of its own")
+    ap.add_argument("--realign-workers", type=int, default=2, help="C5, pipelined: realignment threads, each with an aligner of its own")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -760,13 +795,13 @@ def main():
                     except Exception as e:
                         percall = dict(error=str(e))
                 os.remove(sample)
-        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 2 steps of the default 64
+        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 4 steps of the default 64
         # windows x 100 000 reads, a tenth-size window at full coverage through both CPU checkers -- as a process of its own (this one has let go of its
         # aligner above), so that the driver's default run times the assembler pipeline too
         other = None
         if not args.no_extras and args.config == "C3" and world == 1 and os.environ.get("SLX_BENCH_NO_C5_LEG") != "1":
             try:
-                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
                                    stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
                 ln = [x for x in o.stdout.decode().splitlines() if x.startswith("{")]
                 if o.returncode == 0 and ln:
