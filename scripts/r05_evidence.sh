@@ -10,7 +10,7 @@ case " $SKIP " in *" tests "*) ;; *)
 timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;; esac
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 400 $OUT/bench_default.json
-timeout 900 python bench.py --config C5 --steps 6 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 300 $OUT/bench_c5.json
+timeout 1200 python bench.py --config C5 --steps 12 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 300 $OUT/bench_c5.json
 case " $SKIP " in *" prof "*) ;; *)
 bash scripts/profile_c5.sh $OUT/c5 > $OUT/profile_c5.log 2>&1 ;; esac
 ls $OUT
