@@ -216,11 +216,11 @@ def c5_workload(rank, n_win, reads_per_win, coverage, read_len=150):
     return cfg, refs, bases, quals, offs, win_off, span
 
 
-def c5_cpu_baseline(coverage, read_len, sample_reads):
-    """fml_assemble of the CPU checker (a restatement: fermi-lite is an empty submodule of the reference) on one thread -- the reference
-    runs fermi-lite with n_threads = 1 (fml_opt_init) -- on a window of `sample_reads` reads made by the same generator at the same
-    coverage (a fifth of a bench window in reads and in span)."""
-    from oracle import orc_fml
+def c5_cpu_baseline(coverage, read_len, sample_reads, index_prefix=None):
+    """The CPU checkers on one thread -- the reference runs fermi-lite with n_threads = 1 (fml_opt_init) and one alignSequence per contig -- over BOTH halves of a step:
+    fml_assemble of a window of `sample_reads` reads made by the same generator at the same coverage (a fifth of a bench window in reads and in span), then its contigs
+    through the aligner's checker (orc.align_batch against the index the GPU wrote)."""
+    from oracle import orc, orc_fml
     from seqlib_amd import synth
     cfg = synth.CONFIGS["C2"]
     g = synth.make_reference(cfg)[0][1]
@@ -235,10 +235,20 @@ def c5_cpu_baseline(coverage, read_len, sample_reads):
     t0 = time.time()
     utgs = orc_fml.assemble(orc_fml.default_opt(), R)
     dt = time.time() - t0
-    return dict(value=sample_reads / dt, unit="reads/s", cores=1, kind="port",
-                sample="fml_assemble of the CPU checker on a window of %d reads at %.0fx over %d bp made by the bench's generator (%.1f s, %d contigs, longest %d bp); "
-                       "one thread, as the reference runs fermi-lite (fml_opt_init: n_threads = 1); assembly only, no realignment"
-                       % (sample_reads, coverage, span, dt, len(utgs), max([u["len"] for u in utgs] + [0])))
+    dt_al, n_rec = None, None
+    if index_prefix:
+        oidx = orc.Index.load(index_prefix)
+        t1 = time.time()
+        e_al = orc.align_batch(orc.default_opt(), oidx, [u["seq"] for u in utgs])
+        dt_al = time.time() - t1
+        n_rec = int(e_al["n_hits"])
+        del oidx
+    tot = dt + (dt_al or 0.0)
+    return dict(value=sample_reads / tot, unit="reads/s", cores=1, kind="port", assemble_s=dt, realign_s=dt_al, realigned_records=n_rec,
+                sample="fml_assemble of the CPU checker on a window of %d reads at %.0fx over %d bp made by the bench's generator (%.1f s, %d contigs, longest %d bp)%s; "
+                       "one thread, as the reference runs fermi-lite (fml_opt_init: n_threads = 1) and its per-contig alignSequence loop"
+                       % (sample_reads, coverage, span, dt, len(utgs), max([u["len"] for u in utgs] + [0]),
+                          (", then the contigs through the aligner's checker (%.1f s, %d records)" % (dt_al, n_rec)) if dt_al is not None else " -- assembly only, no realignment"))
 
 
 def main_c5(args):
@@ -435,7 +445,12 @@ def main_c5(args):
                 cells_per_bp = dict(ext=cnt["ext_cells"] / tot_bp, glb=cnt["glb_cells"] / tot_bp, contigs=len(vc), bp=tot_bp, longest=max(len(c) for c in vc))
                 del oidx
             verify_desc += "; checker assembly %.1f s, %d contigs, longest %d bp" % (t_v, len(exp), max([u["len"] for u in exp] + [0]))
-        cpu = None if args.no_cpu_baseline else c5_cpu_baseline(args.coverage, read_len, 20000)
+        cpu = None
+        if not args.no_cpu_baseline:
+            tmpb = tempfile.mkdtemp(prefix="slx_c5b_")
+            prefix_b = os.path.join(tmpb, cfg["name"])
+            idx.WriteIndex(prefix_b)
+            cpu = c5_cpu_baseline(args.coverage, read_len, 20000, prefix_b)
         # the k-mer counting kernels against the HBM roofline: per inserted k-mer one 16-byte table slot read and written back (what fml_count's
         # hash table does per k-mer: the algorithmic figure), per base the ASCII base and quality read once by the plane kernel
         steps = max(args.steps, 1)
