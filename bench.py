@@ -756,7 +756,9 @@ def main():
             try:
                 ub = json.load(open(os.path.join(ROOT, _latest("ubench_rand32.json"))))["table_mb"]
                 l_ref = sum(len(g) for _, g in refs)
-                foot_mb = (2 * l_ref / 4 * 2 + (128 << 20)) / 1e6          # occ planes (32 bytes per 64 symbols of the 2 x l_pac text, both strands) + the k-mer table
+                lut_k = max(2, min(14, int(math.floor(math.log(2 * l_ref + 1, 4))) - 1))          # the library's default table width
+                lut_bytes = (4 ** lut_k) * (16 if 2 * l_ref + 1 >= 1 << 32 else 8)
+                foot_mb = (2 * l_ref / 4 * 2 + lut_bytes) / 1e6          # occ planes (32 bytes per 64 symbols of the 2 x l_pac text, both strands) + the k-mer table
                 sizes = sorted(int(k) for k in ub)
                 at = min(sizes, key=lambda m: abs(math.log(m / foot_mb)))          # the measured table size closest to the footprint
                 ceil_g = ub[str(at)]["g_reads_per_s"]
