@@ -125,3 +125,49 @@ def test_default_step_of_64_windows_by_properties(sl, c2_index):
         assert int(sum(int(x) >> 4 for x in cig if (int(x) & 15) in (0, 1, 4))) == len(s)
         placed += inside
     assert placed >= 0.98 * n_long, (placed, n_long)
+
+
+def test_two_contexts_and_two_aligners_side_by_side(sl, c2_index):
+    """the schedule `bench.py --config C5` runs: two fml contexts assembling and two aligners realigning from four host threads at once -- every object
+    gives what it gives alone (the C-ABI objects share nothing but the device)"""
+    import threading
+    import bench
+    from seqlib_amd import fml
+    idx, _, refs = c2_index
+    n_win, per_win = 4, 20_000
+    work = [bench.c5_workload(r, n_win, per_win, 30.0, READ_LEN) for r in (0, 1)]
+    ctxs = [fml.Context(), fml.Context()]
+    als = [sl.BWAAligner(idx), sl.BWAAligner(idx)]
+    try:
+        for c, w in zip(ctxs, work):
+            c.stage(w[2], w[3], w[4])
+        alone = []
+        for c, w, a in zip(ctxs, work, als):
+            wins = c.assemble_staged(fml.default_opt(), w[5])
+            contigs = [u["seq"] for ws in wins for u in ws]
+            alone.append((wins, a.alignSequences(contigs)))
+        got = [None, None]
+        err = []
+
+        def run(i):
+            try:
+                for _ in range(2):
+                    wins = ctxs[i].assemble_staged(fml.default_opt(), work[i][5])
+                    contigs = [u["seq"] for ws in wins for u in ws]
+                    got[i] = (wins, als[i].alignSequences(contigs))
+            except Exception as e:          # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        for i in (0, 1):
+            assert [[(u["seq"], u["cov"], u["nsr"]) for u in ws] for ws in got[i][0]] == [[(u["seq"], u["cov"], u["nsr"]) for u in ws] for ws in alone[i][0]]
+            for k in FIELDS:
+                assert np.array_equal(got[i][1][k], alone[i][1][k]), (i, k)
+        assert sum(len(ws) for ws in alone[0][0]) > 0
+    finally:
+        for c in ctxs:
+            c.close()
