@@ -454,7 +454,7 @@ struct Graph {
         auto target = [&](int t, int j) { return O.edge_v[O.irr_off[t] + (unsigned long long)j]; };
         auto ovl = [&](int t, int j) { return O.edge_len[O.irr_off[t] + (unsigned long long)j]; };
         std::vector<unsigned char> used((size_t)n + 1, 0);
-        std::vector<int> right, left, all;
+        std::vector<int> right, left, all, dcov;
         for (int t = 0; t < n; ++t) {
             if (!vertex(t) || used[(size_t)t]) continue;
             used[(size_t)t] = used[(size_t)(t ^ 1)] = 1;
@@ -483,15 +483,19 @@ struct Graph {
             Vtx p;
             p.len = tot; p.nsr = (int)all.size();
             p.seq.assign((size_t)tot, 0); p.cov.assign((size_t)tot, 33);
+            // the unitig's bases: a string agrees with the one before it over their overlap (the overlaps are exact), so only what lies beyond it is
+            // new; its coverage: +1 where a string starts, -1 behind its end, summed once (33 + the number of strings over a base, capped at 126)
+            dcov.assign((size_t)tot + 1, 0);
             int pos = 0;
             for (size_t i = 0; i < all.size(); ++i) {
-                if (i) pos += O.len[all[i - 1]] - ovl(all[i - 1], 0);
+                const int ov = i ? ovl(all[i - 1], 0) : 0;
+                if (i) pos += O.len[all[i - 1]] - ov;
                 const unsigned char *s = O.text[all[i]];
-                for (int j = 0; j < O.len[all[i]]; ++j) {
-                    p.seq[(size_t)(pos + j)] = (char)s[j];
-                    if (p.cov[(size_t)(pos + j)] < 126) ++p.cov[(size_t)(pos + j)];
-                }
+                const int l = O.len[all[i]];
+                if (l > ov) memcpy(&p.seq[(size_t)(pos + ov)], s + ov, (size_t)(l - ov));
+                ++dcov[(size_t)pos]; --dcov[(size_t)(pos + l)];
             }
+            for (int x = 0, c = 0; x < tot; ++x) { c += dcov[(size_t)x]; p.cov[(size_t)x] = (char)(33 + c > 126 ? 126 : 33 + c); }
             const int first = all.front(), last = all.back();
             p.k[0] = (uint64_t)(first ^ 1); p.k[1] = (uint64_t)last;
             for (int j = 0; j < deg(first ^ 1); ++j) p.nei[0].push_back(Nei{(uint64_t)(target(first ^ 1, j) ^ 1), (uint64_t)ovl(first ^ 1, j)});
