@@ -812,13 +812,13 @@ def main():
                     except Exception as e:
                         percall = dict(error=str(e))
                 os.remove(sample)
-        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 4 steps of the default 64
+        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 8 steps of the default 64
         # windows x 100 000 reads, a tenth-size window at full coverage through both CPU checkers -- as a process of its own (this one has let go of its
         # aligner above), so that the driver's default run times the assembler pipeline too
         other = None
         if not args.no_extras and args.config == "C3" and world == 1 and os.environ.get("SLX_BENCH_NO_C5_LEG") != "1":
             try:
-                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
                                    stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
                 ln = [x for x in o.stdout.decode().splitlines() if x.startswith("{")]
                 if o.returncode == 0 and ln:
