@@ -121,9 +121,21 @@ __device__ int wave_ksw_global2_bandn(int qlen_, QF qf, int tlen_, TF tf, const 
 #define GB_WAVES (GB_THREADS / WAVE)
 struct GbShared { int scan[2][GB_WAVES], edge[2][GB_WAVES]; int result; };
 
+// rows [i0, i1) of the alignment (dev_cig_seg.h cuts a contig's CIGAR alignment into segments; the plain alignment is [0, tlen) from row -1)
+enum { GI_START = 0, GI_NEUTRAL = 1, GI_LOAD = 2 };
+struct GRun {
+    int i0 = 0, i1 = 0;
+    int init = GI_START;             // GI_START: row -1 state (i0 = 0); GI_NEUTRAL: every offset H = 0, E = -inf (a speculative segment's warm-up); GI_LOAD: window given
+    int rec_row = -1;                // >= 0: the window row rec_row is about to read is stored (win_rec) and direction bytes are written from that row on only
+    const int *win_in = nullptr;     // GI_LOAD: H[NB] then E[NB]
+    int *win_rec = nullptr, *win_out = nullptr;
+    int pick = -1;                   // >= 0: H of this band offset after the last row goes to S.result (the score sits at offset qlen - 1 - (tlen - 1 - w) after row tlen - 1)
+};
+
 template <int CPB, typename QF, typename TF>
-__device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, uint8_t *z, int n_col, GbShared &S)
+__device__ void block_gband_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, uint8_t *z, int n_col, GbShared &S, const GRun &run)
 {
+    constexpr int NB = GB_THREADS * CPB;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -132,27 +144,30 @@ __device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const s
         const int q = j >= 0 && j < qlen ? qf(j) : 4;
         return q == 0 ? mc.c[0] : q == 1 ? mc.c[1] : q == 2 ? mc.c[2] : q == 3 ? mc.c[3] : mc.c[4];
     };
+    const int i0 = run.i0, i1 = run.i1 < tlen ? run.i1 : tlen;
     const int b0 = tid * CPB;                     // this thread holds band offsets b0 .. b0 + CPB - 1; offset b of row i is column j = i - w + b
     int H[CPB], E[CPB];
     uint32_t P[CPB];
 #pragma unroll
     for (int c = 0; c < CPB; ++c) {
-        const int j = b0 + c - w;
+        const int j = i0 + b0 + c - w;
         P[c] = pack_of(j);
-        H[c] = j == 0 ? 0 : (j > 0 && j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF);
-        E[c] = DEV_MINUS_INF;
+        if (run.init == GI_START) { H[c] = j == 0 ? 0 : (j > 0 && j <= qlen && j <= w ? -(o_ins + e_ins * j) : DEV_MINUS_INF); E[c] = DEV_MINUS_INF; }
+        else if (run.init == GI_NEUTRAL) { H[c] = 0; E[c] = DEV_MINUS_INF; }
+        else { H[c] = run.win_in[b0 + c]; E[c] = run.win_in[NB + b0 + c]; }
     }
     // the query code entering at this wave's top offset in row i + 1: column i - w + top, top = first offset of the next wave
     const int top = (wv + 1) * WAVE * CPB;
-    int q_blk = (top - w) >> 6;
+    int q_blk = (i0 + top - w) >> 6;
     uint32_t q_cur = pack_of(q_blk * WAVE + lane), q_next = pack_of((q_blk + 1) * WAVE + lane);
-    int tb_cur = lane < tlen ? tf(lane) : 0;
-    int tb_next = WAVE + lane < tlen ? tf(WAVE + lane) : 0;
+    const int tb0 = i0 & ~(WAVE - 1);
+    int tb_cur = tb0 + lane < tlen ? tf(tb0 + lane) : 0;
+    int tb_next = tb0 + WAVE + lane < tlen ? tf(tb0 + WAVE + lane) : 0;
     __syncthreads();                              // (S may still be read by the previous alignment)
 #pragma unroll 1
-    for (int i = 0; i < tlen; ++i) {
+    for (int i = i0; i < i1; ++i) {
         const int par = i & 1;
-        if ((i & (WAVE - 1)) == 0 && i) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
+        if ((i & (WAVE - 1)) == 0 && i > i0) { tb_cur = tb_next; tb_next = i + WAVE + lane < tlen ? tf(i + WAVE + lane) : 0; }
         const int t = lane_read(tb_cur, i & (WAVE - 1));
         const uint32_t sh = (uint32_t)t << 3;
         const int beg = i > w ? i - w : 0;
@@ -160,21 +175,26 @@ __device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const s
         const int b_lo = beg - (i - w), b_hi = end - (i - w);
         int m[CPB], exl[CPB];
         bool act[CPB];
-        int run = G_NEG;
+        int run_u = G_NEG;
 #pragma unroll
         for (int c = 0; c < CPB; ++c) {
             const int b = b0 + c;
             act[c] = b >= b_lo && b < b_hi;
             m[c] = H[c] + __builtin_amdgcn_sbfe((int)P[c], sh, 8u);
-            exl[c] = run;
+            exl[c] = run_u;
             const int u = act[c] ? m[c] - oe_ins + b * e_ins : G_NEG;
-            run = imax(run, u);
+            run_u = imax(run_u, u);
         }
-        const int incl = dpp_incl_max_scan_g(run);
+        const int incl = dpp_incl_max_scan_g(run_u);
         int lane_ex = dpp_get<0x138, 0xf, 0xf>(G_NEG, incl);
         if (lane == WAVE - 1) S.scan[par][wv] = incl;
         __syncthreads();                          // ---------------- the row's barrier
-        if (i > 0 && lane == WAVE - 1 && wv < GB_WAVES - 1) E[CPB - 1] = S.edge[par ^ 1][wv + 1];      // E'(i, .) of the next wave's lowest offset, stored in row i - 1
+        if (i > i0 && lane == WAVE - 1 && wv < GB_WAVES - 1) E[CPB - 1] = S.edge[par ^ 1][wv + 1];      // E'(i, .) of the next wave's lowest offset, stored in row i - 1
+        if (i == run.rec_row) {                   // a speculative segment's own first row: the window it reads is what the join verifies
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) { run.win_rec[b0 + c] = H[c]; run.win_rec[NB + b0 + c] = E[c]; }
+        }
+        uint8_t *zr = (z && i >= run.rec_row) ? z : nullptr;          // (rec_row = -1: every row writes)
 #pragma unroll
         for (int k = 0; k < GB_WAVES - 1; ++k) { const int v = S.scan[par][k]; if (k < wv) lane_ex = imax(lane_ex, v); }
         int e2v[CPB];
@@ -196,7 +216,7 @@ __device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const s
             tt = m[c] - oe_ins;
             const int f2 = f - e_ins;
             d |= f2 > tt ? 2 << 4 : 0;
-            if (act[c] && z) z[(size_t)i * n_col + (b - b_lo)] = (uint8_t)d;
+            if (act[c] && zr) zr[(size_t)i * n_col + (b - b_lo)] = (uint8_t)d;
             if (act[c]) H[c] = hh;
             if (b == w - (i + 1)) H[c] = -(o_del + e_del * (i + 1));
             e2v[c] = act[c] ? e2 : DEV_MINUS_INF;
@@ -215,11 +235,26 @@ __device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const s
             P[c] = (c == CPB - 1 && lane == WAVE - 1) ? p_top : p_up;
         }
     }
-    // H(tlen-1, qlen-1) sits at offset qlen-1 - (tlen-1-w)
-    const int bf = qlen - 1 - (tlen - 1 - w);
+    if (run.win_out) {                            // the window the next row would read (the waves' edge values still sit in LDS: fetched as that row would)
+        __syncthreads();
+        if (i1 > i0 && lane == WAVE - 1 && wv < GB_WAVES - 1) E[CPB - 1] = S.edge[(i1 - 1) & 1][wv + 1];
 #pragma unroll
-    for (int c = 0; c < CPB; ++c) if (b0 + c == bf) S.result = H[c];
-    __syncthreads();
+        for (int c = 0; c < CPB; ++c) { run.win_out[b0 + c] = H[c]; run.win_out[NB + b0 + c] = E[c]; }
+    }
+    if (run.pick >= 0) {
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) if (b0 + c == run.pick) S.result = H[c];
+        __syncthreads();
+    }
+}
+
+template <int CPB, typename QF, typename TF>
+__device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, int w, uint8_t *z, int n_col, GbShared &S)
+{
+    GRun run;
+    run.i0 = 0; run.i1 = tlen; run.init = GI_START;
+    run.pick = qlen - 1 - (tlen - 1 - w);          // H(tlen-1, qlen-1)
+    block_gband_rows<CPB>(qlen, qf, tlen, tf, o, w, z, n_col, S, run);
     return S.result;
 }
 
@@ -229,8 +264,17 @@ __device__ int block_ksw_global2_bandn(int qlen, QF qf, int tlen, TF tf, const s
 // Mirrors dev_cig_dp_job (dev_fin2.h) with the band kernel above in place of the register-per-column ones.
 // BLOCK: the same job on a 256-thread block -- the alignment on all four waves (block_ksw_global2_bandn), everything else on wave 0.
 struct CigBlockShared { GbShared gb; unsigned long long off; int n_ops_dummy; };
+// (dev_cig_seg.h) a job whose first band try was cut into segments: the plan's entry for it, and the join that replaces the alignment
+struct GJob;
+struct GPlan;
+struct CigSeg { const GPlan *P = nullptr; const GJob *gj = nullptr; unsigned int job_t = 0; int *scratch = nullptr; };
+template <typename QF, typename TF>
+__device__ int gseg_join_any(int lq, QF qf, int rlen, TF tf, const slx_opt &o, const CigSeg &cs, uint8_t *z, GbShared &S);
+__device__ bool gseg_is_cut(const CigSeg &cs, int ww, int n_col, unsigned long long *z_off);
+
 template <bool BLOCK>
-static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, uint32_t slot, int lane, CigBlockShared *SB = nullptr)
+static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chunk &ck, const slx_opt &opt, const FinLists &fl, uint32_t slot, int lane, CigBlockShared *SB = nullptr,
+                                                     const CigSeg *cs = nullptr)
 {
     [[maybe_unused]] const bool wave0 = !BLOCK || threadIdx.x < WAVE;
     const DJob j = fl.jobs[slot];
@@ -266,6 +310,16 @@ static __device__ __noinline__ bool dev_cig_band_job(const DevRef &R, const Chun
             const unsigned long long need = (unsigned long long)n_col * (unsigned long long)rlen;
             unsigned long long off = 0;
             if constexpr (BLOCK) {
+                unsigned long long z_off = 0;
+                if (it == 0 && cs && gseg_is_cut(*cs, ww, n_col, &z_off)) {          // the first band try ran in segments (dev_cig_seg.h): join them; the bytes are in place
+                    z = ck.zarena + z_off;
+                    score = gseg_join_any(lq, qf, rlen, tf, opt, *cs, z, SB->gb);
+                    if (score == last_sc || w2 == opt.w << 2) break;
+                    last_sc = score;
+                    w2 <<= 1;
+                    if (!(score < j.truesc - opt.a)) break;
+                    continue;
+                }
                 __syncthreads();
                 if (threadIdx.x == 0) SB->off = atomicAdd(ck.zused, need);
                 __syncthreads();
@@ -348,38 +402,7 @@ __global__ void __launch_bounds__(64) k_cig_band(DevRef R, Chunk ck, DevOpt dopt
     }
 }
 
-// The largest jobs of the list (`n_block` of them: the list is sorted largest first, wide-band jobs before the others) one BLOCK per job, and IN THE SAME
-// LAUNCH the other jobs one WAVE per job (fl.q_dp starts at n_block): a contig's narrow-band CIGAR is as many rows as its wide-band ones -- one full-length
-// alignment on one wave -- and behind the block jobs it would start when they end.  Blocks below n_block_blocks take block jobs first and then turn their
-// four waves to the wave jobs; the blocks above go to the wave jobs at once, so the longest of those starts with the launch.
-__global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, unsigned int n_block_blocks, unsigned int *queue,
-                                                               uint32_t *rest, unsigned int *n_rest)
-{
-    __shared__ CigBlockShared SB;
-    __shared__ unsigned int s_t;
-    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
-    if (blockIdx.x < n_block_blocks)
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_t = atomicAdd(queue, 1u);
-            __syncthreads();
-            const unsigned int t = s_t;
-            if (t >= n_jobs) break;
-            const uint32_t slot = fl.dp_list[t];
-            if (!dev_cig_band_job<true>(R, ck, dopt.o, fl, slot, (int)(threadIdx.x & (WAVE - 1)), &SB) && threadIdx.x == 0) rest[atomicAdd(n_rest, 1u)] = slot;
-        }
-    // wave jobs (k_cig_band's loop; fl.q_dp was set to n_block before the launch)
-    const int lane = threadIdx.x & (WAVE - 1);
-    const unsigned int n_all = *fl.n_dp;
-    for (;;) {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_all) break;
-        const uint32_t slot = fl.dp_list[t];
-        if (!dev_cig_band_job<false>(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
-    }
-}
+// (k_cig_band_block, the block form of these jobs with the wave jobs in the same launch: dev_cig_seg.h)
 
 // bwa_gen_cigar2 (score only) for mem_patch_reg on a long read, one wave: the band kernel above without direction bytes; a band beyond
 // its 832 columns falls back to the scalar loops on one lane (rows in this wave's stretch of the per-thread scratch).

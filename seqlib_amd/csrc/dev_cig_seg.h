@@ -1,0 +1,239 @@
+// dev_cig_seg.h -- a contig's CIGAR alignment (bwa_gen_cigar2 -> ksw_global2 as reached from mem_reg2aln, /root/reference/src/BWAAligner.cpp:123-128) cut into
+// SEGMENTS that run side by side and are verified where they join -- the scheme of dev_ext_seg.h on the recurrence that needs it least: ksw_global2 has a
+// fixed band and no floors at all, so it commutes with adding a constant to every cell EVERYWHERE, and its direction bytes depend on comparisons only.
+//   * k_gseg_plan: the first band of every long job (the one mem_reg2aln tries first), its traceback stretch in the arena, its segments;
+//   * k_gseg_run: every segment on a block.  Segment 0 starts from row -1; the others start GSEG_WARM rows early from a neutral window (H = 0, E = -inf),
+//     store the window they have at their own first row, write direction bytes from that row on, and store their final window;
+//   * the join (gseg_join, called from dev_cig_band_job on the job's block in k_cig_band_block): the true window at a segment's first row must equal the
+//     speculated one offset for offset up to ONE constant (minus infinity with minus infinity: the entering column's E); then the segment's direction bytes
+//     ARE the scalar ones and its final window, shifted, is the next true window.  A segment that fails is run again from the true window and rewrites its
+//     bytes.  The score is the last window's cell plus the accumulated constant; the traceback and everything after it are unchanged.
+// Later band tries of a job (score below the region's own: twice the band) run whole, as before.
+#pragma once
+#include "dev_cig_band.h"
+
+#ifndef GSEG_LEN
+#define GSEG_LEN 4096
+#endif
+#ifndef GSEG_WARM
+#define GSEG_WARM 768               // rows a speculative segment runs before its own first row (a band of up to 1 000 columns fills from a neutral start in ~w / 4 rows)
+#endif
+#define GSEG_NBMAX (GB_THREADS * 4)
+#define GSEG_WIN (2 * GSEG_NBMAX)   // ints of one stored window: H[NB] then E[NB]
+
+struct GJob { unsigned long long z_off; int ww, n_col, n_seg, seg_base, cpb, pad; unsigned int unit_base, slot; };     // per job of the block list; n_seg < 2: not cut
+struct GUnit { unsigned int job_t; int k; };
+
+struct GPlan {
+    GJob *gjobs; GUnit *units; int *wrec, *wout, *scratch;
+    unsigned int *cnt;              // [0] segment slots, [1] units, [2] unit queue, [4] segments taken as speculated, [5] run again, [6] jobs cut
+    int fail_mod;
+};
+
+// the first band mem_reg2aln gives bwa_gen_cigar2 for this job, as dev_cig_band_job computes it (it = 0)
+struct GGeom { bool valid; int lq, rlen, ww, n_col; bool rev; };
+__device__ inline GGeom gseg_geom(const DevRef &R, const slx_opt &opt, const DJob &j)
+{
+    GGeom g;
+    g.lq = j.qe - j.qb; g.rlen = (int)(j.re - j.rb); g.rev = j.rb >= R.l_pac;
+    g.valid = !(g.lq <= 0 || j.rb >= j.re || (j.rb < R.l_pac && j.re > R.l_pac));
+    int w2 = j.w2 < opt.w << 2 ? j.w2 : opt.w << 2;
+    int max_ins = (int)((double)(((g.lq + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+    int max_del = (int)((double)(((g.lq + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+    int max_gap = max_ins > max_del ? max_ins : max_del;
+    max_gap = max_gap > 1 ? max_gap : 1;
+    const int dl = g.rlen - g.lq < 0 ? g.lq - g.rlen : g.rlen - g.lq;
+    int ww = (max_gap + dl + 1) >> 1;
+    ww = ww < w2 ? ww : w2;
+    ww = ww > dl + 3 ? ww : dl + 3;
+    g.ww = ww;
+    g.n_col = g.lq < 2 * ww + 1 ? g.lq : 2 * ww + 1;
+    return g;
+}
+
+__device__ inline int gseg_count(const GGeom &g)
+{   // segment k starts at row k * GSEG_LEN while it and its warm-up lie where the band is interior (all 2 w + 1 offsets active) and half a segment of rows follows
+    if (!g.valid || 2 * g.ww + 1 > GSEG_NBMAX || 2 * g.ww + 1 > CIG_BAND_MAX_COLS || g.lq <= 2 * g.ww + 1) return 0;          // (wider bands: k_cig_long)
+    long long kq = ((long long)g.lq - g.ww - 1) / GSEG_LEN, kt = ((long long)g.rlen - GSEG_LEN / 2) / GSEG_LEN;
+    long long km = kq < kt ? kq : kt;
+    if ((long long)GSEG_LEN - GSEG_WARM < g.ww + 1) return 0;          // (the first speculative segment's warm-up must start inside the interior too)
+    return km >= 1 ? (int)km + 1 : 0;
+}
+
+__global__ void k_gseg_plan(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, GPlan P)
+{
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    if (t >= n_jobs) return;
+    const uint32_t slot = fl.dp_list[t];
+    const DJob j = fl.jobs[slot];
+    const GGeom g = gseg_geom(R, dopt.o, j);
+    GJob x;
+    x.slot = slot; x.ww = g.ww; x.n_col = g.n_col; x.pad = 0; x.z_off = 0; x.seg_base = 0; x.unit_base = 0;
+    x.cpb = 2 * g.ww + 1 <= GB_THREADS ? 1 : (2 * g.ww + 1 <= 2 * GB_THREADS ? 2 : 4);
+    x.n_seg = dopt.o.e_ins > 0 && dopt.o.e_del > 0 ? gseg_count(g) : 0;
+    if (x.n_seg >= 2) {
+        const unsigned long long need = (unsigned long long)g.n_col * (unsigned long long)g.rlen;
+        const unsigned long long off = atomicAdd(ck.zused, need);
+        if (off + need > ck.zcap) { atomicOr(ck.flags, OVF_ZARENA); x.n_seg = 0; }          // (the chunk is run again with a larger arena)
+        else {
+            x.z_off = off;
+            x.seg_base = (int)atomicAdd(&P.cnt[0], (unsigned int)x.n_seg);
+            x.unit_base = atomicAdd(&P.cnt[1], (unsigned int)x.n_seg);
+            atomicAdd(&P.cnt[6], 1u);
+        }
+    }
+    P.gjobs[t] = x;
+}
+
+__global__ void k_gseg_units(FinLists fl, unsigned int n_block, GPlan P)
+{
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    if (t >= n_jobs) return;
+    const GJob x = P.gjobs[t];
+    for (int k = 0; k < x.n_seg; ++k) { GUnit u; u.job_t = t; u.k = k; P.units[x.unit_base + (unsigned int)k] = u; }
+}
+
+struct GQ { const uint8_t *qseg; int lq; bool rev; __device__ __forceinline__ int operator()(int x) const { return (int)(rev ? qseg[lq - 1 - x] : qseg[x]); } };
+struct GT { const DevRef *R; int64_t rb, re; bool rev; __device__ __forceinline__ int operator()(int y) const { return rev ? ref_base(*R, re - 1 - y) : ref_base(*R, rb + y); } };
+
+template <int CPB>
+__device__ void gseg_run_unit(const slx_opt &opt, const GGeom &g, const GQ &qf, const GT &tf, const GJob &x, int k, uint8_t *z, const GPlan &P, GbShared &S)
+{
+    GRun run;
+    const int r0 = k * GSEG_LEN, r1 = k == x.n_seg - 1 ? g.rlen : (k + 1) * GSEG_LEN;
+    const size_t slot = (size_t)(x.seg_base + k);
+    run.i1 = r1;
+    run.win_out = P.wout + slot * GSEG_WIN;
+    if (k == 0) { run.i0 = 0; run.init = GI_START; }
+    else { run.i0 = r0 - GSEG_WARM; run.init = GI_NEUTRAL; run.rec_row = r0; run.win_rec = P.wrec + slot * GSEG_WIN; }
+    block_gband_rows<CPB>(g.lq, qf, g.rlen, tf, opt, x.ww, z, x.n_col, S, run);
+}
+
+__global__ void __launch_bounds__(GB_THREADS) k_gseg_run(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, GPlan P, unsigned int n_units)
+{
+    __shared__ GbShared S;
+    __shared__ unsigned int s_unit;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_unit = atomicAdd(&P.cnt[2], 1u);
+        __syncthreads();
+        const unsigned int u = s_unit;
+        if (u >= n_units) break;
+        const GUnit v = P.units[u];
+        const GJob x = P.gjobs[v.job_t];
+        const DJob j = fl.jobs[x.slot];
+        const GGeom g = gseg_geom(R, dopt.o, j);
+        const GQ qf{ck.codes + ck.offs[j.r] + j.qb, g.lq, g.rev};
+        const GT tf{&R, j.rb, j.re, g.rev};
+        uint8_t *z = ck.zarena + x.z_off;
+        if (x.cpb == 1) gseg_run_unit<1>(dopt.o, g, qf, tf, x, v.k, z, P, S);
+        else if (x.cpb == 2) gseg_run_unit<2>(dopt.o, g, qf, tf, x, v.k, z, P, S);
+        else gseg_run_unit<4>(dopt.o, g, qf, tf, x, v.k, z, P, S);
+    }
+}
+
+// the join of one job's segments on its block: returns the alignment's score; z holds the scalar direction bytes afterwards
+template <int CPB, typename QF, typename TF>
+__device__ int gseg_join(int lq, QF qf, int rlen, TF tf, const slx_opt &o, const GJob &x, unsigned int job_t, uint8_t *z, const GPlan &P, int *scratch, GbShared &S)
+{
+    constexpr int NB = GB_THREADS * CPB;
+    const int tid = threadIdx.x, w = x.ww;
+    const int *cur = P.wout + (size_t)x.seg_base * GSEG_WIN;          // segment 0 ran from row -1: its final window is true
+    int curC = 0;
+    bool cur_spec = false;
+    auto is_inf = [](int v) { return v < DEV_MINUS_INF / 2; };
+    for (int k = 1; k < x.n_seg; ++k) {
+        const int r0 = k * GSEG_LEN, r1 = k == x.n_seg - 1 ? rlen : (k + 1) * GSEG_LEN;
+        const int *spec = P.wrec + (size_t)(x.seg_base + k) * GSEG_WIN;
+        bool ok = !(P.fail_mod > 0 && (job_t + (unsigned int)k) % (unsigned int)P.fail_mod == 0);
+        int C = 0;
+        if (ok) {
+            C = cur[0] + curC - spec[0];
+            int bad = is_inf(cur[0]) || is_inf(spec[0]) ? 1 : 0;
+            for (int s = tid; s <= 2 * w; s += GB_THREADS) {
+                const int th = cur[s], te = cur[NB + s], sh = spec[s], se = spec[NB + s];
+                if (is_inf(th) || is_inf(sh) || th + curC - sh != C) bad = 1;
+                else if (is_inf(te) != is_inf(se)) bad = 1;
+                else if (!is_inf(te) && te + curC - se != C) bad = 1;
+            }
+            ok = __syncthreads_or(bad) == 0;
+        }
+        if (ok) {
+            if (tid == 0) atomicAdd(&P.cnt[4], 1u);
+            cur = P.wout + (size_t)(x.seg_base + k) * GSEG_WIN; curC = C; cur_spec = true;
+            continue;
+        }
+        if (tid == 0) atomicAdd(&P.cnt[5], 1u);
+        if (cur != scratch || cur_spec) {          // the window made true (minus infinity stays what it is) in this block's own buffer
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {
+                const int s = tid * CPB + c;
+                const int vh = cur[s], ve = cur[NB + s];
+                scratch[s] = is_inf(vh) ? vh : vh + curC; scratch[NB + s] = is_inf(ve) ? ve : ve + curC;
+            }
+        }
+        __syncthreads();
+        GRun run;
+        run.i0 = r0; run.i1 = r1; run.init = GI_LOAD; run.win_in = scratch; run.win_out = scratch;
+        block_gband_rows<CPB>(lq, qf, rlen, tf, o, w, z, x.n_col, S, run);
+        cur = scratch; curC = 0; cur_spec = false;
+        __syncthreads();
+    }
+    // H(tlen-1, qlen-1) sits at offset qlen-1 - (tlen-1-w) of the last window
+    const int bf = lq - 1 - (rlen - 1 - w);
+    return cur[bf] + curC;
+}
+
+__device__ bool gseg_is_cut(const CigSeg &cs, int ww, int n_col, unsigned long long *z_off)
+{
+    if (!cs.gj || cs.gj->n_seg < 2 || cs.gj->ww != ww || cs.gj->n_col != n_col) return false;
+    *z_off = cs.gj->z_off;
+    return true;
+}
+
+template <typename QF, typename TF>
+__device__ int gseg_join_any(int lq, QF qf, int rlen, TF tf, const slx_opt &o, const CigSeg &cs, uint8_t *z, GbShared &S)
+{
+    const GJob &x = *cs.gj;
+    if (x.cpb == 1) return gseg_join<1>(lq, qf, rlen, tf, o, x, cs.job_t, z, *cs.P, cs.scratch, S);
+    if (x.cpb == 2) return gseg_join<2>(lq, qf, rlen, tf, o, x, cs.job_t, z, *cs.P, cs.scratch, S);
+    return gseg_join<4>(lq, qf, rlen, tf, o, x, cs.job_t, z, *cs.P, cs.scratch, S);
+}
+
+// The largest jobs of the list (`n_block` of them: the list is sorted largest first, wide-band jobs before the others) one BLOCK per job, and IN THE SAME
+// LAUNCH the other jobs one WAVE per job (fl.q_dp starts at n_block): a contig's narrow-band CIGAR is as many rows as its wide-band ones -- one full-length
+// alignment on one wave -- and behind the block jobs it would start when they end.  Blocks below n_block_blocks take block jobs first and then turn their
+// four waves to the wave jobs; the blocks above go to the wave jobs at once, so the longest of those starts with the launch.
+__global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsigned int n_block, unsigned int n_block_blocks, unsigned int *queue,
+                                                               uint32_t *rest, unsigned int *n_rest, GPlan plan)
+{
+    __shared__ CigBlockShared SB;
+    __shared__ unsigned int s_t;
+    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    if (blockIdx.x < n_block_blocks)
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_t = atomicAdd(queue, 1u);
+            __syncthreads();
+            const unsigned int t = s_t;
+            if (t >= n_jobs) break;
+            const uint32_t slot = fl.dp_list[t];
+            CigSeg cs;
+            if (plan.gjobs) { cs.P = &plan; cs.gj = plan.gjobs + t; cs.job_t = t; cs.scratch = plan.scratch + (size_t)blockIdx.x * GSEG_WIN; }
+            if (!dev_cig_band_job<true>(R, ck, dopt.o, fl, slot, (int)(threadIdx.x & (WAVE - 1)), &SB, plan.gjobs ? &cs : nullptr) && threadIdx.x == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+        }
+    // wave jobs (k_cig_band's loop; fl.q_dp was set to n_block before the launch)
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned int n_all = *fl.n_dp;
+    for (;;) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(fl.q_dp, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_all) break;
+        const uint32_t slot = fl.dp_list[t];
+        if (!dev_cig_band_job<false>(R, ck, dopt.o, fl, slot, lane) && lane == 0) rest[atomicAdd(n_rest, 1u)] = slot;
+    }
+}
+

@@ -34,6 +34,7 @@
 #include "dev_long.h"
 #include "dev_cig_lane.h"
 #include "dev_cig_band.h"
+#include "dev_cig_seg.h"
 
 #include "slx_align_types.h"
 
@@ -526,6 +527,14 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
         return v;
     }
     {   // segments of the contigs' extensions since the aligner was created: taken as speculated / computed again / second band tries / sides cut
+        static const char *const gs[3] = {"gseg_ok", "gseg_redo", "gseg_jobs"};          // the same for the CIGAR alignments' segments
+        for (int i = 0; i < 3; ++i)
+            if (!strcmp(key, gs[i])) {
+                long long v = 0;
+                auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += wk->gseg_stat[i]; };
+                if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
+                return v;
+            }
         static const char *const xs[4] = {"xseg_ok", "xseg_redo", "xseg_retry", "xseg_sides"};
         for (int i = 0; i < 4; ++i)
             if (!strcmp(key, xs[i])) {

@@ -36,6 +36,7 @@ namespace slxw {
 #include "dev_long.h"
 #include "dev_cig_lane.h"
 #include "dev_cig_band.h"
+#include "dev_cig_seg.h"
 #include "slx_chunk.inc"
 }  // namespace slxw
 

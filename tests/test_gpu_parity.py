@@ -416,15 +416,18 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
             al.set(k, v)
         assert_same(al.alignSequences(seqs), exp, "segmented extensions %s" % (knobs,))
         ok, redo, sides = al.counter("xseg_ok"), al.counter("xseg_redo"), al.counter("xseg_sides")
+        g_ok, g_redo, g_jobs = al.counter("gseg_ok"), al.counter("gseg_redo"), al.counter("gseg_jobs")          # the CIGAR alignments' segments (dev_cig_seg.h)
         if knobs == ():
             assert sides >= len(seqs) and ok > 5 * max(redo, 1), (ok, redo, sides)          # the speculation holds nearly everywhere on these contigs
+            assert g_jobs >= 4 and g_ok > 5 * max(g_redo, 1), (g_ok, g_redo, g_jobs)
             base_ok = ok
         elif knobs == (("xseg_fail", 1),):
             assert ok == 0 and redo >= base_ok, (ok, redo)                                   # every segment computed again
+            assert g_ok == 0 and g_redo > 0, (g_ok, g_redo)
         elif knobs and knobs[0][0] == "xseg_fail":
             assert ok > 0 and redo > 0, (ok, redo)
         elif knobs == (("long_seg", 0),):
-            assert sides == 0
+            assert sides == 0 and g_jobs == 0
     # other scoring: gap costs that differ by kind, a narrower and a wider band (two slots per thread), z-drop off
     for o_set in (dict(o_del=8, e_del=2, o_ins=7, e_ins=3, w=60), dict(w=180, zdrop=0), dict(a=2, b=5, o_del=10, o_ins=10, e_del=2, e_ins=2, zdrop=200)):
         opt = orc.default_opt()
