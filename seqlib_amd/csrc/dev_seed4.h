@@ -88,6 +88,28 @@ __device__ __forceinline__ void set_intv4(const DevFM<I> &fm, int c, I &k0, I &k
 // base of the indexed text T = forward ++ reverse complement (what the FM-index is over) at position p < 2 l_pac, through an 8-byte
 // window of the 2-bit pac (32 bases; the reverse strand walks the same bytes downwards)
 struct RWin { uint64_t bits; int64_t chunk; };
+// do the four read bases at codes[a .. a + 4) equal the four text bases at p .. p + 3?  Answered only when those are the four bases of ONE byte of pac (forward
+// strand: p a multiple of 4; reverse strand: the mirror position ends a byte) and lie on one strand; false otherwise and on any ambiguous read base -- the caller
+// then compares base by base as before.
+__device__ __forceinline__ bool dir4_match(const DevRef &R, const uint8_t *codes, uint64_t a, int64_t p, RWin &w)
+{
+    const bool rev = p >= R.l_pac;
+    if (!rev && p + 3 >= R.l_pac) return false;
+    if (p + 3 >= (R.l_pac << 1)) return false;
+    const int64_t f = rev ? (R.l_pac << 1) - 1 - p : p;          // position of the first of the four on the forward strand; the others follow at f + 1 .. (rev: f - 1 ..)
+    if ((f & 3) != (rev ? 3 : 0)) return false;
+    const int64_t fb = rev ? f - 3 : f;
+    const int64_t ch = fb >> 5;
+    if (ch != w.chunk) { w.bits = *(const uint64_t *)(R.pac + (ch << 3)); w.chunk = ch; }
+    const uint32_t tb = (uint32_t)(w.bits >> (((fb >> 2) & 7) << 3)) & 0xffu;          // b(fb) << 6 | b(fb + 1) << 4 | b(fb + 2) << 2 | b(fb + 3)
+    uint32_t x;
+    __builtin_memcpy(&x, codes + a, 4);
+    if (x & 0xfcfcfcfcu) return false;
+    const uint32_t q0 = x & 3u, q1 = (x >> 8) & 3u, q2 = (x >> 16) & 3u, q3 = x >> 24;
+    const uint32_t qq = rev ? ((q3 << 6 | q2 << 4 | q1 << 2 | q0) ^ 0xffu) : (q0 << 6 | q1 << 4 | q2 << 2 | q3);
+    return qq == tb;
+}
+
 __device__ __forceinline__ int text_at(const DevRef &R, int64_t p, RWin &w)
 {
     const bool rev = p >= R.l_pac;
@@ -587,6 +609,8 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
                     for (int t = 0; t < 32; ++t) {
                         int cq = 4;
                         const int64_t tp = dpos + (int64_t)(i - sx);
+                        // four bases at once where the text side starts a byte of pac: a contig's direct walk is hundreds of thousands of bases on one lane
+                        if (t + 4 <= 32 && i + 4 <= len && dir4_match(R, ck.codes, qoff + (uint64_t)i, tp, rwin)) { i += 4; t += 3; continue; }
                         if (i < len && (cq = qb(i)) <= 3 && tp < (R.l_pac << 1) && text_at(R, tp, rwin) == cq) { ++i; continue; }
                         // end of the read, an ambiguous base, or the occurrence ends here (mismatch / end of the text): bwt_smem1a pushes the
                         // interval and stops -- in the last two cases because the extended interval is empty
