@@ -429,12 +429,19 @@ __device__ __noinline__ int regs_block_dp(const DevRef &R, const slx_opt &o, Reg
     return block_ksw_global2_bandn<4>(l_query, qf, rlen, tf, o, w, nullptr, 0, S.gb);
 }
 
+// (dev_cig_seg.h) alignments computed ahead of the region kernel: true + the score when (read, band asked for, query stretch, reference stretch) is among them
+struct PMemo { const GJob *jobs; const int *off, *n; };          // per read r: jobs[off[r] .. off[r] + n[r])
+__device__ bool pseg_lookup(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re, int *score);
+
 struct WaveScorerLong {
     const DevRef &R; const slx_opt &o; const Chunk &ck; int lane; int *eh_h, *eh_e;
     RegsBlockShared *SB;          // non-null: three helper waves wait at a block barrier for work (k_regs_wave_long)
+    const PMemo *pm = nullptr;    // alignments computed ahead of time (dev_cig_seg.h), looked up by their arguments
+    const int *cur_r = nullptr;   // ... the read in hand
     __device__ int operator()(int w_, int l_query, const uint8_t *qseg, int64_t rb, int64_t re) const
     {
         if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return 0;
+        if (pm) { int ms = 0; if (pseg_lookup(pm, *cur_r, w_, (unsigned long long)(qseg - ck.codes), l_query, rb, re, &ms)) return ms; }
         const int rlen = (int)(re - rb);
         const bool rev = rb >= R.l_pac;
         auto qf = [&](int x) { return (int)(rev ? qseg[l_query - 1 - x] : qseg[x]); };
@@ -476,7 +483,8 @@ struct WaveScorerLong {
 // -- inside a 256-thread block: wave 0 runs the read, waves 1-3 wait at a block barrier and join it for the wide-band alignments of
 // mem_patch_reg (regs_block_dp); the barriers of the region code itself are wave-local in this instantiation (fin_sync, dev_fin.h)
 template <int MAXQ, int NB>
-__global__ void __launch_bounds__(GB_THREADS) k_regs_wave_long(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots)
+__global__ void __launch_bounds__(GB_THREADS) k_regs_wave_long(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const int *order, unsigned int *queue, const unsigned int *n_slots,
+                                                               PMemo pm)
 {
     __shared__ int s_idx[NB], s_ka[NB], s_kb[NB], s_qe[NB], s_rid[NB], s_w[NB];
     __shared__ int64_t s_k64[NB], s_rb[NB];
@@ -495,7 +503,8 @@ __global__ void __launch_bounds__(GB_THREADS) k_regs_wave_long(DevRef R, Chunk c
     ss.idx = s_idx; ss.k64 = s_k64; ss.ka = s_ka; ss.kb = s_kb; ss.m_rb = s_rb; ss.m_qe = s_qe; ss.m_rid = s_rid; ss.m_w = s_w;
     ss.nmax = NB; ss.lane = lane;
     int *eh_h = ck.long_scratch + (size_t)blockIdx.x * WAVE * 2 * ck.long_stride, *eh_e = eh_h + ck.long_stride;
-    WaveScorerLong sc{R, dopt.o, ck, lane, eh_h, eh_e, &SB};
+    int cur_r = 0;
+    WaveScorerLong sc{R, dopt.o, ck, lane, eh_h, eh_e, &SB, pm.jobs ? &pm : nullptr, &cur_r};
     const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_slots);
     for (;;) {
         int slot = 0;
@@ -503,6 +512,7 @@ __global__ void __launch_bounds__(GB_THREADS) k_regs_wave_long(DevRef R, Chunk c
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_todo) break;
         const int r = order ? order[slot] : slot;
+        cur_r = r;
         dev_regs_read<MAXQ>(R, ck, dopt.o, fl, r, sc, lane == 0, &ss);
     }
     if (lane == 0) SB.cmd = 0;

@@ -21,7 +21,15 @@
 #define GSEG_NBMAX (GB_THREADS * 4)
 #define GSEG_WIN (2 * GSEG_NBMAX)   // ints of one stored window: H[NB] then E[NB]
 
-struct GJob { unsigned long long z_off; int ww, n_col, n_seg, seg_base, cpb, pad; unsigned int unit_base, slot; };     // per job of the block list; n_seg < 2: not cut
+struct GJob {          // one alignment: a CIGAR job of the block list, or one of mem_patch_reg's score-only alignments (k_pseg_plan); n_seg < 2: not cut
+    unsigned long long z_off;          // CIGAR jobs: the traceback stretch in the arena
+    unsigned long long q_off;          // first query base (absolute in ck.codes)
+    long long rb, re;
+    int lq, rlen, rev, has_z;
+    int ww, n_col, n_seg, seg_base, cpb, w_arg;          // w_arg: the band the caller asked for (patch jobs: the memo's key)
+    unsigned int unit_base, slot;
+    int score, r;                       // patch jobs: the result, the read
+};
 struct GUnit { unsigned int job_t; int k; };
 
 struct GPlan {
@@ -69,7 +77,8 @@ __global__ void k_gseg_plan(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsign
     const DJob j = fl.jobs[slot];
     const GGeom g = gseg_geom(R, dopt.o, j);
     GJob x;
-    x.slot = slot; x.ww = g.ww; x.n_col = g.n_col; x.pad = 0; x.z_off = 0; x.seg_base = 0; x.unit_base = 0;
+    x.slot = slot; x.ww = g.ww; x.n_col = g.n_col; x.w_arg = j.w2; x.z_off = 0; x.seg_base = 0; x.unit_base = 0; x.has_z = 1; x.score = 0; x.r = j.r;
+    x.q_off = ck.offs[j.r] + (unsigned long long)j.qb; x.rb = j.rb; x.re = j.re; x.lq = g.lq; x.rlen = g.rlen; x.rev = g.rev ? 1 : 0;
     x.cpb = 2 * g.ww + 1 <= GB_THREADS ? 1 : (2 * g.ww + 1 <= 2 * GB_THREADS ? 2 : 4);
     x.n_seg = dopt.o.e_ins > 0 && dopt.o.e_del > 0 ? gseg_count(g) : 0;
     if (x.n_seg >= 2) {
@@ -86,10 +95,10 @@ __global__ void k_gseg_plan(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, unsign
     P.gjobs[t] = x;
 }
 
-__global__ void k_gseg_units(FinLists fl, unsigned int n_block, GPlan P)
+__global__ void k_gseg_units(const unsigned int *n_avail, unsigned int n_block, GPlan P)
 {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int n_jobs = *fl.n_dp < n_block ? *fl.n_dp : n_block;
+    const unsigned int n_jobs = n_avail && *n_avail < n_block ? *n_avail : n_block;
     if (t >= n_jobs) return;
     const GJob x = P.gjobs[t];
     for (int k = 0; k < x.n_seg; ++k) { GUnit u; u.job_t = t; u.k = k; P.units[x.unit_base + (unsigned int)k] = u; }
@@ -99,19 +108,19 @@ struct GQ { const uint8_t *qseg; int lq; bool rev; __device__ __forceinline__ in
 struct GT { const DevRef *R; int64_t rb, re; bool rev; __device__ __forceinline__ int operator()(int y) const { return rev ? ref_base(*R, re - 1 - y) : ref_base(*R, rb + y); } };
 
 template <int CPB>
-__device__ void gseg_run_unit(const slx_opt &opt, const GGeom &g, const GQ &qf, const GT &tf, const GJob &x, int k, uint8_t *z, const GPlan &P, GbShared &S)
+__device__ void gseg_run_unit(const slx_opt &opt, const GQ &qf, const GT &tf, const GJob &x, int k, uint8_t *z, const GPlan &P, GbShared &S)
 {
     GRun run;
-    const int r0 = k * GSEG_LEN, r1 = k == x.n_seg - 1 ? g.rlen : (k + 1) * GSEG_LEN;
+    const int r0 = k * GSEG_LEN, r1 = k == x.n_seg - 1 ? x.rlen : (k + 1) * GSEG_LEN;
     const size_t slot = (size_t)(x.seg_base + k);
     run.i1 = r1;
     run.win_out = P.wout + slot * GSEG_WIN;
     if (k == 0) { run.i0 = 0; run.init = GI_START; }
     else { run.i0 = r0 - GSEG_WARM; run.init = GI_NEUTRAL; run.rec_row = r0; run.win_rec = P.wrec + slot * GSEG_WIN; }
-    block_gband_rows<CPB>(g.lq, qf, g.rlen, tf, opt, x.ww, z, x.n_col, S, run);
+    block_gband_rows<CPB>(x.lq, qf, x.rlen, tf, opt, x.ww, z, x.n_col, S, run);
 }
 
-__global__ void __launch_bounds__(GB_THREADS) k_gseg_run(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, GPlan P, unsigned int n_units)
+__global__ void __launch_bounds__(GB_THREADS) k_gseg_run(DevRef R, Chunk ck, DevOpt dopt, GPlan P, unsigned int n_units)
 {
     __shared__ GbShared S;
     __shared__ unsigned int s_unit;
@@ -123,14 +132,12 @@ __global__ void __launch_bounds__(GB_THREADS) k_gseg_run(DevRef R, Chunk ck, Dev
         if (u >= n_units) break;
         const GUnit v = P.units[u];
         const GJob x = P.gjobs[v.job_t];
-        const DJob j = fl.jobs[x.slot];
-        const GGeom g = gseg_geom(R, dopt.o, j);
-        const GQ qf{ck.codes + ck.offs[j.r] + j.qb, g.lq, g.rev};
-        const GT tf{&R, j.rb, j.re, g.rev};
-        uint8_t *z = ck.zarena + x.z_off;
-        if (x.cpb == 1) gseg_run_unit<1>(dopt.o, g, qf, tf, x, v.k, z, P, S);
-        else if (x.cpb == 2) gseg_run_unit<2>(dopt.o, g, qf, tf, x, v.k, z, P, S);
-        else gseg_run_unit<4>(dopt.o, g, qf, tf, x, v.k, z, P, S);
+        const GQ qf{ck.codes + x.q_off, x.lq, x.rev != 0};
+        const GT tf{&R, x.rb, x.re, x.rev != 0};
+        uint8_t *z = x.has_z ? ck.zarena + x.z_off : nullptr;
+        if (x.cpb == 1) gseg_run_unit<1>(dopt.o, qf, tf, x, v.k, z, P, S);
+        else if (x.cpb == 2) gseg_run_unit<2>(dopt.o, qf, tf, x, v.k, z, P, S);
+        else gseg_run_unit<4>(dopt.o, qf, tf, x, v.k, z, P, S);
     }
 }
 
@@ -237,3 +244,108 @@ __global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- mem_patch_reg's score-only alignments, ahead of the region kernel
+// mem_sort_dedup_patch asks mem_patch_reg for the global alignment of two regions' union -- for a contig split in two by a long indel that is the WHOLE contig, on
+// one block in the middle of the region walk (k_regs_wave_long: 238 ms for the longest contig).  The alignment is a pure function of its arguments
+// (band, query stretch, reference stretch), so the ones the walk will ask for FIRST -- every ordered pair of a read's regions as extension left them that passes
+// mem_patch_reg's own cheap tests -- are computed here ahead of time, in segments like a CIGAR's but without direction bytes, and the region kernel's scorer looks
+// its arguments up (WaveScorerLong) before it computes anything: a hit is the value it would have computed.  Pairs the walk never asks for cost a wasted alignment;
+// calls made on regions an earlier merge changed miss and run in place as before.
+#define PSEG_MAX_REG 8              // reads with more regions than this are left to the walk (repeat-ended contigs keep hundreds of regions)
+#define PSEG_MAX_PAIRS 12
+
+__global__ void k_pseg_plan(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int n_multi, GPlan P, int *memo_off, int *memo_n, unsigned int job_cap)
+{
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_multi) return;
+    const slx_opt &opt = dopt.o;
+    const int r = order ? order[t] : (int)t;
+    const int n = ck.n_reg[r];
+    if (n < 2 || n > PSEG_MAX_REG || !(opt.e_ins > 0 && opt.e_del > 0)) return;
+    const DReg *G = ck.regs + ck.seed_off[r];
+    GJob jobs[PSEG_MAX_PAIRS];
+    int nj = 0, slots = 0, units = 0;
+    for (int x = 0; x < n && nj < PSEG_MAX_PAIRS; ++x)
+        for (int y = 0; y < n && nj < PSEG_MAX_PAIRS; ++y) {
+            if (x == y) continue;
+            const DReg &a = G[x], &b = G[y];          // the call mem_patch_reg(q = a, p = b) of the walk
+            if (a.rid != b.rid || !(a.rb < b.rb) || a.qe == a.qb || b.qe == b.qb) continue;
+            const int w_arg = dev_patch_pre(R, opt, a.rb, a.re, a.qb, a.qe, a.w, b.rb, b.re, b.qb, b.qe, b.w);
+            if (w_arg < 0) continue;
+            // what WaveScorerLong makes of sc(w_arg, b.qe - a.qb, query + a.qb, a.rb, b.re)
+            const int l_query = b.qe - a.qb;
+            const long long rb = a.rb, re = b.re;
+            if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) continue;
+            const int rlen = (int)(re - rb);
+            if (l_query == rlen && w_arg == 0) continue;                       // (ungapped: a sum, computed in place)
+            if (rlen < 2 * GSEG_LEN) continue;                                 // short: in place
+            int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
+            int w = (max_gap + dl + 1) >> 1;
+            w = w < w_arg ? w : w_arg;
+            w = w > dl + 3 ? w : dl + 3;
+            if (2 * w + 1 > CIG_BAND_MAX_COLS) continue;                       // (wider: in place)
+            GJob j;
+            j.z_off = 0; j.has_z = 0; j.q_off = ck.offs[r] + (unsigned long long)a.qb; j.rb = rb; j.re = re; j.lq = l_query; j.rlen = rlen; j.rev = rb >= R.l_pac ? 1 : 0;
+            j.ww = w; j.n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1; j.w_arg = w_arg; j.cpb = 2 * w + 1 <= GB_THREADS ? 1 : (2 * w + 1 <= 2 * GB_THREADS ? 2 : 4);
+            j.slot = 0; j.score = 0; j.r = r; j.unit_base = 0;
+            GGeom g; g.valid = true; g.lq = l_query; g.rlen = rlen; g.ww = w; g.n_col = j.n_col; g.rev = j.rev != 0;
+            j.n_seg = gseg_count(g);
+            if (j.n_seg < 2) j.n_seg = 0;
+            j.seg_base = slots; slots += j.n_seg; units += j.n_seg;
+            jobs[nj++] = j;
+        }
+    if (nj == 0) return;
+    const unsigned int base = atomicAdd(&P.cnt[7], (unsigned int)nj);
+    if (base + (unsigned int)nj > job_cap) return;                             // (no room: this read's alignments run in place)
+    const unsigned int sb = slots ? atomicAdd(&P.cnt[0], (unsigned int)slots) : 0u;
+    unsigned int ub = units ? atomicAdd(&P.cnt[1], (unsigned int)units) : 0u;
+    for (int k = 0; k < nj; ++k) {
+        jobs[k].seg_base += (int)sb;
+        jobs[k].unit_base = ub; ub += (unsigned int)jobs[k].n_seg;
+        P.gjobs[base + (unsigned int)k] = jobs[k];
+    }
+    memo_off[r] = (int)base; memo_n[r] = nj;
+}
+
+// one block per planned alignment: joined from its segments, or whole when it was not cut
+__global__ void __launch_bounds__(GB_THREADS) k_pseg_join(DevRef R, Chunk ck, DevOpt dopt, GPlan P, unsigned int n_jobs)
+{
+    __shared__ GbShared S;
+    __shared__ unsigned int s_job;
+    int *scratch = P.scratch + (size_t)blockIdx.x * GSEG_WIN;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_job = atomicAdd(&P.cnt[3], 1u);
+        __syncthreads();
+        const unsigned int t = s_job;
+        if (t >= n_jobs) break;
+        const GJob x = P.gjobs[t];
+        const GQ qf{ck.codes + x.q_off, x.lq, x.rev != 0};
+        const GT tf{&R, x.rb, x.re, x.rev != 0};
+        int score;
+        if (x.n_seg >= 2) {
+            if (x.cpb == 1) score = gseg_join<1>(x.lq, qf, x.rlen, tf, dopt.o, x, t, nullptr, P, scratch, S);
+            else if (x.cpb == 2) score = gseg_join<2>(x.lq, qf, x.rlen, tf, dopt.o, x, t, nullptr, P, scratch, S);
+            else score = gseg_join<4>(x.lq, qf, x.rlen, tf, dopt.o, x, t, nullptr, P, scratch, S);
+        } else {
+            if (x.cpb == 1) score = block_ksw_global2_bandn<1>(x.lq, qf, x.rlen, tf, dopt.o, x.ww, nullptr, 0, S);
+            else if (x.cpb == 2) score = block_ksw_global2_bandn<2>(x.lq, qf, x.rlen, tf, dopt.o, x.ww, nullptr, 0, S);
+            else score = block_ksw_global2_bandn<4>(x.lq, qf, x.rlen, tf, dopt.o, x.ww, nullptr, 0, S);
+        }
+        if (threadIdx.x == 0) { P.gjobs[t].score = score; atomicAdd(&P.cnt[6], 1u); }
+    }
+}
+
+__device__ bool pseg_lookup(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re, int *score)
+{
+    const int n = pm->n[r];
+    const GJob *j = pm->jobs + pm->off[r];
+    for (int k = 0; k < n; ++k)
+        if (j[k].w_arg == w_arg && j[k].q_off == q_off && j[k].lq == l_query && j[k].rb == (long long)rb && j[k].re == (long long)re) { *score = j[k].score; return true; }
+    return false;
+}

@@ -527,6 +527,12 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
         return v;
     }
     {   // segments of the contigs' extensions since the aligner was created: taken as speculated / computed again / second band tries / sides cut
+        if (!strcmp(key, "pseg_jobs")) {          // mem_patch_reg alignments computed ahead of the region kernel
+            long long v = 0;
+            auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += wk->pseg_stat; };
+            if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
+            return v;
+        }
         static const char *const gs[3] = {"gseg_ok", "gseg_redo", "gseg_jobs"};          // the same for the CIGAR alignments' segments
         for (int i = 0; i < 3; ++i)
             if (!strcmp(key, gs[i])) {

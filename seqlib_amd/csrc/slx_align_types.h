@@ -74,6 +74,8 @@ struct Worker {
     int long_rounds_run = 0; unsigned int long_jobs_run = 0;                       // ... what the last long chunk took
     DevBuf xseg_jobs, xseg_state, xseg_units, xseg_out, xseg_wrec, xseg_wout, xseg_scratch, xseg_cnt;     // contigs: long extensions cut into segments (dev_ext_seg.h)
     DevBuf gseg_jobs, gseg_units, gseg_wrec, gseg_wout, gseg_scratch, gseg_cnt;                 // contigs: CIGAR alignments cut into segments (dev_cig_seg.h)
+    DevBuf pseg_jobs, pseg_idx, pseg_cnt;                                          // ... and mem_patch_reg's alignments computed ahead of the region kernel
+    unsigned int pseg_stat = 0;                                                    // ... how many
     unsigned int gseg_stat[3] = {0, 0, 0};                                         // ... segments taken as speculated / run again / jobs cut
     unsigned int xseg_stat[4] = {0, 0, 0, 0};                                      // ... segments taken as speculated / computed again / second band tries / sides cut, summed over this worker's launches
     DevBuf snap_ia, snap_regs, snap_nreg;   // "keep_stages": chain order and region list as they stand between extension and de-duplication
@@ -101,7 +103,7 @@ struct Worker {
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
                &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &snap_ia, &snap_regs, &snap_nreg,
-               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &gseg_jobs, &gseg_units, &gseg_wrec, &gseg_wout, &gseg_scratch, &gseg_cnt, &xseg_jobs, &xseg_state, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
+               &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &pseg_jobs, &pseg_idx, &pseg_cnt, &gseg_jobs, &gseg_units, &gseg_wrec, &gseg_wout, &gseg_scratch, &gseg_cnt, &xseg_jobs, &xseg_state, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
     }

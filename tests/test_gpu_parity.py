@@ -407,7 +407,9 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
             ref[400000:440000] + tail,                                           # 40 kb then 30 kb of unrelated sequence: z-drop ends the extension
             orc_revcomp(ref[450000:470000] + ref[10000:40000]),                  # a chimeric contig
             mut(ref[480000:592000], 300, ((0.25, 1, 0), (0.75, 0, 2))),          # 112 kb: the wide-packing pipeline
-            ref[5000:14000]]                                                     # 9 kb: a side just long enough to be cut once
+            ref[5000:14000],                                                     # 9 kb: a side just long enough to be cut once
+            mut(ref[140000:215000], 8, ((0.45, 0, 150),)),                       # a 150 bp deletion: beyond the band, two regions that mem_patch_reg joins (75 kb global alignment)
+            orc_revcomp(mut(ref[520000:580000], 6, ((0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0))))]   # a 128 bp insertion
     exp = orc.align_batch(orc.default_opt(), oidx, seqs)
     base_ok = None
     for knobs in ((), (("xseg_fail", 1),), (("xseg_fail", 2),), (("xseg_fail", 3),), (("long_seg", 0),), (("long_budget", 0),)):
@@ -420,6 +422,7 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
         if knobs == ():
             assert sides >= len(seqs) and ok > 5 * max(redo, 1), (ok, redo, sides)          # the speculation holds nearly everywhere on these contigs
             assert g_jobs >= 4 and g_ok > 5 * max(g_redo, 1), (g_ok, g_redo, g_jobs)
+            assert al.counter("pseg_jobs") >= 1          # mem_patch_reg's contig-long alignments were computed ahead of the region kernel
             base_ok = ok
         elif knobs == (("xseg_fail", 1),):
             assert ok == 0 and redo >= base_ok, (ok, redo)                                   # every segment computed again
@@ -427,7 +430,7 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
         elif knobs and knobs[0][0] == "xseg_fail":
             assert ok > 0 and redo > 0, (ok, redo)
         elif knobs == (("long_seg", 0),):
-            assert sides == 0 and g_jobs == 0
+            assert sides == 0 and g_jobs == 0 and al.counter("pseg_jobs") == 0
     # other scoring: gap costs that differ by kind, a narrower and a wider band (two slots per thread), z-drop off
     for o_set in (dict(o_del=8, e_del=2, o_ins=7, e_ins=3, w=60), dict(w=180, zdrop=0), dict(a=2, b=5, o_del=10, o_ins=10, e_del=2, e_ins=2, zdrop=200)):
         opt = orc.default_opt()
