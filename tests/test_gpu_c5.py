@@ -102,12 +102,13 @@ def test_default_step_of_64_windows_by_properties(sl, c2_index):
             if len(s) < 1000:
                 continue
             n_long += 1
-            # within the error model: all but a handful of the 100-mers of a contig (sampled every 50 bp) occur in the window's slice, on either strand
-            for i in range(0, len(s) - 100 + 1, 50):
+            # within the error model: all but a handful of the 100-mers of a contig (sampled every 1 000 bp: a substring search in 500 kb each) occur in the
+            # window's slice, on either strand
+            for i in range(0, len(s) - 100 + 1, 1000):
                 tot_kmers += 1
                 bad_kmers += not (s[i:i + 100] in fwd or s[i:i + 100] in rev)
         assert sum(u["len"] for u in utgs) > 0.9 * span, "window %d: contigs cover %d of %d bp" % (w, sum(u["len"] for u in utgs), span)
-    assert n_long >= n_win and tot_kmers > 100_000 and bad_kmers <= 0.002 * tot_kmers, (n_long, tot_kmers, bad_kmers)
+    assert n_long >= n_win and tot_kmers > 20_000 and bad_kmers <= 0.002 * tot_kmers, (n_long, tot_kmers, bad_kmers)
     al = sl.BWAAligner(idx)
     h = al.alignSequences(contigs)
     off = h["hit_off"]
