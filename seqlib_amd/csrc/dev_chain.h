@@ -115,7 +115,7 @@ __device__ void dev_chain_read(const DevFM<I> &fm, const DevRef &R, const Chunk 
             const I step = x2 > (I)opt.max_occ ? x2 / (I)opt.max_occ : (I)1;
             I k = 0;
             for (int count = 0; k < x2 && count < opt.max_occ; k += step, ++count) {
-                const int64_t rbeg = fm_sa<I>(fm, ix0[i] + k);
+                const int64_t rbeg = intv_pos<I>(fm, ix0[i], k);
                 const int rid = dev_intv2rid(R, rbeg, rbeg + slen);
                 if (rid < 0) continue;           // bridges two contigs or the forward/reverse boundary
                 // lower = first chain with pos == rbeg, else the chain with the largest pos < rbeg

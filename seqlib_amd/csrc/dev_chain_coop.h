@@ -69,7 +69,7 @@ __device__ __noinline__ void dev_chain_read_coop(const DevFM<I> &fm, const DevRe
                 const bool valid = t < count_max;
                 int64_t rb_l = 0; int rid_l = -1;
                 if (valid) {
-                    rb_l = fm_sa<I>(fm, x0 + (I)t * step);
+                    rb_l = intv_pos<I>(fm, x0, (I)t * step);
                     rid_l = dev_intv2rid(R, rb_l, rb_l + slen);
                 }
                 const int nb = count_max - base < 64 ? count_max - base : 64;

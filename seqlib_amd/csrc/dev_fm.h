@@ -21,6 +21,8 @@ struct DevFM {
     int sa_intv;
     const void *lut;          // k-mer table (dev_seed4.h): LutE<I> per lut_k-mer, first base most significant; nullptr = none
     int lut_k;
+    int bwd_direct;           // 1: SMEM pass 1 walks an entry with ONE occurrence backward against the text (dev_seed4.h); such an interval is emitted with its TEXT
+                              // POSITION | pos_flag() in x0 instead of its suffix-array rank (intv_pos below is what every reader of x0 goes through)
     const uint32_t *rep;      // repeat filter (dev_seed4.h, k_rep_filter): one bit per hashed rep_k-mer, set for every rep_k-mer that occurs
     uint64_t rep_mask;        //   at least twice in the indexed text; rep_mask = bits - 1 (a power of two); nullptr = none
     int rep_k;
@@ -135,6 +137,9 @@ __device__ __forceinline__ void fm_extend(const DevFM<I> &fm, const IntvE<I> &ik
     ok.x2 = sz;
 }
 
+// top bit of an interval's x0: the value is a text position (one occurrence), not a rank
+template <typename I> __host__ __device__ __forceinline__ constexpr I pos_flag() { return (I)1 << (sizeof(I) * 8 - 1); }
+
 // bwt_sa: suffix-array value at rank k.  Dense table = one load; otherwise bwa's invPsi walk to the
 // next sampled rank.
 template <typename I>
@@ -156,4 +161,12 @@ __device__ __forceinline__ int64_t fm_sa(const DevFM<I> &fm, I k)
         k = fm.L2[c] + tk[c];
     }
     return (int64_t)(sa + fm.sa_samp[k / (I)fm.sa_intv]);
+}
+
+// text position of occurrence k of an emitted interval (x0, x2): bwt_sa(x0 + k), or the position the interval carries itself
+template <typename I>
+__device__ __forceinline__ int64_t intv_pos(const DevFM<I> &fm, I x0, I k)
+{
+    if (x0 & pos_flag<I>()) return (int64_t)(x0 & ~pos_flag<I>());
+    return fm_sa<I>(fm, x0 + k);
 }

@@ -419,6 +419,7 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
     I v0 = 0, v2 = 0;                              // ... and its interval, loaded at the start of the row
     QWin win; win.bits = 0; win.chunk = 0xffffffffu;
     const bool direct_ok = fm.sa_dense != nullptr;  // (the sampled-SA walk would cost more than it saves)
+    const bool bwd_direct = MODE == 1 && direct_ok && fm.bwd_direct != 0;          // backward steps of one-occurrence entries against the text (below)
     int ones = 0;                                  // consecutive forward steps that ended at one occurrence
     int64_t dpos = 0;                              // S4_DIR: text position of that occurrence of q[sx, i)
     RWin rwin; rwin.bits = 0; rwin.chunk = -1;
@@ -692,12 +693,23 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
                     I nx0 = 0, nx2 = 0; uint32_t nxinf = 0;
                     if (j + 1 < np) wl_get(cur, rev ? np - 2 - j : j + 1, nx0, nx2, nxinf);   // the next entry, in flight behind this step's rank reads
                     if (j < np) {                       // (np == 0: a row of the virtual entry alone)
+                        I o2, o0_;
+                        if (bwd_direct && p2 == (I)1) {
+                            // ONE occurrence: the extension by cb exists iff the text has cb before it -- one (mostly cached) text read instead of two rank reads.
+                            // The entry carries its text position from here on (flag bit in x0); its rank is never needed again: an emitted interval
+                            // is only ever turned into positions (intv_pos).
+                            if (!(p0 & pos_flag<I>())) p0 = (I)fm_sa<I>(fm, p0) | pos_flag<I>();
+                            const int64_t pos = (int64_t)(p0 & ~pos_flag<I>());
+                            o2 = (pos > 0 && text_at(R, pos - 1, rwin) == cb) ? (I)1 : (I)0;
+                            o0_ = (I)(pos - 1) | pos_flag<I>();
+                        } else {
                         RankLd<I> rk, rl;
                         rank_issue<I>(fm, p0 - 1, rk); rank_issue<I>(fm, p0 - 1 + p2, rl);
                         I ckc, clc, dummy;
                         rank_finish<I, false>(rk, cb, ckc, dummy); rank_finish<I, false>(rl, cb, clc, dummy);
-                        const I o2 = clc - ckc;
-                        const I o0_ = l2_of<I>(fm, cb) + 1 + ckc;
+                        o2 = clc - ckc;
+                        o0_ = l2_of<I>(fm, cb) + 1 + ckc;
+                        }
                         if (o2 < min_intv) { if (nc == 0) emit_mem(p0, p2, pinf); }
                         else if (nc == 0 || o2 != last_sz) {
                             if (nc == 0) { nh0 = o0_; nh2 = o2; nhinf = pinf; }

@@ -431,6 +431,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "long_block")) { if (value < 0 || value > (1 << 24)) return SLX_EINVAL; al->long_block = (int)value; }
     else if (!strcmp(key, "long_guess")) al->long_guess = value != 0;
     else if (!strcmp(key, "long_seg")) al->long_seg = value != 0;
+    else if (!strcmp(key, "bwd_direct")) al->bwd_direct = value != 0;
     else if (!strcmp(key, "xseg_fail")) { if (value < 0) return SLX_EINVAL; al->xseg_fail = (int)value; }
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
@@ -1119,7 +1120,9 @@ extern "C" int slx_debug_stage(slx_aligner *al, int64_t read, int what, int64_t 
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t inf = ((const uint32_t *)info.data())[i];
             w.push_back(inf >> 16); w.push_back(inf & 0xffff);
-            w.push_back(wk->last_wide ? (int64_t)((const uint64_t *)x0.data())[i] : (int64_t)((const uint32_t *)x0.data())[i]);
+            // (an interval with one occurrence may carry its text position instead of its rank -- bwd_direct, dev_fm.h: reported as -(position) - 1)
+            if (wk->last_wide) { const uint64_t v = ((const uint64_t *)x0.data())[i]; w.push_back((v >> 63) ? -(int64_t)(v & ~(1ULL << 63)) - 1 : (int64_t)v); }
+            else { const uint32_t v = ((const uint32_t *)x0.data())[i]; w.push_back((v >> 31) ? -(int64_t)(v & 0x7fffffffu) - 1 : (int64_t)v); }
             w.push_back(wk->last_wide ? (int64_t)((const uint64_t *)x2.data())[i] : (int64_t)((const uint32_t *)x2.data())[i]);
         }
     } else if (what == 1) {

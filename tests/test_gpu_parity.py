@@ -453,7 +453,8 @@ def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, gold
     (_, s1), (_, s2) = sim_reads
     seqs = s1[:700] + ["A" * 150, "AC" * 75, "ACG" * 50, "N" * 40 + refs[0][300:410], refs[1][100:1500], refs[2][50:900]] + s2[:300]
     opt = orc.default_opt()
-    for knobs in ((("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1)), (("split_min", 1 << 30),)):
+    n_pos_form = [0]
+    for knobs in ((("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1)), (("split_min", 1 << 30),), (("bwd_direct", 0),)):
         al = sl.BWAAligner(tiny_gpu)
         al.set("keep_stages", 1)
         for k, v in knobs:
@@ -465,9 +466,26 @@ def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, gold
                 exp = orc.stage_dump(opt, tiny_index, sq, what)
                 if what == 1 and len(got) and got[0] == -1:
                     continue                      # exact-match shortcut: the read's only region was written at chaining time (checked as stage 2)
+                if what == 0 and len(got) == len(exp):
+                    # an interval with ONE occurrence may carry its text position instead of its rank (the backward steps of such an entry run against the
+                    # text: bwd_direct, dev_fm.h), reported as -(position) - 1: it must be where the checker's rank points
+                    got = got.reshape(-1, 4).copy()
+                    e4 = exp.reshape(-1, 4)
+                    for row in range(len(got)):
+                        if got[row, 2] < 0:
+                            assert got[row, 3] == 1 and e4[row, 3] == 1
+                            assert int(orc.lib().orc_sa(tiny_index.h, int(e4[row, 2]))) == -int(got[row, 2]) - 1, "read %d interval %d: text position differs" % (i, row)
+                            got[row, 2] = e4[row, 2]
+                            n_pos_form[0] += 1
+                    got = got.reshape(-1)
                 if what == 2:                     # the order of regions is the order of extension: compare as lists
                     got, exp = got.reshape(-1, 10), exp.reshape(-1, 10)
                 assert np.array_equal(got, exp), "read %d (%d bp): %s differ under %s\n gpu=%s\n cpu=%s" % (i, len(sq), name, knobs, got[:40], exp[:40])
+        if knobs == (("bwd_direct", 0),):
+            assert n_pos_form[0] == before          # ... and none with the knob off
+        else:
+            assert n_pos_form[0] > 0
+        before = n_pos_form[0]
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():
