@@ -138,8 +138,10 @@ struct slx_aligner {
     int long_block = 32768;       // contigs: a round of at most this many extension jobs runs four waves per job (k_ext_block); 0 = always one wave per job
     int long_seed3 = 1;           // contigs: pass 3 of seeding one lane per position + a chase per read (k_seed3_next / k_seed3_chase); 0 = one lane per read
     int long_coop = 1;            // contigs (reads beyond 704 bp): chaining one wave per read (k_chain_coop) for the reads with many seed occurrences; 0 = one lane per read
-    int bwd_direct = 1;           // SMEM pass 1: the backward steps of an entry with one occurrence run against the text (one cached read instead of two rank reads); its interval
-                                  // then carries the text position instead of the rank (dev_fm.h: intv_pos).  0 = rank steps throughout
+    int bwd_direct = 0;           // 1 = SMEM pass 1 runs the backward steps of an entry with one occurrence against the text (one text read instead of two rank reads); its interval
+                                  // then carries the text position instead of the rank (dev_fm.h: intv_pos).  Bit-exact (parity suite with the knob on), and SLOWER on C3:
+                                  // 62.2 M reads/s against 63.0 M, seeding 623 against 591 ms per step -- the suffix-array read that turns the rank into a position and the text reads
+                                  // are random reads of their own, the rank reads they replace were mostly L1 hits of the neighbouring entry's block.  Off
     int long_seg = 1;             // contigs: the long sides of an extension job cut into segments of XSEG_LEN rows that run side by side and are verified at the joins
                                   // (dev_ext_seg.h); 0 = every job whole on one block (k_ext_block)
     int xseg_fail = 0;            // test knob: > 0 forces the verification of every xseg_fail-th segment to fail (the segment is then computed again from the true window)

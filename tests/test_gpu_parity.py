@@ -454,7 +454,7 @@ def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, gold
     seqs = s1[:700] + ["A" * 150, "AC" * 75, "ACG" * 50, "N" * 40 + refs[0][300:410], refs[1][100:1500], refs[2][50:900]] + s2[:300]
     opt = orc.default_opt()
     n_pos_form = [0]
-    for knobs in ((("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1)), (("split_min", 1 << 30),), (("bwd_direct", 0),)):
+    for knobs in ((("split_min", 16), ("heavy_seeds", 8), ("cand_seeds", 1), ("bwd_direct", 1)), (("split_min", 1 << 30), ("bwd_direct", 1)), (("bwd_direct", 0),)):
         al = sl.BWAAligner(tiny_gpu)
         al.set("keep_stages", 1)
         for k, v in knobs:
