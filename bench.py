@@ -181,7 +181,7 @@ def spawn_ranks(n):
     any HIP call of this process (device_count() does not initialise the GPU on this image); never re-execs."""
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("SLX_BENCH_SHARE_GPU") != "1":
         sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to report a %d-GPU number from fewer devices\n" % (n, have, n))
         sys.exit(2)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -268,11 +268,20 @@ def main_c5(args):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FermiAssembler / BFC path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SLX_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): the ranks share the visible devices and talk over gloo -- RCCL refuses two ranks on one device.  The
+    # windows' sharding, the barrier / max-over-ranks timing and the line are what the N-GPU run executes; only the transport of two scalars differs.
+    share = os.environ.get("SLX_BENCH_SHARE_GPU") == "1"
+    dev_i = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_i)
+    dev = torch.device("cuda", dev_i)
+    red_dev = torch.device("cpu") if share else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    local_rank = dev_i
     import seqlib_amd
     from seqlib_amd import fml, synth
     idx = seqlib_amd.BWAIndex()
@@ -383,7 +392,7 @@ def main_c5(args):
     fence()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_reads = n_win * per_win

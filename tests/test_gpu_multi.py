@@ -62,6 +62,23 @@ def test_bench_c5_two_ranks():
     assert line["host_threads_per_rank"] >= 1
 
 
+def test_bench_c5_two_ranks_sharing_the_gpu():
+    """the same command on a 1-GPU box: two ranks share the device and talk over gloo (SLX_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one device).  Rank r
+    assembles and realigns windows [r W, (r + 1) W) of the job; the line reports both ranks' reads over the slowest rank's time"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SLX_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5", "--windows", "4", "--reads", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["windows_per_gpu"] == 4 and "x2" in line["config"]["parallelism"]
+    assert line["contig_bit_match_rate"] == 1.0 and line["realigned_contig_bit_match_rate"] in (None, 1.0)
+    assert line["host_threads_per_rank"] >= 1
+
+
 def test_group_of_eight_copy_out_share(sl, orc, tiny_gpu, tiny_index, sim_reads):
     """the group handle with eight entries (device 0 x 8): results equal the oracle's, and the second phase of the call -- sizing the
     merged block and copying every device's arrays to their place in it -- is a small part of the call"""
