@@ -348,9 +348,18 @@ struct __align__(16) FmlHeap1 {          // echeap1_t, 48 bytes
 // index j * 64 + lane, so that lanes working on the same position of their reads -- the common case, every lane advances one base
 // per step -- touch one contiguous stretch.  The pointers below are already offset by the lane; index with FML_L(j).
 #define FML_L(j) ((size_t)(j) * 64)
+typedef __attribute__((address_space(3))) unsigned char fml_lds_u8;
+typedef __attribute__((address_space(3))) unsigned short fml_lds_u16;
+struct FmlEcScratchLds {          // the same with the per-base arrays in LDS (k_fml_ec_lds): address-space pointers, so that the walk's loads are ds_read and
+    fml_lds_u8 *B;                // never wait behind the stack's stores to memory (one counter, vmcnt, orders both on this chip; a flat load would join it)
+    fml_lds_u16 *cv, *oc;
+    struct FmlHeap1 *heap;
+    uint2 *stack;
+};
 struct FmlEcScratch {
     unsigned char *B;          // per base: b | q << 3 | ob << 4
     unsigned short *cv;        // per base: lcov | hcov << 6 | solid_end << 12 | high_end << 13
+    unsigned short *oc;        // per base: the table's value for the k-mer of B that ENDS here (k_fml_occ), FML_OC_ABSENT, or FML_OC_ASK (no such k-mer / no longer known)
     FmlHeap1 *heap;            // heap entries 1 .. (entry 0, the top, lives in registers)
     uint2 *stack;              // x = parent, y = i | b << 16
 };
@@ -361,7 +370,7 @@ __host__ __device__ inline size_t fml_scratch_bytes(int max_len)          // per
     size_t c = (2 * (size_t)max_len + 15) & ~(size_t)15;
     size_t h = sizeof(FmlHeap1) * FML_HEAP_CAP;
     size_t s = ((size_t)(FML_STACK_CAP(max_len) + 8) * 8 + 15) & ~(size_t)15;
-    return b + c + h + s;
+    return b + 2 * c + h + s;
 }
 
 __device__ __forceinline__ FmlEcScratch fml_scratch_of(unsigned char *scratch, size_t lane_bytes, int max_len, size_t wave, int lane)
@@ -370,6 +379,7 @@ __device__ __forceinline__ FmlEcScratch fml_scratch_of(unsigned char *scratch, s
     FmlEcScratch sc;
     sc.B = p + lane; p += 64 * (((size_t)max_len + 15) & ~(size_t)15);
     sc.cv = (unsigned short *)p + lane; p += 64 * ((2 * (size_t)max_len + 15) & ~(size_t)15);
+    sc.oc = (unsigned short *)p + lane; p += 64 * ((2 * (size_t)max_len + 15) & ~(size_t)15);
     sc.heap = (FmlHeap1 *)p + lane; p += 64 * sizeof(FmlHeap1) * FML_HEAP_CAP;
     sc.stack = (uint2 *)p + lane;
     return sc;
@@ -388,57 +398,114 @@ __device__ __forceinline__ int fml_occ(const FmlSlot *tab, const FmlWin &w, uint
     return fml_get(tab, w, fml_key(w.k, x0, x1, mask));
 }
 
+// The table's answer for the k-mer that ends at every text position, one lane per POSITION: bfc_ec_kcov asks for each of them, and
+// bfc_ec1dir asks again for every position its path has not changed (all of them, for a read without errors) -- from a lane that walks
+// its read one dependent probe at a time.  Asked here once, by every lane of the chip at the same time, the walk finds the answers in
+// its own scratch and probes the table only where its k-mer differs from the read's.
+#define FML_OC_ABSENT 0xffffu          // the k-mer is not in the table (bfc_ch_get: -1)
+#define FML_OC_ASK 0xfffeu             // no k-mer of the read ends here (N, read start), or a base under it has changed since: probe
+static __global__ void __launch_bounds__(256) k_fml_occ(FmlPlanes pl, long long total, const FmlWin *wins, int n_win, const FmlSlot *tab, unsigned short *occ)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    int lo = 0, hi = n_win;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].pos0 <= p) lo = mid; else hi = mid; }
+    const FmlWin w = wins[lo];
+    unsigned long long key; bool hq;
+    unsigned int v = FML_OC_ASK;
+    if (fml_kmer_at(pl, p, w, key, hq)) { const int r = fml_get(tab, w, key); v = r < 0 ? FML_OC_ABSENT : (unsigned int)r; }
+    occ[p] = (unsigned short)v;
+}
+
+// a base of B changes at (forward) position fi: the k-mers that end at fi .. fi + k - 1 are no longer the ones k_fml_occ asked about
+template <class SC>
+__device__ __forceinline__ void fml_oc_forget(const SC &sc, int fi, int k, int n)
+{
+    const int to = fi + k < n ? fi + k : n;
+    for (int j = fi; j < to; ++j) sc.oc[FML_L(j)] = (unsigned short)FML_OC_ASK;
+}
+
 // klib's ks_heapdown / ks_heapup on tot_pen (smallest on top), operation for operation -- the order in which equal penalties leave the
 // heap decides between equally cheap paths -- over a heap whose entry 0 is the register `top` and whose entries 1 .. are mem[0 ..].
 // Nearly always the heap holds one state (the read's own path), and then no heap traffic reaches memory at all.
+// (memory entries through an address-space-1 pointer, three 16-byte vectors each: with a plain pointer the optimiser merges "top = e" / "mem[i] = e" into one
+// access through a CHOSEN address, and a `top` that has an address lives in scratch memory -- every pop and push of the one-state heap a round trip)
+typedef unsigned int fml_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) fml_u4 fml_g_u4;
+struct FmlHeapMem {
+    fml_g_u4 *p;
+    __device__ __forceinline__ FmlHeap1 operator[](size_t at) const
+    {
+        const fml_u4 a = p[at * 3], b = p[at * 3 + 1], c = p[at * 3 + 2];
+        FmlHeap1 e;
+        e.tot_pen = (int)a.x; e.i = (int)a.y; e.k = (int)a.z; e.eh[0] = (int)a.w;
+        e.eh[1] = (int)b.x; e.ep[0] = (int)b.y; e.ep[1] = (int)b.z; e.ep[2] = (int)b.w;
+        e.ep[3] = (int)c.x; e.ep[4] = (int)c.y; e.x0 = c.z; e.x1 = c.w;
+        return e;
+    }
+    __device__ __forceinline__ void put(size_t at, const FmlHeap1 &e) const
+    {
+        p[at * 3] = fml_u4{(unsigned int)e.tot_pen, (unsigned int)e.i, (unsigned int)e.k, (unsigned int)e.eh[0]};
+        p[at * 3 + 1] = fml_u4{(unsigned int)e.eh[1], (unsigned int)e.ep[0], (unsigned int)e.ep[1], (unsigned int)e.ep[2]};
+        p[at * 3 + 2] = fml_u4{(unsigned int)e.ep[3], (unsigned int)e.ep[4], e.x0, e.x1};
+    }
+};
 struct FmlHeap {
     FmlHeap1 top;
-    FmlHeap1 *mem;
+    FmlHeapMem mem;
     int n;
-    __device__ __forceinline__ FmlHeap1 get(int i) const { return i == 0 ? top : mem[FML_L(i - 1)]; }
-    __device__ __forceinline__ void set(int i, const FmlHeap1 &e) { if (i == 0) top = e; else mem[FML_L(i - 1)] = e; }
-    __device__ inline FmlHeap1 pop()          // z = l[0]; l[0] = l[--n]; ks_heapdown(0, n, l)
+    // (no get(i) / set(i) that pick between `top` and memory by index: a choice between the two ADDRESSES puts `top` in scratch memory)
+    __device__ __forceinline__ FmlHeap1 pop()          // z = l[0]; l[0] = l[--n]; ks_heapdown(0, n, l)
     {
         const FmlHeap1 z = top;
         --n;
         if (n > 0) {
             const FmlHeap1 tmp = mem[FML_L(n - 1)];
             int i = 0, k = 0;
-            while ((k = (k << 1) + 1) < n) {
+            while ((k = (k << 1) + 1) < n) {          // (k >= 1: the children are in memory)
                 FmlHeap1 ck = mem[FML_L(k - 1)];
                 if (k != n - 1) { const FmlHeap1 c2 = mem[FML_L(k)]; if (ck.tot_pen > c2.tot_pen) { ++k; ck = c2; } }
                 if (ck.tot_pen > tmp.tot_pen) break;
-                set(i, ck); i = k;
+                if (i == 0) top = ck; else mem.put(FML_L(i - 1), ck);
+                i = k;
             }
-            set(i, tmp);
+            if (i == 0) top = tmp; else mem.put(FML_L(i - 1), tmp);
         }
         return z;
     }
-    __device__ inline void push(const FmlHeap1 &r)          // l[n++] = r; ks_heapup(n, l)
+    __device__ __forceinline__ void push(const FmlHeap1 &r)          // l[n++] = r; ks_heapup(n, l)
     {
         int i = n++;
         while (i > 0) {
             const int k = (i - 1) >> 1;
-            const FmlHeap1 pk = get(k);
-            if (r.tot_pen > pk.tot_pen) break;
-            set(i, pk); i = k;
+            if (k == 0) {
+                if (r.tot_pen > top.tot_pen) break;
+                mem.put(FML_L(i - 1), top); i = 0;
+            } else {
+                const FmlHeap1 pk = mem[FML_L(k - 1)];
+                if (r.tot_pen > pk.tot_pen) break;
+                mem.put(FML_L(i - 1), pk); i = k;
+            }
         }
-        set(i, r);
+        if (i == 0) top = r; else mem.put(FML_L(i - 1), r);
     }
 };
 
 struct FmlPen { int ec, ec_high, absent, absent_high, b; };
+__device__ __forceinline__ unsigned int fml_pen_pack(const FmlPen &p) { return (unsigned int)(p.ec | p.ec_high << 1 | p.absent << 2 | p.absent_high << 3 | p.b << 4); }
+__device__ __forceinline__ FmlPen fml_pen_unpack(unsigned int v) { return FmlPen{(int)(v & 1), (int)(v >> 1 & 1), (int)(v >> 2 & 1), (int)(v >> 3 & 1), (int)(v >> 4 & 3)}; }
 
 // bfc_ec1dir in search coordinates: position i is base i of the read (dir 0) or base n - 1 - i of it, complemented (dir 1); the
 // corrected read is written back in place
-__device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, int n, int dir, int start, int end)
+template <class SC>
+__device__ __forceinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, SC sc, int n, int dir, int start, int end)
 {
     const int k = w.k;
     FmlHeap1 z;
     FmlHeap hp;
     int l, n_stack = 0, n_failures = 0, path = -1;
     bool found = false;
-    hp.mem = sc.heap; hp.n = 0;
+    hp.mem.p = (fml_g_u4 *)sc.heap; hp.n = 0;
     auto base_at = [&](int i, int &b, int &q, int &ob, int &lc, int &hc) {
         const int fi = dir ? n - 1 - i : i;
         const int v = sc.B[FML_L(fi)];
@@ -446,6 +513,16 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
         if (dir) { b = b < 4 ? 3 - b : 4; ob = ob < 4 ? 3 - ob : 4; }
         const int c = sc.cv[FML_L(fi)];
         lc = c & 63; hc = c >> 6 & 63;
+    };
+    // the table's value for the path's k-mer that ends at search position i with base b there: the read's own answer (sc.oc) while the k-mer is
+    // the read's -- b is the read's base and the path's last substitution lies before the k-mer (sc.oc is FML_OC_ASK wherever an original N lies
+    // under the k-mer: substitutions of an N are the ones ep[] does not record) -- else a probe
+    auto occ_of = [&](const FmlHeap1 &s, bool own, uint32_t x0, uint32_t x1) -> int {
+        if (own && s.ep[0] <= s.i - k) {
+            const unsigned int m = sc.oc[FML_L(dir ? n - s.i + k - 2 : s.i)];
+            if (m != FML_OC_ASK) return m == FML_OC_ABSENT ? -1 : (int)m;
+        }
+        return fml_occ(tab, w, x0, x1);
     };
     z.tot_pen = 0; z.x0 = z.x1 = 0; z.k = -1;
     for (z.i = start, l = 0; z.i < end; ++z.i) {
@@ -471,11 +548,11 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
             if (have) base_at(z.i, cb, cq, cob, lc, hc);
             int os = -1, n_added = 0, other_ext = 0;
             bool fixed = false;
-            FmlPen added[4];
+            unsigned int added = 0;          // a byte per candidate: FmlPen packed (no indexed private array: that would live in scratch memory)
             if (have && cb < 4) {
                 uint32_t x0 = z.x0, x1 = z.x1;
                 fml_append(k, x0, x1, cb);
-                os = fml_occ(tab, w, x0, x1);
+                os = occ_of(z, true, x0, x1);
                 if (cq && os >= 0 && (os & 0xff) >= w.min_cov + 1 && lc >= w.min_cov + 1) fixed = true;
                 else if ((double)hc > k * .75) fixed = true;
             }
@@ -495,14 +572,14 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
                     pen.ec_high = pen.ec ? cq : 0;
                     pen.absent = pen.absent_high = 0;
                     pen.b = b;
-                    added[n_added++] = pen;
+                    added |= fml_pen_pack(pen) << (8 * n_added++);
                     ++other_ext;
                 } else {
                     pen.ec = pen.ec_high = 0;
                     pen.absent = (os < 0 || (os & 0xff) < w.min_cov) ? 1 : 0;
                     pen.absent_high = pen.absent ? cq : 0;
                     pen.b = b;
-                    added[n_added++] = pen;
+                    added |= fml_pen_pack(pen) << (8 * n_added++);
                 }
             }
             if (!fixed && other_ext == 0) ++n_failures;
@@ -512,13 +589,14 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
                 if (n_added > 1 && hp.n > o.max_heap) {
                     int min_b = -1, mn = 0x7fffffff;
                     for (int b = 0; b < n_added; ++b) {
-                        const int t = o.w_ec * added[b].ec + o.w_ec_high * added[b].ec_high + o.w_absent * added[b].absent + o.w_absent_high * added[b].absent_high;
+                        const FmlPen ab = fml_pen_unpack(added >> (8 * b));
+                        const int t = o.w_ec * ab.ec + o.w_ec_high * ab.ec_high + o.w_absent * ab.absent + o.w_absent_high * ab.absent_high;
                         if (mn > t) mn = t, min_b = b;
                     }
                     first = min_b; last = min_b + 1;
                 }
                 for (int a = first; a < last; ++a) {          // buf_update
-                    const FmlPen pen = added[a];
+                    const FmlPen pen = fml_pen_unpack(added >> (8 * a));
                     FmlHeap1 r = z;
                     sc.stack[FML_L(n_stack)] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
                     r.tot_pen = z.tot_pen + o.w_ec * pen.ec + o.w_ec_high * pen.ec_high + o.w_absent * pen.absent + o.w_absent_high * pen.absent_high;
@@ -539,42 +617,33 @@ __device__ __noinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, cons
         const int i = (int)(e.y & 0xffff), b = (int)(e.y >> 16);
         if (i < n) {
             const int fi = dir ? n - 1 - i : i;
-            sc.B[FML_L(fi)] = (unsigned char)((sc.B[FML_L(fi)] & ~7) | (dir ? 3 - b : b));
+            const int old = sc.B[FML_L(fi)], nb = dir ? 3 - b : b;
+            if ((old & 7) != nb) {
+                sc.B[FML_L(fi)] = (unsigned char)((old & ~7) | nb);
+                if (!dir) fml_oc_forget(sc, fi, k, n);          // (the second direction reads sc.oc; nothing does after it)
+            }
         }
     }
     return 0;
 }
 
 // bfc_ec1 for one read, in place in the ASCII text
-__device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, char *seq, char *qual, int n)
+// bfc_ec1 between bfc_seq_conv and the write-back: the read is in sc.B / sc.oc, n_n of its bases are N; 0 = sc.B holds the corrected read
+template <class SC>
+__device__ __forceinline__ int fml_ec_core(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, SC sc, int n, int n_n)
 {
     const int k = w.k;
-    int n_n = 0;
-    for (int i = 0; i < n; ++i) {          // bfc_seq_conv
-        const int c = fml_nt5((unsigned char)seq[i]);
-        int q = !qual ? 1 : ((int)(unsigned char)qual[i] - 33 >= o.q ? 1 : 0);
-        if (c > 3) q = 0, ++n_n;
-        sc.B[FML_L(i)] = (unsigned char)(c | q << 3 | c << 4);
-    }
     if ((double)n_n > n * .05) return -10;
     if (n < k) return -11;
     {          // bfc_ec_kcov: solid / high ends, then the number of solid (and solid high-quality) k-mers over each base as a sliding count
-        uint32_t x0 = 0, x1 = 0;
-        int l = 0;
-        for (int i = 0; i < n; ++i) {
-            const int c = sc.B[FML_L(i)] & 7;
+        for (int i = 0; i < n; ++i) {          // (the k-mers' counts: k_fml_occ's answers)
+            const int r = sc.oc[FML_L(i)];
             int f = 0;
-            if (c < 4) {
-                fml_append(k, x0, x1, c);
-                if (++l >= k) {
-                    const int r = fml_occ(tab, w, x0, x1);
-                    if (r >= 0) {
-                        const int high = (r >> 8 & 0x3f) >= w.min_cov + 1;
-                        if ((r & 0xff) >= w.min_cov) f = 1 << 12 | high << 13;
-                        else f = high << 13;
-                    }
-                }
-            } else l = 0, x0 = x1 = 0;
+            if (r < (int)FML_OC_ASK) {
+                const int high = (r >> 8 & 0x3f) >= w.min_cov + 1;
+                if ((r & 0xff) >= w.min_cov) f = 1 << 12 | high << 13;
+                else f = high << 13;
+            }
             sc.cv[FML_L(i)] = (unsigned short)f;
         }
         int lc = 0, hc = 0;          // ends in [j, j + k - 1]
@@ -633,24 +702,49 @@ __device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, con
             if (ec < 0 || end >= n) return -12;
             const int at = end - (ec >> 2);
             sc.B[FML_L(at)] = (unsigned char)((sc.B[FML_L(at)] & ~7) | (ec & 3));
+            fml_oc_forget(sc, at, k, n);
             ++end; start = end - k;
         }
     }
     if (fml_ec1dir(tab, w, o, sc, n, 0, start, n) < 0) return -13;
     if (fml_ec1dir(tab, w, o, sc, n, 1, n - end, n) < 0) return -14;          // (nothing has been written to the text yet: the read stays as it was)
+    return 0;
+}
+
+__device__ __forceinline__ unsigned char fml_conv1(int ch, int qch, bool has_q, int q_min)          // bfc_seq_conv of one base: b | q << 3 | ob << 4
+{
+    const int c = fml_nt5(ch);
+    int q = !has_q ? 1 : (qch - 33 >= q_min ? 1 : 0);
+    if (c > 3) q = 0;
+    return (unsigned char)(c | q << 3 | c << 4);
+}
+__device__ __forceinline__ char fml_out_base(int v) { const int b = v & 7; return b != (v >> 4 & 7) ? "acgtn"[b] : "ACGTN"[b]; }
+__device__ __forceinline__ char fml_out_qual(int v) { const int ob = v >> 4 & 7; return (v & 7) != ob ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+'); }
+
+// bfc_ec1 for one read, in place in the ASCII text
+__device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, char *seq, char *qual, const unsigned short *occ, int n)
+{
+    int n_n = 0;
+    for (int i = 0; i < n; ++i) {          // bfc_seq_conv
+        const unsigned char v = fml_conv1((unsigned char)seq[i], qual ? (int)(unsigned char)qual[i] : 0, qual != nullptr, o.q);
+        n_n += (v & 7) > 3;
+        sc.B[FML_L(i)] = v;
+        sc.oc[FML_L(i)] = occ[i];
+    }
+    const int rc = fml_ec_core(tab, w, o, sc, n, n_n);
+    if (rc < 0) return rc;
     for (int i = 0; i < n; ++i) {
-        const int v = sc.B[FML_L(i)], b = v & 7, ob = v >> 4 & 7;
-        const bool diff = b != ob;
-        seq[i] = diff ? "acgtn"[b] : "ACGTN"[b];
-        if (qual) qual[i] = diff ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+');
+        const int v = sc.B[FML_L(i)];
+        seq[i] = fml_out_base(v);
+        if (qual) qual[i] = fml_out_qual(v);
     }
     return 0;
 }
 
 // kmer_correct (flt_uniq = 0): persistent lanes, one read at a time each, reads handed out by an atomic counter
 static __global__ void __launch_bounds__(256) k_fml_ec(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
-                                                const unsigned long long *offs, long long n_reads, unsigned char *scratch, size_t lane_bytes, int max_len,
-                                                unsigned long long *next, int *status)
+                                                const unsigned long long *offs, long long n_reads, const unsigned short *occ, unsigned char *scratch, size_t lane_bytes,
+                                                int max_len, unsigned long long *next, int *status)
 {
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const FmlEcScratch sc = fml_scratch_of(scratch, lane_bytes, max_len, wave, threadIdx.x & 63);
@@ -669,9 +763,81 @@ static __global__ void __launch_bounds__(256) k_fml_ec(const FmlSlot *tab, const
             int lo = 0, hi = n_win;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
             const FmlWin w = wins[lo];
-            rc = w.k > 0 ? fml_ec_read(tab, w, o, sc, bases + b, quals ? quals + b : nullptr, n) : 1;
+            rc = w.k > 0 ? fml_ec_read(tab, w, o, sc, bases + b, quals ? quals + b : nullptr, occ + b, n) : 1;
         }
         if (status) status[r] = rc;
+    }
+}
+
+// The same for short reads (the sequencer's: every read of the batch at most FML_EC_LDS_MAX bases), the walk's per-base arrays in LDS.  k_fml_ec
+// keeps them in memory, and with a megabyte of scratch per wave every pass over a read comes from HBM again: 25 KB of traffic per 150 bp read,
+// a dependent round trip to memory per step of the walk.  Here a block is ONE wave and owns 5 bytes x 64 lanes per base of LDS (B, cv, oc; the
+// stack of the search, written once and read back along one path, and the heap beyond its top entry stay in memory), its 64 consecutive reads
+// enter and leave as whole coalesced rows (lane = base, one read at a time) instead of a byte per lane per step.
+#define FML_EC_LDS_MAX 480          // 5 x 64 x 480 = 150 KB of the CU's 160
+static __global__ void __launch_bounds__(64) k_fml_ec_lds(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
+                                                    const unsigned long long *offs, long long n_reads, const unsigned short *occ, unsigned char *scratch, size_t lane_bytes,
+                                                    int max_len, unsigned long long *next, int *status)
+{
+    extern __shared__ unsigned char fml_lds[];
+    const int lane = threadIdx.x;
+    const size_t row = ((size_t)max_len + 15) & ~(size_t)15;          // bases per lane, as fml_scratch_of rounds
+    const FmlEcScratch gsc = fml_scratch_of(scratch, lane_bytes, max_len, blockIdx.x, lane);          // heap and stack: memory
+    fml_lds_u8 *lB = (fml_lds_u8 *)fml_lds;
+    fml_lds_u16 *lcv = (fml_lds_u16 *)(lB + 64 * row), *loc = (fml_lds_u16 *)(lB + 64 * row * 3);
+    FmlEcScratchLds sc;
+    sc.B = lB + lane; sc.cv = lcv + lane; sc.oc = loc + lane; sc.heap = gsc.heap; sc.stack = gsc.stack;
+    while (true) {
+        unsigned long long r0 = 0;
+        if (lane == 0) r0 = atomicAdd(next, 64ULL);
+        r0 = __shfl(r0, 0);
+        if ((long long)r0 >= n_reads) break;
+        const long long r = (long long)r0 + lane;
+        const bool live = r < n_reads;
+        const unsigned long long b = live ? offs[r] : 0;
+        const int n = live ? (int)(offs[r + 1] - b) : 0;
+        int n_n = 0;
+        const int cnt = (int)((n_reads - (long long)r0) < 64 ? (n_reads - (long long)r0) : 64);
+        for (int j = 0; j < cnt; ++j) {          // bfc_seq_conv, read j of the wave's: lane = base
+            const unsigned long long bj = __shfl(b, j);
+            const int nj = __shfl(n, j);
+            int nn = 0;
+            for (int i = lane; i < nj; i += 64) {
+                const unsigned char v = fml_conv1((unsigned char)bases[bj + i], quals ? (int)(unsigned char)quals[bj + i] : 0, quals != nullptr, o.q);
+                nn += (v & 7) > 3;
+                lB[FML_L(i) + j] = v;
+                loc[FML_L(i) + j] = occ[bj + i];
+            }
+            for (int d = 32; d > 0; d >>= 1) nn += __shfl_xor(nn, d);
+            if (lane == j) n_n = nn;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int rc = 1;
+        if (n > 0) {
+            int lo = 0, hi = n_win;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
+            const FmlWin w = wins[lo];
+            rc = w.k > 0 ? fml_ec_core(tab, w, o, sc, n, n_n) : 1;
+        }
+        if (status && live) status[r] = rc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = 0; j < cnt; ++j) {          // the corrected reads back into the text
+            if (__shfl(rc, j) != 0) continue;
+            const unsigned long long bj = __shfl(b, j);
+            const int nj = __shfl(n, j);
+            for (int i = lane; i < nj; i += 64) {
+                const int v = lB[FML_L(i) + j];
+                bases[bj + i] = fml_out_base(v);
+                if (quals) quals[bj + i] = fml_out_qual(v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 

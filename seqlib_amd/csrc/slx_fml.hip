@@ -77,6 +77,7 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     f->device = device;
     if (const char *e = getenv("SLX_FML_PART_MIN")) f->part_min_bases = atoll(e);       // test hook: batches of at least this many bases count by partitions
     if (const char *e = getenv("SLX_FML_PART")) f->use_part = atoi(e) != 0;           // experiment / test hook: 0 = fml_count with one atomic per k-mer only
+    if (const char *e = getenv("SLX_FML_EC_LDS")) f->ec_lds = atoi(e) != 0;            // test hook: 0 = the correction walks keep their per-base arrays in memory whatever the read length
     if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&f->ev0);
@@ -152,6 +153,7 @@ int fml_upload(slx_fml *f, const char *bases, const char *quals, const uint64_t 
     }
     const uint64_t base0 = n_reads ? offs[0] : 0, total = n_reads ? offs[n_reads] - base0 : 0;
     f->n_reads = n_reads; f->total = (int64_t)total; f->max_len = max_len; f->has_qual = quals != nullptr;
+    f->planes_ok = false;
     f->h_offs.resize((size_t)n_reads + 1);
     for (int64_t i = 0; i <= n_reads; ++i) f->h_offs[(size_t)i] = n_reads ? offs[i] - base0 : 0;
     int rc;
@@ -228,24 +230,40 @@ static int launch_hist(slx_fml *f)          // bfc_ch_hist of every window's tab
     return fml_probe_end(f, 1);
 }
 
-static int run_count_once(slx_fml *f, int q, bool *too_small)
+// the text of d_bases / d_quals as bit planes (dev_fml.h): the k-mer that ends at any position is two shifts and a mask away
+static int pack_planes(slx_fml *f, int q, FmlPlanes *P)
 {
     const int64_t total = f->total;
     const size_t nblk = (size_t)((total + 63) >> 6), words = nblk + 2;
     int rc;
-    if ((rc = f->d_planes.ensure(words * 8 * 5)) || (rc = f->d_stats.ensure(256))) return rc;
+    if ((rc = f->d_planes.ensure(words * 8 * 5))) return rc;
     unsigned long long *pl = f->d_planes.as<unsigned long long>();
     unsigned long long *p0 = pl, *p1 = pl + words, *pn = pl + 2 * words, *pq = pl + 3 * words, *ps = pl + 4 * words;
-    if ((rc = fml_probe_begin(f))) return rc;
+    *P = FmlPlanes{p0, p1, pn, pq, ps};
+    if (f->planes_ok && f->planes_q == q) return SLX_OK;
     FML_HIPCHK(hipMemsetAsync(pl, 0, words * 8 * 5, f->st));
     FML_HIPCHK(hipMemsetAsync(pn, 0xff, 8, f->st));          // the guard block before the text: all N
-    FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
-    FML_HIPCHK(hipMemsetAsync(f->d_stats.p, 0, 256, f->st));
     if (total > 0) {
         hipLaunchKernelGGL(k_fml_starts, dim3((unsigned)((f->n_reads + 255) / 256)), dim3(256), 0, f->st, f->d_offs.as<unsigned long long>(), (long long)f->n_reads, ps);
         hipLaunchKernelGGL(k_fml_pack, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr,
                            (long long)total, q, p0, p1, pn, pq);
-        FmlPlanes P{p0, p1, pn, pq, ps};
+        FML_HIPCHK(hipGetLastError());
+    }
+    f->planes_ok = true; f->planes_q = q;
+    return SLX_OK;
+}
+
+static int run_count_once(slx_fml *f, int q, bool *too_small)
+{
+    const int64_t total = f->total;
+    int rc;
+    if ((rc = f->d_stats.ensure(256))) return rc;
+    if ((rc = fml_probe_begin(f))) return rc;
+    FmlPlanes P;
+    if ((rc = pack_planes(f, q, &P))) return rc;
+    FML_HIPCHK(hipMemsetAsync(f->d_tab.p, 0, (size_t)std::max<uint64_t>(f->n_slots, 1) * sizeof(FmlSlot), f->st));
+    FML_HIPCHK(hipMemsetAsync(f->d_stats.p, 0, 256, f->st));
+    if (total > 0) {
         // large batches: bin the k-mers into partitions, count each partition in LDS, insert every distinct k-mer once (dev_fml.h: overflowing items spill
         // straight into the table); small batches: one contended atomic per k-mer
         bool by_parts = f->part_ok && f->n_parts > 0 && total >= f->part_min_bases &&
@@ -350,18 +368,34 @@ int fml_run_ec(slx_fml *f)
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, f->device);
     const size_t lane_bytes = fml_scratch_bytes(f->max_len);
+    // short reads (every sequencer's): the walk's per-base arrays in LDS, a wave per block, as many blocks per CU as 160 KB hold (k_fml_ec_lds)
+    const size_t lds_bytes = 320 * (((size_t)f->max_len + 15) & ~(size_t)15);
+    const bool in_lds = f->ec_lds && f->max_len <= FML_EC_LDS_MAX;
     int64_t lanes = (int64_t)dev_cus * 2048;          // eight waves per SIMD at most
+    if (in_lds) lanes = (int64_t)dev_cus * 64 * std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds_bytes + 512)));
     lanes = std::min<int64_t>(lanes, ((f->n_reads + 255) / 256) * 256);
     while (lanes > 256 && (size_t)lanes * lane_bytes > (size_t)24 << 30) lanes /= 2;
     lanes = std::max<int64_t>(256, lanes / 256 * 256);
     int rc;
-    if ((rc = f->d_scratch.ensure((size_t)lanes * lane_bytes)) || (rc = f->d_misc.ensure(256))) return rc;
+    if ((rc = f->d_scratch.ensure((size_t)lanes * lane_bytes)) || (rc = f->d_misc.ensure(256)) || (rc = f->d_occ.ensure((size_t)f->total * 2 + 64))) return rc;
     if ((rc = fml_probe_begin(f))) return rc;
+    // every k-mer of the text asked about once, a lane per position, before the walks (a lane per read) begin
+    FmlPlanes P;
+    if ((rc = pack_planes(f, f->last_q, &P))) return rc;
+    hipLaunchKernelGGL(k_fml_occ, dim3((unsigned)((f->total + 255) / 256)), dim3(256), 0, f->st, P, (long long)f->total, f->d_wins.as<FmlWin>(), f->n_win,
+                       (const FmlSlot *)f->d_tab.as<FmlSlot>(), f->d_occ.as<unsigned short>());
     FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
+    if (in_lds) {
+        FML_HIPCHK(hipFuncSetAttribute((const void *)k_fml_ec_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_fml_ec_lds, dim3((unsigned)(lanes / 64)), dim3(64), lds_bytes, f->st, f->d_tab.as<FmlSlot>(), f->d_wins.as<FmlWin>(), f->n_win, ec_opt(f->last_q),
+                           f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
+                           (const unsigned short *)f->d_occ.as<unsigned short>(), f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
+    } else
     hipLaunchKernelGGL(k_fml_ec, dim3((unsigned)(lanes / 256)), dim3(256), 0, f->st, f->d_tab.as<FmlSlot>(), f->d_wins.as<FmlWin>(), f->n_win, ec_opt(f->last_q),
                        f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
-                       f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
+                       (const unsigned short *)f->d_occ.as<unsigned short>(), f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
     FML_HIPCHK(hipGetLastError());
+    f->planes_ok = false;          // (the text has changed under the planes)
     return fml_probe_end(f, 2);
 }
 

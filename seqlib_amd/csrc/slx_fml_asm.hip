@@ -333,7 +333,7 @@ extern "C" int slx_fml_assemble_staged(slx_fml *f, const slx_fml_opt *opt, const
     if (!f->staged) { slx_set_error("slx_fml_assemble_staged: no staged reads (slx_fml_stage first)"); return SLX_EINVAL; }
     FML_HIPCHK(hipSetDevice(f->device));
     f->reset_probes();
-    f->have_count = false;
+    f->have_count = false; f->planes_ok = false;
     if (f->total) {          // the correction rewrites the working copy: start from the staged reads every time
         FML_HIPCHK(hipMemcpyAsync(f->d_bases.p, f->d_bases0.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
         if (f->has_qual) FML_HIPCHK(hipMemcpyAsync(f->d_quals.p, f->d_quals0.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));

@@ -45,6 +45,8 @@ struct slx_fml {
     int64_t n_reads = 0, total = 0;
     int max_len = 0, n_win = 0, last_q = 20;
     bool has_qual = false;
+    bool planes_ok = false;                // d_planes holds the planes of the text now in d_bases / d_quals at quality threshold planes_q
+    int planes_q = -1;
     uint64_t n_slots = 0;
     std::vector<uint64_t> h_offs;          // rebased to 0
     unsigned char *h_text_pin = nullptr;   // the assembly text on the host (pinned, kept between calls: 1 byte per base of both strands)
@@ -56,9 +58,10 @@ struct slx_fml {
     // BFC::Train's table, kept between calls
     bool have_count = false, staged = false;
     FmlWin count_win;
-    FmlDevBuf d_bases0, d_quals0, d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_stats, d_tri, d_index, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5, d_cursor, d_items;
+    FmlDevBuf d_bases0, d_quals0, d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_stats, d_tri, d_index, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5, d_cursor, d_items, d_occ;
     float probe[SLX_FML_N_PROBES] = {0, 0, 0, 0, 0, 0};
     int64_t n_inserted = 0, n_bases = 0, n_distinct = 0;
+    bool ec_lds = true;                     // error correction of short reads with the per-base arrays in LDS (k_fml_ec_lds); SLX_FML_EC_LDS=0 turns it off
     bool use_part = true;                   // fml_count by partitions (k_fml_bin + k_fml_part) when the batch is large enough; SLX_FML_PART=0 turns it off
     bool part_ok = false;                   // ... and the windows of this batch fit the partition limits
     unsigned int n_parts = 0;
@@ -68,7 +71,7 @@ struct slx_fml {
     unsigned long long tri_per_str = 40;          // of the last assemble call
     std::vector<FmlDevBuf *> all_bufs()
     {
-        return {&d_bases0, &d_quals0, &d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_stats, &d_tri, &d_index, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5, &d_cursor, &d_items};
+        return {&d_bases0, &d_quals0, &d_bases, &d_quals, &d_offs, &d_planes, &d_tab, &d_wins, &d_hist, &d_scratch, &d_misc, &d_stats, &d_tri, &d_index, &d_ns, &d_nl, &d_tmp0, &d_tmp1, &d_tmp2, &d_tmp3, &d_tmp4, &d_tmp5, &d_cursor, &d_items, &d_occ};
     }
     void reset_probes() { for (float &p : probe) p = 0; n_inserted = 0; n_bases = 0; }
 };
