@@ -344,42 +344,46 @@ struct __align__(16) FmlHeap1 {          // echeap1_t, 48 bytes
     uint32_t x0, x1;          // forward planes of the last k - 1 (then k) bases; the reverse strand is derived when a key is needed
 };
 
-// Per-lane work areas of the correction kernel, INTERLEAVED across the 64 lanes of a wave: element j of a lane's array sits at
+// Per-lane work areas of the correction kernels, INTERLEAVED across the 64 lanes of a wave: element j of a lane's array sits at
 // index j * 64 + lane, so that lanes working on the same position of their reads -- the common case, every lane advances one base
 // per step -- touch one contiguous stretch.  The pointers below are already offset by the lane; index with FML_L(j).
+//
+// Everything the walk knows about a base is ONE 32-bit word (a step of the walk is one or two coalesced loads):
+//   bits 0-2 b, 3 q, 4-6 ob                    bfc's ecbase_t
+//   bits 7-8  cls     the table's answer for the k-mer of the read that ENDS here, as far as bfc_ec1dir looks at it: 0 = absent or fewer than min_cov
+//                     occurrences, 1 = min_cov, 2 = more, FML_CLS_ASK = no such k-mer (N, read start) or a base under it has changed since: probe
+//   bit 9 solid, bit 10 high                    bfc_ec_kcov's two flags of that k-mer
+//   bits 11-16 lcov, 17-22 hcov                 solid (and solid high) k-mers over this base
+//   bits 23-25 alt0, bit 29 "alt0 known"        that k-mer with its LAST base replaced (bit (b - own - 1) & 3): in the table with min_cov occurrences or more?
+//   bits 26-28 alt1, bit 30 "alt1 known"        ... with its FIRST base replaced: what the walk towards the read's start asks
+// cls / solid / high / alt* come from k_fml_occ, a lane per POSITION, before the walks (a lane per READ) begin.
 #define FML_L(j) ((size_t)(j) * 64)
-typedef __attribute__((address_space(3))) unsigned char fml_lds_u8;
-typedef __attribute__((address_space(3))) unsigned short fml_lds_u16;
-struct FmlEcScratchLds {          // the same with the per-base arrays in LDS (k_fml_ec_lds): address-space pointers, so that the walk's loads are ds_read and
-    fml_lds_u8 *B;                // never wait behind the stack's stores to memory (one counter, vmcnt, orders both on this chip; a flat load would join it)
-    fml_lds_u16 *cv, *oc;
-    struct FmlHeap1 *heap;
-    uint2 *stack;
-};
+#define FML_CLS_ASK 3u
+#define FML_W_CLS(v) ((v) >> 7 & 3u)
+#define FML_W_SOLID(v) ((v) >> 9 & 1u)
+#define FML_W_HIGH(v) ((v) >> 10 & 1u)
+#define FML_W_LCOV(v) ((int)((v) >> 11 & 63u))
+#define FML_W_HCOV(v) ((int)((v) >> 17 & 63u))
+#define FML_W_FORGET(v) (((v) | FML_CLS_ASK << 7) & ~(3u << 29))
 struct FmlEcScratch {
-    unsigned char *B;          // per base: b | q << 3 | ob << 4
-    unsigned short *cv;        // per base: lcov | hcov << 6 | solid_end << 12 | high_end << 13
-    unsigned short *oc;        // per base: the table's value for the k-mer of B that ENDS here (k_fml_occ), FML_OC_ABSENT, or FML_OC_ASK (no such k-mer / no longer known)
-    FmlHeap1 *heap;            // heap entries 1 .. (entry 0, the top, lives in registers)
+    unsigned int *W;           // per base: see above
+    struct FmlHeap1 *heap;     // heap entries 1 .. (entry 0, the top, lives in registers)
     uint2 *stack;              // x = parent, y = i | b << 16
 };
 
 __host__ __device__ inline size_t fml_scratch_bytes(int max_len)          // per LANE (a wave owns 64 times this, contiguous)
 {
-    size_t b = ((size_t)max_len + 15) & ~(size_t)15;
-    size_t c = (2 * (size_t)max_len + 15) & ~(size_t)15;
+    size_t b = (4 * (size_t)max_len + 15) & ~(size_t)15;
     size_t h = sizeof(FmlHeap1) * FML_HEAP_CAP;
     size_t s = ((size_t)(FML_STACK_CAP(max_len) + 8) * 8 + 15) & ~(size_t)15;
-    return b + 2 * c + h + s;
+    return b + h + s;
 }
 
 __device__ __forceinline__ FmlEcScratch fml_scratch_of(unsigned char *scratch, size_t lane_bytes, int max_len, size_t wave, int lane)
 {
     unsigned char *p = scratch + wave * 64 * lane_bytes;
     FmlEcScratch sc;
-    sc.B = p + lane; p += 64 * (((size_t)max_len + 15) & ~(size_t)15);
-    sc.cv = (unsigned short *)p + lane; p += 64 * ((2 * (size_t)max_len + 15) & ~(size_t)15);
-    sc.oc = (unsigned short *)p + lane; p += 64 * ((2 * (size_t)max_len + 15) & ~(size_t)15);
+    sc.W = (unsigned int *)p + lane; p += 64 * ((4 * (size_t)max_len + 15) & ~(size_t)15);
     sc.heap = (FmlHeap1 *)p + lane; p += 64 * sizeof(FmlHeap1) * FML_HEAP_CAP;
     sc.stack = (uint2 *)p + lane;
     return sc;
@@ -398,12 +402,12 @@ __device__ __forceinline__ int fml_occ(const FmlSlot *tab, const FmlWin &w, uint
     return fml_get(tab, w, fml_key(w.k, x0, x1, mask));
 }
 
-// The table's answer for the k-mer that ends at every text position, one lane per POSITION: bfc_ec_kcov asks for each of them, and
-// bfc_ec1dir asks again for every position its path has not changed (all of them, for a read without errors) -- from a lane that walks
-// its read one dependent probe at a time.  Asked here once, by every lane of the chip at the same time, the walk finds the answers in
-// its own scratch and probes the table only where its k-mer differs from the read's.
-#define FML_OC_ABSENT 0xffffu          // the k-mer is not in the table (bfc_ch_get: -1)
-#define FML_OC_ASK 0xfffeu             // no k-mer of the read ends here (N, read start), or a base under it has changed since: probe
+// The table's answers for the k-mer that ends at every text position, one lane per POSITION: bfc_ec_kcov asks for each of them, and
+// bfc_ec1dir asks again for every position its path has not changed (all of them, for a read without errors), plus -- wherever the base is
+// not "fixed" (low quality, or a k-mer seen too rarely) -- for the three k-mers with another base at the path's end.  A lane that walks its
+// read asks one dependent probe at a time, and a wave's 64 walks take their turns at it; asked here, by every lane of the chip at once, the
+// walks find the answers beside their bases and probe the table only where the path differs from the read.
+// occ[p]: bits 0-1 cls, 2 solid, 3 high, 4-6 alt0, 7-9 alt1, 10 alt0 known, 11 alt1 known (the word's fields, see above).
 static __global__ void __launch_bounds__(256) k_fml_occ(FmlPlanes pl, long long total, const FmlWin *wins, int n_win, const FmlSlot *tab, unsigned short *occ)
 {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -411,18 +415,54 @@ static __global__ void __launch_bounds__(256) k_fml_occ(FmlPlanes pl, long long 
     int lo = 0, hi = n_win;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].pos0 <= p) lo = mid; else hi = mid; }
     const FmlWin w = wins[lo];
-    unsigned long long key; bool hq;
-    unsigned int v = FML_OC_ASK;
-    if (fml_kmer_at(pl, p, w, key, hq)) { const int r = fml_get(tab, w, key); v = r < 0 ? FML_OC_ABSENT : (unsigned int)r; }
+    const int k = w.k;
+    unsigned int v = FML_CLS_ASK;
+    if (k > 0) {
+        const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+        if (fml_extract(pl.pn, p, mask) == 0 && (fml_extract(pl.ps, p, mask) & (mask >> 1)) == 0) {
+            const uint32_t x0 = fml_extract(pl.p0, p, mask), x1 = fml_extract(pl.p1, p, mask), xq = fml_extract(pl.pq, p, mask);
+            const int r = fml_get(tab, w, fml_key(k, x0, x1, mask));
+            const int cnt = r & 0xff;
+            const unsigned int cls = r < 0 || cnt < w.min_cov ? 0u : cnt == w.min_cov ? 1u : 2u;
+            v = cls | (r >= 0 && cnt >= w.min_cov ? 4u : 0u) | (r >= 0 && (r >> 8 & 0x3f) >= w.min_cov + 1 ? 8u : 0u);
+            // the other bases are asked about where bfc_ec1dir would: not at a high-quality base whose k-mer occurs more than min_cov times (lcov may still
+            // make it ask there, a few bases from the ends of a read: the walk probes for itself then)
+            for (int side = 0; side < 2; ++side) {
+                const int at = side ? k - 1 : 0;          // the bit of the base that is replaced: the last base (walk to the end), the first (walk to the start)
+                if ((xq >> at & 1u) && cls == 2u) continue;
+                const int own = (int)((x1 >> at & 1u) << 1 | (x0 >> at & 1u));
+                unsigned int bits = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const int b = (own + 1 + d) & 3;
+                    const uint32_t y0 = (x0 & ~(1u << at)) | (uint32_t)(b & 1) << at, y1 = (x1 & ~(1u << at)) | (uint32_t)(b >> 1) << at;
+                    const int s = fml_get(tab, w, fml_key(k, y0, y1, mask));
+                    if (!(s < 0 || (s & 0xff) < w.min_cov)) bits |= 1u << d;
+                }
+                v |= bits << (4 + 3 * side) | 1u << (10 + side);
+            }
+        }
+    }
     occ[p] = (unsigned short)v;
 }
 
-// a base of B changes at (forward) position fi: the k-mers that end at fi .. fi + k - 1 are no longer the ones k_fml_occ asked about
-template <class SC>
-__device__ __forceinline__ void fml_oc_forget(const SC &sc, int fi, int k, int n)
+// bfc_seq_conv of one base, with what k_fml_occ found for the k-mer that ends there
+__device__ __forceinline__ unsigned int fml_word0(int ch, int qch, bool has_q, int q_min, unsigned int oc)
 {
+    const int c = fml_nt5(ch);
+    int q = !has_q ? 1 : (qch - 33 >= q_min ? 1 : 0);
+    if (c > 3) q = 0;
+    return (unsigned int)(c | q << 3 | c << 4) | (oc & 0xfu) << 7 | (oc >> 4 & 0xffu) << 23;
+}
+__device__ __forceinline__ char fml_out_base(unsigned int v) { const int b = v & 7; return b != (int)(v >> 4 & 7) ? "acgtn"[b] : "ACGTN"[b]; }
+__device__ __forceinline__ char fml_out_qual(unsigned int v) { const int ob = v >> 4 & 7; return (int)(v & 7) != ob ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+'); }
+
+// a base of the read changes at (forward) position fi: the k-mers that end at fi .. fi + k - 1 are no longer the ones k_fml_occ asked about
+template <class SC>
+__device__ __forceinline__ void fml_set_base(const SC &sc, int fi, int nb, int k, int n)
+{
+    sc.W[FML_L(fi)] = (sc.W[FML_L(fi)] & ~7u) | (unsigned int)nb;
     const int to = fi + k < n ? fi + k : n;
-    for (int j = fi; j < to; ++j) sc.oc[FML_L(j)] = (unsigned short)FML_OC_ASK;
+    for (int j = fi; j < to; ++j) sc.W[FML_L(j)] = FML_W_FORGET(sc.W[FML_L(j)]);
 }
 
 // klib's ks_heapdown / ks_heapup on tot_pen (smallest on top), operation for operation -- the order in which equal penalties leave the
@@ -432,27 +472,30 @@ __device__ __forceinline__ void fml_oc_forget(const SC &sc, int fi, int k, int n
 // access through a CHOSEN address, and a `top` that has an address lives in scratch memory -- every pop and push of the one-state heap a round trip)
 typedef unsigned int fml_u4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) fml_u4 fml_g_u4;
-struct FmlHeapMem {
+struct FmlHeapMem {          // heap entries 1 .. in memory, entry e of a lane 64 entries after entry e - 1 (FML_L)
     fml_g_u4 *p;
-    __device__ __forceinline__ FmlHeap1 operator[](size_t at) const
+    __device__ __forceinline__ FmlHeap1 get(int idx) const
     {
-        const fml_u4 a = p[at * 3], b = p[at * 3 + 1], c = p[at * 3 + 2];
+        const size_t at = FML_L(idx) * 3;
+        const fml_u4 a = p[at], b = p[at + 1], c = p[at + 2];
         FmlHeap1 e;
         e.tot_pen = (int)a.x; e.i = (int)a.y; e.k = (int)a.z; e.eh[0] = (int)a.w;
         e.eh[1] = (int)b.x; e.ep[0] = (int)b.y; e.ep[1] = (int)b.z; e.ep[2] = (int)b.w;
         e.ep[3] = (int)c.x; e.ep[4] = (int)c.y; e.x0 = c.z; e.x1 = c.w;
         return e;
     }
-    __device__ __forceinline__ void put(size_t at, const FmlHeap1 &e) const
+    __device__ __forceinline__ void put(int idx, const FmlHeap1 &e) const
     {
-        p[at * 3] = fml_u4{(unsigned int)e.tot_pen, (unsigned int)e.i, (unsigned int)e.k, (unsigned int)e.eh[0]};
-        p[at * 3 + 1] = fml_u4{(unsigned int)e.eh[1], (unsigned int)e.ep[0], (unsigned int)e.ep[1], (unsigned int)e.ep[2]};
-        p[at * 3 + 2] = fml_u4{(unsigned int)e.ep[3], (unsigned int)e.ep[4], e.x0, e.x1};
+        const size_t at = FML_L(idx) * 3;
+        p[at] = fml_u4{(unsigned int)e.tot_pen, (unsigned int)e.i, (unsigned int)e.k, (unsigned int)e.eh[0]};
+        p[at + 1] = fml_u4{(unsigned int)e.eh[1], (unsigned int)e.ep[0], (unsigned int)e.ep[1], (unsigned int)e.ep[2]};
+        p[at + 2] = fml_u4{(unsigned int)e.ep[3], (unsigned int)e.ep[4], e.x0, e.x1};
     }
 };
+template <class HM>
 struct FmlHeap {
     FmlHeap1 top;
-    FmlHeapMem mem;
+    HM mem;
     int n;
     // (no get(i) / set(i) that pick between `top` and memory by index: a choice between the two ADDRESSES puts `top` in scratch memory)
     __device__ __forceinline__ FmlHeap1 pop()          // z = l[0]; l[0] = l[--n]; ks_heapdown(0, n, l)
@@ -460,16 +503,16 @@ struct FmlHeap {
         const FmlHeap1 z = top;
         --n;
         if (n > 0) {
-            const FmlHeap1 tmp = mem[FML_L(n - 1)];
+            const FmlHeap1 tmp = mem.get(n - 1);
             int i = 0, k = 0;
             while ((k = (k << 1) + 1) < n) {          // (k >= 1: the children are in memory)
-                FmlHeap1 ck = mem[FML_L(k - 1)];
-                if (k != n - 1) { const FmlHeap1 c2 = mem[FML_L(k)]; if (ck.tot_pen > c2.tot_pen) { ++k; ck = c2; } }
+                FmlHeap1 ck = mem.get(k - 1);
+                if (k != n - 1) { const FmlHeap1 c2 = mem.get(k); if (ck.tot_pen > c2.tot_pen) { ++k; ck = c2; } }
                 if (ck.tot_pen > tmp.tot_pen) break;
-                if (i == 0) top = ck; else mem.put(FML_L(i - 1), ck);
+                if (i == 0) top = ck; else mem.put(i - 1, ck);
                 i = k;
             }
-            if (i == 0) top = tmp; else mem.put(FML_L(i - 1), tmp);
+            if (i == 0) top = tmp; else mem.put(i - 1, tmp);
         }
         return z;
     }
@@ -480,186 +523,402 @@ struct FmlHeap {
             const int k = (i - 1) >> 1;
             if (k == 0) {
                 if (r.tot_pen > top.tot_pen) break;
-                mem.put(FML_L(i - 1), top); i = 0;
+                mem.put(i - 1, top); i = 0;
             } else {
-                const FmlHeap1 pk = mem[FML_L(k - 1)];
+                const FmlHeap1 pk = mem.get(k - 1);
                 if (r.tot_pen > pk.tot_pen) break;
-                mem.put(FML_L(i - 1), pk); i = k;
+                mem.put(i - 1, pk); i = k;
             }
         }
-        if (i == 0) top = r; else mem.put(FML_L(i - 1), r);
+        if (i == 0) top = r; else mem.put(i - 1, r);
     }
 };
+
+// what a walk works on: its words, its stack, the memory of its heap
+struct FmlEcMem {          // k_fml_ec: everything in memory (FmlEcScratch)
+    typedef FmlHeapMem HM;
+    unsigned int *W;
+    uint2 *stack;
+    HM hm;
+};
+__device__ __forceinline__ FmlEcMem fml_ec_mem(const FmlEcScratch &g)
+{
+    FmlEcMem sc;
+    sc.W = g.W; sc.stack = g.stack; sc.hm.p = (fml_g_u4 *)g.heap;
+    return sc;
+}
 
 struct FmlPen { int ec, ec_high, absent, absent_high, b; };
 __device__ __forceinline__ unsigned int fml_pen_pack(const FmlPen &p) { return (unsigned int)(p.ec | p.ec_high << 1 | p.absent << 2 | p.absent_high << 3 | p.b << 4); }
 __device__ __forceinline__ FmlPen fml_pen_unpack(unsigned int v) { return FmlPen{(int)(v & 1), (int)(v >> 1 & 1), (int)(v >> 2 & 1), (int)(v >> 3 & 1), (int)(v >> 4 & 3)}; }
 
+// bfc_ch_get for up to N keys at once: the first slots' loads (16 bytes: key and count) leave together -- one round trip for all where a lane asking one
+// after the other waits N times -- then each key's probe sequence is finished on its own.  want: bit j = key j is asked; r[j] = bfc_ch_get's value, -1 = absent.
+template <int N>
+__device__ __forceinline__ void fml_get_n(const FmlSlot *tab, const FmlWin &w, const unsigned long long (&key)[N], unsigned int want, int (&r)[N])
+{
+    typedef unsigned long long fml_slot2 __attribute__((ext_vector_type(2)));
+    const fml_slot2 *t = (const fml_slot2 *)(tab + w.tab_off);
+    unsigned int at[N];
+    fml_slot2 s0[N];
+    for (int j = 0; j < N; ++j) { at[j] = (unsigned int)fml_mix64(key[j]) & w.tab_mask; s0[j] = (want >> j & 1u) ? t[at[j]] : fml_slot2{0ULL, 0ULL}; }
+    for (int j = 0; j < N; ++j) {
+        r[j] = -1;
+        if (!(want >> j & 1u)) continue;
+        fml_slot2 sl = s0[j];
+        unsigned int i = at[j];
+        while (sl.x != key[j] + 1 && sl.x != 0) { i = (i + 1) & w.tab_mask; sl = t[i]; }
+        if (sl.x != 0) r[j] = fml_val(sl.y);
+    }
+}
+__device__ __forceinline__ unsigned int fml_cls_of(int r, int min_cov) { return r < 0 || (r & 0xff) < min_cov ? 0u : (r & 0xff) == min_cov ? 1u : 2u; }
+
 // bfc_ec1dir in search coordinates: position i is base i of the read (dir 0) or base n - 1 - i of it, complemented (dir 1); the
-// corrected read is written back in place
+// corrected read is written back in place.
+//
+// The search is a loop of steps (pop the cheapest state, extend it by one base), and a step needs the table only where the path has left the read:
+// behind a substitution, at a base k_fml_occ did not ask the other three bases for.  Such a step costs dependent probes of a table in memory, a step
+// without one a load or two of the lane's own words -- and a wave's 64 walks each meet theirs at different steps: taken as they come, nearly every step of the wave waits for some
+// lane's probe.  So a step comes in two forms.  fml_step<false> LOOKS at the state on top of the heap and, if extending it needs the table, leaves
+// everything as it is and reports "blocked"; the wave runs such steps until every lane is blocked or done, then the blocked lanes take one
+// fml_step<true> TOGETHER (their probes in flight at the same time), and so on: as many waits per wave as the busiest lane has, not as all have together.
+#ifdef FML_EC_PROF          // experiment builds only: where a wave's cycles go (wave-level sums; lane 0 adds)
+__device__ unsigned long long g_fml_prof[16];
+#define FML_PROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fml_prof[i], (unsigned long long)(v)); } while (0)
+#define FML_PROF_NOW() __builtin_readcyclecounter()
+#else
+#define FML_PROF_ADD(i, v) do { } while (0)
+#define FML_PROF_NOW() 0ULL
+#endif
+
 template <class SC>
-__device__ __forceinline__ int fml_ec1dir(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, SC sc, int n, int dir, int start, int end)
+struct FmlWalk {
+    FmlHeap<typename SC::HM> hp;
+    int n, dir, end, n_stack, n_kept, n_failures, path, rv;          // rv: 0 = a path was found (path = its last base-changing step), < 0 = bfc_ec1dir's failures
+    // what fml_lookahead asked the table: the classes (2 bits each) of the k-mers that end at la_pos0 .. la_pos0 + la_len - 1 on the path that had its last two
+    // substitutions at la_s (base la_bs) and la_s1 and follows the read from la_pos0 on
+    int la_pos0, la_len, la_s, la_s1, la_bs;
+    unsigned long long la_cls;
+#ifdef FML_EC_PROF
+    unsigned long long pf_a, pf_b, pf_c, pf_n2;
+#endif
+};
+
+#define FML_LA_MAX 30          // positions per lookahead (2 bits each in la_cls)
+#define FML_LA_CHUNK 10        // probes in flight at a time
+// Behind a substitution the path's next k - 1 k-mers are not the read's: k_fml_occ knows nothing about them, and asking one per step makes k - 1 waits of every
+// correction (and, in the second walk, of every base the first one changed: the read's k-mers there are new).  They are all known the moment the path gets there --
+// the state's k - 1 bases and the read's bases that follow -- so the first step that needs one asks for all of them, FML_LA_CHUNK probes in flight at a time.
+// Exact: a state finds its k-mer here only if its last two substitutions are the record's (positions, and the base at the last one while that lies under
+// the k-mer), the one before them lay outside every k-mer of the run when it was built, and no N of the read lies under any of them (a substituted N is not in ep[]).
+template <class SC>
+__device__ __forceinline__ bool fml_lookahead(const FmlSlot *tab, const FmlWin &w, const SC &sc, FmlWalk<SC> &S, const FmlHeap1 &zt)
+{
+    const int k = w.k, n = S.n, dir = S.dir, pos0 = zt.i, s = zt.ep[0];
+    const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+    if (zt.ep[1] >= 0 && zt.ep[1] > pos0 - k) return false;
+    for (int q = pos0 - k + 1 > 0 ? pos0 - k + 1 : 0; q < pos0; ++q)
+        if ((sc.W[FML_L(dir ? n - 1 - q : q)] >> 4 & 7u) == 4u) return false;
+    int len = s > pos0 - k ? s + k - pos0 : k;
+    if (len > n - pos0) len = n - pos0;
+    if (len > FML_LA_MAX) len = FML_LA_MAX;
+    uint32_t x0 = zt.x0, x1 = zt.x1;
+    unsigned long long classes = 0;
+    int got = 0;
+    bool open = true;
+    for (int c = 0; c < len && open; c += FML_LA_CHUNK) {
+        unsigned long long key[FML_LA_CHUNK];
+        int r[FML_LA_CHUNK];
+        unsigned int want = 0;
+        for (int j = 0; j < FML_LA_CHUNK; ++j) {
+            key[j] = 0;
+            if (!open || c + j >= len) continue;
+            const unsigned int v = sc.W[FML_L(dir ? n - 1 - (pos0 + c + j) : pos0 + c + j)];
+            int b = (int)(v & 7u);
+            if (b > 3 || (v >> 4 & 7u) == 4u) { open = false; continue; }          // (an N of the read, substituted or not: the run ends before it)
+            if (dir) b = 3 - b;
+            fml_append(k, x0, x1, b);
+            key[j] = fml_key(k, x0, x1, mask);
+            want |= 1u << j;
+        }
+        fml_get_n<FML_LA_CHUNK>(tab, w, key, want, r);
+        for (int j = 0; j < FML_LA_CHUNK; ++j)
+            if (want >> j & 1u) { classes |= (unsigned long long)fml_cls_of(r[j], w.min_cov) << (2 * (c + j)); ++got; }
+    }
+    if (got == 0) return false;
+    S.la_pos0 = pos0; S.la_len = got; S.la_s = s; S.la_s1 = zt.ep[1]; S.la_cls = classes;
+    S.la_bs = s > pos0 - k && s >= 0 ? (int)((zt.x1 >> (pos0 - 1 - s) & 1u) << 1 | (zt.x0 >> (pos0 - 1 - s) & 1u)) : -1;
+    return true;
+}
+
+
+// 0 = stepped, 1 = blocked (only fml_step<false>; nothing has changed), 2 = the search is over (S.rv, S.path)
+template <bool SLOW, class SC>
+__device__ __forceinline__ int fml_step(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, const SC &sc, FmlWalk<SC> &S)
+{
+    const int k = w.k, n = S.n, dir = S.dir;
+    if (S.hp.n == 0) { S.rv = -2; return 2; }
+#ifdef FML_EC_PROF
+    const unsigned long long q0 = FML_PROF_NOW();
+#endif
+    const FmlHeap1 zt = S.hp.top;          // (the state pop() will return)
+    bool stop = zt.i - S.end > o.max_end_ext;
+    const bool have = zt.i < n;
+    int cb = 4, cq = 0, cob = 4, lc = 0, hc = 0;
+    unsigned int cls = 0;          // of the path's k-mer with the read's base at i (stays 0 = "absent" where there is none)
+    bool fixed = false, alt_known = false;
+    unsigned int alt_ok = 0;          // bit b: the path's k-mer with base b at i is in the table min_cov times or more
+    if (!stop) {
+        // m: the word that holds k_fml_occ's answers for the READ's k-mer that ends at search position i (dir 1: it ends k - 1 bases further on in the read).
+        // They are the path's while the path is the read there: no substitution within the k-mer's first k - 1 bases (ep[0]; a substituted N is not in
+        // ep[], but no k-mer of the read lies over an N: FML_CLS_ASK, nothing known) and, for the k-mer with the read's own base, that base at its end
+        unsigned int m = FML_CLS_ASK << 7;
+        if (have) {
+            const unsigned int v = sc.W[FML_L(dir ? n - 1 - zt.i : zt.i)];
+            cb = v & 7; cq = v >> 3 & 1; cob = v >> 4 & 7;
+            if (dir) { cb = cb < 4 ? 3 - cb : 4; cob = cob < 4 ? 3 - cob : 4; }
+            lc = FML_W_LCOV(v); hc = FML_W_HCOV(v);
+            m = dir ? (unsigned int)sc.W[FML_L(n - zt.i + k - 2)] : v;
+            if (zt.ep[0] > zt.i - k) m = FML_CLS_ASK << 7;
+        }
+        if (have && cb < 4) {
+            cls = FML_W_CLS(m);
+            if (cls == FML_CLS_ASK) {
+                auto in_record = [&]() -> bool {
+                    if (!((unsigned int)(zt.i - S.la_pos0) < (unsigned int)S.la_len && zt.ep[0] == S.la_s && zt.ep[1] == S.la_s1)) return false;
+                    if (S.la_s <= zt.i - k || S.la_s < 0) return true;
+                    const int sh = zt.i - 1 - S.la_s;
+                    return (int)((zt.x1 >> sh & 1u) << 1 | (zt.x0 >> sh & 1u)) == S.la_bs;
+                };
+                bool hit = in_record();
+                if (!hit) {
+                    if (!SLOW) return 1;
+                    hit = fml_lookahead(tab, w, sc, S, zt);
+                }
+                if (hit) cls = (unsigned int)(S.la_cls >> (2 * (zt.i - S.la_pos0))) & 3u;
+                else {
+                    uint32_t x0 = zt.x0, x1 = zt.x1;
+                    fml_append(k, x0, x1, cb);
+                    cls = fml_cls_of(fml_occ(tab, w, x0, x1), w.min_cov);
+                }
+            }
+            if (cq && cls == 2u && lc >= w.min_cov + 1) fixed = true;
+            else if ((double)hc > k * .75) fixed = true;
+        }
+        // the other bases: all or none of them pass bfc's tests on the path's history
+        bool others = !(fixed && have);
+        if (have && others) {
+            if (cq && zt.eh[FML_EC_HIST_HIGH - 1] >= 0 && zt.i - zt.eh[FML_EC_HIST_HIGH - 1] < o.win_multi_ec) others = false;
+            if (zt.ep[FML_EC_HIST - 1] >= 0 && zt.i - zt.ep[FML_EC_HIST - 1] < o.win_multi_ec) others = false;
+        }
+        if (others) {
+            alt_known = (m >> (29 + dir) & 1u) != 0;
+            if (alt_known) {
+                const unsigned int bits = m >> (23 + 3 * dir) & 7u;
+                for (int b = 0; b < 4; ++b) if (b != cb && (bits >> ((dir ? cb - b - 1 : b - cb - 1) & 3) & 1u)) alt_ok |= 1u << b;
+            } else {
+                if (!SLOW) return 1;
+                const uint32_t mask = (uint32_t)((1ULL << k) - 1);
+                unsigned long long key[4];          // the other bases (all four past the read's end or at an N): their probes together
+                int r4[4];
+                unsigned int want = 0;
+                for (int b = 0; b < 4; ++b) {
+                    key[b] = 0;
+                    if (have && b == cb) continue;
+                    uint32_t x0 = zt.x0, x1 = zt.x1;
+                    fml_append(k, x0, x1, b);
+                    key[b] = fml_key(k, x0, x1, mask);
+                    want |= 1u << b;
+                }
+                fml_get_n<4>(tab, w, key, want, r4);
+                for (int b = 0; b < 4; ++b) if ((want >> b & 1u) && fml_cls_of(r4[b], w.min_cov) != 0u) alt_ok |= 1u << b;
+            }
+        }
+    }
+#ifdef FML_EC_PROF
+    const unsigned long long q1 = FML_PROF_NOW();
+#endif
+    const FmlHeap1 z = S.hp.pop();
+#ifdef FML_EC_PROF
+    const unsigned long long q2 = FML_PROF_NOW();
+#endif
+    if (!stop) {
+        int n_added = 0, other_ext = 0;
+        unsigned int added = 0;          // a byte per candidate: FmlPen packed (no indexed private array: that would live in scratch memory)
+        for (int b = 0; b < 4; ++b) {
+            FmlPen pen;
+            if (!have || b != cb) {
+                if (!(alt_ok >> b & 1u)) continue;          // (fixed, the history tests, a k-mer the table does not hold often enough: alt_ok has no bit)
+                pen.ec = have && cob < 4 ? 1 : 0;
+                pen.ec_high = pen.ec ? cq : 0;
+                pen.absent = pen.absent_high = 0;
+                pen.b = b;
+                added |= fml_pen_pack(pen) << (8 * n_added++);
+                ++other_ext;
+            } else {
+                pen.ec = pen.ec_high = 0;
+                pen.absent = cls == 0u ? 1 : 0;
+                pen.absent_high = pen.absent ? cq : 0;
+                pen.b = b;
+                added |= fml_pen_pack(pen) << (8 * n_added++);
+            }
+        }
+#ifdef FML_EC_PROF
+        if (!SLOW) S.pf_n2 += FML_PROF_NOW() - q2;
+#endif
+        if (!fixed && other_ext == 0) ++S.n_failures;
+        if (S.n_failures > n * 2 || S.n_stack > FML_STACK_CAP(n)) { S.rv = -3; return 2; }
+        if (have || n_added == 1) {
+            int first = 0, last = n_added;
+            if (n_added > 1 && S.hp.n > o.max_heap) {
+                int min_b = -1, mn = 0x7fffffff;
+                for (int b = 0; b < n_added; ++b) {
+                    const FmlPen ab = fml_pen_unpack(added >> (8 * b));
+                    const int t = o.w_ec * ab.ec + o.w_ec_high * ab.ec_high + o.w_absent * ab.absent + o.w_absent_high * ab.absent_high;
+                    if (mn > t) mn = t, min_b = b;
+                }
+                first = min_b; last = min_b + 1;
+            }
+            for (int a = first; a < last; ++a) {          // buf_update
+                const FmlPen pen = fml_pen_unpack(added >> (8 * a));
+                FmlHeap1 r = z;
+                // bfc's stack holds every step of every path, and the winner is read back through its parent links: a chain of dependent reads of memory as
+                // long as the read.  Only the steps that CHANGE a base of the read have anything to say then, so only those are kept (k = the path's last
+                // such step); n_stack still counts every step, for the cap.
+                if (have && pen.b != cb) {
+                    sc.stack[FML_L(S.n_kept)] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
+                    r.k = S.n_kept++;
+                }
+                ++S.n_stack;
+                r.tot_pen = z.tot_pen + o.w_ec * pen.ec + o.w_ec_high * pen.ec_high + o.w_absent * pen.absent + o.w_absent_high * pen.absent_high;
+                r.i = z.i + 1;
+                if (pen.ec_high) { r.eh[1] = z.eh[0]; r.eh[0] = z.i; }
+                if (pen.ec) { r.ep[4] = z.ep[3]; r.ep[3] = z.ep[2]; r.ep[2] = z.ep[1]; r.ep[1] = z.ep[0]; r.ep[0] = z.i; }
+                fml_append(k, r.x0, r.x1, pen.b);
+                S.hp.push(r);
+            }
+        } else stop = true;
+    }
+#ifdef FML_EC_PROF
+    if (!SLOW) { S.pf_a += q1 - q0; S.pf_b += q2 - q1; S.pf_c += FML_PROF_NOW() - q2; }
+#endif
+    if (stop) { S.path = z.k; S.rv = 0; return 2; }
+    return 0;
+}
+
+// the first state of a walk: the k - 1 bases before the k-th good base from `start` on; false = bfc_ec1dir's "no k-mer before `end`"
+template <class SC>
+__device__ __forceinline__ bool fml_walk_begin(const SC &sc, const FmlWin &w, FmlWalk<SC> &S, int n, int dir, int start, int end)
 {
     const int k = w.k;
+    S.n = n; S.dir = dir; S.end = end; S.n_stack = S.n_kept = S.n_failures = 0; S.path = -1; S.rv = -1;
+    S.hp.mem = sc.hm; S.hp.n = 0;
+    S.la_len = 0; S.la_pos0 = 0; S.la_s = S.la_s1 = S.la_bs = -1; S.la_cls = 0;
+#ifdef FML_EC_PROF
+    if (!dir) S.pf_a = S.pf_b = S.pf_c = S.pf_n2 = 0;
+#endif
     FmlHeap1 z;
-    FmlHeap hp;
-    int l, n_stack = 0, n_failures = 0, path = -1;
-    bool found = false;
-    hp.mem.p = (fml_g_u4 *)sc.heap; hp.n = 0;
-    auto base_at = [&](int i, int &b, int &q, int &ob, int &lc, int &hc) {
-        const int fi = dir ? n - 1 - i : i;
-        const int v = sc.B[FML_L(fi)];
-        b = v & 7; q = v >> 3 & 1; ob = v >> 4 & 7;
-        if (dir) { b = b < 4 ? 3 - b : 4; ob = ob < 4 ? 3 - ob : 4; }
-        const int c = sc.cv[FML_L(fi)];
-        lc = c & 63; hc = c >> 6 & 63;
-    };
-    // the table's value for the path's k-mer that ends at search position i with base b there: the read's own answer (sc.oc) while the k-mer is
-    // the read's -- b is the read's base and the path's last substitution lies before the k-mer (sc.oc is FML_OC_ASK wherever an original N lies
-    // under the k-mer: substitutions of an N are the ones ep[] does not record) -- else a probe
-    auto occ_of = [&](const FmlHeap1 &s, bool own, uint32_t x0, uint32_t x1) -> int {
-        if (own && s.ep[0] <= s.i - k) {
-            const unsigned int m = sc.oc[FML_L(dir ? n - s.i + k - 2 : s.i)];
-            if (m != FML_OC_ASK) return m == FML_OC_ABSENT ? -1 : (int)m;
-        }
-        return fml_occ(tab, w, x0, x1);
-    };
+    int l;
     z.tot_pen = 0; z.x0 = z.x1 = 0; z.k = -1;
     for (z.i = start, l = 0; z.i < end; ++z.i) {
-        int b, q, ob, lc, hc;
-        base_at(z.i, b, q, ob, lc, hc);
+        int b = (int)(sc.W[FML_L(dir ? n - 1 - z.i : z.i)] & 7u);
+        if (dir) b = b < 4 ? 3 - b : 4;
         if (b < 4) {
             if (++l == k) break;
             fml_append(k, z.x0, z.x1, b);
         } else l = 0, z.x0 = z.x1 = 0;
     }
-    if (z.i >= end) return -1;
+    if (z.i >= end) return false;
     for (int i = 0; i < FML_EC_HIST; ++i) z.ep[i] = -1;
     for (int i = 0; i < FML_EC_HIST_HIGH; ++i) z.eh[i] = -1;
-    hp.push(z);
-    while (true) {
-        bool stop = false;
-        if (hp.n == 0) return -2;
-        z = hp.pop();
-        if (z.i - end > o.max_end_ext) stop = true;
-        if (!stop) {
-            const bool have = z.i < n;
-            int cb = 4, cq = 0, cob = 4, lc = 0, hc = 0;
-            if (have) base_at(z.i, cb, cq, cob, lc, hc);
-            int os = -1, n_added = 0, other_ext = 0;
-            bool fixed = false;
-            unsigned int added = 0;          // a byte per candidate: FmlPen packed (no indexed private array: that would live in scratch memory)
-            if (have && cb < 4) {
-                uint32_t x0 = z.x0, x1 = z.x1;
-                fml_append(k, x0, x1, cb);
-                os = occ_of(z, true, x0, x1);
-                if (cq && os >= 0 && (os & 0xff) >= w.min_cov + 1 && lc >= w.min_cov + 1) fixed = true;
-                else if ((double)hc > k * .75) fixed = true;
-            }
-            for (int b = 0; b < 4; ++b) {
-                FmlPen pen;
-                if (fixed && have && b != cb) continue;
-                if (!have || b != cb) {
-                    if (have) {
-                        if (cq && z.eh[FML_EC_HIST_HIGH - 1] >= 0 && z.i - z.eh[FML_EC_HIST_HIGH - 1] < o.win_multi_ec) continue;
-                        if (z.ep[FML_EC_HIST - 1] >= 0 && z.i - z.ep[FML_EC_HIST - 1] < o.win_multi_ec) continue;
-                    }
-                    uint32_t x0 = z.x0, x1 = z.x1;
-                    fml_append(k, x0, x1, b);
-                    const int s = fml_occ(tab, w, x0, x1);
-                    if (s < 0 || (s & 0xff) < w.min_cov) continue;
-                    pen.ec = have && cob < 4 ? 1 : 0;
-                    pen.ec_high = pen.ec ? cq : 0;
-                    pen.absent = pen.absent_high = 0;
-                    pen.b = b;
-                    added |= fml_pen_pack(pen) << (8 * n_added++);
-                    ++other_ext;
-                } else {
-                    pen.ec = pen.ec_high = 0;
-                    pen.absent = (os < 0 || (os & 0xff) < w.min_cov) ? 1 : 0;
-                    pen.absent_high = pen.absent ? cq : 0;
-                    pen.b = b;
-                    added |= fml_pen_pack(pen) << (8 * n_added++);
-                }
-            }
-            if (!fixed && other_ext == 0) ++n_failures;
-            if (n_failures > n * 2 || n_stack > FML_STACK_CAP(n)) return -3;
-            if (have || n_added == 1) {
-                int first = 0, last = n_added;
-                if (n_added > 1 && hp.n > o.max_heap) {
-                    int min_b = -1, mn = 0x7fffffff;
-                    for (int b = 0; b < n_added; ++b) {
-                        const FmlPen ab = fml_pen_unpack(added >> (8 * b));
-                        const int t = o.w_ec * ab.ec + o.w_ec_high * ab.ec_high + o.w_absent * ab.absent + o.w_absent_high * ab.absent_high;
-                        if (mn > t) mn = t, min_b = b;
-                    }
-                    first = min_b; last = min_b + 1;
-                }
-                for (int a = first; a < last; ++a) {          // buf_update
-                    const FmlPen pen = fml_pen_unpack(added >> (8 * a));
-                    FmlHeap1 r = z;
-                    sc.stack[FML_L(n_stack)] = make_uint2((unsigned int)z.k, (unsigned int)z.i | (unsigned int)pen.b << 16);
-                    r.tot_pen = z.tot_pen + o.w_ec * pen.ec + o.w_ec_high * pen.ec_high + o.w_absent * pen.absent + o.w_absent_high * pen.absent_high;
-                    r.i = z.i + 1;
-                    r.k = n_stack++;
-                    if (pen.ec_high) { r.eh[1] = z.eh[0]; r.eh[0] = z.i; }
-                    if (pen.ec) { r.ep[4] = z.ep[3]; r.ep[3] = z.ep[2]; r.ep[2] = z.ep[1]; r.ep[1] = z.ep[0]; r.ep[0] = z.i; }
-                    fml_append(k, r.x0, r.x1, pen.b);
-                    hp.push(r);
-                }
-            } else stop = true;
-        }
-        if (stop) { path = z.k; found = true; break; }
-    }
-    if (!found) return -1;
-    for (l = path; l >= 0; l = (int)sc.stack[FML_L(l)].x) {
+    S.hp.push(z);
+    return true;
+}
+
+// the winning path into the read: its base-changing steps, last one first
+template <class SC>
+__device__ __forceinline__ void fml_walk_apply(const SC &sc, const FmlWin &w, const FmlWalk<SC> &S)
+{
+    const int n = S.n, dir = S.dir;
+    for (int l = S.path; l >= 0; l = (int)sc.stack[FML_L(l)].x) {
         const uint2 e = sc.stack[FML_L(l)];
         const int i = (int)(e.y & 0xffff), b = (int)(e.y >> 16);
         if (i < n) {
-            const int fi = dir ? n - 1 - i : i;
-            const int old = sc.B[FML_L(fi)], nb = dir ? 3 - b : b;
-            if ((old & 7) != nb) {
-                sc.B[FML_L(fi)] = (unsigned char)((old & ~7) | nb);
-                if (!dir) fml_oc_forget(sc, fi, k, n);          // (the second direction reads sc.oc; nothing does after it)
+            const int fi = dir ? n - 1 - i : i, nb = dir ? 3 - b : b;
+            const unsigned int old = sc.W[FML_L(fi)];
+            if ((int)(old & 7u) != nb) {
+                if (!dir) fml_set_base(sc, fi, nb, w.k, n);          // (the second direction reads k_fml_occ's answers; nothing does after it)
+                else sc.W[FML_L(fi)] = (old & ~7u) | (unsigned int)nb;
             }
         }
     }
-    return 0;
 }
 
-// bfc_ec1 for one read, in place in the ASCII text
-// bfc_ec1 between bfc_seq_conv and the write-back: the read is in sc.B / sc.oc, n_n of its bases are N; 0 = sc.B holds the corrected read
+// Both bfc_ec1dir calls of a read -- from the island to the read's end, then (on the result) from the island to its start -- as ONE loop of the wave:
+// a lane whose first walk is over goes on with its second while its neighbours are still in their first (the island lies anywhere in a read: the two
+// walks of a read add up to its length, each alone is anything).  0 = both walks done, -13 / -14 = bfc_ec1's failures.
+template <class SC>
+__device__ __forceinline__ int fml_ec_walks(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, const SC &sc, int n, int start, int end)
+{
+    FmlWalk<SC> S;
+    if (!fml_walk_begin(sc, w, S, n, 0, start, n)) return -13;
+    int state = 0, rc = 0;          // 0 running, 1 blocked, 2 this walk is over, 3 all over
+    unsigned long long pf_fast = 0, pf_slow = 0, pf_it = 0, pf_run = 0, pf_rounds = 0, pf_blk = 0;
+    while (true) {
+        const unsigned long long t0 = FML_PROF_NOW();
+        while (true) {
+            if (state == 0) state = fml_step<false>(tab, w, o, sc, S);
+            // go on while it pays: a step of the blocked lanes (their probes) costs four to five steps of the running ones, and about one step in ten blocks --
+            // waiting for more blocked lanes than running ones idles more lanes in the steps than it saves in the rounds (measured: 4 : 1 was the worse rule)
+            const int run = __popcll(__ballot(state == 0)), blk = __popcll(__ballot(state == 1));
+            pf_it += 1; pf_run += run;
+            if (run == 0 || blk >= run) break;
+        }
+        const unsigned long long t1 = FML_PROF_NOW();
+        pf_rounds += 1; pf_blk += __popcll(__ballot(state == 1));
+        if (state == 1) state = fml_step<true>(tab, w, o, sc, S);
+        if (state == 2) {
+            if (S.rv < 0) { rc = S.dir ? -14 : -13; state = 3; }          // (nothing has been written to the text yet: the read stays as it was)
+            else {
+                fml_walk_apply(sc, w, S);
+                if (S.dir) state = 3;
+                else if (fml_walk_begin(sc, w, S, n, 1, n - end, n)) state = 0;
+                else { rc = -14; state = 3; }
+            }
+        }
+        const unsigned long long t2 = FML_PROF_NOW();
+        pf_fast += t1 - t0; pf_slow += t2 - t1;
+        if (!__ballot(state == 0)) break;
+    }
+#ifdef FML_EC_PROF
+    FML_PROF_ADD(12, S.pf_a); FML_PROF_ADD(13, S.pf_b); FML_PROF_ADD(14, S.pf_c); FML_PROF_ADD(15, S.pf_n2);
+#endif
+    FML_PROF_ADD(4, pf_fast); FML_PROF_ADD(5, pf_slow); FML_PROF_ADD(8, pf_it); FML_PROF_ADD(9, pf_run); FML_PROF_ADD(10, pf_rounds); FML_PROF_ADD(11, pf_blk);
+    return rc;
+}
+
+// bfc_ec1 between bfc_seq_conv and the write-back: the read is in sc.W (fml_word0), n_n of its bases are N; 0 = sc.W holds the corrected read
 template <class SC>
 __device__ __forceinline__ int fml_ec_core(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, SC sc, int n, int n_n)
 {
     const int k = w.k;
     if ((double)n_n > n * .05) return -10;
     if (n < k) return -11;
-    {          // bfc_ec_kcov: solid / high ends, then the number of solid (and solid high-quality) k-mers over each base as a sliding count
-        for (int i = 0; i < n; ++i) {          // (the k-mers' counts: k_fml_occ's answers)
-            const int r = sc.oc[FML_L(i)];
-            int f = 0;
-            if (r < (int)FML_OC_ASK) {
-                const int high = (r >> 8 & 0x3f) >= w.min_cov + 1;
-                if ((r & 0xff) >= w.min_cov) f = 1 << 12 | high << 13;
-                else f = high << 13;
-            }
-            sc.cv[FML_L(i)] = (unsigned short)f;
-        }
+    {          // bfc_ec_kcov: the number of solid (and solid high-quality) k-mers over each base as a sliding count of k_fml_occ's two flags
         int lc = 0, hc = 0;          // ends in [j, j + k - 1]
-        for (int i = 0; i < k - 1 && i < n; ++i) { const int f = sc.cv[FML_L(i)]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
+        for (int i = 0; i < k - 1 && i < n; ++i) { const unsigned int f = sc.W[FML_L(i)]; lc += FML_W_SOLID(f); hc += FML_W_SOLID(f) & FML_W_HIGH(f); }
         for (int j = 0; j < n; ++j) {
-            if (j + k - 1 < n) { const int f = sc.cv[FML_L(j + k - 1)]; lc += f >> 12 & 1; hc += (f >> 12 & 1) & (f >> 13 & 1); }
-            const int fj = sc.cv[FML_L(j)];
-            sc.cv[FML_L(j)] = (unsigned short)((fj & 0x3000) | lc | hc << 6);
-            lc -= fj >> 12 & 1; hc -= (fj >> 12 & 1) & (fj >> 13 & 1);
+            if (j + k - 1 < n) { const unsigned int f = sc.W[FML_L(j + k - 1)]; lc += FML_W_SOLID(f); hc += FML_W_SOLID(f) & FML_W_HIGH(f); }
+            const unsigned int fj = sc.W[FML_L(j)];
+            sc.W[FML_L(j)] = (fj & ~(0xfffu << 11)) | (unsigned int)lc << 11 | (unsigned int)hc << 17;
+            lc -= FML_W_SOLID(fj); hc -= FML_W_SOLID(fj) & FML_W_HIGH(fj);
         }
     }
     int start = 0, end = 0;
     {          // bfc_ec_best_island
         int l = 0, mx = 0, mx_i = -1, i;
         for (i = k - 1; i < n; ++i) {
-            if (!(sc.cv[FML_L(i)] >> 12 & 1)) {
+            if (!FML_W_SOLID((unsigned int)sc.W[FML_L(i)])) {
                 if (l > mx) mx = l, mx_i = i;
                 l = 0;
             } else ++l;
@@ -673,7 +932,7 @@ __device__ __forceinline__ int fml_ec_core(const FmlSlot *tab, const FmlWin &w, 
                 int ll = 0;
                 x0 = x1 = 0;
                 for (end = start; end < n; ++end) {
-                    const int c = sc.B[FML_L(end)] & 7;
+                    const int c = (int)(sc.W[FML_L(end)] & 7u);
                     if (c < 4) {
                         fml_append(k, x0, x1, c);
                         if (++ll == k) break;
@@ -700,93 +959,30 @@ __device__ __forceinline__ int fml_ec_core(const FmlSlot *tab, const FmlWin &w, 
                 start = end - (k >> 1);
             }
             if (ec < 0 || end >= n) return -12;
-            const int at = end - (ec >> 2);
-            sc.B[FML_L(at)] = (unsigned char)((sc.B[FML_L(at)] & ~7) | (ec & 3));
-            fml_oc_forget(sc, at, k, n);
+            fml_set_base(sc, end - (ec >> 2), ec & 3, k, n);
             ++end; start = end - k;
         }
     }
-    if (fml_ec1dir(tab, w, o, sc, n, 0, start, n) < 0) return -13;
-    if (fml_ec1dir(tab, w, o, sc, n, 1, n - end, n) < 0) return -14;          // (nothing has been written to the text yet: the read stays as it was)
-    return 0;
+    return fml_ec_walks(tab, w, o, sc, n, start, end);
 }
 
-__device__ __forceinline__ unsigned char fml_conv1(int ch, int qch, bool has_q, int q_min)          // bfc_seq_conv of one base: b | q << 3 | ob << 4
-{
-    const int c = fml_nt5(ch);
-    int q = !has_q ? 1 : (qch - 33 >= q_min ? 1 : 0);
-    if (c > 3) q = 0;
-    return (unsigned char)(c | q << 3 | c << 4);
-}
-__device__ __forceinline__ char fml_out_base(int v) { const int b = v & 7; return b != (v >> 4 & 7) ? "acgtn"[b] : "ACGTN"[b]; }
-__device__ __forceinline__ char fml_out_qual(int v) { const int ob = v >> 4 & 7; return (v & 7) != ob ? (char)(34 + ob) : ((v >> 3 & 1) ? '?' : '+'); }
-
-// bfc_ec1 for one read, in place in the ASCII text
-__device__ __noinline__ int fml_ec_read(const FmlSlot *tab, const FmlWin &w, const FmlEcOpt &o, FmlEcScratch sc, char *seq, char *qual, const unsigned short *occ, int n)
-{
-    int n_n = 0;
-    for (int i = 0; i < n; ++i) {          // bfc_seq_conv
-        const unsigned char v = fml_conv1((unsigned char)seq[i], qual ? (int)(unsigned char)qual[i] : 0, qual != nullptr, o.q);
-        n_n += (v & 7) > 3;
-        sc.B[FML_L(i)] = v;
-        sc.oc[FML_L(i)] = occ[i];
-    }
-    const int rc = fml_ec_core(tab, w, o, sc, n, n_n);
-    if (rc < 0) return rc;
-    for (int i = 0; i < n; ++i) {
-        const int v = sc.B[FML_L(i)];
-        seq[i] = fml_out_base(v);
-        if (qual) qual[i] = fml_out_qual(v);
-    }
-    return 0;
-}
-
-// kmer_correct (flt_uniq = 0): persistent lanes, one read at a time each, reads handed out by an atomic counter
-static __global__ void __launch_bounds__(256) k_fml_ec(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
+// kmer_correct (flt_uniq = 0): persistent waves, 64 consecutive reads at a time each (handed out by an atomic counter), a lane per read: the lanes then
+// walk reads of the same window and (nearly always) the same length in step.  The text of the 64 reads is one stretch of memory and enters (bfc_seq_conv)
+// and leaves as such, lane = byte; what a lane works on in between is its column of the wave's words (FmlEcScratch).
+// (The words were tried in LDS -- a wave per block, four blocks per CU at 150 bp: the walks are bound by instruction issue and by the waits of the blocked
+// steps, and twelve waves per CU on words in memory overlap both better than four on words in LDS: 130 ms against 163 per 6.4 M reads.)
+#ifndef FML_EC_WAVES
+#define FML_EC_WAVES 3          // waves per SIMD the compiler is asked to leave room for (measured per 6.4 M reads: 2 = 189 VGPRs, 116 ms; 3 = 168 VGPRs, 89 ms; 4 = 128 VGPRs and 440 bytes of spills, 119 ms)
+#endif
+static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
                                                 const unsigned long long *offs, long long n_reads, const unsigned short *occ, unsigned char *scratch, size_t lane_bytes,
                                                 int max_len, unsigned long long *next, int *status)
 {
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const FmlEcScratch sc = fml_scratch_of(scratch, lane_bytes, max_len, wave, threadIdx.x & 63);
-    while (true) {
-        // a wave takes 64 consecutive reads: its lanes then walk reads of the same window and (nearly always) the same length in step
-        unsigned long long r0 = 0;
-        if ((threadIdx.x & 63) == 0) r0 = atomicAdd(next, 64ULL);
-        r0 = __shfl(r0, 0);
-        if ((long long)r0 >= n_reads) break;
-        const long long r = (long long)r0 + (threadIdx.x & 63);
-        if (r >= n_reads) continue;
-        const unsigned long long b = offs[r];
-        const int n = (int)(offs[r + 1] - b);
-        int rc = 1;
-        if (n > 0) {
-            int lo = 0, hi = n_win;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
-            const FmlWin w = wins[lo];
-            rc = w.k > 0 ? fml_ec_read(tab, w, o, sc, bases + b, quals ? quals + b : nullptr, occ + b, n) : 1;
-        }
-        if (status) status[r] = rc;
-    }
-}
-
-// The same for short reads (the sequencer's: every read of the batch at most FML_EC_LDS_MAX bases), the walk's per-base arrays in LDS.  k_fml_ec
-// keeps them in memory, and with a megabyte of scratch per wave every pass over a read comes from HBM again: 25 KB of traffic per 150 bp read,
-// a dependent round trip to memory per step of the walk.  Here a block is ONE wave and owns 5 bytes x 64 lanes per base of LDS (B, cv, oc; the
-// stack of the search, written once and read back along one path, and the heap beyond its top entry stay in memory), its 64 consecutive reads
-// enter and leave as whole coalesced rows (lane = base, one read at a time) instead of a byte per lane per step.
-#define FML_EC_LDS_MAX 480          // 5 x 64 x 480 = 150 KB of the CU's 160
-static __global__ void __launch_bounds__(64) k_fml_ec_lds(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
-                                                    const unsigned long long *offs, long long n_reads, const unsigned short *occ, unsigned char *scratch, size_t lane_bytes,
-                                                    int max_len, unsigned long long *next, int *status)
-{
-    extern __shared__ unsigned char fml_lds[];
-    const int lane = threadIdx.x;
-    const size_t row = ((size_t)max_len + 15) & ~(size_t)15;          // bases per lane, as fml_scratch_of rounds
-    const FmlEcScratch gsc = fml_scratch_of(scratch, lane_bytes, max_len, blockIdx.x, lane);          // heap and stack: memory
-    fml_lds_u8 *lB = (fml_lds_u8 *)fml_lds;
-    fml_lds_u16 *lcv = (fml_lds_u16 *)(lB + 64 * row), *loc = (fml_lds_u16 *)(lB + 64 * row * 3);
-    FmlEcScratchLds sc;
-    sc.B = lB + lane; sc.cv = lcv + lane; sc.oc = loc + lane; sc.heap = gsc.heap; sc.stack = gsc.stack;
+    const int lane = threadIdx.x & 63;
+    const FmlEcScratch gsc = fml_scratch_of(scratch, lane_bytes, max_len, wave, lane);
+    const FmlEcMem sc = fml_ec_mem(gsc);
+    unsigned int *wW = gsc.W - lane;          // the wave's words: base i of lane j at wW[FML_L(i) + j]
     while (true) {
         unsigned long long r0 = 0;
         if (lane == 0) r0 = atomicAdd(next, 64ULL);
@@ -794,50 +990,57 @@ static __global__ void __launch_bounds__(64) k_fml_ec_lds(const FmlSlot *tab, co
         if ((long long)r0 >= n_reads) break;
         const long long r = (long long)r0 + lane;
         const bool live = r < n_reads;
-        const unsigned long long b = live ? offs[r] : 0;
-        const int n = live ? (int)(offs[r + 1] - b) : 0;
-        int n_n = 0;
         const int cnt = (int)((n_reads - (long long)r0) < 64 ? (n_reads - (long long)r0) : 64);
-        for (int j = 0; j < cnt; ++j) {          // bfc_seq_conv, read j of the wave's: lane = base
-            const unsigned long long bj = __shfl(b, j);
-            const int nj = __shfl(n, j);
-            int nn = 0;
-            for (int i = lane; i < nj; i += 64) {
-                const unsigned char v = fml_conv1((unsigned char)bases[bj + i], quals ? (int)(unsigned char)quals[bj + i] : 0, quals != nullptr, o.q);
-                nn += (v & 7) > 3;
-                lB[FML_L(i) + j] = v;
-                loc[FML_L(i) + j] = occ[bj + i];
-            }
-            for (int d = 32; d > 0; d >>= 1) nn += __shfl_xor(nn, d);
-            if (lane == j) n_n = nn;
+        const unsigned long long b0 = offs[r0];
+        const int rel = (int)(offs[live ? r : (long long)r0 + cnt] - b0);          // where the lane's read starts in the wave's text
+        const int n = live ? (int)(offs[r + 1] - b0) - rel : 0;
+        const int tot = (int)(offs[(long long)r0 + cnt] - b0);
+        const unsigned long long tp0 = FML_PROF_NOW();
+        // byte t of the wave's text is base t - rel_j of read j, the last read that starts at or before t (six shuffles find it): bfc_seq_conv
+        auto read_of = [&](int t) -> int {
+            int lo = 0;
+            for (int s2 = 32; s2 > 0; s2 >>= 1) { const int mid = lo + s2; if (mid < cnt && __shfl(rel, mid) <= t) lo = mid; }
+            return lo;
+        };
+        for (int t0 = 0; t0 < tot; t0 += 64) {
+            const int t = t0 + lane;
+            const int j = read_of(t < tot ? t : tot - 1);
+            const int rel_j = __shfl(rel, j);
+            if (t < tot) wW[FML_L(t - rel_j) + j] = fml_word0((unsigned char)bases[b0 + t], quals ? (int)(unsigned char)quals[b0 + t] : 0, quals != nullptr, o.q, occ[b0 + t]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rc = 1;
+        const unsigned long long tp1 = FML_PROF_NOW();
         if (n > 0) {
             int lo = 0, hi = n_win;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
             const FmlWin w = wins[lo];
+            int n_n = 0;
+            for (int i = 0; i < n; ++i) n_n += (sc.W[FML_L(i)] & 7u) > 3u;
             rc = w.k > 0 ? fml_ec_core(tab, w, o, sc, n, n_n) : 1;
         }
         if (status && live) status[r] = rc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int j = 0; j < cnt; ++j) {          // the corrected reads back into the text
-            if (__shfl(rc, j) != 0) continue;
-            const unsigned long long bj = __shfl(b, j);
-            const int nj = __shfl(n, j);
-            for (int i = lane; i < nj; i += 64) {
-                const int v = lB[FML_L(i) + j];
-                bases[bj + i] = fml_out_base(v);
-                if (quals) quals[bj + i] = fml_out_qual(v);
+        const unsigned long long tp2 = FML_PROF_NOW();
+        FML_PROF_ADD(0, tp1 - tp0); FML_PROF_ADD(1, tp2 - tp1); FML_PROF_ADD(3, 1);
+        for (int t0 = 0; t0 < tot; t0 += 64) {          // the corrected reads back into the text
+            const int t = t0 + lane;
+            const int j = read_of(t < tot ? t : tot - 1);
+            const int rel_j = __shfl(rel, j), rc_j = __shfl(rc, j);
+            if (t < tot && rc_j == 0) {
+                const unsigned int v = wW[FML_L(t - rel_j) + j];
+                bases[b0 + t] = fml_out_base(v);
+                if (quals) quals[b0 + t] = fml_out_qual(v);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FML_PROF_ADD(2, FML_PROF_NOW() - tp2);
     }
 }
 

@@ -77,7 +77,6 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     f->device = device;
     if (const char *e = getenv("SLX_FML_PART_MIN")) f->part_min_bases = atoll(e);       // test hook: batches of at least this many bases count by partitions
     if (const char *e = getenv("SLX_FML_PART")) f->use_part = atoi(e) != 0;           // experiment / test hook: 0 = fml_count with one atomic per k-mer only
-    if (const char *e = getenv("SLX_FML_EC_LDS")) f->ec_lds = atoi(e) != 0;            // test hook: 0 = the correction walks keep their per-base arrays in memory whatever the read length
     if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&f->ev0);
@@ -369,10 +368,7 @@ int fml_run_ec(slx_fml *f)
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, f->device);
     const size_t lane_bytes = fml_scratch_bytes(f->max_len);
     // short reads (every sequencer's): the walk's per-base arrays in LDS, a wave per block, as many blocks per CU as 160 KB hold (k_fml_ec_lds)
-    const size_t lds_bytes = 320 * (((size_t)f->max_len + 15) & ~(size_t)15);
-    const bool in_lds = f->ec_lds && f->max_len <= FML_EC_LDS_MAX;
     int64_t lanes = (int64_t)dev_cus * 2048;          // eight waves per SIMD at most
-    if (in_lds) lanes = (int64_t)dev_cus * 64 * std::max<int64_t>(1, (int64_t)((160 * 1024) / (lds_bytes + 512)));
     lanes = std::min<int64_t>(lanes, ((f->n_reads + 255) / 256) * 256);
     while (lanes > 256 && (size_t)lanes * lane_bytes > (size_t)24 << 30) lanes /= 2;
     lanes = std::max<int64_t>(256, lanes / 256 * 256);
@@ -385,17 +381,23 @@ int fml_run_ec(slx_fml *f)
     hipLaunchKernelGGL(k_fml_occ, dim3((unsigned)((f->total + 255) / 256)), dim3(256), 0, f->st, P, (long long)f->total, f->d_wins.as<FmlWin>(), f->n_win,
                        (const FmlSlot *)f->d_tab.as<FmlSlot>(), f->d_occ.as<unsigned short>());
     FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
-    if (in_lds) {
-        FML_HIPCHK(hipFuncSetAttribute((const void *)k_fml_ec_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_fml_ec_lds, dim3((unsigned)(lanes / 64)), dim3(64), lds_bytes, f->st, f->d_tab.as<FmlSlot>(), f->d_wins.as<FmlWin>(), f->n_win, ec_opt(f->last_q),
-                           f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
-                           (const unsigned short *)f->d_occ.as<unsigned short>(), f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
-    } else
     hipLaunchKernelGGL(k_fml_ec, dim3((unsigned)(lanes / 256)), dim3(256), 0, f->st, f->d_tab.as<FmlSlot>(), f->d_wins.as<FmlWin>(), f->n_win, ec_opt(f->last_q),
                        f->d_bases.as<char>(), f->has_qual ? f->d_quals.as<char>() : nullptr, f->d_offs.as<unsigned long long>(), (long long)f->n_reads,
                        (const unsigned short *)f->d_occ.as<unsigned short>(), f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
     FML_HIPCHK(hipGetLastError());
     f->planes_ok = false;          // (the text has changed under the planes)
+#ifdef FML_EC_PROF
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(f->st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fml_prof), sizeof(h));
+        fprintf(stderr, "[fml ec prof] tasks %llu; cycles per task: conv %.0f core %.0f write-back %.0f; dir0 fast %.0f slow %.0f, dir1 fast %.0f slow %.0f; per task: fast iterations %.1f (lanes running %.1f), rounds %.1f (lanes blocked %.1f); lane 0's fast steps per task: look %.0f pop %.0f expand+push %.0f cycles, %.1f with a heap of more than two\n",
+                h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[3], (double)h[6] / h[3], (double)h[7] / h[3],
+                (double)h[8] / h[3], (double)h[9] / (double)(h[8] ? h[8] : 1), (double)h[10] / h[3], (double)h[11] / (double)(h[10] ? h[10] : 1), (double)h[12] / h[3], (double)h[13] / h[3], (double)h[14] / h[3], (double)h[15] / h[3]);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fml_prof), z, sizeof(z));
+    }
+#endif
     return fml_probe_end(f, 2);
 }
 

@@ -61,7 +61,6 @@ struct slx_fml {
     FmlDevBuf d_bases0, d_quals0, d_bases, d_quals, d_offs, d_planes, d_tab, d_wins, d_hist, d_scratch, d_misc, d_stats, d_tri, d_index, d_ns, d_nl, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5, d_cursor, d_items, d_occ;
     float probe[SLX_FML_N_PROBES] = {0, 0, 0, 0, 0, 0};
     int64_t n_inserted = 0, n_bases = 0, n_distinct = 0;
-    bool ec_lds = true;                     // error correction of short reads with the per-base arrays in LDS (k_fml_ec_lds); SLX_FML_EC_LDS=0 turns it off
     bool use_part = true;                   // fml_count by partitions (k_fml_bin + k_fml_part) when the batch is large enough; SLX_FML_PART=0 turns it off
     bool part_ok = false;                   // ... and the windows of this batch fit the partition limits
     unsigned int n_parts = 0;
