@@ -1044,8 +1044,29 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
     }
 }
 
-// worker_ec with flt_uniq: max_streak per read and the keep / trim / drop decision
-static __global__ void __launch_bounds__(256) k_fml_streak(const FmlSlot *tab, const FmlWin *wins, int n_win, const char *bases, const unsigned long long *offs,
+// worker_ec with flt_uniq, first half: "a k-mer of a read ends here and the table holds it more than once" for every text position, as one more plane
+// (one wave per 64 positions, the ballot is the word -- k_fml_pack's bit order).  A lane per POSITION asks the table; a lane per read asking its 130
+// k-mers one after the other was 37 ms of mostly waiting per 6.4 M reads.
+static __global__ void __launch_bounds__(256) k_fml_multi(FmlPlanes pl, long long total, const FmlWin *wins, int n_win, const FmlSlot *tab, unsigned long long *pm)
+{
+    const long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blk * 64 >= total) return;
+    const long long p = blk * 64 + 63 - lane;
+    bool ok = false;
+    if (p < total) {
+        int lo = 0, hi = n_win;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].pos0 <= p) lo = mid; else hi = mid; }
+        const FmlWin w = wins[lo];
+        unsigned long long key; bool hq;
+        if (fml_kmer_at(pl, p, w, key, hq)) ok = fml_get(tab, w, key) > 0;
+    }
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) pm[blk + 1] = m;
+}
+
+// ... second half: max_streak per read over that plane, and the keep / trim / drop decision
+static __global__ void __launch_bounds__(256) k_fml_streak(const unsigned long long *pm, const FmlWin *wins, int n_win, const unsigned long long *offs,
                                                     long long n_reads, float min_trim_frac, int *new_start, int *new_len)
 {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1056,21 +1077,14 @@ static __global__ void __launch_bounds__(256) k_fml_streak(const FmlSlot *tab, c
     if (n > 0) {
         int lo = 0, hi = n_win;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
-        const FmlWin w = wins[lo];
-        const int k = w.k;
+        const int k = wins[lo].k;
         if (k > 0) {
-            unsigned long long mx = 0, t = 0;
-            uint32_t x0 = 0, x1 = 0;
-            int l = 0;
+            unsigned long long mx = 0, t = 0, word = 0;
             for (int i = 0; i < n; ++i) {
-                const int c = fml_nt5((unsigned char)bases[b + i]);
-                if (c < 4) {
-                    fml_append(k, x0, x1, c);
-                    if (++l >= k) {
-                        if (fml_occ(tab, w, x0, x1) > 0) t += 1ULL << 32;
-                        else t = (unsigned long long)(i + 1);
-                    } else t = (unsigned long long)(i + 1);
-                } else l = 0, x0 = x1 = 0, t = (unsigned long long)(i + 1);
+                const unsigned long long p = b + (unsigned long long)i;
+                if (i == 0 || (p & 63) == 0) word = pm[(p >> 6) + 1];
+                if (word >> (63 - (int)(p & 63)) & 1ULL) t += 1ULL << 32;          // (a k-mer ends here -- no N, k bases into the read -- and occurs more than once)
+                else t = (unsigned long long)(i + 1);
                 mx = mx > t ? mx : t;
             }
             if (mx >> 32 && (double)((mx >> 32) + k - 1) / n > (double)min_trim_frac) {

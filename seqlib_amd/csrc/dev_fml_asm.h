@@ -259,7 +259,7 @@ static __global__ void __launch_bounds__(256) k_asm_reduce(const unsigned char *
 // The same for the vertices with more than 64 overlaps (reads inside repeats and low-complexity tracts: hundreds to thousands of
 // overlaps each): one BLOCK per vertex, the edge list in LDS.  Rank and "a longer overlap with the same target exists" come out of one
 // all-against-all pass (both are order-free); the witnesses of the reduction are tried longest overlap first.  More than
-// FML_BIG_CAP edges: k_asm_reduce_huge, through memory.
+// FML_BIG_CAP edges: k_asm_huge_*, through memory.
 #define FML_BIG_CAP 4096
 static __global__ void __launch_bounds__(256) k_asm_reduce_big(const unsigned char *text, const FmlStr *strs, const int *big_list, const unsigned int *n_big,
                                                                const unsigned long long *eoff, const unsigned int *cur, const FmlEdge *edges,
@@ -332,22 +332,18 @@ static __global__ void __launch_bounds__(256) k_asm_reduce_big(const unsigned ch
     }
 }
 
-// the same through memory, for a vertex with more overlaps than k_asm_reduce_big's LDS holds
-static __global__ void __launch_bounds__(256) k_asm_reduce_huge(const unsigned char *text, const FmlStr *strs, const int *big_list, const unsigned int *n_big,
-                                                               const unsigned long long *eoff, const unsigned int *cur,
-                                                               const FmlEdge *edges, FmlEdge *sorted, unsigned char *flags, unsigned int *n_irr, unsigned long long *irr_off,
-                                                               FmlEdge *out, unsigned long long *out_n)
+// The same through memory, for a vertex with more overlaps than k_asm_reduce_big's LDS holds (a few dozen per batch, 4 000 - 10 000 overlaps each: reads
+// inside low-complexity tracts).  Rank, "a longer overlap with the same target exists" and the witness search are all-against-all over one vertex's
+// list: a vertex is FML_HUGE_SLICES blocks in each of three launches (a launch per phase: each needs the one before it complete), then one wave
+// writes its irreducible edges out in order.
+#define FML_HUGE_SLICES 16
+static __global__ void __launch_bounds__(256) k_asm_huge_rank(const int *list, const unsigned long long *eoff, const unsigned int *cur, const FmlEdge *edges, FmlEdge *sorted)
 {
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= (long long)*n_big) return;
-    const long long u = big_list[b];
+    const long long u = list[blockIdx.x];
     const int d = (int)cur[u];
-    const unsigned long long base = eoff[u];
-    const FmlEdge *e = edges + base;
-    FmlEdge *s = sorted + base;
-    unsigned char *fl = flags + base;
-    for (int i = lane; i < d; i += 64) {
+    const FmlEdge *e = edges + eoff[u];
+    FmlEdge *s = sorted + eoff[u];
+    for (int i = (int)blockIdx.y * 256 + (int)threadIdx.x; i < d; i += 256 * FML_HUGE_SLICES) {
         const FmlEdge me = e[i];
         int r = 0;
         for (int j = 0; j < d; ++j) {
@@ -356,28 +352,37 @@ static __global__ void __launch_bounds__(256) k_asm_reduce_huge(const unsigned c
         }
         s[r] = me;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int j = lane; j < d; j += 64) {
+}
+static __global__ void __launch_bounds__(256) k_asm_huge_dup(const int *list, const unsigned long long *eoff, const unsigned int *cur, const FmlEdge *sorted, unsigned char *flags)
+{
+    const long long u = list[blockIdx.x];
+    const int d = (int)cur[u];
+    const FmlEdge *s = sorted + eoff[u];
+    unsigned char *fl = flags + eoff[u];
+    for (int j = (int)blockIdx.y * 256 + (int)threadIdx.x; j < d; j += 256 * FML_HUGE_SLICES) {
         const int vj = s[j].v;
         int f = 0;
         for (int k = 0; k < j; ++k)
             if (s[k].v == vj) { f = 1; break; }
         fl[j] = (unsigned char)f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+static __global__ void __launch_bounds__(256) k_asm_huge_witness(const unsigned char *text, const FmlStr *strs, const int *list, const unsigned long long *eoff, const unsigned int *cur,
+                                                                 const FmlEdge *sorted, unsigned char *flags)
+{
+    const long long u = list[blockIdx.x];
+    const int d = (int)cur[u];
+    const FmlEdge *s = sorted + eoff[u];
+    unsigned char *fl = flags + eoff[u];
     const FmlStr su = strs[u];
-    for (int j = lane; j < d; j += 64) {
+    for (int j = (int)blockIdx.y * 256 + (int)threadIdx.x; j < d; j += 256 * FML_HUGE_SLICES) {
         if (fl[j] == 1) continue;
         const FmlEdge ej = s[j];
         const FmlStr sj = strs[ej.v];
         const int aj = su.len - ej.len;
         bool drop = false;
         for (int k = 0; k < j && !drop; ++k) {
-            if (fl[k] == 1) continue;          // (another lane may be turning fl[k] from 0 into 2 right now: either reads as "not a copy")
+            if (fl[k] == 1) continue;          // (another thread may be turning fl[k] from 0 into 2 right now: either reads as "not a copy")
             const FmlEdge ek = s[k];
             if (ek.len == ej.len) continue;
             const FmlStr sk = strs[ek.v];
@@ -387,9 +392,17 @@ static __global__ void __launch_bounds__(256) k_asm_reduce_huge(const unsigned c
         }
         if (drop) fl[j] = 2;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+static __global__ void __launch_bounds__(256) k_asm_huge_emit(const int *list, const unsigned int *n_list, const unsigned long long *eoff, const unsigned int *cur, const FmlEdge *sorted,
+                                                              const unsigned char *flags, unsigned int *n_irr, unsigned long long *irr_off, FmlEdge *out, unsigned long long *out_n)
+{
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= (long long)*n_list) return;
+    const long long u = list[b];
+    const int d = (int)cur[u];
+    const FmlEdge *s = sorted + eoff[u];
+    const unsigned char *fl = flags + eoff[u];
     int keep = 0;
     for (int j = lane; j < d; j += 64) keep += fl[j] == 0;
     for (int o = 32; o > 0; o >>= 1) keep += __shfl_xor(keep, o);

@@ -407,9 +407,16 @@ int fml_run_streak(slx_fml *f)
     int rc;
     if ((rc = f->d_ns.ensure(((size_t)f->n_reads + 1) * 4)) || (rc = f->d_nl.ensure(((size_t)f->n_reads + 1) * 4))) return rc;
     if (f->n_reads == 0) return SLX_OK;
+    const size_t nblk = (size_t)((f->total + 63) >> 6);
+    if ((rc = f->d_occ.ensure((nblk + 2) * 8))) return rc;
     if ((rc = fml_probe_begin(f))) return rc;
-    hipLaunchKernelGGL(k_fml_streak, dim3((unsigned)((f->n_reads + 255) / 256)), dim3(256), 0, f->st, f->d_tab.as<FmlSlot>(), f->d_wins.as<FmlWin>(), f->n_win,
-                       f->d_bases.as<char>(), f->d_offs.as<unsigned long long>(), (long long)f->n_reads, .8f, f->d_ns.as<int>(), f->d_nl.as<int>());
+    FmlPlanes P;
+    if ((rc = pack_planes(f, f->last_q, &P))) return rc;
+    unsigned long long *pm = f->d_occ.as<unsigned long long>();
+    FML_HIPCHK(hipMemsetAsync(pm, 0, 8, f->st));          // (the guard word before the text)
+    hipLaunchKernelGGL(k_fml_multi, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, f->st, P, (long long)f->total, f->d_wins.as<FmlWin>(), f->n_win, (const FmlSlot *)f->d_tab.as<FmlSlot>(), pm);
+    hipLaunchKernelGGL(k_fml_streak, dim3((unsigned)((f->n_reads + 255) / 256)), dim3(256), 0, f->st, (const unsigned long long *)pm, f->d_wins.as<FmlWin>(), f->n_win,
+                       f->d_offs.as<unsigned long long>(), (long long)f->n_reads, .8f, f->d_ns.as<int>(), f->d_nl.as<int>());
     FML_HIPCHK(hipGetLastError());
     return fml_probe_end(f, 3);
 }

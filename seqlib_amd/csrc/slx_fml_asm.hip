@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <thread>
+#include <functional>
 #include <vector>
 #include <unistd.h>
 #include "slx_fml_internal.h"
@@ -38,6 +39,7 @@ int fml_host_cpus()
 
 namespace {
 
+struct FmlWiden { __host__ __device__ unsigned long long operator()(unsigned int v) const { return (unsigned long long)v; } };
 struct AsmWin { int64_t str0 = 0, str1 = 0; slx_magopt mag; int min_match = 0; };
 
 // The strings of the batch: for every read whose kept stretch is at least min_match long, the stretch and its reverse complement.
@@ -52,31 +54,60 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     const auto tm0 = now();
     float tm_strs = 0, tm_gpu = 0, tm_down = 0;
     if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
+    // (two passes over the windows' reads, each over the host's CPUs: how many strings and bases a window contributes, then -- after a prefix sum over the
+    // windows -- the strings themselves; one thread pushing 12.7 M strings back was 64 ms of every 64-window call)
     std::vector<FmlStr> strs;
-    strs.reserve(2 * h_nl.size());
     std::vector<AsmWin> aw((size_t)n_win);
-    unsigned long long text_len = 0;
+    std::vector<unsigned long long> w_bases((size_t)n_win + 1, 0), w_strs((size_t)n_win + 1, 0);
     int kk = FML_SEED_MAX;
     for (int w = 0; w < n_win; ++w) {
         const slx_fml_opt &o = wopt[(size_t)w];
         if (o.min_asm_ovlp < 1) { slx_set_error("fml: min_asm_ovlp = %d", o.min_asm_ovlp); return SLX_EINVAL; }
-        aw[(size_t)w].str0 = (int64_t)strs.size();
         aw[(size_t)w].mag = o.mag_opt;
         aw[(size_t)w].mag.min_merge_len = o.min_merge_len;          // misc.c: fml_mag_clean
         aw[(size_t)w].min_match = o.min_asm_ovlp;
         kk = std::min(kk, o.min_asm_ovlp);
+    }
+    auto over_windows = [&](const std::function<void(int)> &fn) {
+        std::atomic<int> next(0);
+        auto work = [&]() { for (;;) { const int w = next.fetch_add(1); if (w >= n_win) break; fn(w); } };
+        const int n_thr = std::max(1, std::min(n_win, fml_host_cpus()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    };
+    over_windows([&](int w) {
+        const int mo = wopt[(size_t)w].min_asm_ovlp;
+        unsigned long long nb = 0, nsr = 0;
         for (int64_t r = f->wins[(size_t)w].read0; r < f->wins[(size_t)w].read1; ++r) {
             const int l = h_nl[(size_t)r];
-            if (l < o.min_asm_ovlp || l <= 0) continue;
-            for (int s = 0; s < 2; ++s) {
+            if (l < mo || l <= 0) continue;
+            nb += 2ULL * (unsigned long long)l; nsr += 2;
+        }
+        w_bases[(size_t)w + 1] = nb; w_strs[(size_t)w + 1] = nsr;
+    });
+    for (int w = 0; w < n_win; ++w) {
+        w_bases[(size_t)w + 1] += w_bases[(size_t)w]; w_strs[(size_t)w + 1] += w_strs[(size_t)w];
+        aw[(size_t)w].str0 = (int64_t)w_strs[(size_t)w]; aw[(size_t)w].str1 = (int64_t)w_strs[(size_t)w + 1];
+    }
+    const unsigned long long text_len = w_bases[(size_t)n_win];
+    strs.resize((size_t)w_strs[(size_t)n_win]);
+    over_windows([&](int w) {
+        const int mo = wopt[(size_t)w].min_asm_ovlp;
+        unsigned long long at = w_bases[(size_t)w];
+        size_t si = (size_t)w_strs[(size_t)w];
+        for (int64_t r = f->wins[(size_t)w].read0; r < f->wins[(size_t)w].read1; ++r) {
+            const int l = h_nl[(size_t)r];
+            if (l < mo || l <= 0) continue;
+            for (int s2 = 0; s2 < 2; ++s2) {
                 FmlStr t;
-                t.off = text_len; t.src = f->h_offs[(size_t)r] + (unsigned long long)h_ns[(size_t)r]; t.len = l; t.win = w;
-                strs.push_back(t);
-                text_len += (unsigned long long)l;
+                t.off = at; t.src = f->h_offs[(size_t)r] + (unsigned long long)h_ns[(size_t)r]; t.len = l; t.win = w;
+                strs[si++] = t;
+                at += (unsigned long long)l;
             }
         }
-        aw[(size_t)w].str1 = (int64_t)strs.size();
-    }
+    });
     const long long n_str = (long long)strs.size();
     tm_strs = ms_since(tm0);
     // one min_match per batch on the device (the windows of a batch share the caller's options)
@@ -97,18 +128,17 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     std::vector<unsigned char> h_cont((size_t)n_str + 1);
     std::vector<int> h_rep((size_t)n_str + 1);
     std::vector<unsigned int> h_cnt((size_t)n_str + 1), h_nirr((size_t)n_str + 1);
-    std::vector<unsigned long long> h_eoff((size_t)n_str + 2), h_stroff((size_t)n_str + 2), h_irroff((size_t)n_str + 1);
+    std::vector<unsigned long long> h_irroff((size_t)n_str + 1);
     std::vector<FmlEdge> h_out;
     if (n_str > 0) {
         int rc;
         FmlDevBuf &d_strs = f->d_tmp0, &d_text = f->d_tmp1, &d_keys = f->d_tmp2, &d_vals = f->d_tmp3, &d_sort = f->d_tmp4, &d_graph = f->d_tmp5;
-        for (long long t = 0; t <= n_str; ++t) h_stroff[(size_t)t] = t < n_str ? strs[(size_t)t].off : text_len;
         // d_graph: rep | cnt | cur | n_irr | irr_off | str_off | eoff | contained, one allocation
         const size_t ns = (size_t)n_str + 2;
         const size_t g_bytes = ns * (4 + 4 + 4 + 4 + 8 + 8 + 8 + 1) + 256;
         if ((rc = d_strs.ensure(ns * sizeof(FmlStr))) || (rc = d_text.ensure((size_t)text_len + 64)) || (rc = d_keys.ensure(ns * 8 * 2)) ||
             (rc = d_vals.ensure(ns * 4 * 2)) || (rc = d_graph.ensure(g_bytes)) || (rc = f->d_misc.ensure(256))) return rc;
-        unsigned long long *d_irroff = d_graph.as<unsigned long long>(), *d_stroff = d_irroff + ns, *d_eoff = d_stroff + ns;
+        unsigned long long *d_irroff = d_graph.as<unsigned long long>(), *d_eoff = d_irroff + 2 * ns;          // (a spare array between them)
         int *d_rep = (int *)(d_eoff + ns);
         unsigned int *d_cnt = (unsigned int *)(d_rep + ns), *d_cur = d_cnt + ns, *d_nirr = d_cur + ns;
         unsigned char *d_cont = (unsigned char *)(d_nirr + ns);
@@ -116,7 +146,6 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         unsigned int *vals_in = d_vals.as<unsigned int>(), *vals_out = vals_in + ns;
         if ((rc = fml_probe_begin(f))) return rc;
         FML_HIPCHK(hipMemcpyAsync(d_strs.p, strs.data(), (size_t)n_str * sizeof(FmlStr), hipMemcpyHostToDevice, f->st));
-        FML_HIPCHK(hipMemcpyAsync(d_stroff, h_stroff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
         FML_HIPCHK(hipMemsetAsync(d_cnt, 0, ns * 4 * 3, f->st));          // cnt, cur, n_irr
         FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
         hipLaunchKernelGGL(k_asm_strings, dim3((unsigned)((n_str + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), d_strs.as<FmlStr>(), n_str, d_text.as<unsigned char>());
@@ -148,15 +177,23 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                                (const unsigned long long *)d_hkey, (const unsigned int *)d_hval, hmask, d_rep, d_cont, d_cnt, f->d_tri.as<FmlTriple>(), tri_cap, d_trin);
             FML_HIPCHK(hipGetLastError());
             FML_HIPCHK(hipMemcpyAsync(&n_tri, d_trin, 8, hipMemcpyDeviceToHost, f->st));
-            FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
             FML_HIPCHK(hipStreamSynchronize(f->st));
             if (n_tri <= tri_cap) break;
             tri_cap = n_tri + n_tri / 8;          // (the marks of containment and the counts are idempotent: the join simply runs again)
             f->tri_per_str = std::max<unsigned long long>(f->tri_per_str, tri_cap / (unsigned long long)n_str + 1);
         }
+        // where a vertex's overlaps start: the exclusive sum of the counts, on the device (cnt[n_str] = 0: entry n_str of the sum is the number of edges)
         unsigned long long n_edges = 0;
-        for (long long t = 0; t < n_str; ++t) { h_eoff[(size_t)t] = n_edges; n_edges += h_cnt[(size_t)t]; }
-        h_eoff[(size_t)n_str] = n_edges;
+        {
+            size_t sb = 0;
+            hipcub::TransformInputIterator<unsigned long long, FmlWiden, const unsigned int *> cnt64((const unsigned int *)d_cnt, FmlWiden());          // (sums in 64 bits)
+            FML_HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, cnt64, d_eoff, (int)(n_str + 1), f->st));
+            if ((rc = d_sort.ensure(sb + 256))) return rc;
+            FML_HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_sort.p, sb, cnt64, d_eoff, (int)(n_str + 1), f->st));
+            FML_HIPCHK(hipMemcpyAsync(&n_edges, d_eoff + n_str, 8, hipMemcpyDeviceToHost, f->st));
+            FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));          // (for the counters, read at the end)
+            FML_HIPCHK(hipStreamSynchronize(f->st));
+        }
         // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
         FmlDevBuf &d_edges = f->d_scratch;
         // (e_out: every wave of k_asm_reduce may leave most of one FML_OUT_CHUNK unused)
@@ -165,7 +202,6 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         FmlEdge *e_raw = d_edges.as<FmlEdge>(), *e_sorted = e_raw + n_edges + 1, *e_out = e_sorted + n_edges + 1;
         unsigned char *e_flags = (unsigned char *)(e_out + out_cap);
         int *big_list = (int *)(((uintptr_t)(e_flags + n_edges + 1) + 15) & ~(uintptr_t)15), *huge_list = big_list + ns;
-        FML_HIPCHK(hipMemcpyAsync(d_eoff, h_eoff.data(), ((size_t)n_str + 1) * 8, hipMemcpyHostToDevice, f->st));
         if (n_tri)
             hipLaunchKernelGGL(k_asm_scatter, dim3((unsigned)((n_tri + 255) / 256)), dim3(256), 0, f->st, f->d_tri.as<FmlTriple>(), n_tri, (const int *)d_rep, (const unsigned char *)d_cont,
                                (const unsigned long long *)d_eoff, d_cur, e_raw);
@@ -184,8 +220,13 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             FML_HIPCHK(hipMemcpyAsync(&n_huge, d_nhuge, 4, hipMemcpyDeviceToHost, f->st));
             FML_HIPCHK(hipStreamSynchronize(f->st));
             if (n_huge) {
-                hipLaunchKernelGGL(k_asm_reduce_huge, dim3((n_huge + 3) / 4), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), (const int *)huge_list, (const unsigned int *)d_nhuge,
-                                   (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, e_sorted, e_flags, d_nirr, d_irroff, e_out, d_outn);
+                const dim3 hg(n_huge, FML_HUGE_SLICES);
+                hipLaunchKernelGGL(k_asm_huge_rank, hg, dim3(256), 0, f->st, (const int *)huge_list, (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, e_sorted);
+                hipLaunchKernelGGL(k_asm_huge_dup, hg, dim3(256), 0, f->st, (const int *)huge_list, (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_sorted, e_flags);
+                hipLaunchKernelGGL(k_asm_huge_witness, hg, dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), (const int *)huge_list, (const unsigned long long *)d_eoff,
+                                   (const unsigned int *)d_cur, (const FmlEdge *)e_sorted, e_flags);
+                hipLaunchKernelGGL(k_asm_huge_emit, dim3((n_huge + 3) / 4), dim3(256), 0, f->st, (const int *)huge_list, (const unsigned int *)d_nhuge, (const unsigned long long *)d_eoff,
+                                   (const unsigned int *)d_cur, (const FmlEdge *)e_sorted, (const unsigned char *)e_flags, d_nirr, d_irroff, e_out, d_outn);
                 FML_HIPCHK(hipGetLastError());
             }
         }
