@@ -19,6 +19,11 @@ Beside `value` (reads resident in HBM -> hits resident in HBM) the line carries 
 it: `value_host_to_host` (pinned host reads -> host SoA hits through slx_align_batch) and `value_bamrecords`
 (the C++ class: UnalignedSequenceVector -> BamRecordPtrVector, on a bounded sample, tools/bamrec_bench.cpp).
 """
+import os
+# Four objects with streams of their own drive the GPU side by side in the C5 pipeline (two fml contexts, two aligners of three workers each): the HIP runtime maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run one after the other -- two aligners' realignments took exactly
+# twice one's.  Read when the runtime initialises, so it is set before anything imports torch (INTEGRATION.md says the same to a C++ caller).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import ctypes as C
 import json
@@ -310,15 +315,19 @@ def main_c5(args):
     split = {"assemble_s": 0.0, "realign_s": 0.0, "realign_stage_ms": {}}
     split_lock = threading.Lock()
 
+    timeline = []          # (what, object, start, end) of every assembly / realignment call: where a pipelined run's time goes
+
     def assemble(c=None):
         c = c or ctx
         t_a = time.time()
         wins = c.assemble_staged(opt, win_off)
+        t_c = time.time()
         ms, ins, nb = c.probe_ms()
         contigs = [u["seq"] for w in wins for u in w]
         fit = [c for c in contigs if len(c) <= max_len]
         with split_lock:
             split["assemble_s"] += time.time() - t_a
+            timeline.append(("assemble", ctxs.index(c), t_a, t_c, time.time(), {k: round(v) for k, v in ms.items()}))
         return wins, contigs, fit, ms, ins, nb
 
     def realign(fit, a=None):
@@ -327,6 +336,7 @@ def main_c5(args):
         hits = a.alignSequences(fit) if fit else None
         with split_lock:
             split["realign_s"] += time.time() - t_b
+            timeline.append(("realign", aligners.index(a), t_b, time.time(), time.time(), {k: round(v) for k, v in a.stage_ms().items() if v >= 0.5}))
             for k, v in a.stage_ms().items():
                 split["realign_stage_ms"][k] = split["realign_stage_ms"].get(k, 0.0) + v
         return hits
@@ -375,6 +385,7 @@ def main_c5(args):
     acc = {}
     ins_acc = nb_acc = 0
     split.update(assemble_s=0.0, realign_s=0.0, realign_stage_ms={})
+    del timeline[:]
     fence()
     t0 = time.time()
     marks = [t0]
@@ -391,6 +402,12 @@ def main_c5(args):
         ins_acc += ins; nb_acc += nb
     fence()
     dt = time.time() - t0
+    if os.environ.get("SLX_BENCH_PAIR_PROBE") and len(aligners) > 1:          # experiment: two realignments side by side after the run, nothing else on the GPU
+        for rep in range(3):
+            th = [threading.Thread(target=realign, args=(done[-1][2], a2)) for a2 in aligners[:2]]
+            tq = time.time()
+            [x.start() for x in th]; [x.join() for x in th]
+            print("[pair probe] %.0f ms, %s" % ((time.time() - tq) * 1e3, timeline[-1][5] if timeline else None), file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -529,6 +546,8 @@ def main_c5(args):
             "probe_ms_per_step": {k: v / steps for k, v in acc.items()},
             "counters": counters,
             "step_ms": [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])], "read_generation_s": t_gen,
+            "timeline_ms": [[w, i, round((a - t0) * 1e3), round((b - t0) * 1e3), round((c - t0) * 1e3), st] for w, i, a, b, c, st in sorted(timeline, key=lambda x: x[2])],
+            "timeline_is": "[call, object, start, end of the C-ABI call, end with the host-side list handling, the call's own stage timers] in ms from the start of the timed region",
         }
         print(json.dumps(out))
         sys.stdout.flush()

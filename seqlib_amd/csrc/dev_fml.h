@@ -402,6 +402,27 @@ __device__ __forceinline__ int fml_occ(const FmlSlot *tab, const FmlWin &w, uint
     return fml_get(tab, w, fml_key(w.k, x0, x1, mask));
 }
 
+// bfc_ch_get for up to N keys at once: the first slots' loads (16 bytes: key and count) leave together -- one round trip for all where a lane asking one
+// after the other waits N times -- then each key's probe sequence is finished on its own.  want: bit j = key j is asked; r[j] = bfc_ch_get's value, -1 = absent.
+template <int N>
+__device__ __forceinline__ void fml_get_n(const FmlSlot *tab, const FmlWin &w, const unsigned long long (&key)[N], unsigned int want, int (&r)[N])
+{
+    typedef unsigned long long fml_slot2 __attribute__((ext_vector_type(2)));
+    const fml_slot2 *t = (const fml_slot2 *)(tab + w.tab_off);
+    unsigned int at[N];
+    fml_slot2 s0[N];
+    for (int j = 0; j < N; ++j) { at[j] = (unsigned int)fml_mix64(key[j]) & w.tab_mask; s0[j] = (want >> j & 1u) ? t[at[j]] : fml_slot2{0ULL, 0ULL}; }
+    for (int j = 0; j < N; ++j) {
+        r[j] = -1;
+        if (!(want >> j & 1u)) continue;
+        fml_slot2 sl = s0[j];
+        unsigned int i = at[j];
+        while (sl.x != key[j] + 1 && sl.x != 0) { i = (i + 1) & w.tab_mask; sl = t[i]; }
+        if (sl.x != 0) r[j] = fml_val(sl.y);
+    }
+}
+__device__ __forceinline__ unsigned int fml_cls_of(int r, int min_cov) { return r < 0 || (r & 0xff) < min_cov ? 0u : (r & 0xff) == min_cov ? 1u : 2u; }
+
 // The table's answers for the k-mer that ends at every text position, one lane per POSITION: bfc_ec_kcov asks for each of them, and
 // bfc_ec1dir asks again for every position its path has not changed (all of them, for a read without errors), plus -- wherever the base is
 // not "fixed" (low quality, or a k-mer seen too rarely) -- for the three k-mers with another base at the path's end.  A lane that walks its
@@ -432,12 +453,15 @@ static __global__ void __launch_bounds__(256) k_fml_occ(FmlPlanes pl, long long 
                 if ((xq >> at & 1u) && cls == 2u) continue;
                 const int own = (int)((x1 >> at & 1u) << 1 | (x0 >> at & 1u));
                 unsigned int bits = 0;
+                unsigned long long key3[3];
+                int r3[3];
                 for (int d = 0; d < 3; ++d) {
                     const int b = (own + 1 + d) & 3;
                     const uint32_t y0 = (x0 & ~(1u << at)) | (uint32_t)(b & 1) << at, y1 = (x1 & ~(1u << at)) | (uint32_t)(b >> 1) << at;
-                    const int s = fml_get(tab, w, fml_key(k, y0, y1, mask));
-                    if (!(s < 0 || (s & 0xff) < w.min_cov)) bits |= 1u << d;
+                    key3[d] = fml_key(k, y0, y1, mask);
                 }
+                fml_get_n<3>(tab, w, key3, 7u, r3);          // (the three probes in flight together)
+                for (int d = 0; d < 3; ++d) if (fml_cls_of(r3[d], w.min_cov) != 0u) bits |= 1u << d;
                 v |= bits << (4 + 3 * side) | 1u << (10 + side);
             }
         }
@@ -551,27 +575,6 @@ __device__ __forceinline__ FmlEcMem fml_ec_mem(const FmlEcScratch &g)
 struct FmlPen { int ec, ec_high, absent, absent_high, b; };
 __device__ __forceinline__ unsigned int fml_pen_pack(const FmlPen &p) { return (unsigned int)(p.ec | p.ec_high << 1 | p.absent << 2 | p.absent_high << 3 | p.b << 4); }
 __device__ __forceinline__ FmlPen fml_pen_unpack(unsigned int v) { return FmlPen{(int)(v & 1), (int)(v >> 1 & 1), (int)(v >> 2 & 1), (int)(v >> 3 & 1), (int)(v >> 4 & 3)}; }
-
-// bfc_ch_get for up to N keys at once: the first slots' loads (16 bytes: key and count) leave together -- one round trip for all where a lane asking one
-// after the other waits N times -- then each key's probe sequence is finished on its own.  want: bit j = key j is asked; r[j] = bfc_ch_get's value, -1 = absent.
-template <int N>
-__device__ __forceinline__ void fml_get_n(const FmlSlot *tab, const FmlWin &w, const unsigned long long (&key)[N], unsigned int want, int (&r)[N])
-{
-    typedef unsigned long long fml_slot2 __attribute__((ext_vector_type(2)));
-    const fml_slot2 *t = (const fml_slot2 *)(tab + w.tab_off);
-    unsigned int at[N];
-    fml_slot2 s0[N];
-    for (int j = 0; j < N; ++j) { at[j] = (unsigned int)fml_mix64(key[j]) & w.tab_mask; s0[j] = (want >> j & 1u) ? t[at[j]] : fml_slot2{0ULL, 0ULL}; }
-    for (int j = 0; j < N; ++j) {
-        r[j] = -1;
-        if (!(want >> j & 1u)) continue;
-        fml_slot2 sl = s0[j];
-        unsigned int i = at[j];
-        while (sl.x != key[j] + 1 && sl.x != 0) { i = (i + 1) & w.tab_mask; sl = t[i]; }
-        if (sl.x != 0) r[j] = fml_val(sl.y);
-    }
-}
-__device__ __forceinline__ unsigned int fml_cls_of(int r, int min_cov) { return r < 0 || (r & 0xff) < min_cov ? 0u : (r & 0xff) == min_cov ? 1u : 2u; }
 
 // bfc_ec1dir in search coordinates: position i is base i of the read (dir 0) or base n - 1 - i of it, complemented (dir 1); the
 // corrected read is written back in place.

@@ -298,6 +298,12 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     return SLX_OK;
 }
 
+// Several aligners (and fml contexts) side by side in one process -- the C5 pipeline drives four objects from four host threads -- have a dozen streams
+// between them; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless told otherwise, and two aligners whose streams share queues run
+// one after the other (measured: two realignments side by side took exactly twice one's time; 1.2 x with 8 queues).  The runtime reads the variable when it
+// initialises: set here at load time unless the caller has set it; a process that has already made HIP calls keeps what it started with.
+__attribute__((constructor)) static void slx_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static std::mutex g_live_mu;
 static int g_live_aligners = 0;                 // single-device aligners alive: the pinned-block pool is released with the last one
 static void pin_pool_release_all();

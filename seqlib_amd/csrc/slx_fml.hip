@@ -79,6 +79,8 @@ extern "C" int slx_fml_create(int device, slx_fml **out)
     if (const char *e = getenv("SLX_FML_PART")) f->use_part = atoi(e) != 0;           // experiment / test hook: 0 = fml_count with one atomic per k-mer only
     if (const char *e = getenv("SLX_FML_TAB_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 1024) f->tab_div = v; }     // experiment hook: first table size = 2 x bases / v
     hipError_t e = hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->st_copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_copy, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&f->ev0);
     if (e == hipSuccess) e = hipEventCreate(&f->ev1);
     if (e != hipSuccess) { delete f; slx_set_error("HIP error %s creating the fml context", hipGetErrorString(e)); return SLX_ENODEVICE; }
@@ -92,8 +94,11 @@ extern "C" void slx_fml_free(slx_fml *f)
     (void)hipSetDevice(f->device);
     for (FmlDevBuf *b : f->all_bufs()) b->release();
     if (f->h_text_pin) (void)hipHostFree(f->h_text_pin);
+    f->h_asm.release(); f->h_asm2.release();
     if (f->ev0) (void)hipEventDestroy(f->ev0);
     if (f->ev1) (void)hipEventDestroy(f->ev1);
+    if (f->st_copy) (void)hipStreamDestroy(f->st_copy);
+    if (f->ev_copy) (void)hipEventDestroy(f->ev_copy);
     if (f->st) (void)hipStreamDestroy(f->st);
     delete f;
 }

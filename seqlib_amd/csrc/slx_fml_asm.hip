@@ -54,9 +54,9 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     const auto tm0 = now();
     float tm_strs = 0, tm_gpu = 0, tm_down = 0;
     if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
+    if (f->st_copy) (void)hipStreamSynchronize(f->st_copy);          // (a call that failed half way may have left its text copy in flight)
     // (two passes over the windows' reads, each over the host's CPUs: how many strings and bases a window contributes, then -- after a prefix sum over the
     // windows -- the strings themselves; one thread pushing 12.7 M strings back was 64 ms of every 64-window call)
-    std::vector<FmlStr> strs;
     std::vector<AsmWin> aw((size_t)n_win);
     std::vector<unsigned long long> w_bases((size_t)n_win + 1, 0), w_strs((size_t)n_win + 1, 0);
     int kk = FML_SEED_MAX;
@@ -92,7 +92,15 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         aw[(size_t)w].str0 = (int64_t)w_strs[(size_t)w]; aw[(size_t)w].str1 = (int64_t)w_strs[(size_t)w + 1];
     }
     const unsigned long long text_len = w_bases[(size_t)n_win];
-    strs.resize((size_t)w_strs[(size_t)n_win]);
+    const long long n_str = (long long)w_strs[(size_t)n_win];
+    // one pinned stretch: strings | irr_off | rep | cnt | n_irr | contained
+    const size_t ns_h = (size_t)n_str + 2;
+    if (f->h_asm.ensure(ns_h * (sizeof(FmlStr) + 8 + 4 + 4 + 4 + 1) + 256)) { slx_set_error("fml: out of pinned host memory (%lld strings)", n_str); return SLX_ENOMEM; }
+    FmlStr *const strs = (FmlStr *)f->h_asm.p;
+    unsigned long long *const h_irroff = (unsigned long long *)(strs + ns_h);
+    int *const h_rep = (int *)(h_irroff + ns_h);
+    unsigned int *const h_cnt = (unsigned int *)(h_rep + ns_h), *const h_nirr = h_cnt + ns_h;
+    unsigned char *const h_cont = (unsigned char *)(h_nirr + ns_h);
     over_windows([&](int w) {
         const int mo = wopt[(size_t)w].min_asm_ovlp;
         unsigned long long at = w_bases[(size_t)w];
@@ -108,7 +116,6 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             }
         }
     });
-    const long long n_str = (long long)strs.size();
     tm_strs = ms_since(tm0);
     // one min_match per batch on the device (the windows of a batch share the caller's options)
     const int min_match = n_win ? aw[0].min_match : 1;
@@ -125,11 +132,8 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         f->h_text_cap = want;
     }
     unsigned char *const h_text = f->h_text_pin;
-    std::vector<unsigned char> h_cont((size_t)n_str + 1);
-    std::vector<int> h_rep((size_t)n_str + 1);
-    std::vector<unsigned int> h_cnt((size_t)n_str + 1), h_nirr((size_t)n_str + 1);
-    std::vector<unsigned long long> h_irroff((size_t)n_str + 1);
-    std::vector<FmlEdge> h_out;
+    const FmlEdge *h_out = nullptr;
+    unsigned long long n_out = 0;
     if (n_str > 0) {
         int rc;
         FmlDevBuf &d_strs = f->d_tmp0, &d_text = f->d_tmp1, &d_keys = f->d_tmp2, &d_vals = f->d_tmp3, &d_sort = f->d_tmp4, &d_graph = f->d_tmp5;
@@ -145,10 +149,15 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         unsigned long long *keys_in = d_keys.as<unsigned long long>(), *keys_out = keys_in + ns;
         unsigned int *vals_in = d_vals.as<unsigned int>(), *vals_out = vals_in + ns;
         if ((rc = fml_probe_begin(f))) return rc;
-        FML_HIPCHK(hipMemcpyAsync(d_strs.p, strs.data(), (size_t)n_str * sizeof(FmlStr), hipMemcpyHostToDevice, f->st));
+        FML_HIPCHK(hipMemcpyAsync(d_strs.p, strs, (size_t)n_str * sizeof(FmlStr), hipMemcpyHostToDevice, f->st));
         FML_HIPCHK(hipMemsetAsync(d_cnt, 0, ns * 4 * 3, f->st));          // cnt, cur, n_irr
         FML_HIPCHK(hipMemsetAsync(f->d_misc.p, 0, 256, f->st));
         hipLaunchKernelGGL(k_asm_strings, dim3((unsigned)((n_str + 3) / 4)), dim3(256), 0, f->st, f->d_bases.as<char>(), d_strs.as<FmlStr>(), n_str, d_text.as<unsigned char>());
+        // the text is final here and the graph stage on the host wants all of it (1.9 GB for 64 windows): it leaves on a stream of its own, under the sort, the join
+        // and the reduction, instead of after them
+        FML_HIPCHK(hipEventRecord(f->ev_copy, f->st));
+        FML_HIPCHK(hipStreamWaitEvent(f->st_copy, f->ev_copy, 0));
+        FML_HIPCHK(hipMemcpyAsync(h_text, d_text.p, (size_t)text_len, hipMemcpyDeviceToHost, f->st_copy));
         hipLaunchKernelGGL(k_asm_keys, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), n_str, kk, keys_in, vals_in, d_rep, d_cont);
         FML_HIPCHK(hipGetLastError());
         size_t tmp_bytes = 0;
@@ -191,7 +200,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             if ((rc = d_sort.ensure(sb + 256))) return rc;
             FML_HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_sort.p, sb, cnt64, d_eoff, (int)(n_str + 1), f->st));
             FML_HIPCHK(hipMemcpyAsync(&n_edges, d_eoff + n_str, 8, hipMemcpyDeviceToHost, f->st));
-            FML_HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));          // (for the counters, read at the end)
+            FML_HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));          // (for the counters, read at the end)
             FML_HIPCHK(hipStreamSynchronize(f->st));
         }
         // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
@@ -230,25 +239,36 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                 FML_HIPCHK(hipGetLastError());
             }
         }
-        unsigned long long n_out = 0;
         if (times) { (void)hipStreamSynchronize(f->st); tm_gpu = ms_since(tm0); }
         FML_HIPCHK(hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_rep.data(), d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_cont.data(), d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_nirr.data(), d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_irroff.data(), d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipMemcpyAsync(h_text, d_text.p, (size_t)text_len, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_rep, d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_cont, d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_nirr, d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
+        FML_HIPCHK(hipMemcpyAsync(h_irroff, d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
-        h_out.resize((size_t)n_out + 1);
-        if (n_out) FML_HIPCHK(hipMemcpy(h_out.data(), e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
-        { unsigned long long fo = 0, fi = 0; for (long long t = 0; t < n_str; ++t) { fo += h_cnt[(size_t)t]; fi += h_nirr[(size_t)t]; }          // (n_tri and n_out count reserved slots, some unused)
-          f->n_overlaps = (int64_t)fo; f->n_irreducible = (int64_t)fi; }
+        FML_HIPCHK(hipStreamSynchronize(f->st_copy));
+        // the edges, then (filled per window below) their targets and lengths as the graph stage wants them: edges | edge_v | edge_len
+        if (f->h_asm2.ensure(((size_t)n_out + 1) * (sizeof(FmlEdge) + 8) + 256)) { slx_set_error("fml: out of pinned host memory (%llu edges)", n_out); return SLX_ENOMEM; }
+        h_out = (const FmlEdge *)f->h_asm2.p;
+        if (n_out) FML_HIPCHK(hipMemcpy(f->h_asm2.p, e_out, (size_t)n_out * sizeof(FmlEdge), hipMemcpyDeviceToHost));
+        {   // (n_tri and n_out count reserved slots, some unused: the counters are the sums of the per-string counts)
+            std::vector<unsigned long long> po((size_t)n_win, 0), pi((size_t)n_win, 0);
+            over_windows([&](int w) {
+                unsigned long long fo = 0, fi = 0;
+                for (int64_t t = aw[(size_t)w].str0; t < aw[(size_t)w].str1; ++t) { fo += h_cnt[(size_t)t]; fi += h_nirr[(size_t)t]; }
+                po[(size_t)w] = fo; pi[(size_t)w] = fi;
+            });
+            unsigned long long fo = 0, fi = 0;
+            for (int w = 0; w < n_win; ++w) { fo += po[(size_t)w]; fi += pi[(size_t)w]; }
+            f->n_overlaps = (int64_t)fo; f->n_irreducible = (int64_t)fi;
+        }
         f->n_strings = (int64_t)n_str; f->asm_text_len = (int64_t)text_len; f->n_big_vertices = (int64_t)n_big; f->n_huge_vertices = (int64_t)n_huge;
     }
     tm_down = ms_since(tm0);
     // ---- per window on the host: chains, cleaning, records -- the windows are independent, so they go over the host's CPUs
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> ev(h_out.size()), el(h_out.size());
+    if (!h_out) { if (f->h_asm2.ensure(256)) { slx_set_error("fml: out of pinned host memory"); return SLX_ENOMEM; } h_out = (const FmlEdge *)f->h_asm2.p; }
+    int *const ev = (int *)((FmlEdge *)f->h_asm2.p + n_out + 1), *const el = ev + n_out + 1;
     std::atomic<int> next_win(0);
     auto work = [&]() {
         for (;;) {
@@ -266,8 +286,8 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                 for (unsigned int j = 0; j < h_nirr[(size_t)(a.str0 + t)]; ++j) { ev[(size_t)(o + j)] = h_out[(size_t)(o + j)].v - (int)a.str0; el[(size_t)(o + j)] = h_out[(size_t)(o + j)].len; }
             }
             fmlg::Overlaps O;
-            O.n_str = n; O.len = len.data(); O.text = txt.data(); O.rep = rep.data(); O.contained = h_cont.data() + a.str0;
-            O.n_irr = h_nirr.data() + a.str0; O.irr_off = h_irroff.data() + a.str0; O.edge_v = ev.data(); O.edge_len = el.data(); O.min_match = a.min_match;
+            O.n_str = n; O.len = len.data(); O.text = txt.data(); O.rep = rep.data(); O.contained = h_cont + a.str0;
+            O.n_irr = h_nirr + a.str0; O.irr_off = h_irroff + a.str0; O.edge_v = ev; O.edge_len = el; O.min_match = a.min_match;
             fmlg::Graph g;
             g.build(O);
             g.clean_graph(a.mag);

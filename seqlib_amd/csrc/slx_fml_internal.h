@@ -36,9 +36,27 @@ struct FmlDevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// host memory the context keeps between calls, pinned: what an assembly call hands to and takes from the device (a fresh std::vector per call is zero-filled
+// and pageable -- half a gigabyte of both for 64 windows -- and every copy into it goes through a staging buffer)
+struct FmlPinned {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct slx_fml {
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st_copy = nullptr;          // st_copy: the assembly text on its way to the host while the overlap kernels run
+    hipEvent_t ev_copy = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::mutex mu;
     // the batch resident in HBM
@@ -51,6 +69,7 @@ struct slx_fml {
     std::vector<uint64_t> h_offs;          // rebased to 0
     unsigned char *h_text_pin = nullptr;   // the assembly text on the host (pinned, kept between calls: 1 byte per base of both strands)
     size_t h_text_cap = 0;
+    FmlPinned h_asm, h_asm2;                 // the string list and the per-string results of an assembly call; its edges
     std::vector<FmlWin> wins;
     std::vector<slx_fml_opt> wopt;         // per window: the caller's options after fml_opt_adjust on the window's reads
     std::vector<float> kcov;
