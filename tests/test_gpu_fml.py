@@ -153,6 +153,26 @@ def test_correct_windows_match_oracle(F, G, ctx, genome, flt):
             assert n_changed > 1000          # the test must exercise the search, not only the no-op path
 
 
+def test_correct_hard_windows_match_oracle(F, G, ctx, genome):
+    """the walks where the read's own answers run out: errors within k of each other, N under most k-mers, reads that end inside the first k-mer, reads of
+    three times the usual length (lookahead runs of the maximum length, a heap that grows), empty reads between them"""
+    wins = [U.sim_window(genome["bcr"][20000:32000], 4000, err=0.04, seed=31, n_frac=0.01),
+            U.sim_window(genome["abl"][2000:14000], 900, length=450, err=0.02, seed=32, ragged=True),
+            U.sim_window(genome["tp53"][3000:9000], 2000, length=60, err=0.03, seed=33, n_frac=0.005, ragged=True)]
+    for w, (seqs, quals, _) in enumerate(wins):
+        seqs, quals = list(seqs), list(quals)
+        for at in (0, 17, len(seqs) // 2, len(seqs) - 1):          # an empty read and a 5-base read here and there
+            seqs[at] = b"" if at % 2 else seqs[at][:5]
+            quals[at] = quals[at][:len(seqs[at])]
+        b, q, o = G.flatten(seqs, quals)
+        kcov, eck, ns, nl = ctx.correct(G.default_opt(), b, q, o, [0, len(seqs)], flt_uniq=0)
+        ek, ekcov, es, eq = _oracle_window(F, seqs, quals, 0)
+        assert eck[0] == ek and kcov[0] == np.float32(ekcov), (w, eck[0], ek)
+        assert G.unflatten(b, o) == es, "window %d: corrected reads differ" % w
+        assert G.unflatten(q, o) == eq, "window %d: rewritten qualities differ" % w
+        assert sum(a != b_ for a, b_ in zip(es, seqs)) > len(seqs) // 4          # most reads are changed: the searches branch
+
+
 def test_correction_returns_reads_to_truth(G, ctx, genome):
     seqs, quals, truth = U.sim_window(genome["bcr"][60000:90000], 8000, seed=21)
     b, q, o = G.flatten(seqs, quals)
