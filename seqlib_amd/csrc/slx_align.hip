@@ -41,6 +41,19 @@
 static const char *STAGE_NAMES[SLX_N_STAGES] = {"encode", "seed", "scan", "chain", "extend", "finalize", "compact", "total"};
 extern "C" const char *slx_stage_name(int i) { return i >= 0 && i < SLX_N_STAGES ? STAGE_NAMES[i] : ""; }
 
+// A small result (a per-read call: a few hundred bytes) packed by one kernel straight into pinned host memory -- slx_hits_pack's layout; the general path
+// is a header upload, eleven device-to-device copies and one download
+#define SLX_BOUNCE_BYTES (256u << 10)
+#define SLX_PACK_PARTS 13
+struct PackSpec { const unsigned char *src[SLX_PACK_PARTS]; unsigned int bytes[SLX_PACK_PARTS], at[SLX_PACK_PARTS]; int n; long long hdr[4]; };
+__global__ void k_pack_small(PackSpec s, unsigned char *dst)
+{
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (t < 32) dst[t] = ((const unsigned char *)s.hdr)[t];
+    for (int i = 0; i < s.n; ++i)
+        for (unsigned int b = t; b < s.bytes[i]; b += nt) dst[s.at[i] + b] = s.src[i][b];
+}
+
 // longest read of a chunk, whether its offsets are monotonic, and its first / last offset -- on the device, so that a 10 M-read
 // batch does not copy 80 MB of offsets to the host to learn four numbers.  stat: [0] max length, [1] non-monotonic flag, [2] offs[0], [3] offs[n]
 __global__ void k_len_stats(const uint64_t *offs, int n, unsigned long long *stat)
@@ -235,6 +248,7 @@ static int add_worker(slx_aligner *al)
     al->workers.push_back(wk);
     { const int rc = make_worker_stream(al, wk); if (rc != SLX_OK) return rc; }
     { const int rc = set_seed_stream(al, wk); if (rc != SLX_OK) return rc; }
+    HIPCHK(hipHostMalloc((void **)&wk->h_mail, 256, hipHostMallocDefault));
     for (int b = 0; b < 6; ++b) HIPCHK(hipEventCreate(&wk->dbg_ev[b]));
     for (int i = 0; i <= SLX_N_STAGES; ++i) HIPCHK(hipEventCreate(&wk->ev[i]));
     for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&wk->ev_probe[i]));
@@ -382,12 +396,14 @@ extern "C" void slx_aligner_free(slx_aligner *al)
         for (int i = 0; i <= SLX_N_STAGES; ++i) if (wk->ev[i]) (void)hipEventDestroy(wk->ev[i]);
         for (int i = 0; i < 6; ++i) if (wk->dbg_ev[i]) (void)hipEventDestroy(wk->dbg_ev[i]);
         for (int i = 0; i < 6; ++i) if (wk->ev_probe[i]) (void)hipEventDestroy(wk->ev_probe[i]);
+        if (wk->h_mail) (void)hipHostFree(wk->h_mail);
         if (wk->stream) (void)hipStreamDestroy(wk->stream);
         if (wk->seed_stream) (void)hipStreamDestroy(wk->seed_stream);
         if (wk->ev_seed_in) (void)hipEventDestroy(wk->ev_seed_in);
         if (wk->ev_seed_out) (void)hipEventDestroy(wk->ev_seed_out);
         delete wk;
     }
+    if (al->h_bounce) (void)hipHostFree(al->h_bounce);
     if (al->stream) (void)hipStreamDestroy(al->stream);
     delete al;
     bool last;
@@ -617,8 +633,10 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
         unsigned long long stat[4] = {0, 0, 0, 0};
         HIPCHK(hipMemsetAsync(wk->len_stat.p, 0, 32, wk->stream));
         hipLaunchKernelGGL(k_len_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, wk->stream, d_offs + r0, n, wk->len_stat.as<unsigned long long>());
-        HIPCHK(hipMemcpyAsync(stat, wk->len_stat.p, 32, hipMemcpyDeviceToHost, wk->stream));
+        { MailSpec ms{}; ms.src[0] = wk->len_stat.as<unsigned int>(); ms.words[0] = 8; ms.n = 1;
+          hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, wk->stream, ms, wk->h_mail); }
         HIPCHK(hipStreamSynchronize(wk->stream));
+        memcpy(stat, wk->h_mail, 32);
         if (stat[1]) { slx_set_error("read offsets are not monotonic in reads [%lld, %lld)", (long long)r0, (long long)(r0 + n)); return SLX_EINVAL; }
         const int max_len = (int)std::min<unsigned long long>(stat[0], 1u << 30);
         if (max_len > SLX_MAX_READ_LEN) {
@@ -1017,6 +1035,27 @@ extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *
     // one packed image on the device, ONE device-to-host copy, and the result's arrays are views into it
     const bool sam = dv.xa_parent != nullptr;
     const uint64_t bytes = packed_size((uint64_t)dv.n_reads, (uint64_t)dv.n_hits, (uint64_t)dv.n_cigar, sam);
+    if (bytes <= SLX_BOUNCE_BYTES && dv.on_device) {          // a small result: one kernel writes the packed image into pinned host memory, the caller's block is a copy of that
+        if (!al->h_bounce) HIPCHK(hipHostMalloc((void **)&al->h_bounce, SLX_BOUNCE_BYTES, hipHostMallocDefault));
+        const size_t N = (size_t)dv.n_reads, H = (size_t)dv.n_hits, Cg = (size_t)dv.n_cigar;
+        PackSpec ps{};
+        size_t at = 32;
+        auto add = [&](const void *src, size_t b) { ps.src[ps.n] = (const unsigned char *)src; ps.bytes[ps.n] = (unsigned int)b; ps.at[ps.n] = (unsigned int)at; ++ps.n; at += b; };
+        add(dv.hit_off, 8 * (N + 1)); add(dv.pos, 8 * H); add(dv.cig_off, 8 * (H + 1)); add(dv.rid, 4 * H); add(dv.score, 4 * H);
+        add(dv.nm, 4 * H); add(dv.na, 4 * H); add(dv.n_cigar_ops, 4 * H); add(dv.cigar, 4 * Cg); add(dv.flag, 2 * H); add(dv.mapq, H);
+        if (sam) { at = (at + 3) & ~(size_t)3; add(dv.xa_parent, 4 * H); add(dv.sub, 4 * H); }
+        ps.hdr[0] = dv.n_reads; ps.hdr[1] = dv.n_hits; ps.hdr[2] = dv.n_cigar; ps.hdr[3] = sam ? 1 : 0;
+        void *blk = malloc(bytes);
+        if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); return SLX_ENOMEM; }
+        hipLaunchKernelGGL(k_pack_small, dim3((unsigned)std::min<uint64_t>(64, (bytes + 4095) / 4096)), dim3(256), 0, al->stream, ps, al->h_bounce);
+        const hipError_t e = hipStreamSynchronize(al->stream);
+        if (e != hipSuccess) { free(blk); HIPCHK(e); }
+        memcpy(blk, al->h_bounce, bytes);
+        out->n_reads = dv.n_reads; out->n_hits = dv.n_hits; out->n_cigar = dv.n_cigar; out->on_device = 0;
+        out->block = blk; out->block_pinned = 0; out->block_bytes = bytes;
+        view_packed(out, (uint8_t *)blk, dv.n_reads, dv.n_hits, dv.n_cigar, sam);
+        return SLX_OK;
+    }
     if ((rc = al->st_pack.ensure(bytes)) != SLX_OK) return rc;
     if ((rc = pack_locked(al, &dv, al->st_pack.p)) != SLX_OK) return rc;
     void *blk = nullptr;

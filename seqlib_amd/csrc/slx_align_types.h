@@ -52,6 +52,19 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// The host sizes every stage by a few counters of the one before.  Each used to come back with a hipMemcpyAsync of its own into a pageable local -- five after
+// seeding, three before the compaction: ~20 us apiece, a third of a one-read call.  k_mail gathers them with ONE launch and writes them straight into pinned
+// host memory the worker keeps (the stream's synchronisation, which the host needs anyway, makes them visible): no copy at all.
+#define SLX_MAIL_PARTS 6
+struct MailSpec { const unsigned int *src[SLX_MAIL_PARTS]; int words[SLX_MAIL_PARTS]; int n; };
+static __global__ void k_mail(MailSpec s, unsigned int *dst)
+{
+    int at = 0;
+    for (int i = 0; i < s.n; ++i) {
+        for (int w = (int)threadIdx.x; w < s.words[i]; w += (int)blockDim.x) dst[at + w] = s.src[i][w];
+        at += s.words[i];
+    }
+}
 struct slx_aligner;
 
 // One worker = one HIP stream with its own work areas and result buffers.  A large batch is split into contiguous
@@ -62,6 +75,7 @@ struct Worker {
     hipStream_t seed_stream = nullptr;   // optional: the persistent seeding kernels on a stream of their own, confined to a CU mask that leaves some CUs
                                          // of the chip to the latency-bound kernels of the other workers ("seed_free_cus" knob)
     hipEvent_t ev_seed_in = nullptr, ev_seed_out = nullptr;
+    unsigned int *h_mail = nullptr;      // 64 words of pinned host memory k_mail writes the few counters into that the host sizes the next stage by (one launch, no copy)
     DevBuf codes, offs_rel, intv_n, intv_info, intv_x0, intv_x2, l_rep, seed_cnt, seed_off, scan_tmp;
     DevBuf s_rbeg, s_ql, s_next, c_pos, c_head, c_tail, c_n, c_rid, c_w, c_first, c_kept, ia, ib, ic, srt, regs, hits;
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
@@ -206,6 +220,7 @@ struct slx_aligner {
     DevBuf o_hit_off, o_rid, o_pos, o_flag, o_mapq, o_score, o_nm, o_na, o_ncig, o_cig_off, o_cigar, o_xa, o_sub;
     // staging of the host-buffer entry (cached between calls: the per-read alignSequence pays no hipMalloc)
     DevBuf st_bases, st_offs, st_pack;
+    unsigned char *h_bounce = nullptr;   // pinned: a small result is packed straight into it by one kernel (SLX_BOUNCE_BYTES)
     float stage_ms[SLX_N_STAGES];
     float probe_ms[SLX_N_PROBES] = {0, 0, 0};   // kernel groups of the last batch, summed over the workers' launches (HIP events on the workers' streams)
     int64_t probe_reads = 0;
