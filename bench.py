@@ -840,19 +840,19 @@ def main():
                     except Exception as e:
                         percall = dict(error=str(e))
                 os.remove(sample)
-        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 8 steps of the default 64
+        # ---- BASELINE config 5 beside the headline: a bounded leg of `bench.py --config C5` -- 1 warm-up + 12 steps (~8 s; the pipeline's fill is ~2.3 s of them) of the default 64
         # windows x 100 000 reads, a tenth-size window at full coverage through both CPU checkers -- as a process of its own (this one has let go of its
         # aligner above), so that the driver's default run times the assembler pipeline too
         other = None
         if not args.no_extras and args.config == "C3" and world == 1 and os.environ.get("SLX_BENCH_NO_C5_LEG") != "1":
             try:
-                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "12", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
                                    stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
                 ln = [x for x in o.stdout.decode().splitlines() if x.startswith("{")]
                 if o.returncode == 0 and ln:
                     c5 = json.loads(ln[-1])
                     other = {"C5": {k: c5.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "contigs", "contig_bit_match_rate", "realigned_contig_bit_match_rate",
-                                                           "verified", "roofline", "step_split_ms", "probe_ms_per_step", "realign_extension_rounds", "counters", "step_ms", "config")}}
+                                                           "verified", "roofline", "step_split_ms", "probe_ms_per_step", "realign_extension_rounds", "counters", "step_ms", "timeline_ms", "config")}}
                 else:
                     other = {"C5": dict(error="exit code %d" % o.returncode)}
             except Exception as e:
