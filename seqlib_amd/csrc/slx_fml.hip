@@ -373,7 +373,7 @@ int fml_run_ec(slx_fml *f)
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, f->device);
     const size_t lane_bytes = fml_scratch_bytes(f->max_len);
     // short reads (every sequencer's): the walk's per-base arrays in LDS, a wave per block, as many blocks per CU as 160 KB hold (k_fml_ec_lds)
-    int64_t lanes = (int64_t)dev_cus * 2048;          // eight waves per SIMD at most
+    int64_t lanes = (int64_t)dev_cus * 4 * FML_EC_WAVES * 64;          // persistent waves: as many as are resident (a work area each: 16 KB per lane at 150 bp)
     lanes = std::min<int64_t>(lanes, ((f->n_reads + 255) / 256) * 256);
     while (lanes > 256 && (size_t)lanes * lane_bytes > (size_t)24 << 30) lanes /= 2;
     lanes = std::max<int64_t>(256, lanes / 256 * 256);
