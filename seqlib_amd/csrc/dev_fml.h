@@ -608,7 +608,9 @@ struct FmlWalk {
 };
 
 #define FML_LA_MAX 30          // positions per lookahead (2 bits each in la_cls)
-#define FML_LA_CHUNK 10        // probes in flight at a time
+#ifndef FML_LA_CHUNK
+#define FML_LA_CHUNK 3         // probes in flight at a time (ten at a time hold 80 VGPRs for the keys and slots: the kernel's peak, a wave per SIMD less)
+#endif
 // Behind a substitution the path's next k - 1 k-mers are not the read's: k_fml_occ knows nothing about them, and asking one per step makes k - 1 waits of every
 // correction (and, in the second walk, of every base the first one changed: the read's k-mers there are new).  They are all known the moment the path gets there --
 // the state's k - 1 bases and the read's bases that follow -- so the first step that needs one asks for all of them, FML_LA_CHUNK probes in flight at a time.
@@ -975,7 +977,7 @@ __device__ __forceinline__ int fml_ec_core(const FmlSlot *tab, const FmlWin &w, 
 // (The words were tried in LDS -- a wave per block, four blocks per CU at 150 bp: the walks are bound by instruction issue and by the waits of the blocked
 // steps, and twelve waves per CU on words in memory overlap both better than four on words in LDS: 130 ms against 163 per 6.4 M reads.)
 #ifndef FML_EC_WAVES
-#define FML_EC_WAVES 3          // waves per SIMD the compiler is asked to leave room for (measured per 6.4 M reads: 2 = 189 VGPRs, 116 ms; 3 = 168 VGPRs, 89 ms; 4 = 128 VGPRs and 440 bytes of spills, 119 ms)
+#define FML_EC_WAVES 4          // waves per SIMD the compiler is asked to leave room for (measured per 6.4 M reads, lookahead chunks of 10: 2 = 189 VGPRs, 116 ms; 3 = 168 VGPRs, 89 ms; 4 = 128 VGPRs and 440 bytes of spills, 119 ms -- chunks of 3: 4 = 128 VGPRs, 12 bytes of spills, 81 ms; 5 = 96 VGPRs, 140 bytes, 112 ms)
 #endif
 static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSlot *tab, const FmlWin *wins, int n_win, FmlEcOpt o, char *bases, char *quals,
                                                 const unsigned long long *offs, long long n_reads, const unsigned short *occ, unsigned char *scratch, size_t lane_bytes,
