@@ -110,6 +110,37 @@ __device__ __forceinline__ bool dir4_match(const DevRef &R, const uint8_t *codes
     return qq == tb;
 }
 
+// ... and the same for 32 bases against ONE 8-byte chunk of pac (forward strand: p a multiple of 32; reverse strand: the mirror position ends a chunk): a contig
+// that matches the reference is one SMEM of tens of kilobases, and four bases per step still walked it for ~80 ms on its lane.  Four read bases pack into a
+// byte with one multiply (x = q0 | q1 << 8 | q2 << 16 | q3 << 24; x * (2^30 + 2^20 + 2^10 + 1) >> 24 = q0 << 6 | q1 << 4 | q2 << 2 | q3: the products that
+// land in bits 24-31 are exactly these four), eight such bytes are pac's chunk; on the reverse strand the chunk holds the complement of the read's bases in
+// reverse order: bytes swapped, the four pairs of every byte swapped, all bits flipped.
+__device__ __forceinline__ bool dir32_match(const DevRef &R, const uint8_t *codes, uint64_t a, int64_t p, RWin &w)
+{
+    const bool rev = p >= R.l_pac;
+    if (!rev && p + 31 >= R.l_pac) return false;
+    if (p + 31 >= (R.l_pac << 1)) return false;
+    const int64_t f = rev ? (R.l_pac << 1) - 1 - p : p;
+    if ((f & 31) != (rev ? 31 : 0)) return false;
+    const int64_t ch = f >> 5;
+    if (ch != w.chunk) { w.bits = *(const uint64_t *)(R.pac + (ch << 3)); w.chunk = ch; }
+    uint32_t x[8];
+    __builtin_memcpy(x, codes + a, 32);
+    uint32_t amb = 0;
+    uint64_t q = 0;
+    for (int j = 0; j < 8; ++j) {
+        amb |= x[j];
+        q |= (uint64_t)((x[j] * 0x40100401u) >> 24) << (8 * j);
+    }
+    if (amb & 0xfcfcfcfcu) return false;
+    if (rev) {
+        q = __builtin_bswap64(q);
+        q = ((q & 0x0303030303030303ULL) << 6) | ((q & 0x0c0c0c0c0c0c0c0cULL) << 2) | ((q >> 2) & 0x0c0c0c0c0c0c0c0cULL) | ((q >> 6) & 0x0303030303030303ULL);
+        q = ~q;
+    }
+    return q == w.bits;
+}
+
 __device__ __forceinline__ int text_at(const DevRef &R, int64_t p, RWin &w)
 {
     const bool rev = p >= R.l_pac;
@@ -610,6 +641,8 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
                     for (int t = 0; t < 32; ++t) {
                         int cq = 4;
                         const int64_t tp = dpos + (int64_t)(i - sx);
+                        // thirty-two bases at once where the text side starts a chunk of pac (a step of the loop's budget each: up to 1 024 bases per turn)
+                        if (i + 32 <= len && dir32_match(R, ck.codes, qoff + (uint64_t)i, tp, rwin)) { i += 32; continue; }
                         // four bases at once where the text side starts a byte of pac: a contig's direct walk is hundreds of thousands of bases on one lane
                         if (t + 4 <= 32 && i + 4 <= len && dir4_match(R, ck.codes, qoff + (uint64_t)i, tp, rwin)) { i += 4; t += 3; continue; }
                         if (i < len && (cq = qb(i)) <= 3 && tp < (R.l_pac << 1) && text_at(R, tp, rwin) == cq) { ++i; continue; }
