@@ -433,6 +433,9 @@ __device__ __noinline__ int regs_block_dp(const DevRef &R, const slx_opt &o, Reg
 struct PMemo { const GJob *jobs; const int *off, *n; };          // per read r: jobs[off[r] .. off[r] + n[r])
 __device__ bool pseg_lookup(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re, int *score);
 
+#ifdef PSEG_DEBUG
+__device__ void pseg_debug_miss(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re);
+#endif
 struct WaveScorerLong {
     const DevRef &R; const slx_opt &o; const Chunk &ck; int lane; int *eh_h, *eh_e;
     RegsBlockShared *SB;          // non-null: three helper waves wait at a block barrier for work (k_regs_wave_long)
@@ -442,6 +445,9 @@ struct WaveScorerLong {
     {
         if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return 0;
         if (pm) { int ms = 0; if (pseg_lookup(pm, *cur_r, w_, (unsigned long long)(qseg - ck.codes), l_query, rb, re, &ms)) return ms; }
+#ifdef PSEG_DEBUG
+        if (pm && lane == 0 && re - rb >= 16384) pseg_debug_miss(pm, *cur_r, w_, (unsigned long long)(qseg - ck.codes), l_query, rb, re);
+#endif
         const int rlen = (int)(re - rb);
         const bool rev = rb >= R.l_pac;
         auto qf = [&](int x) { return (int)(rev ? qseg[l_query - 1 - x] : qseg[x]); };

@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(GB_THREADS) k_cig_band_block(DevRef R, Chunk c
 // its arguments up (WaveScorerLong) before it computes anything: a hit is the value it would have computed.  Pairs the walk never asks for cost a wasted alignment;
 // calls made on regions an earlier merge changed miss and run in place as before.
 #define PSEG_MAX_REG 8              // reads with more regions than this are left to the walk (repeat-ended contigs keep hundreds of regions)
-#define PSEG_MAX_PAIRS 12
+#define PSEG_MAX_PAIRS 24
+#define PSEG_EMU_REG 96             // ... the walk's own sequence of merges is followed for reads with up to this many (its long alignments are few whatever the number of regions)
 
 __global__ void k_pseg_plan(DevRef R, Chunk ck, DevOpt dopt, const int *order, unsigned int n_multi, GPlan P, int *memo_off, int *memo_n, unsigned int job_cap)
 {
@@ -262,42 +263,85 @@ __global__ void k_pseg_plan(DevRef R, Chunk ck, DevOpt dopt, const int *order, u
     const slx_opt &opt = dopt.o;
     const int r = order ? order[t] : (int)t;
     const int n = ck.n_reg[r];
-    if (n < 2 || n > PSEG_MAX_REG || !(opt.e_ins > 0 && opt.e_del > 0)) return;
+    if (n < 2 || n > PSEG_EMU_REG || !(opt.e_ins > 0 && opt.e_del > 0)) return;
     const DReg *G = ck.regs + ck.seed_off[r];
     GJob jobs[PSEG_MAX_PAIRS];
     int nj = 0, slots = 0, units = 0;
+    // the alignment mem_patch_reg(q = a, p = b) would ask for, as a job (false: it asks for none, or for one that runs in place)
+    auto plan = [&](int64_t a_rb, int64_t a_re, int a_qb, int a_qe, int a_w, int64_t b_rb, int64_t b_re, int b_qb, int b_qe, int b_w, int *w_out) -> bool {
+        const int w_arg = dev_patch_pre(R, opt, a_rb, a_re, a_qb, a_qe, a_w, b_rb, b_re, b_qb, b_qe, b_w);
+        *w_out = w_arg;
+        if (w_arg < 0 || nj >= PSEG_MAX_PAIRS) return false;
+        // what WaveScorerLong makes of sc(w_arg, b.qe - a.qb, query + a.qb, a.rb, b.re)
+        const int l_query = b_qe - a_qb;
+        const long long rb = a_rb, re = b_re;
+        if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) return false;
+        const int rlen = (int)(re - rb);
+        if (l_query == rlen && w_arg == 0) return false;                   // (ungapped: a sum, computed in place)
+        if (rlen < 2 * GSEG_LEN) return false;                             // short: in place
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
+        int w = (max_gap + dl + 1) >> 1;
+        w = w < w_arg ? w : w_arg;
+        w = w > dl + 3 ? w : dl + 3;
+        if (2 * w + 1 > CIG_BAND_MAX_COLS) return false;                   // (wider: in place)
+        const unsigned long long q_off = ck.offs[r] + (unsigned long long)a_qb;
+        for (int k = 0; k < nj; ++k)          // (the same question twice: once)
+            if (jobs[k].w_arg == w_arg && jobs[k].q_off == q_off && jobs[k].lq == l_query && jobs[k].rb == rb && jobs[k].re == re) return true;
+        GJob j;
+        j.z_off = 0; j.has_z = 0; j.q_off = q_off; j.rb = rb; j.re = re; j.lq = l_query; j.rlen = rlen; j.rev = rb >= R.l_pac ? 1 : 0;
+        j.ww = w; j.n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1; j.w_arg = w_arg; j.cpb = 2 * w + 1 <= GB_THREADS ? 1 : (2 * w + 1 <= 2 * GB_THREADS ? 2 : 4);
+        j.slot = 0; j.score = 0; j.r = r; j.unit_base = 0;
+        GGeom g; g.valid = true; g.lq = l_query; g.rlen = rlen; g.ww = w; g.n_col = j.n_col; g.rev = j.rev != 0;
+        j.n_seg = gseg_count(g);
+        if (j.n_seg < 2) j.n_seg = 0;
+        j.seg_base = slots; slots += j.n_seg; units += j.n_seg;
+        jobs[nj++] = j;
+        return true;
+    };
+    // First what the walk asks when every merge before it has SUCCEEDED -- mem_sort_dedup_patch itself, run on a copy of the regions' geometry with every patch
+    // that passes the cheap tests taken as made: a contig cut into three or more collinear pieces (r1 r2 r3 by end) merges r1 into r2 and then asks about
+    // (r1 + r2, r3), an alignment of the whole contig that no pair of the original regions describes; round 5's first form knew the pairs only, and that one
+    // ran in place in the region kernel, 110 ms on four waves for the longest contig.  (Redundancy is judged on the sum of the scores: a guess, like the rest.)
+    {
+        struct PR { int64_t rb, re; int qb, qe, w, score, rid; };
+        PR a[PSEG_EMU_REG];
+        int ord[PSEG_EMU_REG];
+        for (int x = 0; x < n; ++x) { const DReg &g = G[x]; a[x] = PR{g.rb, g.re, g.qb, g.qe, g.w, g.score, g.rid}; ord[x] = x; }
+        for (int x = 1; x < n; ++x) { const int v = ord[x]; int y = x - 1; while (y >= 0 && a[ord[y]].re > a[v].re) { ord[y + 1] = ord[y]; --y; } ord[y + 1] = v; }
+        for (int i = 1; i < n; ++i) {
+            PR &pp = a[ord[i]];
+            if (pp.qe == pp.qb) continue;
+            if (pp.rid != a[ord[i - 1]].rid || pp.rb >= a[ord[i - 1]].re + opt.max_chain_gap) continue;
+            for (int j = i - 1; j >= 0 && pp.rid == a[ord[j]].rid && pp.rb < a[ord[j]].re + opt.max_chain_gap; --j) {
+                PR &q = a[ord[j]];
+                if (q.qe == q.qb) continue;
+                const int64_t orr = q.re - pp.rb;
+                const int64_t oq = q.qb < pp.qb ? q.qe - pp.qb : pp.qe - q.qb;
+                const int64_t mr = q.re - q.rb < pp.re - pp.rb ? q.re - q.rb : pp.re - pp.rb;
+                const int64_t mq = q.qe - q.qb < pp.qe - pp.qb ? q.qe - q.qb : pp.qe - pp.qb;
+                if ((float)orr > opt.mask_level_redun * (float)mr && (float)oq > opt.mask_level_redun * (float)mq) {
+                    if (pp.score < q.score) { pp.qe = pp.qb; break; } else q.qe = q.qb;
+                } else if (q.rb < pp.rb) {
+                    int w_arg;
+                    (void)plan(q.rb, q.re, q.qb, q.qe, q.w, pp.rb, pp.re, pp.qb, pp.qe, pp.w, &w_arg);
+                    if (w_arg >= 0) { pp.score += q.score; pp.w = w_arg; pp.rb = q.rb; pp.qb = q.qb; q.qe = q.qb; }
+                }
+            }
+        }
+    }
+    // ... then every ordered pair of the regions as they are (what the walk asks where a merge before it failed), for reads with a handful of regions
+    if (n <= PSEG_MAX_REG)
     for (int x = 0; x < n && nj < PSEG_MAX_PAIRS; ++x)
         for (int y = 0; y < n && nj < PSEG_MAX_PAIRS; ++y) {
             if (x == y) continue;
             const DReg &a = G[x], &b = G[y];          // the call mem_patch_reg(q = a, p = b) of the walk
             if (a.rid != b.rid || !(a.rb < b.rb) || a.qe == a.qb || b.qe == b.qb) continue;
-            const int w_arg = dev_patch_pre(R, opt, a.rb, a.re, a.qb, a.qe, a.w, b.rb, b.re, b.qb, b.qe, b.w);
-            if (w_arg < 0) continue;
-            // what WaveScorerLong makes of sc(w_arg, b.qe - a.qb, query + a.qb, a.rb, b.re)
-            const int l_query = b.qe - a.qb;
-            const long long rb = a.rb, re = b.re;
-            if (l_query <= 0 || rb >= re || (rb < R.l_pac && re > R.l_pac)) continue;
-            const int rlen = (int)(re - rb);
-            if (l_query == rlen && w_arg == 0) continue;                       // (ungapped: a sum, computed in place)
-            if (rlen < 2 * GSEG_LEN) continue;                                 // short: in place
-            int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-            int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
-            int max_gap = max_ins > max_del ? max_ins : max_del;
-            max_gap = max_gap > 1 ? max_gap : 1;
-            const int dl = rlen - l_query < 0 ? l_query - rlen : rlen - l_query;
-            int w = (max_gap + dl + 1) >> 1;
-            w = w < w_arg ? w : w_arg;
-            w = w > dl + 3 ? w : dl + 3;
-            if (2 * w + 1 > CIG_BAND_MAX_COLS) continue;                       // (wider: in place)
-            GJob j;
-            j.z_off = 0; j.has_z = 0; j.q_off = ck.offs[r] + (unsigned long long)a.qb; j.rb = rb; j.re = re; j.lq = l_query; j.rlen = rlen; j.rev = rb >= R.l_pac ? 1 : 0;
-            j.ww = w; j.n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1; j.w_arg = w_arg; j.cpb = 2 * w + 1 <= GB_THREADS ? 1 : (2 * w + 1 <= 2 * GB_THREADS ? 2 : 4);
-            j.slot = 0; j.score = 0; j.r = r; j.unit_base = 0;
-            GGeom g; g.valid = true; g.lq = l_query; g.rlen = rlen; g.ww = w; g.n_col = j.n_col; g.rev = j.rev != 0;
-            j.n_seg = gseg_count(g);
-            if (j.n_seg < 2) j.n_seg = 0;
-            j.seg_base = slots; slots += j.n_seg; units += j.n_seg;
-            jobs[nj++] = j;
+            int w_arg;
+            (void)plan(a.rb, a.re, a.qb, a.qe, a.w, b.rb, b.re, b.qb, b.qe, b.w, &w_arg);
         }
     if (nj == 0) return;
     const unsigned int base = atomicAdd(&P.cnt[7], (unsigned int)nj);
@@ -341,6 +385,14 @@ __global__ void __launch_bounds__(GB_THREADS) k_pseg_join(DevRef R, Chunk ck, De
     }
 }
 
+#ifdef PSEG_DEBUG          // experiment builds: what the walk asked for and did not find
+__device__ void pseg_debug_miss(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re)
+{
+    printf("[pseg miss] read %d: w %d lq %d qoff %llu rb %lld re %lld; memo has %d:", r, w_arg, l_query, q_off, (long long)rb, (long long)re, pm->n[r]);
+    for (int k = 0; k < pm->n[r]; ++k) { const GJob &j = pm->jobs[pm->off[r] + k]; printf(" (w %d lq %d qoff %llu rb %lld re %lld)", j.w_arg, j.lq, j.q_off, j.rb, j.re); }
+    printf("\n");
+}
+#endif
 __device__ bool pseg_lookup(const PMemo *pm, int r, int w_arg, unsigned long long q_off, int l_query, int64_t rb, int64_t re, int *score)
 {
     const int n = pm->n[r];
