@@ -49,7 +49,7 @@ struct PackSpec { const unsigned char *src[SLX_PACK_PARTS]; unsigned int bytes[S
 __global__ void k_pack_small(PackSpec s, unsigned char *dst)
 {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    if (t < 32) dst[t] = ((const unsigned char *)s.hdr)[t];
+    if (t < 32 && s.hdr[0] >= 0) dst[t] = ((const unsigned char *)s.hdr)[t];          // (hdr[0] < 0: no header -- a group member's pieces go to their places in the merged block)
     for (int i = 0; i < s.n; ++i)
         for (unsigned int b = t; b < s.bytes[i]; b += nt) dst[s.at[i] + b] = s.src[i][b];
 }
@@ -854,7 +854,7 @@ void *pin_acquire(uint64_t bytes, uint64_t *cap)
     }
     void *p = nullptr;
     const uint64_t want = bytes + bytes / 16;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }          // (every device of a group writes into it)
     *cap = want;
     return p;
 }
@@ -986,6 +986,23 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
         if (h0) hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, p.hit_off, p.hit_off, np, h0);
         if (c0 && h) hipLaunchKernelGGL(k_shift_offsets, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, st, p.cig_off, p.cig_off, h, c0);
         HIPCHK(hipGetLastError());
+        // a member's eleven (thirteen) arrays to their places in the merged block: one kernel writing straight into the pinned block while the pieces are small
+        // (a copy each costs more than the bytes: eight members x eleven copies were 30 ms of a 100 ms call), a copy per array when they are not
+        const uint64_t piece_bytes = 8 * (uint64_t)np + 39 * (uint64_t)h + 4 * (uint64_t)c + (sam ? 8 * (uint64_t)h : 0);
+        if (is_pinned && piece_bytes <= (8u << 20) && bytes < (1ull << 32)) {
+            PackSpec ps{};
+            ps.hdr[0] = -1;
+            auto add = [&](const void *src, const void *dst, size_t b) { if (!b) return; ps.src[ps.n] = (const unsigned char *)src; ps.bytes[ps.n] = (unsigned int)b; ps.at[ps.n] = (unsigned int)((const uint8_t *)dst - (const uint8_t *)blk); ++ps.n; };
+#define OUTK(field, cnt, base) add(p.field, out->field + (base), (size_t)(cnt) * sizeof *p.field)
+            OUTK(hit_off, np, lo[(size_t)g]); OUTK(cig_off, h, h0); OUTK(rid, h, h0); OUTK(pos, h, h0); OUTK(flag, h, h0); OUTK(mapq, h, h0); OUTK(score, h, h0);
+            OUTK(nm, h, h0); OUTK(na, h, h0); OUTK(n_cigar_ops, h, h0); OUTK(cigar, c, c0);
+            if (sam && p.xa_parent) { OUTK(xa_parent, h, h0); OUTK(sub, h, h0); }
+#undef OUTK
+            if (ps.n) hipLaunchKernelGGL(k_pack_small, dim3((unsigned)std::min<uint64_t>(256, (piece_bytes + 4095) / 4096 + 1)), dim3(256), 0, st, ps, (unsigned char *)blk);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            return (int)SLX_OK;
+        }
 #define OUT(field, cnt, base) if ((cnt) > 0) HIPCHK(hipMemcpyAsync(out->field + (base), p.field, (size_t)(cnt) * sizeof *p.field, hipMemcpyDeviceToHost, st))
         OUT(hit_off, np, lo[(size_t)g]); OUT(cig_off, h, h0); OUT(rid, h, h0); OUT(pos, h, h0); OUT(flag, h, h0); OUT(mapq, h, h0); OUT(score, h, h0);
         OUT(nm, h, h0); OUT(na, h, h0); OUT(n_cigar_ops, h, h0); OUT(cigar, c, c0);
