@@ -585,14 +585,6 @@ __device__ __forceinline__ FmlPen fml_pen_unpack(unsigned int v) { return FmlPen
 // lane's probe.  So a step comes in two forms.  fml_step<false> LOOKS at the state on top of the heap and, if extending it needs the table, leaves
 // everything as it is and reports "blocked"; the wave runs such steps until every lane is blocked or done, then the blocked lanes take one
 // fml_step<true> TOGETHER (their probes in flight at the same time), and so on: as many waits per wave as the busiest lane has, not as all have together.
-#ifdef FML_EC_PROF          // experiment builds only: where a wave's cycles go (wave-level sums; lane 0 adds)
-__device__ unsigned long long g_fml_prof[16];
-#define FML_PROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fml_prof[i], (unsigned long long)(v)); } while (0)
-#define FML_PROF_NOW() __builtin_readcyclecounter()
-#else
-#define FML_PROF_ADD(i, v) do { } while (0)
-#define FML_PROF_NOW() 0ULL
-#endif
 
 template <class SC>
 struct FmlWalk {
@@ -602,9 +594,6 @@ struct FmlWalk {
     // substitutions at la_s (base la_bs) and la_s1 and follows the read from la_pos0 on
     int la_pos0, la_len, la_s, la_s1, la_bs;
     unsigned long long la_cls;
-#ifdef FML_EC_PROF
-    unsigned long long pf_a, pf_b, pf_c, pf_n2;
-#endif
 };
 
 #define FML_LA_MAX 30          // positions per lookahead (2 bits each in la_cls)
@@ -663,9 +652,6 @@ __device__ __forceinline__ int fml_step(const FmlSlot *tab, const FmlWin &w, con
 {
     const int k = w.k, n = S.n, dir = S.dir;
     if (S.hp.n == 0) { S.rv = -2; return 2; }
-#ifdef FML_EC_PROF
-    const unsigned long long q0 = FML_PROF_NOW();
-#endif
     const FmlHeap1 zt = S.hp.top;          // (the state pop() will return)
     bool stop = zt.i - S.end > o.max_end_ext;
     const bool have = zt.i < n;
@@ -740,13 +726,7 @@ __device__ __forceinline__ int fml_step(const FmlSlot *tab, const FmlWin &w, con
             }
         }
     }
-#ifdef FML_EC_PROF
-    const unsigned long long q1 = FML_PROF_NOW();
-#endif
     const FmlHeap1 z = S.hp.pop();
-#ifdef FML_EC_PROF
-    const unsigned long long q2 = FML_PROF_NOW();
-#endif
     if (!stop) {
         int n_added = 0, other_ext = 0;
         unsigned int added = 0;          // a byte per candidate: FmlPen packed (no indexed private array: that would live in scratch memory)
@@ -768,9 +748,6 @@ __device__ __forceinline__ int fml_step(const FmlSlot *tab, const FmlWin &w, con
                 added |= fml_pen_pack(pen) << (8 * n_added++);
             }
         }
-#ifdef FML_EC_PROF
-        if (!SLOW) S.pf_n2 += FML_PROF_NOW() - q2;
-#endif
         if (!fixed && other_ext == 0) ++S.n_failures;
         if (S.n_failures > n * 2 || S.n_stack > FML_STACK_CAP(n)) { S.rv = -3; return 2; }
         if (have || n_added == 1) {
@@ -804,9 +781,6 @@ __device__ __forceinline__ int fml_step(const FmlSlot *tab, const FmlWin &w, con
             }
         } else stop = true;
     }
-#ifdef FML_EC_PROF
-    if (!SLOW) { S.pf_a += q1 - q0; S.pf_b += q2 - q1; S.pf_c += FML_PROF_NOW() - q2; }
-#endif
     if (stop) { S.path = z.k; S.rv = 0; return 2; }
     return 0;
 }
@@ -819,9 +793,6 @@ __device__ __forceinline__ bool fml_walk_begin(const SC &sc, const FmlWin &w, Fm
     S.n = n; S.dir = dir; S.end = end; S.n_stack = S.n_kept = S.n_failures = 0; S.path = -1; S.rv = -1;
     S.hp.mem = sc.hm; S.hp.n = 0;
     S.la_len = 0; S.la_pos0 = 0; S.la_s = S.la_s1 = S.la_bs = -1; S.la_cls = 0;
-#ifdef FML_EC_PROF
-    if (!dir) S.pf_a = S.pf_b = S.pf_c = S.pf_n2 = 0;
-#endif
     FmlHeap1 z;
     int l;
     z.tot_pen = 0; z.x0 = z.x1 = 0; z.k = -1;
@@ -868,19 +839,14 @@ __device__ __forceinline__ int fml_ec_walks(const FmlSlot *tab, const FmlWin &w,
     FmlWalk<SC> S;
     if (!fml_walk_begin(sc, w, S, n, 0, start, n)) return -13;
     int state = 0, rc = 0;          // 0 running, 1 blocked, 2 this walk is over, 3 all over
-    unsigned long long pf_fast = 0, pf_slow = 0, pf_it = 0, pf_run = 0, pf_rounds = 0, pf_blk = 0;
     while (true) {
-        const unsigned long long t0 = FML_PROF_NOW();
         while (true) {
             if (state == 0) state = fml_step<false>(tab, w, o, sc, S);
             // go on while it pays: a step of the blocked lanes (their probes) costs four to five steps of the running ones, and about one step in ten blocks --
             // waiting for more blocked lanes than running ones idles more lanes in the steps than it saves in the rounds (measured: 4 : 1 was the worse rule)
             const int run = __popcll(__ballot(state == 0)), blk = __popcll(__ballot(state == 1));
-            pf_it += 1; pf_run += run;
             if (run == 0 || blk >= run) break;
         }
-        const unsigned long long t1 = FML_PROF_NOW();
-        pf_rounds += 1; pf_blk += __popcll(__ballot(state == 1));
         if (state == 1) state = fml_step<true>(tab, w, o, sc, S);
         if (state == 2) {
             if (S.rv < 0) { rc = S.dir ? -14 : -13; state = 3; }          // (nothing has been written to the text yet: the read stays as it was)
@@ -891,14 +857,9 @@ __device__ __forceinline__ int fml_ec_walks(const FmlSlot *tab, const FmlWin &w,
                 else { rc = -14; state = 3; }
             }
         }
-        const unsigned long long t2 = FML_PROF_NOW();
-        pf_fast += t1 - t0; pf_slow += t2 - t1;
         if (!__ballot(state == 0)) break;
     }
-#ifdef FML_EC_PROF
-    FML_PROF_ADD(12, S.pf_a); FML_PROF_ADD(13, S.pf_b); FML_PROF_ADD(14, S.pf_c); FML_PROF_ADD(15, S.pf_n2);
-#endif
-    FML_PROF_ADD(4, pf_fast); FML_PROF_ADD(5, pf_slow); FML_PROF_ADD(8, pf_it); FML_PROF_ADD(9, pf_run); FML_PROF_ADD(10, pf_rounds); FML_PROF_ADD(11, pf_blk);
+
     return rc;
 }
 
@@ -1000,7 +961,6 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
         const int rel = (int)(offs[live ? r : (long long)r0 + cnt] - b0);          // where the lane's read starts in the wave's text
         const int n = live ? (int)(offs[r + 1] - b0) - rel : 0;
         const int tot = (int)(offs[(long long)r0 + cnt] - b0);
-        const unsigned long long tp0 = FML_PROF_NOW();
         // byte t of the wave's text is base t - rel_j of read j, the last read that starts at or before t (six shuffles find it): bfc_seq_conv
         auto read_of = [&](int t) -> int {
             int lo = 0;
@@ -1017,7 +977,6 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rc = 1;
-        const unsigned long long tp1 = FML_PROF_NOW();
         if (n > 0) {
             int lo = 0, hi = n_win;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wins[mid].read0 <= r) lo = mid; else hi = mid; }
@@ -1030,8 +989,7 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long tp2 = FML_PROF_NOW();
-        FML_PROF_ADD(0, tp1 - tp0); FML_PROF_ADD(1, tp2 - tp1); FML_PROF_ADD(3, 1);
+
         for (int t0 = 0; t0 < tot; t0 += 64) {          // the corrected reads back into the text
             const int t = t0 + lane;
             const int j = read_of(t < tot ? t : tot - 1);
@@ -1045,7 +1003,7 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        FML_PROF_ADD(2, FML_PROF_NOW() - tp2);
+
     }
 }
 

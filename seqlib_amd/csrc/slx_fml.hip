@@ -391,18 +391,6 @@ int fml_run_ec(slx_fml *f)
                        (const unsigned short *)f->d_occ.as<unsigned short>(), f->d_scratch.as<unsigned char>(), lane_bytes, f->max_len, f->d_misc.as<unsigned long long>(), (int *)nullptr);
     FML_HIPCHK(hipGetLastError());
     f->planes_ok = false;          // (the text has changed under the planes)
-#ifdef FML_EC_PROF
-    {
-        unsigned long long h[16];
-        (void)hipStreamSynchronize(f->st);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fml_prof), sizeof(h));
-        fprintf(stderr, "[fml ec prof] tasks %llu; cycles per task: conv %.0f core %.0f write-back %.0f; dir0 fast %.0f slow %.0f, dir1 fast %.0f slow %.0f; per task: fast iterations %.1f (lanes running %.1f), rounds %.1f (lanes blocked %.1f); lane 0's fast steps per task: look %.0f pop %.0f expand+push %.0f cycles, %.1f with a heap of more than two\n",
-                h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[3], (double)h[6] / h[3], (double)h[7] / h[3],
-                (double)h[8] / h[3], (double)h[9] / (double)(h[8] ? h[8] : 1), (double)h[10] / h[3], (double)h[11] / (double)(h[10] ? h[10] : 1), (double)h[12] / h[3], (double)h[13] / h[3], (double)h[14] / h[3], (double)h[15] / h[3]);
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fml_prof), z, sizeof(z));
-    }
-#endif
     return fml_probe_end(f, 2);
 }
 
