@@ -47,11 +47,21 @@ struct XRun {
     int minv = 0x7fffffff;           // spec: the smallest H / M a band cell held from rec_row on (what bwa's floors compare with zero)
 };
 
-template <int CPB, typename QF, typename TF>
-__device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S, XRun &run)
+// NW = the waves that share the window: XB_WAVES (a block per extension: a row is ~60 instructions per thread and three block barriers), or 1 -- the same code on ONE
+// wave with four times the slots per lane, its "barriers" the wave's own order: ~250 instructions per row and no waiting, the better form when a launch has thousands
+// of segments (k_xseg_run_w).  S is the sharing waves' own.
+template <int NW>
+__device__ __forceinline__ void xb_barrier()
 {
-    constexpr int NB = XB_THREADS * CPB;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    if (NW > 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+}
+template <int CPB, int NW, typename QF, typename TF>
+__device__ void block_band_rows_n(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S, XRun &run)
+{
+    constexpr int NT = NW * WAVE;
+    constexpr int NB = NT * CPB;
+    const int tid = NW > 1 ? (int)threadIdx.x : (int)(threadIdx.x & (WAVE - 1)), lane = tid & (WAVE - 1), wv = tid >> 6;
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins, zdrop = o.zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const bool spec = run.spec != 0;
@@ -76,11 +86,11 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
     auto q_block = [&](int blk) { const int j = blk * WAVE + lane; return (j >= 0 && j < qlen) ? qf(j) : 4; };
     int q_blk = (i0 - w + NB) >> 6;
     int qb_cur = 4, qb_next = 4;                                   // the entering columns' codes: only the last wave uses them
-    if (wv == XB_WAVES - 1) { qb_cur = q_block(q_blk); qb_next = q_block(q_blk + 1); }
+    if (wv == NW - 1) { qb_cur = q_block(q_blk); qb_next = q_block(q_blk + 1); }
     int minv = 0x7fffffff;
     bool broke = false;
     run.valid = 1; run.n_rec = 0;
-    __syncthreads();                                               // (S may still be read by the previous extension's last row)
+    xb_barrier<NW>();                                               // (S may still be read by the previous extension's last row)
     int i = i0;
     for (; i < i1; ++i) {
         if (!spec && i >= qlen && ext_tail_done(tail_top - (i - qlen) * e_del, max, gscore)) { broke = true; break; }
@@ -91,7 +101,7 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         const int b = i - w;
         const int jt = b + NB;
         int q_top = 4;
-        if (wv == XB_WAVES - 1) {
+        if (wv == NW - 1) {
             if ((jt >> 6) != q_blk) { qb_cur = qb_next; ++q_blk; qb_next = q_block(q_blk + 1); }
             q_top = __builtin_amdgcn_readlane(qb_cur, __builtin_amdgcn_readfirstlane(jt & (WAVE - 1)));
         }
@@ -129,11 +139,11 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         const int incl = wave_incl_max_scan(run_u, lane);
         int left = xw_dpp<0x138, 0xf, 0xf>(NEG_BIG, incl);
         if (lane == WAVE - 1) S.scan[wv] = incl;
-        __syncthreads();                                           // ---------------- barrier 1
+        xb_barrier<NW>();                                           // ---------------- barrier 1
         {
             int pre = NEG_BIG;
 #pragma unroll
-            for (int k = 0; k < XB_WAVES - 1; ++k) { const int v = S.scan[k]; if (k < wv) pre = pre > v ? pre : v; }
+            for (int k = 0; k < NW - 1; ++k) { const int v = S.scan[k]; if (k < wv) pre = pre > v ? pre : v; }
             left = left > pre ? left : pre;
         }
         int H[CPB], hkey = -1;
@@ -153,10 +163,10 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         }
         const int wkey = wave_max(hkey);
         if (lane == WAVE - 1) { S.key[wv] = wkey; S.edge_up[wv] = H[CPB - 1]; }
-        __syncthreads();                                           // ---------------- barrier 2
+        xb_barrier<NW>();                                           // ---------------- barrier 2
         int mk = -1;
 #pragma unroll
-        for (int k = 0; k < XB_WAVES; ++k) { const int v = S.key[k]; mk = mk > v ? mk : v; }
+        for (int k = 0; k < NW; ++k) { const int v = S.key[k]; mk = mk > v ? mk : v; }
         const int m = mk >= 0 ? mk >> 10 : 0;
         const int mj = mk >= 0 ? b + (mk & 1023) : -1;
         {   // eh[j + 1].h = H(i, j) for the band's columns, eh[beg].h = h1, eh[end].e = 0 (an empty band still stores h1 into eh[end])
@@ -195,7 +205,7 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             }
             if (lane == 0) { S.first[wv] = wf; S.last[wv] = wl; S.hole[wv] = hb ? 1 : 0; S.dn_h[wv] = Sh[0]; S.dn_e[wv] = Se[0]; S.dn_q[wv] = Q[0]; }
         }
-        __syncthreads();                                           // ---------------- barrier 3
+        xb_barrier<NW>();                                           // ---------------- barrier 3
         if (at_end) {
             const int h1 = end > beg ? S.h1 : h1_init;
             max_ie = gscore > h1 ? max_ie : i;
@@ -218,11 +228,11 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             int first_nz = beg, last_nz = end;
             bool any_hole = false;
 #pragma unroll
-            for (int k = 0; k < XB_WAVES; ++k) any_hole |= S.hole[k] != 0;
+            for (int k = 0; k < NW; ++k) any_hole |= S.hole[k] != 0;
             if (any_hole) {
                 first_nz = -1; last_nz = -1;
 #pragma unroll
-                for (int k = 0; k < XB_WAVES; ++k) {
+                for (int k = 0; k < NW; ++k) {
                     const int f = S.first[k], l = S.last[k];
                     if (f >= 0 && first_nz < 0) first_nz = f;
                     if (l >= 0) last_nz = l;
@@ -235,10 +245,10 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         }
         {   // the window moves one column up
             int nh = xw_dpp<0x130, 0xf, 0xf>(0, Sh[0]), ne = xw_dpp<0x130, 0xf, 0xf>(0, Se[0]), nq = xw_dpp<0x130, 0xf, 0xf>(4, Q[0]);
-            if (lane == WAVE - 1 && wv < XB_WAVES - 1) { nh = S.dn_h[wv + 1]; ne = S.dn_e[wv + 1]; nq = S.dn_q[wv + 1]; }
+            if (lane == WAVE - 1 && wv < NW - 1) { nh = S.dn_h[wv + 1]; ne = S.dn_e[wv + 1]; nq = S.dn_q[wv + 1]; }
 #pragma unroll
             for (int c = 0; c < CPB - 1; ++c) { Sh[c] = Sh[c + 1]; Se[c] = Se[c + 1]; Q[c] = Q[c + 1]; }
-            const bool top = tid == XB_THREADS - 1;
+            const bool top = tid == NT - 1;
             Sh[CPB - 1] = top ? ((jt >= 0 && jt <= qlen) ? ramp(jt) : 0) : nh;
             Se[CPB - 1] = top ? 0 : ne;
             Q[CPB - 1] = top ? q_top : nq;
@@ -251,15 +261,21 @@ __device__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         for (int c = 0; c < CPB; ++c) { run.win_out[tid * CPB + c] = Sh[c]; run.win_out[NB + tid * CPB + c] = Se[c]; }
     }
     if (spec) {                                                    // the smallest value a floor saw, over the block
-        __syncthreads();
+        xb_barrier<NW>();
         const int wm = -wave_max(-minv);
         if (lane == 0) S.scan[wv] = wm;
-        __syncthreads();
+        xb_barrier<NW>();
         int mv = S.scan[0];
 #pragma unroll
-        for (int k = 1; k < XB_WAVES; ++k) mv = mv < S.scan[k] ? mv : S.scan[k];
+        for (int k = 1; k < NW; ++k) mv = mv < S.scan[k] ? mv : S.scan[k];
         run.minv = mv;
     }
+}
+
+template <int CPB, typename QF, typename TF>
+__device__ __forceinline__ void block_band_rows(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, int h0, int amax, XbShared &S, XRun &run)
+{
+    block_band_rows_n<CPB, XB_WAVES>(qlen, qf, tlen, tf, o, mr, w, h0, amax, S, run);
 }
 
 template <int CPB, typename QF, typename TF>

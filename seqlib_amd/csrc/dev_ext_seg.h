@@ -146,8 +146,8 @@ __global__ void k_xseg_units(unsigned int n_jobs, XPlan P)
     }
 }
 
-// ---- the segments, one block each
-template <int CPB>
+// ---- the segments, one block each (NW = XB_WAVES) or one wave each (NW = 1: four times the slots per lane)
+template <int CPB, int NW>
 __device__ void xseg_run_unit(const DevRef &R, const slx_opt &opt, const MatRows &mr, int amax, const XSide &sd, int k, int h0_left, const XPlan &P, int slot, XbShared &S)
 {
     XRun run;
@@ -160,8 +160,8 @@ __device__ void xseg_run_unit(const DevRef &R, const slx_opt &opt, const MatRows
     else { run.i0 = r0 - XSEG_WARM; run.init = XI_NEUTRAL; run.spec = 1; run.rec_row = r0; run.win_rec = P.wrec + (size_t)slot * XSEG_WIN; run.rec = so->rec; h0 = 0; }
     const XQ qf{sd.q, sd.q_dir};
     const XT tf{&R, sd.t0, sd.t_dir};
-    block_band_rows<CPB>(sd.qlen, qf, sd.tlen, tf, opt, mr, sd.w, h0, amax, S, run);
-    if (threadIdx.x == 0) { so->t = run.t; so->valid = run.valid; so->ended = run.ended; so->n_rec = run.n_rec; so->minv = run.minv; }
+    block_band_rows_n<CPB, NW>(sd.qlen, qf, sd.tlen, tf, opt, mr, sd.w, h0, amax, S, run);
+    if ((NW > 1 ? threadIdx.x : (threadIdx.x & (WAVE - 1))) == 0) { so->t = run.t; so->valid = run.valid; so->ended = run.ended; so->n_rec = run.n_rec; so->minv = run.minv; }
 }
 
 __global__ void __launch_bounds__(XB_THREADS) k_xseg_run(DevRef R, Chunk ck, DevOpt dopt, const FirstJob *jobs, const unsigned int *job_list, XPlan P, unsigned int n_units)
@@ -182,8 +182,33 @@ __global__ void __launch_bounds__(XB_THREADS) k_xseg_run(DevRef R, Chunk ck, Dev
         const FirstJob j = jobs[job_list ? job_list[v.job_k] : v.job_k];
         const XSide sd = xside_of(j, ck.codes + j.q_off, v.side, opt, amax, v.btry);
         const int slot = x.seg_base[v.side][v.btry] + v.k;
-        if (sd.cpb == 1) xseg_run_unit<1>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
-        else xseg_run_unit<2>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
+        if (sd.cpb == 1) xseg_run_unit<1, XB_WAVES>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
+        else xseg_run_unit<2, XB_WAVES>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S);
+    }
+}
+
+// The same with a WAVE per segment, for a pass with thousands of them (the second extension round of a contig batch: ~5 000): four waves and three block barriers
+// per row keep a segment's latency down, and that is worth nothing once every CU has a dozen segments waiting -- 94 ms at 11 % of the issue rate.  The same
+// function with the window's slots four (eight) per lane: no barrier, four times the segments in flight.
+__global__ void __launch_bounds__(XB_THREADS, 5) k_xseg_run_w(DevRef R, Chunk ck, DevOpt dopt, const FirstJob *jobs, const unsigned int *job_list, XPlan P, unsigned int n_units)
+{
+    const slx_opt &opt = dopt.o;
+    const MatRows mr = make_matrows(opt.mat);
+    const int amax = xseg_amax(opt);
+    __shared__ XbShared S[XB_WAVES];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    for (;;) {
+        unsigned int u = 0;
+        if (lane == 0) u = atomicAdd(&P.cnt[2], 1u);
+        u = (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= n_units) break;
+        const XUnit v = P.units[u];
+        const XJob x = P.xjobs[v.job_k];
+        const FirstJob j = jobs[job_list ? job_list[v.job_k] : v.job_k];
+        const XSide sd = xside_of(j, ck.codes + j.q_off, v.side, opt, amax, v.btry);
+        const int slot = x.seg_base[v.side][v.btry] + v.k;
+        if (sd.cpb == 1) xseg_run_unit<XB_WAVES, 1>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S[wv]);
+        else xseg_run_unit<2 * XB_WAVES, 1>(R, opt, mr, amax, sd, v.k, j.s_len * opt.a, P, slot, S[wv]);
     }
 }
 

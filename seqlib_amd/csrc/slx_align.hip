@@ -454,6 +454,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "long_guess")) al->long_guess = value != 0;
     else if (!strcmp(key, "long_seg")) al->long_seg = value != 0;
     else if (!strcmp(key, "bwd_direct")) al->bwd_direct = value != 0;
+    else if (!strcmp(key, "xseg_wave_min")) { if (value < 0) return SLX_EINVAL; al->xseg_wave_min = (int)value; }
     else if (!strcmp(key, "xseg_fail")) { if (value < 0) return SLX_EINVAL; al->xseg_fail = (int)value; }
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }

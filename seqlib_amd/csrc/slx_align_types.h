@@ -158,6 +158,7 @@ struct slx_aligner {
                                   // are random reads of their own, the rank reads they replace were mostly L1 hits of the neighbouring entry's block.  Off
     int long_seg = 1;             // contigs: the long sides of an extension job cut into segments of XSEG_LEN rows that run side by side and are verified at the joins
                                   // (dev_ext_seg.h); 0 = every job whole on one block (k_ext_block)
+    int xseg_wave_min = 2048;     // a pass with at least this many segments runs them one WAVE each (k_xseg_run_w), fewer: a block each (latency); 0 = never
     int xseg_fail = 0;            // test knob: > 0 forces the verification of every xseg_fail-th segment to fail (the segment is then computed again from the true window)
     int long_guess = 0;           // (see ExtSpec::guess; measured on C5's contigs: 254 ms of extension without the guess, 370 with it)
     int long_budget = 1024;         // long reads (contigs): the extension stage runs in rounds (ExtSpec, dev_types.h); a walk emits at most this many

@@ -412,7 +412,9 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
             orc_revcomp(mut(ref[520000:580000], 6, ((0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0), (0.6, 16, 0))))]   # a 128 bp insertion
     exp = orc.align_batch(orc.default_opt(), oidx, seqs)
     base_ok = None
-    for knobs in ((), (("xseg_fail", 1),), (("xseg_fail", 2),), (("xseg_fail", 3),), (("long_seg", 0),), (("long_budget", 0),)):
+    # ("xseg_wave_min", 1): every pass runs its segments one WAVE each (k_xseg_run_w: what a pass with thousands of segments does), alone and with forced failures
+    for knobs in ((), (("xseg_fail", 1),), (("xseg_fail", 2),), (("xseg_fail", 3),), (("long_seg", 0),), (("long_budget", 0),), (("xseg_wave_min", 1),),
+                  (("xseg_wave_min", 1), ("xseg_fail", 2))):
         al = sl.BWAAligner(idx)
         for k, v in knobs:
             al.set(k, v)
@@ -427,7 +429,9 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
         elif knobs == (("xseg_fail", 1),):
             assert ok == 0 and redo >= base_ok, (ok, redo)                                   # every segment computed again
             assert g_ok == 0 and g_redo > 0, (g_ok, g_redo)
-        elif knobs and knobs[0][0] == "xseg_fail":
+        elif knobs == (("xseg_wave_min", 1),):
+            assert ok == base_ok and sides >= len(seqs), (ok, base_ok)                       # the same segments taken as speculated, whoever ran them
+        elif knobs and knobs[-1][0] == "xseg_fail":
             assert ok > 0 and redo > 0, (ok, redo)
         elif knobs == (("long_seg", 0),):
             assert sides == 0 and g_jobs == 0 and al.counter("pseg_jobs") == 0
@@ -441,8 +445,11 @@ def test_long_extensions_in_verified_segments(sl, orc, tmp_path):
         for i in range(25):
             al.opt.mat[i] = opt.mat[i]
         sub = seqs[1:4] + seqs[5:7]
-        assert_same(al.alignSequences(sub), orc.align_batch(opt, oidx, sub), "segmented extensions, options %s" % (o_set,))
+        e_sub = orc.align_batch(opt, oidx, sub)
+        assert_same(al.alignSequences(sub), e_sub, "segmented extensions, options %s" % (o_set,))
         assert al.counter("xseg_sides") > 0
+        al.set("xseg_wave_min", 1)
+        assert_same(al.alignSequences(sub), e_sub, "segmented extensions one wave each, options %s" % (o_set,))
 
 
 def test_stage_by_stage_vs_oracle(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
