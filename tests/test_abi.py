@@ -168,3 +168,17 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"oracle[/.]|liborc|orc_[a-z]|from oracle|import oracle", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_library_load_asks_for_eight_hardware_queues():
+    """several aligners / fml contexts side by side need more than the runtime's four hardware queues ("Hardware queues"): the library sets
+    GPU_MAX_HW_QUEUES when it is loaded unless the environment already has it -- checked in a fresh interpreter, without the Python package's own default"""
+    import subprocess, sys
+    from seqlib_amd import _ffi
+    # (the C environment, which the HIP runtime reads: os.environ is Python's copy from start-up)
+    code = ("import ctypes; ctypes.CDLL(%r); c = ctypes.CDLL(None); c.getenv.restype = ctypes.c_char_p; "
+            "v = c.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else None)") % _ffi.SO_PATH
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "16"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "16"
