@@ -964,7 +964,10 @@ static __global__ void __launch_bounds__(256, FML_EC_WAVES) k_fml_ec(const FmlSl
         // byte t of the wave's text is base t - rel_j of read j, the last read that starts at or before t (six shuffles find it): bfc_seq_conv
         auto read_of = [&](int t) -> int {
             int lo = 0;
-            for (int s2 = 32; s2 > 0; s2 >>= 1) { const int mid = lo + s2; if (mid < cnt && __shfl(rel, mid) <= t) lo = mid; }
+            for (int s2 = 32; s2 > 0; s2 >>= 1) {          // (every lane takes part in every shuffle: a lane that sat one out would hand its neighbours nothing)
+                const int mid = lo + s2, v = __shfl(rel, mid < cnt ? mid : 0);
+                if (mid < cnt && v <= t) lo = mid;
+            }
             return lo;
         };
         for (int t0 = 0; t0 < tot; t0 += 64) {

@@ -173,6 +173,27 @@ def test_correct_hard_windows_match_oracle(F, G, ctx, genome):
         assert sum(a != b_ for a, b_ in zip(es, seqs)) > len(seqs) // 4          # most reads are changed: the searches branch
 
 
+def test_correct_batches_that_end_in_a_partial_wave(F, G, ctx, genome):
+    """the correction kernel's waves take 64 consecutive reads and move their text as one stretch (lane = byte, the read of a byte found by shuffles): batches of
+    50, 77, 130 and 191 ragged reads leave the last wave 50, 13, 2 and 63 reads -- every lane must still take part in every shuffle --, and a window of reads that
+    are all shorter than k has nothing to correct or assemble"""
+    for n in (50, 77, 130, 191):
+        seqs, quals, _ = U.sim_window(genome["abl"][5000:5600], n, length=120, err=0.02, seed=40 + n, ragged=True)
+        b, q, o = G.flatten(seqs, quals)
+        kcov, eck, ns, nl = ctx.correct(G.default_opt(), b, q, o, [0, n], flt_uniq=0)
+        ek, ekcov, es, eq = _oracle_window(F, seqs, quals, 0)
+        assert eck[0] == ek and kcov[0] == np.float32(ekcov), (n, eck[0], ek)
+        assert G.unflatten(b, o) == es and G.unflatten(q, o) == eq, "batch of %d reads: corrected reads differ" % n
+    short = [b"ACGTACGTAC"] * 50
+    b, q, o = G.flatten(short, [b"I" * 10] * 50)
+    assert ctx.assemble(G.default_opt(), b, q, o, [0, 50]) == [[]]
+    seqs, quals, _ = U.sim_window(genome["abl"][5000:8000], 1200, length=100, err=0.0, seed=77)
+    b2, q2, o2 = G.flatten(short + seqs, [b"I" * 10] * 50 + quals)
+    wins = ctx.assemble(G.default_opt(), b2, q2, o2, [0, 50, 50 + len(seqs)])
+    exp = F.assemble(F.default_opt(), F.Reads(seqs, quals))
+    assert wins[0] == [] and sorted(u["seq"] for u in wins[1]) == sorted(u["seq"] for u in exp)
+
+
 def test_correction_returns_reads_to_truth(G, ctx, genome):
     seqs, quals, truth = U.sim_window(genome["bcr"][60000:90000], 8000, seed=21)
     b, q, o = G.flatten(seqs, quals)
