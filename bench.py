@@ -865,7 +865,7 @@ def main():
                                    "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], sum(len(g) for _, g in refs), len(refs),
                                                                                       "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
                                                                                       " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
-                       "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
+                       "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": al.counter("hw_queues"), "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
                        "headline": "value = reads resident in HBM -> hits resident in HBM over the K timed steps (the contract's timed region); value_host_to_host = host "
                                    "reads -> host SoA hits through slx_align_batch (the metric as SURVEY 8d words it, PCIe inside); value_bamrecords = SeqLib::BWAAligner::alignSequences with BamRecord output over the whole batch (the north-star "
                                    "sentence read literally); value_per_call = one alignSequence call per read, the reference's calling convention"},

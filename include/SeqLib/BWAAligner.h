@@ -230,9 +230,7 @@ public:
     {
         if (index_->IsEmpty()) return;                       // nothing to do if no index (src/BWAAligner.cpp:101)
         Flush();                                             // queued calls came first: they keep the earlier lrand48 draws
-        const uint64_t offs[2] = {0, (uint64_t)seq.size()};
-        const char *names[1] = {name.c_str()};
-        run(seq.data(), offs, 1, names, nullptr, hardclip, keepSecFrac, maxSecondary, &out, nullptr);
+        combine_call(seq, name, out, hardclip, keepSecFrac, maxSecondary);
     }
     void alignSequence(const UnalignedSequence &us, BamRecordPtrVector &out, bool hardclip, double keepSecFrac, int maxSecondary) const
     {
@@ -570,6 +568,77 @@ private:
             const size_t l_name = reads ? (*reads)[(size_t)(base + i)].Name.size() : std::strlen(nm);
             build_read(h, i, seq, nm, l_name, hardclip, (reads && copyComment_) ? &(*reads)[(size_t)(base + i)].Com : nullptr, dst);
         }
+    }
+
+    // ---- concurrent callers of the per-read entry: flat combining ----------------------------------------
+    // The reference's alignSequence is const, lock-free and re-entrant (SeqLib/BWAAligner.h:51-63): T threads that share one aligner each align
+    // their own read at the same time.  Here a call is a GPU round trip of ~450 us whatever it holds, and the device handle serves one call at
+    // a time -- so T callers would get one round trip each, one after another.  Instead the first caller to arrive becomes the LEADER of a round:
+    // it takes every call that is waiting with the same glue arguments (its own included), reserves their lrand48 draws in one step in ARRIVAL
+    // order (the order in which the reference's threads would have drawn from the process-global stream), aligns them as ONE batch and builds
+    // every caller's records into that caller's vector; callers that arrive while a round runs wait and are served by the next round, led by
+    // one of them.  A lone caller is a leader with a round of one: the single-thread behaviour (records, draws, exceptions) is unchanged.
+    struct CombReq {
+        const std::string *seq, *name; BamRecordPtrVector *out; bool hardclip; double ksf; int maxsec;
+        bool done = false; std::exception_ptr err;
+    };
+    struct Combiner { std::mutex mu; std::condition_variable cv; std::vector<CombReq *> waiting; bool leader = false; };
+    mutable Combiner comb_;
+
+    void combine_call(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double ksf, int maxsec) const
+    {
+        CombReq me{&seq, &name, &out, hardclip, ksf, maxsec};
+        std::unique_lock<std::mutex> lk(comb_.mu);
+        comb_.waiting.push_back(&me);
+        for (;;) {
+            if (me.done) break;
+            if (comb_.leader) { comb_.cv.wait(lk); continue; }
+            // lead one round: the waiting calls whose arguments equal the first one's, in arrival order (the others wait for the next round)
+            comb_.leader = true;
+            std::vector<CombReq *> round, rest;
+            const CombReq &f = *comb_.waiting.front();
+            for (CombReq *r : comb_.waiting) (r->hardclip == f.hardclip && r->ksf == f.ksf && r->maxsec == f.maxsec ? round : rest).push_back(r);
+            comb_.waiting.swap(rest);
+            lk.unlock();
+            std::exception_ptr err;
+            try { run_round(round); } catch (...) { err = std::current_exception(); }
+            lk.lock();
+            for (CombReq *r : round) { r->err = err; r->done = true; }
+            comb_.leader = false;
+            comb_.cv.notify_all();
+        }
+        lk.unlock();
+        if (me.err) std::rethrow_exception(me.err);
+    }
+
+    void run_round(const std::vector<CombReq *> &round) const
+    {
+        const int64_t n = (int64_t)round.size();
+        if (n == 1) {                                        // the lone caller: no copy of the read
+            const uint64_t offs[2] = {0, (uint64_t)round[0]->seq->size()};
+            const char *names[1] = {round[0]->name->c_str()};
+            run(round[0]->seq->data(), offs, 1, names, nullptr, round[0]->hardclip, round[0]->ksf, round[0]->maxsec, round[0]->out, nullptr);
+            return;
+        }
+        std::string bases;
+        std::vector<uint64_t> offs((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) { bases += *round[(size_t)i]->seq; offs[(size_t)i + 1] = bases.size(); }
+        slx_aligner *al = handle();
+        uint64_t state;
+        {
+            std::lock_guard<std::mutex> g(rng_mutex());
+            state = slx_lrand48_peek_libc();
+            slx_lrand48_skip_libc((uint64_t)n);
+        }
+        slx_hits h;
+        throw_rc(slx_align_batch(al, &memopt_, bases.data(), offs.data(), n, state, 0, round[0]->hardclip ? 1 : 0, round[0]->ksf, round[0]->maxsec, &h));
+        try {
+            for (int64_t i = 0; i < n; ++i) {
+                const CombReq &r = *round[(size_t)i];
+                build_read(h, i, std::string_view(bases.data() + offs[(size_t)i], r.seq->size()), r.name->c_str(), r.name->size(), r.hardclip, nullptr, *r.out);
+            }
+        } catch (...) { slx_hits_free(&h); throw; }
+        slx_hits_free(&h);
     }
 
     // one read (the reference's calling convention): one GPU round trip, records built on the calling thread

@@ -212,8 +212,10 @@ int  slx_aligner_stage_ms(const slx_aligner *al, float ms[SLX_N_STAGES]);
 const char *slx_stage_name(int i);
 /* kernel groups of the last batch: duration summed over the workers' launches, from HIP events recorded on the worker's own
  * stream around the group, and the reads those launches processed.  [0] seeding (k_seed12m<1>, k_seed2_select, k_seed12m<2>, k_seed2_coop, k_seed3m, k_seed_epi), [1] the extension
- * family (k_extend_cand | k_cand_lane_prep + k_ext_lanes, k_first_prep, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_lanes + k_cig_dp) */
-#define SLX_N_PROBES 3
+ * family (k_extend_cand | k_cand_lane_prep + k_ext_lanes, k_first_prep, k_first_diag, k_ext_first, k_ext_replay, k_extend_reg), [2] CIGAR (k_cig_fast + k_cig_lanes + k_cig_dp),
+ * [3] chaining (the light / heavy partition, k_chain, k_chain_coop: SA lookups, mem_chain, mem_chain_flt), [4] regions (k_regs1, k_regs_wave, k_regs: mem_sort_dedup_patch,
+ * mem_mark_primary_se, mem_reg2aln's MAPQ and the CIGAR jobs' geometry), [5] hits (k_hits: the glue's sort and secondary filters) */
+#define SLX_N_PROBES 6
 int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t *n_reads);
 /* how many launches of each of those groups the sums cover (= chunks of the last batch over all workers and devices) */
 int  slx_aligner_probe_launches(const slx_aligner *al);

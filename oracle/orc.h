@@ -172,6 +172,17 @@ typedef struct {
     uint64_t glb_cells;     /* ksw_global2 cells */
     uint64_t glb_jobs;
     uint64_t n_reads, n_hits, n_cigar_ops, read_bases;
+    /* chaining and region stages (bench.py roofline_chain / roofline_fin) */
+    uint64_t n_seeds;       /* seeds mem_chain makes (one bwt_sa each; those that bridge contigs are dropped before chaining) */
+    uint64_t n_merge_tests; /* test_and_merge calls (one kbtree interval lookup each) */
+    uint64_t n_chains;      /* chains created (kb_put) */
+    uint64_t n_chains_kept; /* ... left by mem_chain_flt */
+    uint64_t n_flt_pairs;   /* chain pairs compared by mem_chain_flt */
+    uint64_t n_regs;        /* regions mem_chain2aln leaves, before mem_sort_dedup_patch */
+    uint64_t n_dedup_pairs; /* region pairs compared by mem_sort_dedup_patch */
+    uint64_t n_patch;       /* mem_patch_reg alignments among them (their ksw_global2 cells are in glb_cells) */
+    uint64_t n_regs_out;    /* regions after mem_sort_dedup_patch (= NA summed) */
+    uint64_t patch_cells;   /* the part of glb_cells spent in mem_patch_reg */
 } orc_counters;
 void orc_counters_reset(void);
 void orc_counters_get(orc_counters *out);

@@ -76,7 +76,8 @@ class BatchOut(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_extend", "n_occ_block", "n_sa", "n_invpsi", "ref_bases", "ext_cells",
                                           "ext_jobs", "glb_cells", "glb_jobs", "n_reads", "n_hits", "n_cigar_ops",
-                                          "read_bases")]
+                                          "read_bases", "n_seeds", "n_merge_tests", "n_chains", "n_chains_kept", "n_flt_pairs", "n_regs",
+                                          "n_dedup_pairs", "n_patch", "n_regs_out", "patch_cells")]
 
 
 def lib():
@@ -280,7 +281,12 @@ def counters():
 
 def read_fastq(path, limit=None):
     names, seqs = [], []
-    with open(path) as f:
+    if path.endswith(".gz"):
+        import gzip
+        opener = lambda: gzip.open(path, "rt")
+    else:
+        opener = lambda: open(path)
+    with opener() as f:
         while True:
             h = f.readline()
             if not h:

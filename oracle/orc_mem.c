@@ -548,11 +548,14 @@ static int mem_chain(const orc_opt *opt, const orc_index *idx, int len, const ui
             s.score = s.len = slen;
             rid = bns_intv2rid(idx, s.rbeg, s.rbeg + s.len);
             if (rid < 0) continue; /* bridging contigs or the forward-reverse boundary */
+            ++g_cnt.n_seeds;
             if (n_keys) {
                 orc_chain *lower = kb_interval_lower(root, s.rbeg);
+                ++g_cnt.n_merge_tests;
                 if (!lower || !test_and_merge(opt, l_pac, lower, &s, rid)) to_add = 1;
             } else to_add = 1;
             if (to_add) {
+                ++g_cnt.n_chains;
                 orc_chain tmp;
                 memset(&tmp, 0, sizeof tmp);
                 tmp.pos = s.rbeg;
@@ -619,6 +622,7 @@ static int mem_chain_flt(const orc_opt *opt, int n_chn, orc_chain *a)
         int large_ovlp = 0;
         for (k = 0; k < n_kept; ++k) {
             int j = chains[k];
+            ++g_cnt.n_flt_pairs;
             int b_max = chn_beg(a[j]) > chn_beg(a[i]) ? chn_beg(a[j]) : chn_beg(a[i]);
             int e_min = chn_end(a[j]) < chn_end(a[i]) ? chn_end(a[j]) : chn_end(a[i]);
             if (e_min > b_max && (!a[j].is_alt || a[i].is_alt)) {
@@ -654,6 +658,7 @@ static int mem_chain_flt(const orc_opt *opt, int n_chn, orc_chain *a)
         if (c->kept == 0) free(c->seeds);
         else a[k++] = a[i];
     }
+    g_cnt.n_chains_kept += (uint64_t)k;
     return k;
 }
 
@@ -1137,8 +1142,11 @@ static int mem_patch_reg(const orc_opt *opt, const orc_index *idx, uint8_t *quer
     } else if (w > opt->w << 2 || r >= PATCH_MAX_R_BW * 2) return 0;
     w += a->w + b->w;
     w = w < opt->w << 2 ? w : opt->w << 2;
+    ++g_cnt.n_patch;
+    const uint64_t cells_before = g_cnt.glb_cells;
     gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w, idx->l_pac, idx->pac, b->qe - a->qb, query + a->qb,
                a->rb, b->re, &score, 0, 0);
+    g_cnt.patch_cells += g_cnt.glb_cells - cells_before;
     q_s = (int)((double)(b->qe - a->qb) / ((b->qe - b->qb) + (a->qe - a->qb)) * (b->score + a->score) + .499);
     r_s = (int)((double)(b->re - a->rb) / ((b->re - b->rb) + (a->re - a->rb)) * (b->score + a->score) + .499);
     if ((double)score / (q_s > r_s ? q_s : r_s) < PATCH_MIN_SC_RATIO) return 0;
@@ -1149,7 +1157,8 @@ static int mem_patch_reg(const orc_opt *opt, const orc_index *idx, uint8_t *quer
 static int mem_sort_dedup_patch(const orc_opt *opt, const orc_index *idx, uint8_t *query, int n, orc_reg *a)
 {
     int m, i, j;
-    if (n <= 1) return n;
+    g_cnt.n_regs += (uint64_t)n;
+    if (n <= 1) { g_cnt.n_regs_out += (uint64_t)n; return n; }
     introsort_ars2((size_t)n, a); /* by END position */
     for (i = 0; i < n; ++i) a[i].n_comp = 1;
     for (i = 1; i < n; ++i) {
@@ -1159,6 +1168,7 @@ static int mem_sort_dedup_patch(const orc_opt *opt, const orc_index *idx, uint8_
             orc_reg *q = &a[j];
             int64_t or_, oq, mr, mq;
             int score, w;
+            ++g_cnt.n_dedup_pairs;
             if (q->qe == q->qb) continue;
             or_ = q->re - p->rb;
             oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
@@ -1188,6 +1198,7 @@ static int mem_sort_dedup_patch(const orc_opt *opt, const orc_index *idx, uint8_
             a[i].qe = a[i].qb;
     for (i = 1, m = 1; i < n; ++i)
         if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    g_cnt.n_regs_out += (uint64_t)m;
     return m;
 }
 

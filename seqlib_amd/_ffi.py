@@ -12,7 +12,7 @@ SO_PATH = os.environ.get("SLX_LIB") or os.path.join(HERE, "libseqlib_amd.so")   
 
 SLX_OK, SLX_EINVAL, SLX_EIO, SLX_ENOMEM, SLX_ENODEVICE, SLX_EUNSUPPORTED, SLX_EINTERNAL = 0, -1, -2, -3, -4, -5, -6
 SLX_N_STAGES = 8
-SLX_N_PROBES = 3
+SLX_N_PROBES = 6
 SLX_MAX_READ_LEN = 1000000
 SLX_F_REG2SAM = 0x40000000
 

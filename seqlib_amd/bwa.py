@@ -241,11 +241,11 @@ class BWAAligner:
             return buf[:n.value].copy()
 
     def probe_ms(self):
-        """({"seed", "extend", "cigar"} -> ms, reads): summed launch durations of three kernel groups of the last batch
+        """({"seed", "extend", "cigar", "chain", "regions", "hits"} -> ms, reads): summed launch durations of six kernel groups of the last batch
         (HIP events on the workers' own streams)"""
         ms, n = (C.c_float * _ffi.SLX_N_PROBES)(), C.c_int64()
         _ffi.check(_ffi.lib().slx_aligner_probe_ms(self._handle(), ms, C.byref(n)))
-        return dict(seed=ms[0], extend=ms[1], cigar=ms[2]), n.value
+        return dict(seed=ms[0], extend=ms[1], cigar=ms[2], chain=ms[3], regions=ms[4], hits=ms[5]), n.value
 
     def probe_launches(self):
         """launches of each probed kernel group in the last batch (chunks over all workers and devices)"""

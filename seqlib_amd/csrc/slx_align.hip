@@ -207,6 +207,7 @@ static int build_rep_filter(slx_aligner *al)
 }
 
 #define SLX_MAX_WORKERS 8
+static int env_hw_queues() { const char *e = getenv("GPU_MAX_HW_QUEUES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }
 
 // Three workers, each taking its part of a batch in chunks of up to 16 M reads.  Measured alternatives on C3 (50 M reads): chunks of 8 M reads
 // (two per worker) 53.4 M reads/s against 55.1 M (the single-read tails of a chunk are paid once per chunk); four / five workers
@@ -266,6 +267,7 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
     al->max_threads = al->n_cu * al->threads_per_cu;
     int rcw;
     al->n_workers = default_workers();
+    al->hw_queues = env_hw_queues();
     for (int k = 0; k < al->n_workers; ++k) if ((rcw = add_worker(al)) != SLX_OK) return rcw;
     HIPCHK(hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking));
     al->host_idx = idx;
@@ -314,9 +316,9 @@ static int aligner_init(slx_aligner *al, const slx_index *idx, const int *device
 
 // Several aligners (and fml contexts) side by side in one process -- the C5 pipeline drives four objects from four host threads -- have a dozen streams
 // between them; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless told otherwise, and two aligners whose streams share queues run
-// one after the other (measured: two realignments side by side took exactly twice one's time; 1.2 x with 8 queues).  The runtime reads the variable when it
-// initialises: set here at load time unless the caller has set it; a process that has already made HIP calls keeps what it started with.
-__attribute__((constructor)) static void slx_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// one after the other (measured: two realignments side by side took exactly twice one's time; 1.2 x with 8 queues).  The runtime reads the variable ONCE, when
+// it initialises, for every HIP user of the process: that is the application's setting to make, not a library's (bench.py and the tests export
+// it themselves).  The library only REPORTS what it found: slx_aligner_counter(al, "hw_queues") = the variable's value when the aligner was created, 4 if unset.
 
 static std::mutex g_live_mu;
 static int g_live_aligners = 0;                 // single-device aligners alive: the pinned-block pool is released with the last one
@@ -543,6 +545,7 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
 {   // what the last batch held (diagnostics and tests: "did that kernel see any work?"); -1 for an unknown key
     if (!al || !key) return -1;
     if (!strcmp(key, "workers")) return al->is_group ? al->subs[0]->n_workers : al->n_workers;     // (per device)
+    if (!strcmp(key, "hw_queues")) return al->hw_queues;          // GPU_MAX_HW_QUEUES as the process had it when the aligner was created (4 = the runtime's default)
     if (!strcmp(key, "long_rounds") || !strcmp(key, "long_jobs")) {       // extension rounds / seed jobs of the last long-read chunk (largest over the workers)
         long long v = 0;
         const bool rounds = key[5] == 'r';

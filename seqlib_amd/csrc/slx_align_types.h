@@ -103,7 +103,7 @@ struct Worker {
     hipEvent_t ev[SLX_N_STAGES + 1];
     hipEvent_t ev_probe[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around the seeding kernels / the extension family / the CIGAR kernels
     float stage_ms[SLX_N_STAGES];
-    float probe_ms[SLX_N_PROBES] = {0, 0, 0};
+    float probe_ms[SLX_N_PROBES] = {0, 0, 0, 0, 0, 0};
     int n_chunks = 0;                    // chunks this worker ran in the current batch
     long long cnt[4] = {0, 0, 0, 0};     // ... and what they held: heavy reads, pass-2 calls as single items, of those one wave each, pass-2 whole reads
     int64_t n_hits = 0, n_cig = 0;
@@ -204,6 +204,7 @@ struct slx_aligner {
     int seed_free_cus = 0;        // see "seed_free_cus" in slx_aligner_set
     int stream_prio = 0;
     int n_workers = 3;            // concurrent parts of a large batch
+    int hw_queues = 4;            // GPU_MAX_HW_QUEUES of the process when the aligner was created (reported, never set: slx_aligner_counter "hw_queues")
     int active_k = 1;             // workers running in the current call
     int64_t min_split = 1 << 18;  // batches smaller than 2 * min_split run on one worker
     int max_threads = 0;
@@ -223,7 +224,7 @@ struct slx_aligner {
     DevBuf st_bases, st_offs, st_pack;
     unsigned char *h_bounce = nullptr;   // pinned: a small result is packed straight into it by one kernel (SLX_BOUNCE_BYTES)
     float stage_ms[SLX_N_STAGES];
-    float probe_ms[SLX_N_PROBES] = {0, 0, 0};   // kernel groups of the last batch, summed over the workers' launches (HIP events on the workers' streams)
+    float probe_ms[SLX_N_PROBES] = {0, 0, 0, 0, 0, 0};   // kernel groups of the last batch, summed over the workers' launches (HIP events on the workers' streams)
     int64_t probe_reads = 0;
     long long counters[4] = {0, 0, 0, 0};       // slx_aligner_counter: sums of the workers' cnt[] over the last batch
     int probe_launches = 0;                     // chunks (= launches of each kernel group) of the last batch, over all workers

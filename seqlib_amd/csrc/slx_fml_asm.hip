@@ -205,8 +205,9 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         }
         // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
         FmlDevBuf &d_edges = f->d_scratch;
-        // (e_out: every wave of k_asm_reduce may leave most of one FML_OUT_CHUNK unused)
-        const unsigned long long out_cap = n_edges + 1 + (unsigned long long)grid_str * 4 * FML_OUT_CHUNK;
+        // (e_out: a wave of k_asm_reduce that meets a vertex with more kept edges than its stretch has left abandons the rest of it -- up to 63 of FML_OUT_CHUNK = 128
+        // slots per stretch, so reserved slots stay below 128 / 65 x kept edges --, and leaves most of its last stretch unused; n_out is checked after the launches)
+        const unsigned long long out_cap = 2 * (n_edges + 1) + (unsigned long long)grid_str * 4 * FML_OUT_CHUNK;
         if ((rc = d_edges.ensure((size_t)(n_edges + 1) * (sizeof(FmlEdge) * 2 + 1) + (size_t)out_cap * sizeof(FmlEdge) + ns * 8 + 256))) return rc;
         FmlEdge *e_raw = d_edges.as<FmlEdge>(), *e_sorted = e_raw + n_edges + 1, *e_out = e_sorted + n_edges + 1;
         unsigned char *e_flags = (unsigned char *)(e_out + out_cap);
@@ -247,6 +248,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         FML_HIPCHK(hipMemcpyAsync(h_irroff, d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
         FML_HIPCHK(hipStreamSynchronize(f->st_copy));
+        if (n_out > out_cap) { slx_set_error("fml: the reduction reserved %llu edge slots, %llu were sized (internal)", n_out, out_cap); return SLX_EINTERNAL; }
         // the edges, then (filled per window below) their targets and lengths as the graph stage wants them: edges | edge_v | edge_len
         if (f->h_asm2.ensure(((size_t)n_out + 1) * (sizeof(FmlEdge) + 8) + 256)) { slx_set_error("fml: out of pinned host memory (%llu edges)", n_out); return SLX_ENOMEM; }
         h_out = (const FmlEdge *)f->h_asm2.p;

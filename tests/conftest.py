@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the application's setting: aligners / fml contexts side by side in one process; read when the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):
@@ -39,6 +41,14 @@ def sim_reads(orc):
 
 @pytest.fixture(scope="session")
 def sl():
+    # torch brings its own copy of the HIP runtime: a test that wants device tensors (the device-resident entry) needs torch to initialise the GPU BEFORE
+    # libseqlib_amd.so pulls in /opt/rocm's -- the order bench.py uses; the other way round torch finds "no HIP GPUs"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import seqlib_amd
     from seqlib_amd import _ffi
     _ffi.lib()   # raises if the HIP extension is missing: there is no fallback

@@ -245,36 +245,62 @@ static int thread_checks(const std::string &prefix, const std::string &fastq, lo
     while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q) && (long)reads.size() < n)
         reads.emplace_back(h.substr(1), s, q);
     n = (long)reads.size();
-    std::vector<std::string> pass1((size_t)n), pass2((size_t)n), par((size_t)n);
-    for (int rep = 0; rep < 2; ++rep)
+    // concurrent calls are combined into shared GPU round trips (BWAAligner.h, "flat combining"): once with one argument set for every call, once with the
+    // glue arguments differing from read to read (a round only takes the calls whose arguments agree; the others are served by the next one)
+    for (int mixed = 0; mixed < 2; ++mixed) {
+        auto hc = [&](long i) { return mixed && i % 3 == 0; };
+        auto ms = [&](long i) { return mixed && i % 5 == 0 ? 1 : 10; };
+        std::vector<std::string> pass1((size_t)n), pass2((size_t)n), par((size_t)n);
+        for (int rep = 0; rep < 2; ++rep)
+            for (long i = 0; i < n; ++i) {
+                BamRecordPtrVector out;
+                bwa.alignSequence(reads[(size_t)i], out, hc(i), 0.9, ms(i));
+                (rep ? pass2 : pass1)[(size_t)i] = rec_key(out);
+            }
+        std::atomic<long> next(0);
+        std::atomic<int> failures(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&]() {
+                try {
+                    for (long i; (i = next.fetch_add(1)) < n;) {
+                        BamRecordPtrVector out;
+                        bwa.alignSequence(reads[(size_t)i], out, hc(i), 0.9, ms(i));
+                        par[(size_t)i] = rec_key(out);
+                        for (auto &r : out) if (r->Qname() != reads[(size_t)i].Name) ++failures;          // a caller gets ITS read's records
+                    }
+                } catch (const std::exception &e) { std::fprintf(stderr, "thread: %s\n", e.what()); ++failures; }
+            });
+        for (auto &x : th) x.join();
+        CHECK(failures == 0);
+        long stable = 0, bad = 0;
         for (long i = 0; i < n; ++i) {
-            BamRecordPtrVector out;
-            bwa.alignSequence(reads[(size_t)i], out, false, 0.9, 10);
-            (rep ? pass2 : pass1)[(size_t)i] = rec_key(out);
+            if (pass1[(size_t)i] != pass2[(size_t)i]) continue;        // depends on the tie-breaking draw
+            ++stable;
+            if (par[(size_t)i] != pass1[(size_t)i]) { if (!bad) std::fprintf(stderr, "read %ld differs:\n %s\n %s\n", i, par[(size_t)i].c_str(), pass1[(size_t)i].c_str()); ++bad; }
         }
-    std::atomic<long> next(0);
-    std::atomic<int> failures(0);
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t)
-        th.emplace_back([&]() {
-            try {
-                for (long i; (i = next.fetch_add(1)) < n;) {
-                    BamRecordPtrVector out;
-                    bwa.alignSequence(reads[(size_t)i], out, false, 0.9, 10);
-                    par[(size_t)i] = rec_key(out);
-                }
-            } catch (const std::exception &e) { std::fprintf(stderr, "thread: %s\n", e.what()); ++failures; }
-        });
-    for (auto &x : th) x.join();
-    CHECK(failures == 0);
-    long stable = 0, bad = 0;
-    for (long i = 0; i < n; ++i) {
-        if (pass1[(size_t)i] != pass2[(size_t)i]) continue;        // depends on the tie-breaking draw
-        ++stable;
-        if (par[(size_t)i] != pass1[(size_t)i]) { if (!bad) std::fprintf(stderr, "read %ld differs:\n %s\n %s\n", i, par[(size_t)i].c_str(), pass1[(size_t)i].c_str()); ++bad; }
+        std::printf("threads=%d reads=%ld mixed=%d stable=%ld mismatches=%ld\n", T, n, mixed, stable, bad);
+        CHECK(bad == 0 && stable > n * 9 / 10);
     }
-    std::printf("threads=%d reads=%ld stable=%ld mismatches=%ld\n", T, n, stable, bad);
-    CHECK(bad == 0 && stable > n * 9 / 10);
+    {   // an error in a shared round reaches every caller of that round as the exception a lone call would throw, and the aligner stays usable
+        std::atomic<int> threw(0), fine(0);
+        const std::string too_long((size_t)SLX_MAX_READ_LEN + 8, 'A');
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                for (int k = 0; k < 4; ++k) {
+                    BamRecordPtrVector out;
+                    try { bwa.alignSequence(t == 0 ? too_long : reads[(size_t)((t * 4 + k) % n)].Seq, "x", out, false, 0.9, 10); ++fine; }
+                    catch (const std::exception &) { ++threw; }
+                }
+            });
+        for (auto &x : th) x.join();
+        CHECK(threw >= 4);                       // thread 0's four calls at least (and whoever shared a round with them)
+        BamRecordPtrVector out;
+        bwa.alignSequence(reads[0].Seq, "after", out, false, 0.9, 10);
+        CHECK(!out.empty());
+        std::printf("error rounds: %d calls threw, %d were fine\n", threw.load(), fine.load());
+    }
     return 0;
 }
 

@@ -170,15 +170,16 @@ def test_product_does_not_touch_the_oracle():
     assert not bad, bad
 
 
-def test_library_load_asks_for_eight_hardware_queues():
-    """several aligners / fml contexts side by side need more than the runtime's four hardware queues ("Hardware queues"): the library sets
-    GPU_MAX_HW_QUEUES when it is loaded unless the environment already has it -- checked in a fresh interpreter, without the Python package's own default"""
+def test_library_load_leaves_the_environment_alone():
+    """several aligners / fml contexts side by side want more than the runtime's four hardware queues ("Hardware queues"), but
+    GPU_MAX_HW_QUEUES is read once per PROCESS by the HIP runtime and belongs to the application: loading the library, or importing the Python
+    package, must not set it -- checked in a fresh interpreter on the C environment (os.environ is Python's copy from start-up)"""
     import subprocess, sys
     from seqlib_amd import _ffi
-    # (the C environment, which the HIP runtime reads: os.environ is Python's copy from start-up)
-    code = ("import ctypes; ctypes.CDLL(%r); c = ctypes.CDLL(None); c.getenv.restype = ctypes.c_char_p; "
-            "v = c.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else None)") % _ffi.SO_PATH
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys; sys.path.insert(0, %r); ctypes.CDLL(%r); import seqlib_amd; c = ctypes.CDLL(None); c.getenv.restype = ctypes.c_char_p; "
+            "v = c.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else None)") % (root, _ffi.SO_PATH)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "8"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "None"
     env["GPU_MAX_HW_QUEUES"] = "16"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "16"

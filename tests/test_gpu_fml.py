@@ -194,6 +194,62 @@ def test_correct_batches_that_end_in_a_partial_wave(F, G, ctx, genome):
     assert wins[0] == [] and sorted(u["seq"] for u in wins[1]) == sorted(u["seq"] for u in exp)
 
 
+@pytest.mark.timeout(1800)
+def test_window_shape_sweep(F, G, ctx, genome):
+    """the aligner's batch-shape sweep (tests/test_gpu_parity.py::test_batch_shape_sweep) for this library's entry points: windows of 1, 2, 3, 31,
+    50, 63, 64, 65, 127, 129, 255, 257 and 1 000 reads -- a last wave of every fill in the kernels that take 64 reads or 64 strings per wave --
+    alone, and all thirteen as ONE call (window boundaries inside waves), through correct (both filters), assemble and direct_assemble"""
+    sizes = (1, 2, 3, 31, 50, 63, 64, 65, 127, 129, 255, 257, 1000)
+    wins = []
+    for n in sizes:
+        span = max(300, min(4000, n * 12))                       # ~12x of 150 bp reads, at least a couple of reads deep
+        wins.append(U.sim_window(genome["bcr"][30000 + 7 * n:30000 + 7 * n + span], n, length=150 if n % 2 else 110, err=0.01, seed=900 + n, ragged=(n % 3 == 0)))
+    opt = G.default_opt()
+
+    def check_correct(group, flt):
+        seqs = [s for w in group for s in wins[w][0]]
+        quals = [q for w in group for q in wins[w][1]]
+        win_off = np.cumsum([0] + [len(wins[w][0]) for w in group])
+        b, q, o = G.flatten(seqs, quals)
+        kcov, eck, ns, nl = ctx.correct(opt, b, q, o, win_off, flt_uniq=flt)
+        got_s, got_q = G.unflatten(b, o), G.unflatten(q, o)
+        for gi, w in enumerate(group):
+            ek, ekcov, es, eq = _oracle_window(F, wins[w][0], wins[w][1], flt)
+            tag = "window of %d reads (call of %d windows, flt %d)" % (sizes[w], len(group), flt)
+            assert eck[gi] == ek and kcov[gi] == np.float32(ekcov), tag
+            r0, r1 = win_off[gi], win_off[gi + 1]
+            if flt:
+                for i in range(r0, r1):
+                    assert wins[w][0][i - r0][ns[i]:ns[i] + nl[i]] == es[i - r0], tag
+            else:
+                assert got_s[r0:r1] == es and got_q[r0:r1] == eq, tag
+
+    def check_assemble(group):
+        seqs = [s for w in group for s in wins[w][0]]
+        quals = [q for w in group for q in wins[w][1]]
+        win_off = np.cumsum([0] + [len(wins[w][0]) for w in group])
+        b, q, o = G.flatten(seqs, quals)
+        got = ctx.assemble(opt, b, q, o, win_off)
+        for gi, w in enumerate(group):
+            exp = F.assemble(F.default_opt(), F.Reads(wins[w][0], wins[w][1]))
+            _same_utgs(got[gi], exp, "window of %d reads (call of %d windows)" % (sizes[w], len(group)))
+
+    for w in range(len(sizes)):
+        check_correct([w], 0)
+        check_correct([w], 1)
+        check_assemble([w])
+    everything = list(range(len(sizes)))
+    check_correct(everything, 0)
+    check_correct(everything, 1)
+    check_assemble(everything)
+    check_assemble(everything[::-1])
+    # the overlap graph straight from given reads (FermiAssembler::DirectAssemble)
+    for w in (0, 2, 4, 7, 9, 12):
+        b, _, o = G.flatten(wins[w][0])
+        got = ctx.direct_assemble(G.default_opt(), 20.0, b, o)
+        _same_utgs(got, F.direct_assemble(F.default_opt(), 20.0, F.Reads(wins[w][0])), "direct_assemble of %d reads" % sizes[w])
+
+
 def test_correction_returns_reads_to_truth(G, ctx, genome):
     seqs, quals, truth = U.sim_window(genome["bcr"][60000:90000], 8000, seed=21)
     b, q, o = G.flatten(seqs, quals)

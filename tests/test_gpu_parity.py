@@ -41,6 +41,116 @@ def test_fixture_reads_match_oracle_and_golden(sl, orc, tiny_gpu, tiny_index, si
         assert "\n".join(lines) + "\n" == open(os.path.join(golden_dir, fn)).read()
 
 
+def test_full_fixture_20000_reads(sl, orc, tiny_gpu, tiny_index, golden_dir):
+    """SURVEY 8d "always run the real fixture": ALL of the reference's tests/data/sim1_bcr.fq + sim2_bcr.fq (10 000 reads each) x tiny.fa:
+    GPU == oracle == the committed records (whose primaries tests/test_oracle.py::test_wgsim_truth_full_fixture holds against the wgsim
+    truth in the read names -- the only position truth the reference carries); once per file and once as one 20 000-read batch"""
+    import gzip
+    both, exp_both = [], []
+    for k in (1, 2):
+        _, seqs = orc.read_fastq(os.path.join(golden_dir, "sim%d_bcr.fq.gz" % k))
+        assert len(seqs) == 10000
+        al = sl.BWAAligner(tiny_gpu)
+        got = al.alignSequences(seqs)
+        assert_same(got, orc.align_batch(orc.default_opt(), tiny_index, seqs), "sim%d_bcr.fq" % k)
+        lines = []
+        for i in range(len(seqs)):
+            for j, r in enumerate(sl.records_of(got, i)):
+                lines.append("\t".join(map(str, [i, j, r["flag"], r["rid"], r["pos"], r["mapq"], sl.cigar_str(r["cigar"]), r["AS"], r["NM"], r["NA"]])))
+        assert "\n".join(lines) + "\n" == gzip.open(os.path.join(golden_dir, "sim%d_full.records.tsv.gz" % k), "rt").read()
+        both += seqs
+    al = sl.BWAAligner(tiny_gpu)
+    al.set("split_min", 16)
+    al.set("heavy_seeds", 8)
+    al.set("chunk_reads", 7777)
+    assert_same(al.alignSequences(both), orc.align_batch(orc.default_opt(), tiny_index, both), "both files as one batch, production schedule in ragged chunks")
+
+
+SWEEP_SIZES = (1, 2, 3, 31, 50, 63, 64, 65, 127, 129, 255, 257, 1000)
+SWEEP_KNOBS = ((), (("workers", 1),), (("min_split", 2),), (("chunk_reads", 37),), (("split_min", 1), ("heavy_seeds", 1)), (("split_min", 1), ("heavy_seeds", 3), ("cand_seeds", 1)),
+               (("split_min", 1), ("heavy_seeds", 3), ("cand_seeds", 1), ("cand_lanes", 0)), (("split_min", 1), ("heavy_seeds", 3), ("cand_seeds", 1), ("cand_lanes", 1), ("cand_lane_seeds", 1)),
+               (("split_min", 1), ("heavy_seeds", 8), ("ext_split", 0)), (("split_min", 1), ("heavy_seeds", 3), ("coop_lim1", 2), ("coop_lim2", 3)),
+               (("split_min", 1), ("heavy_seeds", 8), ("regs_big", 2)), (("split_min", 1), ("heavy_seeds", 8), ("first_diag", 0), ("lane_narrow", 0)),
+               (("regs_big", 2),), (("regs_big", 1 << 30),), (("cig_lanes", 0),), (("p2_items", 0),), (("p2_coop", 0),), (("p2_items_cap", 3),), (("dense_sa", 0),),
+               (("chain_mode", 0),), (("wide_index", 1),), (("lut_k", 0),), (("cap_intv", 2),), (("seed_quota", 64),), (("rep_k", 0),))
+
+
+def _sweep_pool(orc, golden_dir, sim_reads):
+    """reads of every kind the kernels route differently: fixture reads of both files, the edge cases, long reads (seed filter,
+    block extension kernels, band CIGAR kernels) -- shuffled so that every batch prefix is a mix"""
+    names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    (_, s1), (_, s2) = sim_reads
+    rng = np.random.default_rng(611)
+    pool = list(s1[:600]) + list(s2[:600]) + ["", "ACGT", "N" * 150, "A" * 150, "AC" * 75, "ACGTACGTACGTACGTAC", refs[0][5000:5150].lower()] * 6
+    for L in (19, 20, 33, 75, 100, 149, 151, 250, 400, 699, 760, 1200, 2500):
+        for _ in range(4):
+            c = int(rng.integers(0, 4))
+            p0 = int(rng.integers(0, len(refs[c]) - L))
+            t = list(refs[c][p0:p0 + L])
+            for q in rng.integers(0, L, size=max(1, L // 60)):
+                t[int(q)] = "ACGT"[int(rng.integers(0, 4))]
+            if L > 200:
+                del t[L // 3:L // 3 + 3]
+            pool.append("".join(t))
+    return [pool[int(i)] for i in rng.permutation(len(pool))]
+
+
+@pytest.mark.timeout(1800)
+def test_batch_shape_sweep(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir):
+    """The class of bug cfbfae0 fixed in one kernel (a lane that sits out a shuffle, a loop bound taken from a full wave), looked for in all of
+    them: batches of 1, 2, 3, 31, 50, 63, 64, 65, 127, 129, 255, 257 and 1 000 mixed reads -- last waves of every fill -- through every entry
+    point (host batch, device-resident batch + slx_hits_pack, one read per call, a group handle, the record mode, hard clips) and every
+    schedule knob that routes reads to other kernels, against the oracle.  Every batch starts at a different offset of the pool so that the
+    partial wave holds different kinds of reads."""
+    import torch
+    from seqlib_amd import _ffi, gather
+    pool = _sweep_pool(orc, golden_dir, sim_reads)
+    opt = orc.default_opt()
+    checked = 0
+    for n_i, n in enumerate(SWEEP_SIZES):
+        lo = (n_i * 97) % (len(pool) - n)
+        seqs = pool[lo:lo + n]
+        exp = orc.align_batch(opt, tiny_index, seqs)
+        for knobs in SWEEP_KNOBS:
+            al = sl.BWAAligner(tiny_gpu)
+            for k, v in knobs:
+                al.set(k, v)
+            assert_same(al.alignSequences(seqs), exp, "n=%d %s" % (n, knobs))
+            checked += 1
+        # hard clips, the glue's filters at other settings
+        al = sl.BWAAligner(tiny_gpu)
+        assert_same(al.alignSequences(seqs, hardclip=True, keepSecFrac=0.0, maxSecondary=3),
+                    orc.align_batch(opt, tiny_index, seqs, hardclip=True, keep_sec_frac=0.0, max_secondary=3), "n=%d hardclip" % n)
+        # device-resident entry + the packed image
+        bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in seqs])
+        d_bases = torch.from_numpy(np.concatenate([bases, np.zeros(8, np.uint8)])).cuda()
+        d_offs = torch.from_numpy(offs.view(np.int64).copy()).cuda()
+        al = sl.BWAAligner(tiny_gpu)
+        h = al.align_device(d_bases.data_ptr(), d_offs.data_ptr(), n, first_ordinal=0)
+        sz = al.packed_size(h)
+        buf = torch.empty(sz, dtype=torch.uint8, device="cuda")
+        al.pack_into(h, buf.data_ptr(), sz)
+        torch.cuda.synchronize()
+        got = gather.unpack(buf.cpu().numpy())
+        for k in FIELDS:
+            assert np.array_equal(got[k], exp[k]), "n=%d device entry + pack: %s" % (n, k)
+        # a group handle (device 0 three times: shards of n / 3 reads, fewer reads than members for n < 3)
+        al = sl.BWAAligner(tiny_gpu, device=[0, 0, 0])
+        assert_same(al.alignSequences(seqs), exp, "n=%d group of three" % n)
+        # one read per call
+        if n <= 65:
+            al = sl.BWAAligner(tiny_gpu)
+            for i, sq in enumerate(seqs):
+                assert al.alignSequence(sq) == sl.records_of(exp, i), "n=%d per-call read %d" % (n, i)
+        # bwa's own record mode
+        if n in (1, 3, 50, 65, 257):
+            _check_sam_mode(sl, orc, tiny_gpu, tiny_index, seqs, "n=%d record mode" % n)
+            _check_sam_mode(sl, orc, tiny_gpu, tiny_index, seqs, "n=%d record mode, wave region kernel" % n, knobs=(("regs_big", 2), ("split_min", 1), ("heavy_seeds", 8)))
+    assert checked == len(SWEEP_SIZES) * len(SWEEP_KNOBS)
+
+
 def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads):
     """the production schedule (light / heavy partition, cooperative chaining, split extension) forced on a small batch
     with low seed-count thresholds"""

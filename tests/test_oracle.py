@@ -103,6 +103,64 @@ def test_wgsim_truth(orc, tiny_index, sim_reads):
     assert ok >= tot - 15, (ok, tot)  # junction reads may put the primary on the other side of the fusion
 
 
+def _golden_full(golden_dir, k):
+    import gzip
+    return gzip.open(os.path.join(golden_dir, "sim%d_full.records.tsv.gz" % k), "rt").read()
+
+
+@pytest.fixture(scope="module")
+def full_fixture(orc, golden_dir):
+    """the reference's two fixture files in full (tests/data/sim{1,2}_bcr.fq: 10 000 reads each), SURVEY 8d"""
+    return [orc.read_fastq(os.path.join(golden_dir, "sim%d_bcr.fq.gz" % k)) for k in (1, 2)]
+
+
+def test_full_fixture_golden_current(orc, tiny_index, full_fixture, golden_dir):
+    """all 20 000 fixture reads through the oracle's batch entry == the committed records (make_golden.py goes read by read through
+    align_sequence: the two entries of the checker agree as well), and the head-3000 files are prefixes of the full ones"""
+    import seqlib_amd.bwa as B
+    for k, (names, seqs) in zip((1, 2), full_fixture):
+        assert len(seqs) == 10000
+        res = orc.align_batch(orc.default_opt(), tiny_index, seqs)
+        lines = []
+        for i in range(len(seqs)):
+            for j, r in enumerate(B.records_of(res, i)):
+                lines.append("\t".join(map(str, [i, j, r["flag"], r["rid"], r["pos"], r["mapq"], orc.cigar_str(r["cigar"]), r["AS"], r["NM"], r["NA"]])))
+        txt = _golden_full(golden_dir, k)
+        assert "\n".join(lines) + "\n" == txt, "sim%d" % k
+        head = open(os.path.join(golden_dir, "sim%d_head3000.records.tsv" % k)).read()
+        assert txt.startswith(head)
+
+
+def test_wgsim_truth_full_fixture(orc, tiny_index, full_fixture, golden_dir):
+    """the only position truth the reference holds: wgsim wrote every fragment's two ends into the read names.  Every one of the 20 000
+    reads has a record, and its primary lands on an end of its fragment (within indel slack) except where the fragment crosses the
+    BCR-ABL junction of the simulated genome or the read is a repeat copy; reads of file 1 come from one end, reads of file 2 from the
+    other, on opposite strands."""
+    bad = n_rev = 0
+    for k, (names, seqs) in zip((1, 2), full_fixture):
+        recs = {}
+        for l in _golden_full(golden_dir, k).splitlines():
+            f = l.split("\t")
+            if f[1] == "0":
+                recs[int(f[0])] = f
+        assert len(recs) == len(seqs), "every fixture read has a record"
+        for i, nm in enumerate(names):
+            s, e = _truth(nm)
+            f = recs[i]
+            rid, pos, cig = int(f[3]), int(f[4]), f[6]
+            import re
+            ops = [(int(a), b) for a, b in re.findall(r"(\d+)([MIDSH])", cig)]
+            reflen = sum(a for a, b in ops if b in "MD")
+            lead = ops[0][0] if ops[0][1] == "S" else 0
+            trail = ops[-1][0] if ops[-1][1] == "S" else 0
+            cands = [_bcrabl_to_tiny(x) for x in (s, e - 149)]
+            hit = any(rid == c[0] and (abs((pos - lead) - c[1]) <= 12 or abs((pos + reflen + trail) - (c[1] + 150)) <= 12) for c in cands)
+            bad += not hit
+            n_rev += (int(f[2]) & 16) != 0
+    assert bad <= 40, bad        # 16 today: junction-crossing fragments and reads inside repeats
+    assert 9000 <= n_rev <= 11000, n_rev
+
+
 def test_record_invariants(orc, tiny_index, sim_reads, golden_dir):
     """sum(query-consuming ops) == read length; error-free unique read => 150M AS150 MAPQ60 NM0."""
     (n1, s1), _ = sim_reads
