@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CU x 4 SIMD x 16 lanes/cycle x 2.4 GHz = 39.3 T int32 lane-ops/s
 DEFAULT_READS = {"C1": 1000, "C2": 10_000_000, "C3": 50_000_000, "C4": 25_000_000, "C4h": 25_000_000}
-ROUND = "r05"
+ROUND = "r06"
 def _latest(name):
     """profiles/<round>_<name> of this round, else of the latest earlier round that has one (the line names the file it used)"""
     for r in range(int(ROUND[1:]), 0, -1):
@@ -222,38 +222,39 @@ def c5_workload(rank, n_win, reads_per_win, coverage, read_len=150):
 
 
 def c5_cpu_baseline(coverage, read_len, sample_reads, index_prefix=None):
-    """The CPU checkers on one thread -- the reference runs fermi-lite with n_threads = 1 (fml_opt_init) and one alignSequence per contig -- over BOTH halves of a step:
-    fml_assemble of a window of `sample_reads` reads made by the same generator at the same coverage (a fifth of a bench window in reads and in span), then its contigs
-    through the aligner's checker (orc.align_batch against the index the GPU wrote)."""
-    from oracle import orc, orc_fml
-    from seqlib_amd import synth
-    cfg = synth.CONFIGS["C2"]
-    g = synth.make_reference(cfg)[0][1]
-    span = int(sample_reads * read_len / coverage)
-    r = np.ascontiguousarray(synth.make_reads(g[:span], sample_reads, read_len, 6999)[:sample_reads])
-    rng = np.random.Generator(np.random.PCG64(98))
-    q = np.full(r.shape, ord("I"), dtype=np.uint8)
-    q[rng.random(r.shape) < 0.05] = ord("#")
-    seqs = [r[i].tobytes() for i in range(sample_reads)]
-    qs = [q[i].tobytes() for i in range(sample_reads)]
-    R = orc_fml.Reads(seqs, qs)
-    t0 = time.time()
-    utgs = orc_fml.assemble(orc_fml.default_opt(), R)
-    dt = time.time() - t0
-    dt_al, n_rec = None, None
-    if index_prefix:
-        oidx = orc.Index.load(index_prefix)
-        t1 = time.time()
-        e_al = orc.align_batch(orc.default_opt(), oidx, [u["seq"] for u in utgs])
-        dt_al = time.time() - t1
-        n_rec = int(e_al["n_hits"])
-        del oidx
-    tot = dt + (dt_al or 0.0)
-    return dict(value=sample_reads / tot, unit="reads/s", cores=1, kind="port", assemble_s=dt, realign_s=dt_al, realigned_records=n_rec,
-                sample="fml_assemble of the CPU checker on a window of %d reads at %.0fx over %d bp made by the bench's generator (%.1f s, %d contigs, longest %d bp)%s; "
-                       "one thread, as the reference runs fermi-lite (fml_opt_init: n_threads = 1) and its per-contig alignSequence loop"
-                       % (sample_reads, coverage, span, dt, len(utgs), max([u["len"] for u in utgs] + [0]),
-                          (", then the contigs through the aligner's checker (%.1f s, %d records)" % (dt_al, n_rec)) if dt_al is not None else " -- assembly only, no realignment"))
+    """The CPU checkers over BOTH halves of a step, window-parallel on the cores this rank may use: one process per core (oracle/cpu_bench_c5.py), each
+    with a window of `sample_reads` reads of its own made by the same generator at the same coverage (a fifth of a bench window in reads and in span), each on ONE thread --
+    the reference runs fermi-lite with n_threads = 1 (fml_opt_init) and one alignSequence per contig; windows are independent.  The processes are started, build their
+    windows, and are released together; value = all their reads / the slowest one's time."""
+    cores = rank_cpus()
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench_c5", index_prefix or "-", str(sample_reads), str(coverage), str(read_len), str(w)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True) for w in range(cores)]
+    res = []
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("oracle.cpu_bench_c5 did not start")
+        t0 = time.time()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        for p in procs:
+            res.append(json.loads(p.stdout.readline()))
+            p.wait(timeout=600)
+        wall = time.time() - t0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    one = [r["assemble_s"] + r["realign_s"] for r in res]
+    return dict(value=sample_reads * cores / wall, unit="reads/s", cores=cores, kind="port", wall_s=wall,
+                assemble_s=sum(r["assemble_s"] for r in res) / cores, realign_s=sum(r["realign_s"] for r in res) / cores,
+                single_thread=sample_reads / (sum(one) / cores), realigned_records=sum(r["records"] for r in res),
+                sample="%d processes side by side (the CPUs this rank may use), each ONE thread on a window of its own: fml_assemble of the CPU checker on %d reads at %.0fx over %d bp made by the "
+                       "bench's generator (mean %.1f s, %d contigs in all, longest %d bp), then its contigs through the aligner's checker against the index the GPU wrote (mean %.1f s, %d records); "
+                       "wall %.1f s from a common start to the slowest process; single_thread = one such process's own rate (the reference's configuration: fml_opt_init n_threads = 1)"
+                       % (cores, sample_reads, coverage, res[0]["span"], sum(r["assemble_s"] for r in res) / cores, sum(r["contigs"] for r in res), max(r["longest"] for r in res),
+                          sum(r["realign_s"] for r in res) / cores, sum(r["records"] for r in res), wall))
 
 
 def main_c5(args):
@@ -430,6 +431,7 @@ def main_c5(args):
         match = match_realign = None
         verify_desc = None
         cells_per_bp = None
+        fml_cnt, n_verified_reads = None, 0
         if args.verify != 0:
             from oracle import orc, orc_fml
             if args.verify > 0:
@@ -450,26 +452,39 @@ def main_c5(args):
             seqs = [raw_b[i * read_len:(i + 1) * read_len] for i in range(m)]
             qs = [raw_q[i * read_len:(i + 1) * read_len] for i in range(m)]
             t_v = time.time()
+            orc_fml.lib().orc_fml_counters_reset_totals()
             exp = orc_fml.assemble(orc_fml.default_opt(), orc_fml.Reads(seqs, qs))
             t_v = time.time() - t_v
+            n_verified_reads = m
             b2, q2, o2 = fml.flatten(seqs, qs)
             got = ctx.assemble(opt, b2, q2, o2, [0, m])[0]
             match = float(len(got) == len(exp) and all(a["seq"] == e["seq"] and a["cov"] == e["cov"] and a["nsr"] == e["nsr"] and a["ovlp"] == e["ovlp"] for a, e in zip(got, exp)))
             ctx.stage(bases, quals, offs)
+            fml_cnt = orc_fml.counters()          # table probes and heap pops of the checker's two passes over this window (roofline_asm below)
             vc = [u["seq"] for u in got if len(u["seq"]) <= max_len]
+            tmpd = tempfile.mkdtemp(prefix="slx_c5_")
+            prefix = os.path.join(tmpd, cfg["name"])
+            idx.WriteIndex(prefix)
+            oidx = orc.Index.load(prefix)
             if vc:
-                tmpd = tempfile.mkdtemp(prefix="slx_c5_")
-                prefix = os.path.join(tmpd, cfg["name"])
-                idx.WriteIndex(prefix)
-                oidx = orc.Index.load(prefix)
-                orc.lib().orc_counters_reset()
                 e_al = orc.align_batch(orc.default_opt(), oidx, vc)
-                cnt = orc.counters()
                 g_al = al.alignSequences(vc)
                 match_realign = compare(g_al, e_al, len(vc))
-                tot_bp = sum(len(c) for c in vc)
-                cells_per_bp = dict(ext=cnt["ext_cells"] / tot_bp, glb=cnt["glb_cells"] / tot_bp, contigs=len(vc), bp=tot_bp, longest=max(len(c) for c in vc))
-                del oidx
+            # DP cells per contig base for the rooflines: the oracle's counts over contigs the TIMED step realigned -- those of its first windows (the
+            # verification window above is a tenth of a window in the default line's leg and gave another density than `--config C5`'s whole window; the step's own contigs
+            # are the same in both)
+            n_cw = min(n_win, int(os.environ.get("SLX_C5_CELL_WINDOWS", "4")))
+            cc = [u["seq"] for w in done[-1][0][:n_cw] for u in w if len(u["seq"]) <= max_len]
+            if cc:
+                orc.lib().orc_counters_reset()
+                t_c = time.time()
+                orc.align_batch(orc.default_opt(), oidx, cc)
+                t_c = time.time() - t_c
+                cnt = orc.counters()
+                tot_bp = sum(len(c) for c in cc)
+                cells_per_bp = dict(ext=cnt["ext_cells"] / tot_bp, glb=cnt["glb_cells"] / tot_bp, contigs=len(cc), bp=tot_bp, longest=max(len(c) for c in cc), windows=n_cw,
+                                    sa=cnt["n_sa"] / tot_bp, seeds=cnt["n_seeds"] / tot_bp, chains=cnt["n_chains"] / tot_bp, occ_blocks=cnt["n_occ_block"] / tot_bp, checker_s=t_c)
+            del oidx
             verify_desc += "; checker assembly %.1f s, %d contigs, longest %d bp" % (t_v, len(exp), max([u["len"] for u in exp] + [0]))
         cpu = None
         if not args.no_cpu_baseline:
@@ -512,11 +527,51 @@ def main_c5(args):
                                              "into segments run side by side and verified at the joins; k_ext_block; k_ext_first<8004>)",
                         achieved=ach / 1e12, peak=VALU_PEAK_LANE_OPS / 1e12, unit="T int32 lane-op/s", frac=ach / VALU_PEAK_LANE_OPS,
                         traffic=None, ops_per_cell=14, ext_cells_per_contig_bp=cells_per_bp["ext"], realigned_bp_per_step=realigned_bp, kernel_ms=ext_ms,
-                        cells_source="orc_ksw_extend2's cell count over the verified window's %d contigs (%d bp, longest %d)" % (cells_per_bp["contigs"], cells_per_bp["bp"], cells_per_bp["longest"]),
+                        cells_source="orc_ksw_extend2's cell count over the %d contigs of the last timed step's first %d windows (%d bp, longest %d; checker %.1f s)"
+                                     % (cells_per_bp["contigs"], cells_per_bp["windows"], cells_per_bp["bp"], cells_per_bp["longest"], cells_per_bp["checker_s"]),
                         valu_busy=(pmc or {}).get("ext_valu_busy"), valu_busy_source=_latest("c5_pmc_summary.json") if pmc and pmc.get("ext_valu_busy") is not None else None,
                         cigar_and_patch=dict(glb_cells_per_contig_bp=cells_per_bp["glb"], kernel_ms=fin_ms,
                                              achieved=14.0 * cells_per_bp["glb"] * realigned_bp / (fin_ms * 1e-3) / 1e12 if fin_ms > 0 else None,
                                              note="ksw_global2 cells of mem_patch_reg and the CIGARs (k_regs_wave_long, k_cig_band_block) over the finalize stage's stream time"))
+        # the realignment's chain stage (the extension's equal in stream time: VERDICT r5 weak 7) and the assembly half (k_fml_ec / k_fml_occ, k_asm_*): HBM-side
+        # prices from the checkers' counts -- per contig base for the aligner's stages, per read for the correction, the library's own counters for the overlap stage
+        roof_chain, roof_asm = None, None
+        chain_ms = split["realign_stage_ms"].get("chain", 0.0) / steps
+        seed_ms = split["realign_stage_ms"].get("seed", 0.0) / steps
+        if cells_per_bp and chain_ms > 0:
+            cb = 8.0 * cells_per_bp["sa"] + 2 * 24.0 * cells_per_bp["seeds"] + 40.0 * cells_per_bp["chains"]
+            roof_chain = dict(bound="hbm", kernel="chaining of the contigs (k_chain_coop: a wave per contig, thousands of seeds each; k_flt_score / k_flt_seeds: mem_flt_chained_seeds' "
+                                                  "Smith-Waterman of every short seed) -- the chain stage of the realignment",
+                              achieved=cb * realigned_bp / (chain_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=cb * realigned_bp / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              traffic=None, algorithmic_bytes_per_contig_bp=cb, kernel_ms=chain_ms,
+                              per_contig_bp=dict(sa_lookups=cells_per_bp["sa"], seeds=cells_per_bp["seeds"], chains=cells_per_bp["chains"]),
+                              achieved_basis="8 B per suffix-array lookup + 2 x 24 B per seed + 40 B per chain (the oracle's counts over the same contigs as roofline) x realigned bases / the "
+                                             "chain stage's stream time; a latency stage (one contig = one wave walking a tree), not a bandwidth one",
+                              seed_stage=dict(kernel_ms=seed_ms, occ_blocks_per_contig_bp=cells_per_bp["occ_blocks"],
+                                              achieved_gbs=64.0 * cells_per_bp["occ_blocks"] * realigned_bp / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else None,
+                                              frac=64.0 * cells_per_bp["occ_blocks"] * realigned_bp / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if seed_ms > 0 else None,
+                                              basis="64 B per Occ block bwa's SMEM walk touches (SURVEY 8d) x realigned bases / the seed stage's stream time"))
+        ec_ms = (acc.get("correct", 0.0) + acc.get("filter", 0.0)) / steps
+        ov_ms = acc.get("overlap", 0.0) / steps
+        if ec_ms > 0 and ov_ms > 0:
+            look = fml_cnt["tot_lookups"] / max(n_verified_reads, 1) if fml_cnt else None
+            pops = fml_cnt["tot_heap_pops"] / max(n_verified_reads, 1) if fml_cnt else None
+            ec_bytes = (16.0 * look + 4.0 * read_len) * n_reads if look is not None else None          # a 16-byte table slot per probe; base + quality read and written
+            ov_bytes = 13.0 * counters["text_bytes"] + 40.0 * counters["overlaps"] + 16.0 * counters["irreducible"]
+            roof_asm = dict(bound="hbm", kernel="assembly half: BFC correction + unique-k-mer filter (k_fml_ec, k_fml_occ, k_fml_streak: hash-table probes of the correction walks) and the overlap "
+                                                "stage (k_asm_seeds / k_asm_index / k_asm_join / k_asm_scatter / k_asm_reduce*: seed index probes, overlap verification, transitive reduction)",
+                            correct=dict(kernel_ms=ec_ms, table_probes_per_read=look, heap_pops_per_read=pops, algorithmic_bytes_per_step=ec_bytes,
+                                         achieved=ec_bytes / (ec_ms * 1e-3) / 1e9 if ec_bytes else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                                         frac=ec_bytes / (ec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ec_bytes else None,
+                                         basis="16 B (one table slot) per bfc_ch_get of the checker's fml_correct + fml_fltuniq passes over the verified window, per read, + 4 B per base "
+                                               "(base and quality read, written back) x the step's reads / the correct + filter probes' stream time"),
+                            overlap=dict(kernel_ms=ov_ms, text_bytes=counters["text_bytes"], overlaps=counters["overlaps"], irreducible=counters["irreducible"], algorithmic_bytes_per_step=ov_bytes,
+                                         achieved=ov_bytes / (ov_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=ov_bytes / (ov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         basis="per text byte: the byte + one 12-byte seed-index slot; per overlap found: a 12-byte triple and an 8-byte edge, each written and read (40 B); per "
+                                               "irreducible edge: 8 B written and read -- the library's counters of the last call / the overlap probe's stream time.  350 M overlaps are "
+                                               "materialised to keep 11.6 M: the redundancy is in the algorithm (DESIGN section 8), not in the bytes per overlap"),
+                            achieved=((ec_bytes or 0.0) + ov_bytes) / ((ec_ms + ov_ms) * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=((ec_bytes or 0.0) + ov_bytes) / ((ec_ms + ov_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
         out = {
             "metric": "reads/sec through the FermiAssembler window pipeline (BFC correct -> fml_assemble -> contigs realigned via BWAAligner)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -526,8 +581,8 @@ def main_c5(args):
                                    "keepSecFrac=0.9 maxSecondary=10" % (n_win, per_win, read_len, args.coverage, span, cfg["name"], 19 if per_win * read_len > 1 << 23 else 0,
                                                                       sum(len(g) for _, g in refs)),
                        "windows_per_gpu": n_win, "reads_per_window": per_win, "read_len": read_len, "parallelism": "window-sharded x%d, no data-path collective" % world},
-            "roofline": roof, "roofline_count": roof_count, "cpu_baseline": cpu,
-            "host_threads_per_rank": rank_cpus(),
+            "roofline": roof, "roofline_chain": roof_chain, "roofline_asm": roof_asm, "roofline_count": roof_count, "cpu_baseline": cpu,
+            "host_threads_per_rank": rank_cpus(), "hw_queues": al.counter("hw_queues"),
             "windows_per_s": n_win * world / (dt / args.steps),
             "contigs": {"n": len(contigs), "total_bp": sum(lens), "longest": lens[:5], "n50": n50, "realigned": len(fit), "realigned_bp": sum(len(c) for c in fit),
                         "skipped_longer_than_max_read_len": len(contigs) - len(fit), "records": int(hits["n_hits"]) if hits is not None else 0},
@@ -639,6 +694,7 @@ def main():
         k, v = kv.split("=")
         al.set(k, int(v))
     n_workers = al.counter("workers")
+    hw_queues = al.counter("hw_queues")          # GPU_MAX_HW_QUEUES as the library found it (4 = unset)
     d_bases = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_offs = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * read_len
     torch.cuda.synchronize()
@@ -808,6 +864,67 @@ def main():
                                 valu_busy=(pmc or {}).get("ext_valu_busy") if pmc and pmc.get("config") == args.config else None,
                                 valu_busy_source=("%s: %s" % (PMC_SUMMARY, pmc.get("valu_busy_formula", "formula and units in that file")))
                                 if pmc and pmc.get("config") == args.config else None)
+        # ---- the other two stages of a step: chaining and finalize, priced from the oracle's counts of what bwa's algorithm does there
+        roof_chain, roof_fin = None, None
+        chain_ms = probe_acc.get("chain", 0.0) / args.steps
+        reg_ms = probe_acc.get("regions", 0.0) / args.steps
+        hit_ms = probe_acc.get("hits", 0.0) / args.steps
+        same_cfg = bool(pmc and pmc.get("config") == args.config)
+        if per_read is not None and chain_ms > 0 and per_read.get("n_seeds") is not None:
+            # mem_chain: one bwt_sa per seed occurrence (on bwa's layout the sampled-SA walk: a 64-byte Occ line per invPsi hop + the 8-byte sample), the seed written
+            # into its chain and read again by mem_chain_weight / mem_chain_flt (mem_seed_t = 24 B), a 40-byte mem_chain_t per chain made
+            chain_bytes = 64.0 * per_read["n_invpsi"] + 8.0 * per_read["n_sa"] + 2 * 24.0 * per_read["n_seeds"] + 40.0 * per_read["n_chains"]
+            mean_ms = chain_ms / launches
+            ach = chain_bytes * n / launches / (mean_ms * 1e-3) / 1e9
+            roof_chain = dict(bound="hbm", kernel="chaining: light / heavy partition + k_chain (a lane per read) + k_chain_coop<768> / <4096> (a wave per heavy read): suffix-array lookups, mem_chain "
+                                                  "on klib's kbtree, mem_chain_weight, mem_chain_flt",
+                              achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                              achieved_basis="ALGORITHMIC bytes per read on bwa's own layout (64 B x invPsi hops + 8 B x bwt_sa calls of the sampled suffix array; 2 x 24 B per seed; 40 B per chain: "
+                                             "the oracle's counts) x reads per launch / mean launch duration.  The kernels read a dense suffix array instead (one 4-byte read per seed): see random_access",
+                              algorithmic_bytes_per_read=chain_bytes, kernel_ms=chain_ms, kernel_ms_mean_launch=mean_ms, launches_per_step=launches,
+                              per_read=dict(sa_lookups=per_read["n_sa"], invpsi_hops=per_read["n_invpsi"], seeds=per_read["n_seeds"], merge_tests=per_read["n_merge_tests"],
+                                            chains=per_read["n_chains"], chains_kept=per_read["n_chains_kept"], filter_pairs=per_read["n_flt_pairs"]),
+                              timing="HIP events on each worker's stream from the start of the chain stage to the start of the extension group; summed over the step's launches")
+            try:      # what the memory system gives dependent random reads at the dense suffix array's footprint (one per seed)
+                ub = json.load(open(os.path.join(ROOT, _latest("ubench_rand32.json"))))["table_mb"]
+                l_ref = sum(len(g) for _, g in refs)
+                sa_mb = (2 * l_ref + 1) * (8 if 2 * l_ref + 1 >= 1 << 32 else 4) / 1e6
+                at = min(sorted(int(k) for k in ub), key=lambda m: abs(math.log(m / sa_mb)))
+                acc_g = per_read["n_sa"] * n / launches / (mean_ms * 1e-3) / 1e9
+                roof_chain["random_access"] = dict(accesses_per_read=per_read["n_sa"], achieved_g_per_s=acc_g, ceiling_from_ubench_g_per_s=ub[str(at)]["g_reads_per_s"],
+                                                   frac=acc_g / ub[str(at)]["g_reads_per_s"], footprint_mb=sa_mb, ubench_table_mb=at,
+                                                   note="one dependent read per seed: the stage is not bound by these -- see valu_lane_utilisation / wait_frac (divergent tree walks on single lanes)",
+                                                   source="%s (scripts/ubench_rand32.sh; not measured in this run)" % _latest("ubench_rand32.json"))
+            except Exception:
+                roof_chain["random_access"] = None
+            if same_cfg and pmc.get("chain"):
+                roof_chain.update({k: pmc["chain"].get(k) for k in ("valu_busy", "valu_lane_utilisation", "wait_frac_of_wave_cycles", "by_kernel")}, counters_source=PMC_SUMMARY)
+        fin_ms = reg_ms + cig_ms + hit_ms
+        if per_read is not None and fin_ms > 0 and per_read.get("n_regs") is not None:
+            glb = per_read.get("glb_cells", 0.0)
+            ops = 14.0 * glb * n
+            ach = ops / (fin_ms * 1e-3)
+            # the memory side of the same stage: every region read and written (mem_alnreg_t = 88 B) by sort / de-duplication / primary marking, the reference bases of the
+            # CIGAR alignments (2 bits each), the read, the hit written (32 B) with its CIGAR words
+            fin_bytes = 2 * 88.0 * per_read["n_regs"] + per_read["read_bases"] + 32.0 * per_read["n_hits"] + 4.0 * per_read["n_cigar_ops"]
+            roof_fin = dict(bound="valu", kernel="finalize: regions (k_regs1, k_regs_wave<160,640|2048>, k_regs<160>: mem_sort_dedup_patch, mem_mark_primary_se, MAPQ) + CIGAR "
+                                                "(k_cig_fast, k_cig_lanes, k_cig_dp: ksw_global2 + traceback, NM) + hits (k_hits: the glue's sort and secondary filters)",
+                            achieved=ach / 1e12, peak=VALU_PEAK_LANE_OPS / 1e12, unit="T int32 lane-op/s", frac=ach / VALU_PEAK_LANE_OPS, traffic=None,
+                            achieved_basis="14 lane-ops x the oracle's ksw_global2 cells (CIGAR alignments + mem_patch_reg) x reads per step / the three groups' summed stream time; the stage's other "
+                                           "work (sorts of a few regions, hashing, MAPQ) is counted in per_read but not priced in ops: most reads have one region and no DP (k_cig_fast)",
+                            ops_per_cell=14, glb_cells_per_read=glb, patch_cells_per_read=per_read.get("patch_cells"), kernel_ms=fin_ms, regions_ms=reg_ms, cigar_ms=cig_ms, hits_ms=hit_ms,
+                            per_read=dict(regions_in=per_read["n_regs"], dedup_pairs=per_read["n_dedup_pairs"], patch_alignments=per_read["n_patch"], regions_out=per_read["n_regs_out"],
+                                          cigar_jobs=per_read.get("glb_jobs"), hits=per_read["n_hits"], cigar_ops=per_read["n_cigar_ops"]),
+                            hbm_side=dict(algorithmic_bytes_per_read=fin_bytes, achieved_gbs=fin_bytes * n / (fin_ms * 1e-3) / 1e9, frac=fin_bytes * n / (fin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          basis="2 x 88 B per region (mem_alnreg_t read and written), the read, 32 B per hit, 4 B per CIGAR op"),
+                            timing="HIP events on each worker's stream: end of the extension group -> start of the CIGAR group (regions), the CIGAR group, its end -> end of the finalize stage (hits)")
+            if same_cfg:
+                for grp in ("regions", "cigar", "hits"):
+                    if pmc.get(grp):
+                        roof_fin[grp + "_counters"] = {k: pmc[grp].get(k) for k in ("valu_busy", "valu_lane_utilisation", "wait_frac_of_wave_cycles", "by_kernel")}
+                roof_fin["counters_source"] = PMC_SUMMARY
+        priced = seed_ms + ext_ms + cig_ms + chain_ms + reg_ms + hit_ms
+        stage_total = sum(v for k, v in stage_acc.items() if k != "total") / args.steps
         # ---- the C++ class end to end with BamRecord materialisation (tools/bamrec_bench.cpp), last: it is a process of its own with
         # its own copy of the index in HBM, so this process lets go of its aligner and reads first
         bam, percall = None, None
@@ -846,13 +963,13 @@ def main():
         other = None
         if not args.no_extras and args.config == "C3" and world == 1 and os.environ.get("SLX_BENCH_NO_C5_LEG") != "1":
             try:
-                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "12", "--warmup", "1", "--no-cpu-baseline", "--verify", "-10"],
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "C5", "--steps", "12", "--warmup", "1", "--verify", "-10"],
                                    stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
                 ln = [x for x in o.stdout.decode().splitlines() if x.startswith("{")]
                 if o.returncode == 0 and ln:
                     c5 = json.loads(ln[-1])
                     other = {"C5": {k: c5.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "contigs", "contig_bit_match_rate", "realigned_contig_bit_match_rate",
-                                                           "verified", "roofline", "step_split_ms", "probe_ms_per_step", "realign_extension_rounds", "counters", "step_ms", "timeline_ms", "config")}}
+                                                           "verified", "roofline", "roofline_chain", "roofline_asm", "roofline_count", "cpu_baseline", "step_split_ms", "probe_ms_per_step", "realign_extension_rounds", "counters", "step_ms", "timeline_ms", "config")}}
                 else:
                     other = {"C5": dict(error="exit code %d" % o.returncode)}
             except Exception as e:
@@ -865,11 +982,15 @@ def main():
                                    "hardclip=false keepSecFrac=0.9 maxSecondary=10" % (args.config, cfg["name"], sum(len(g) for _, g in refs), len(refs),
                                                                                       "u64" if 2 * sum(len(g) for _, g in refs) + 1 >= 1 << 32 else "u32", n, read_len,
                                                                                       " (pairs = two single-end reads 300+-30 bp apart)" if cfg.get("pairs") else ""),
-                       "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": al.counter("hw_queues"), "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
+                       "reads_per_gpu": n, "read_len": read_len, "workers": n_workers, "hw_queues": hw_queues, "parallelism": "read-sharded x%d, index replicated, RCCL gather to rank 0" % world,
                        "headline": "value = reads resident in HBM -> hits resident in HBM over the K timed steps (the contract's timed region); value_host_to_host = host "
                                    "reads -> host SoA hits through slx_align_batch (the metric as SURVEY 8d words it, PCIe inside); value_bamrecords = SeqLib::BWAAligner::alignSequences with BamRecord output over the whole batch (the north-star "
                                    "sentence read literally); value_per_call = one alignSequence call per read, the reference's calling convention"},
-            "roofline": roof, "roofline_ext": roof_ext, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_ext": roof_ext, "roofline_chain": roof_chain, "roofline_fin": roof_fin, "cpu_baseline": cpu,
+            "priced_stream_ms_per_step": dict(seed=seed_ms, extend=ext_ms, cigar=cig_ms, chain=chain_ms, regions=reg_ms, hits=hit_ms, priced=priced, all_stages=stage_total,
+                                              share=priced / stage_total if stage_total > 0 else None,
+                                              note="kernel groups that carry a roofline object (roofline: seed; roofline_ext: extend + cigar; roofline_chain: chain; roofline_fin: regions + cigar + hits) "
+                                                   "against the summed stage timers; the rest is encode, scans, compaction and the host syncs between stages"),
             "value_is": "device_resident: the bench contract's timed region starts with the reads in HBM (VERDICT r3 asked for the host-to-host rate as the headline; "
                         "the contract rules the PCIe-inclusive rate out as `value`, so it stays beside it as value_host_to_host)",
             "value_host_to_host": h2h, "value_bamrecords": bam, "value_per_call": percall, "other_configs": other,

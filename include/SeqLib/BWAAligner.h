@@ -36,6 +36,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "seqlib_amd.h"
 #include "SeqLib/BWAIndex.h"
 #include "SeqLib/BamRecord.h"
@@ -44,6 +47,45 @@
 namespace SeqLib {
 
 namespace detail {
+// 4-bit sequence of a record from the ASCII read (src/BWAAligner.cpp:208-220): dst[(sl + 1) / 2] bytes, high nibble first.  rev: the read backwards with the
+// reference's reverse map -- A -> 8, T -> 1, C and G unchanged.  Only the exact letters A C G T are bases (lower case is 15, as in the reference's switch).
+inline void pack_seq4_scalar(const uint8_t *cp, int from, int sl, bool rev, uint8_t *dst)
+{
+    for (int j = from; j < sl; ++j) {
+        const uint8_t c = rev ? cp[sl - 1 - j] : cp[j];
+        uint8_t v = 15;
+        switch (c) { case 'A': v = rev ? 8 : 1; break; case 'C': v = 2; break; case 'G': v = 4; break; case 'T': v = rev ? 1 : 8; break; }
+        dst[j >> 1] |= (uint8_t)(v << ((~j & 1) << 2));
+    }
+}
+inline void pack_seq4(const uint8_t *cp, int sl, bool rev, uint8_t *dst)
+{
+    int done = 0;
+#if defined(__SSE2__)
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    const __m128i vA = _mm_set1_epi8(rev ? 8 : 1), vC = _mm_set1_epi8(2), vG = _mm_set1_epi8(4), vT = _mm_set1_epi8(rev ? 1 : 8), vN = _mm_set1_epi8(15);
+    const __m128i lo = _mm_set1_epi16(0x00ff), zero = _mm_setzero_si128();
+    auto block = [&](int at) {                               // bases [at, at + 16) of the output, at even
+        __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(rev ? cp + sl - 16 - at : cp + at));
+        if (rev) {                                           // byte order reversed: swap inside the 16-bit words, then reverse the eight words
+            c = _mm_or_si128(_mm_srli_epi16(c, 8), _mm_slli_epi16(c, 8));
+            c = _mm_shufflelo_epi16(c, _MM_SHUFFLE(0, 1, 2, 3));
+            c = _mm_shufflehi_epi16(c, _MM_SHUFFLE(0, 1, 2, 3));
+            c = _mm_shuffle_epi32(c, _MM_SHUFFLE(1, 0, 3, 2));
+        }
+        __m128i v = _mm_or_si128(_mm_or_si128(_mm_and_si128(_mm_cmpeq_epi8(c, cA), vA), _mm_and_si128(_mm_cmpeq_epi8(c, cC), vC)),
+                                 _mm_or_si128(_mm_and_si128(_mm_cmpeq_epi8(c, cG), vG), _mm_and_si128(_mm_cmpeq_epi8(c, cT), vT)));
+        v = _mm_or_si128(v, _mm_and_si128(_mm_cmpeq_epi8(v, zero), vN));
+        const __m128i w = _mm_or_si128(_mm_slli_epi16(_mm_and_si128(v, lo), 4), _mm_srli_epi16(v, 8));          // word k = base 2k << 4 | base 2k + 1
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(dst + (at >> 1)), _mm_packus_epi16(w, w));
+    };
+    for (; done + 16 <= sl; done += 16) block(done);
+    if (sl >= 16 && done < sl) { const int at = (sl - 16) & ~1; block(at); done = at + 16; }          // the tail as one more block that overlaps the last (same bytes again)
+#endif
+    std::memset(dst + (done >> 1), 0, (size_t)(((sl + 1) >> 1) - (done >> 1)));
+    pack_seq4_scalar(cp, done, sl, rev, dst);
+}
+
 // CPUs this process may actually use: hardware threads, cut down to the CPU affinity mask, to the cgroup's CPU quota and to this rank's share (a container
 // that shows 256 hardware threads with a quota of 16 CPUs runs 256 busy threads at a sixteenth of their speed each).
 inline unsigned effective_cpus()
@@ -358,20 +400,14 @@ private:
 
     // record construction of src/BWAAligner.cpp:151-248 for hit k of `h`.  Same bytes as the reference builds; one allocation
     // for the data blob, sized for the tags it ends with (the reference reallocs at each bam_aux_append).  xa / sa / xs: the
-    // extra tags of a UseBwaMemRecords record (XA:Z where :240 puts it, XS:i and SA:Z after AS:i).
+    // extra tags of a UseBwaMemRecords record (XA:Z where :240 puts it, XS:i and SA:Z after AS:i).  With a slab writer (the batch
+    // path) the record's two shells and its blob are carved out of the builder thread's current slab instead of three mallocs.
     static BamRecordPtr make_record(const slx_hits &h, int64_t k, const std::string_view seq, const char *name, size_t l_name, bool hardclip,
-                                    const std::string *xa = nullptr, const std::string *sa = nullptr, const int32_t *xs = nullptr, const std::string *md = nullptr)
+                                    const std::string *xa = nullptr, const std::string *sa = nullptr, const int32_t *xs = nullptr, const std::string *md = nullptr,
+                                    detail::SlabWriter *sw = nullptr)
     {
-        auto b = std::make_shared<BamRecord>();
-        bam1_t *r = b->b.get();
         const uint32_t *cig = h.cigar + h.cig_off[k];
         const int n_cigar = h.n_cigar_ops[k];
-        r->core.tid = h.rid[k];
-        r->core.pos = h.pos[k];
-        r->core.qual = h.mapq[k];
-        r->core.flag = h.flag[k];                          // reverse (0x10) and secondary (0x100) already folded in
-        r->core.n_cigar = (uint32_t)n_cigar;
-        r->core.mtid = -1; r->core.mpos = -1; r->core.isize = 0;
         size_t tstart = 0, clen = seq.size();
         if (hardclip) {                                     // :164-177 (clips arrive as H here; bwa's op 3 there)
             clen = 0;
@@ -383,32 +419,45 @@ private:
             assert(clen && tstart + clen <= seq.size());
         }
         const std::string_view clipped = seq.substr(tstart, clen);
-        r->core.l_qname = (uint16_t)(l_name + 1);
-        r->core.l_qseq = (int32_t)clipped.size();
-        const int l_core = r->core.l_qname + (n_cigar << 2) + ((r->core.l_qseq + 1) >> 1) + r->core.l_qseq;
+        const int sl = (int)clipped.size();
+        const int l_core = (int)(l_name + 1) + (n_cigar << 2) + ((sl + 1) >> 1) + sl;
         const int l_tags = 3 * 7 + (xa && !xa->empty() ? 4 + (int)xa->size() : 0) + (sa && !sa->empty() ? 4 + (int)sa->size() : 0) + (xs ? 7 : 0) +
                            (md && !md->empty() ? 4 + (int)md->size() : 0);
-        r->data = static_cast<uint8_t *>(std::malloc((size_t)(l_core + l_tags)));
-        if (!r->data) throw std::bad_alloc();
+        BamRecordPtr b;
+        bam1_t *r;
+        if (sw) {
+            detail::Slab *slab = sw->ensure((size_t)(l_core + l_tags) + 384);          // the blob + the two shells with their control blocks
+            auto box = std::allocate_shared<Bam1Box>(detail::SlabAlloc<Bam1Box>(slab));
+            r = &box->b;
+            r->data = static_cast<uint8_t *>(slab->take((size_t)(l_core + l_tags)));
+            slab->retain();
+            box->slab = slab;
+            r->mempolicy = BAM_USER_OWNS_DATA;          // never realloc'ed or freed: a record that outgrows it moves to memory of its own (hts_compat.h)
+            b = std::allocate_shared<BamRecord>(detail::SlabAlloc<BamRecord>(slab), std::shared_ptr<bam1_t>(box, r));
+        } else {
+            b = std::make_shared<BamRecord>();
+            r = b->b.get();
+            r->data = static_cast<uint8_t *>(std::malloc((size_t)(l_core + l_tags)));
+            if (!r->data) throw std::bad_alloc();
+        }
+        r->core.tid = h.rid[k];
+        r->core.pos = h.pos[k];
+        r->core.qual = h.mapq[k];
+        r->core.flag = h.flag[k];                          // reverse (0x10) and secondary (0x100) already folded in
+        r->core.n_cigar = (uint32_t)n_cigar;
+        r->core.mtid = -1; r->core.mpos = -1; r->core.isize = 0;
+        r->core.l_qname = (uint16_t)(l_name + 1);
+        r->core.l_qseq = (int32_t)sl;
         r->m_data = (uint32_t)(l_core + l_tags);
         r->l_data = l_core;
         std::memcpy(r->data, name, l_name);
         r->data[l_name] = 0;
         std::memcpy(r->data + r->core.l_qname, cig, (size_t)n_cigar << 2);
         uint8_t *seqbuf = r->data + r->core.l_qname + (r->core.n_cigar << 2);
-        const int sl = (int)clipped.size();
-        std::memset(seqbuf, 0, (size_t)((sl + 1) >> 1) + (size_t)sl);   // (reference: malloc; quals past [0] are zero here)
-        static const struct Nib { uint8_t f[256], r[256]; Nib() {
-            for (int c = 0; c < 256; ++c) { f[c] = 15; r[c] = 15; }
-            f['A'] = 1; f['C'] = 2; f['G'] = 4; f['T'] = 8;
-            r['A'] = 8; r['C'] = 2; r['G'] = 4; r['T'] = 1;  // :208-220 -- A<->T swapped, C and G left as they are (reference behaviour)
-        } } nib;
-        const uint8_t *cp = reinterpret_cast<const uint8_t *>(clipped.data());
-        if (h.flag[k] & BAM_FREVERSE) {
-            for (int j = 0; j < sl; ++j) seqbuf[j >> 1] |= (uint8_t)(nib.r[cp[sl - 1 - j]] << ((~j & 1) << 2));
-        } else {
-            for (int p = 0; p < sl; ++p) seqbuf[p >> 1] |= (uint8_t)(nib.f[cp[p]] << ((~p & 1) << 2));
-        }
+        // :208-220 -- 4-bit codes A 1, C 2, G 4, T 8, anything else 15; on the reverse strand the read backwards with A<->T swapped and C, G left as they
+        // are (reference behaviour); the qualities: [0] = 0xff, the rest zero here (the reference leaves its malloc'ed bytes)
+        detail::pack_seq4(reinterpret_cast<const uint8_t *>(clipped.data()), sl, (h.flag[k] & BAM_FREVERSE) != 0, seqbuf);
+        std::memset(seqbuf + ((sl + 1) >> 1), 0, (size_t)sl);
         if (sl > 0) bam_get_qual(r)[0] = 0xff;
         b->AddIntTag("NA", h.na[k]);
         b->AddIntTag("NM", h.nm[k]);
@@ -498,13 +547,13 @@ private:
     // all records of read i of a result: the glue's (src/BWAAligner.cpp:136-248), or -- UseBwaMemRecords -- bwa's own, from the entries
     // the C-ABI hands over (SLX_F_REG2SAM): records (sub >= 0) and the alternatives (xa_parent) that make up their XA:Z
     void build_read(const slx_hits &h, int64_t i, const std::string_view seq, const char *name, size_t l_name, bool hardclip, const std::string *com,
-                    BamRecordPtrVector &dst) const
+                    BamRecordPtrVector &dst, detail::SlabWriter *sw = nullptr) const
     {
         const int64_t k0 = h.hit_off[i], k1 = h.hit_off[i + 1];
         if (!h.xa_parent) {
             if (k1 > k0) dst.reserve(dst.size() + (size_t)(k1 - k0));
             for (int64_t k = k0; k < k1; ++k) {
-                BamRecordPtr rec = make_record(h, k, seq, name, l_name, hardclip);
+                BamRecordPtr rec = make_record(h, k, seq, name, l_name, hardclip, nullptr, nullptr, nullptr, nullptr, sw);
                 if (com) rec->AddZTag("BC", *com);
                 dst.push_back(std::move(rec));              // appended: `out` is never cleared (src/BWAAligner.cpp:97-98)
             }
@@ -550,7 +599,7 @@ private:
         dst.reserve(dst.size() + (size_t)n_rec);
         for (int64_t j = 0; j < n_rec; ++j) {
             const std::string md = md_string(h, rec[(size_t)j], seq);
-            BamRecordPtr r = make_record(h, rec[(size_t)j], seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[rec[(size_t)j]], &md);
+            BamRecordPtr r = make_record(h, rec[(size_t)j], seq, name, l_name, hardclip, &xa[(size_t)j], &sa[(size_t)j], &h.sub[rec[(size_t)j]], &md, sw);
             if (com) r->AddZTag("BC", *com);
             dst.push_back(std::move(r));
         }
@@ -582,8 +631,12 @@ private:
         const std::string *seq, *name; BamRecordPtrVector *out; bool hardclip; double ksf; int maxsec;
         bool done = false; std::exception_ptr err;
     };
-    struct Combiner { std::mutex mu; std::condition_variable cv; std::vector<CombReq *> waiting; bool leader = false; };
+    struct Combiner { std::mutex mu; std::condition_variable cv; std::vector<CombReq *> waiting; bool leader = false; uint64_t rounds = 0, calls = 0; };
     mutable Combiner comb_;
+public:
+    // rounds led and calls served by them since the aligner was created (calls / rounds = how many concurrent callers shared a GPU round trip)
+    void CombinedCallStats(uint64_t &rounds, uint64_t &calls) const { std::lock_guard<std::mutex> g(comb_.mu); rounds = comb_.rounds; calls = comb_.calls; }
+private:
 
     void combine_call(const std::string &seq, const std::string &name, BamRecordPtrVector &out, bool hardclip, double ksf, int maxsec) const
     {
@@ -604,6 +657,7 @@ private:
             try { run_round(round); } catch (...) { err = std::current_exception(); }
             lk.lock();
             for (CombReq *r : round) { r->err = err; r->done = true; }
+            ++comb_.rounds; comb_.calls += round.size();
             comb_.leader = false;
             comb_.cv.notify_all();
         }
@@ -679,6 +733,7 @@ private:
         unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)detail::effective_cpus());
         T = std::max(1u, std::min(T, 512u));
         if (n < 8192) T = 1;
+        const bool use_slabs = n >= env_long("SEQLIB_AMD_SLAB_MIN_READS", 8192) && env_long("SEQLIB_AMD_SLABS", 1) != 0;
         detail::TaskPool pool(T);
         const int parts = (int)std::min<int64_t>((int64_t)T * 4, std::max<int64_t>(1, chunk / 2048));   // tasks per stage of a chunk
 
@@ -762,10 +817,19 @@ private:
                 J.built = pool.submit(parts, [&, c](int t) {
                     const ChunkJob &Jc = jobs[(size_t)c];
                     const int64_t mm = Jc.hi - Jc.lo;
+                    // the records of this stretch of reads come out of slabs this task fills (BamRecord.h, detail::Slab): no malloc per record.  SEQLIB_AMD_SLABS=0
+                    // keeps every record in allocations of its own.
+                    detail::SlabWriter writer;
+                    detail::SlabWriter *sw = use_slabs ? &writer : nullptr;
+                    const int64_t i0 = mm * t / parts, i1 = mm * (t + 1) / parts;
                     // the sequence of a record comes from the caller's reads (the staging slot is reused two chunks later)
-                    for (int64_t i = mm * t / parts; i < mm * (t + 1) / parts; ++i) {
+                    for (int64_t i = i0; i < i1; ++i) {
                         const UnalignedSequence &us = reads[(size_t)(Jc.lo + i)];
-                        build_read(Jc.h, i, us.Seq, us.Name.c_str(), us.Name.size(), hardclip, copyComment_ ? &us.Com : nullptr, out[(size_t)(Jc.lo + i)]);
+                        if (sw && !(i & 255)) {               // what is left of the stretch sizes the task's last slab: records still to come x (shells + blob of a read like this one)
+                            const int64_t k_left = Jc.h.hit_off[i1] - Jc.h.hit_off[i];
+                            writer.hint_bytes = (size_t)k_left * (us.Seq.size() + (us.Seq.size() >> 1) + us.Name.size() + 256);
+                        }
+                        build_read(Jc.h, i, us.Seq, us.Name.c_str(), us.Name.size(), hardclip, copyComment_ ? &us.Com : nullptr, out[(size_t)(Jc.lo + i)], sw);
                     }
                 }, false);
             }

@@ -4,12 +4,16 @@
 // 255-274,646-664,861-917,960-970,1039-1054; the rest of that 70-method class (mate/pair fields,
 // interval algebra, pile-up helpers) is BAM utility API outside this path.
 #pragma once
+#include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <regex>
 #include <stdexcept>
 #include <string>
@@ -19,6 +23,84 @@
 
 namespace SeqLib {
 
+namespace detail {
+// Record memory of the BATCH path (BWAAligner::alignSequences): a chunk yields millions of records, and three mallocs per record (the shared_ptr<BamRecord>, the
+// bam1_t with its control block, the data blob) plus the first touch of ~400 fresh bytes each were most of a record's cost on the host.  A slab is one large
+// block (2 MB) that a builder thread fills front to back with the shells and blobs of a few thousand consecutive records; every allocation
+// made in it holds one reference, and the block is freed when the last of them is gone -- so a single surviving record keeps its slab (up to 2 MB) alive.  The
+// per-read entry points (alignSequence) never use slabs.
+struct Slab {
+    std::atomic<long> refs{1};          // 1 = the builder's own hold while it fills the slab
+    size_t cap = 0, used = 0;
+    static constexpr size_t kAlign = 16, kHeader = 64, kBytes = (size_t)2 << 20;
+    // full-size slabs are recycled through a process-wide pool (warm pages: the first touch of fresh memory costs more than everything else a record needs);
+    // at most pool_cap() of them are kept -- SEQLIB_AMD_SLAB_POOL_MB, default 2 048 MB -- and trim_pool() returns them to the system
+    struct Pool { std::mutex mu; std::vector<Slab *> free_; size_t cap; Pool() { const char *e = std::getenv("SEQLIB_AMD_SLAB_POOL_MB"); cap = (size_t)(e && *e ? std::atol(e) : 2048) * ((size_t)1 << 20) / kBytes; }
+                  ~Pool() { for (Slab *s : free_) std::free(s); } };
+    static Pool &pool() { static Pool p; return p; }
+    static void trim_pool() { Pool &P = pool(); std::lock_guard<std::mutex> g(P.mu); for (Slab *s : P.free_) std::free(s); P.free_.clear(); }
+    static Slab *make(size_t bytes)
+    {
+        bytes = (bytes + 4095) & ~(size_t)4095;
+        void *p = nullptr;
+        if (bytes == kBytes) {
+            Pool &P = pool();
+            std::lock_guard<std::mutex> g(P.mu);
+            if (!P.free_.empty()) { p = P.free_.back(); P.free_.pop_back(); }
+        }
+        if (!p && (::posix_memalign(&p, 4096, bytes) != 0 || !p)) throw std::bad_alloc();
+        Slab *s = new (p) Slab();
+        s->cap = bytes; s->used = kHeader;
+        return s;
+    }
+    void destroy()
+    {
+        const size_t c = cap;
+        this->~Slab();
+        if (c == kBytes) {
+            Pool &P = pool();
+            std::lock_guard<std::mutex> g(P.mu);
+            if (P.free_.size() < P.cap) { P.free_.push_back(this); return; }
+        }
+        std::free(this);
+    }
+    size_t room() const { return cap - used; }
+    void *take(size_t n) { void *p = reinterpret_cast<char *>(this) + used; used += (n + kAlign - 1) & ~(kAlign - 1); return p; }          // the caller checked room()
+    void retain() { refs.fetch_add(1, std::memory_order_relaxed); }
+    void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) destroy(); }
+};
+static_assert(sizeof(Slab) <= Slab::kHeader, "slab header");
+// std::allocate_shared's allocator over the builder's current slab: one reference per allocation, returned by deallocate
+template <class T> struct SlabAlloc {
+    using value_type = T;
+    Slab *slab;
+    explicit SlabAlloc(Slab *s) : slab(s) {}
+    template <class U> SlabAlloc(const SlabAlloc<U> &o) : slab(o.slab) {}
+    T *allocate(size_t n) { slab->retain(); return static_cast<T *>(slab->take(n * sizeof(T))); }
+    void deallocate(T *, size_t) { slab->release(); }
+    template <class U> bool operator==(const SlabAlloc<U> &o) const { return slab == o.slab; }
+    template <class U> bool operator!=(const SlabAlloc<U> &o) const { return slab != o.slab; }
+};
+// one builder thread's view: the slab it is filling, replaced when a record does not fit
+struct SlabWriter {
+    Slab *cur = nullptr;
+    size_t hint_bytes = Slab::kBytes;          // what the builder still expects to write (sizes its last slab)
+    ~SlabWriter() { if (cur) cur->release(); }
+    SlabWriter() = default;
+    SlabWriter(const SlabWriter &) = delete;
+    SlabWriter &operator=(const SlabWriter &) = delete;
+    Slab *ensure(size_t bytes)
+    {
+        if (cur && cur->room() >= bytes) return cur;
+        if (cur) cur->release();
+        cur = nullptr;
+        const size_t want = std::max(bytes + Slab::kHeader, std::min(Slab::kBytes, hint_bytes + Slab::kHeader + 4096));
+        cur = Slab::make(want);
+        return cur;
+    }
+};
+}  // namespace detail
+
 struct Bam1Deleter {            // /root/reference/SeqLib/BamWalker.h:19-24
     void operator()(bam1_t *b) const { if (b) bam_destroy1(b); }
 };
@@ -26,8 +108,9 @@ struct Bam1Deleter {            // /root/reference/SeqLib/BamWalker.h:19-24
 // bam_init1's calloc plus the control block): the record's shared_ptr<bam1_t> aliases the member of this box.
 struct Bam1Box {
     bam1_t b;
+    detail::Slab *slab = nullptr;          // the slab b.data lies in (BAM_USER_OWNS_DATA set), if any: this box holds one reference
     Bam1Box() { std::memset(&b, 0, sizeof b); }
-    ~Bam1Box() { std::free(b.data); }
+    ~Bam1Box() { if (!(b.mempolicy & BAM_USER_OWNS_DATA)) std::free(b.data); if (slab) slab->release(); }
     Bam1Box(const Bam1Box &) = delete;
     Bam1Box &operator=(const Bam1Box &) = delete;
 };
@@ -108,6 +191,7 @@ class BamRecord {
 public:
     BamRecord() : b(make_bam1()) {}
     explicit BamRecord(bam1_t *raw) : b(raw, Bam1Deleter()) {}
+    explicit BamRecord(std::shared_ptr<bam1_t> owned) : b(std::move(owned)) {}          // (the batch path's slab-backed records)
     BamRecord(const BamRecord &) = delete;
     BamRecord &operator=(const BamRecord &) = delete;
     BamRecord(BamRecord &&) = default;

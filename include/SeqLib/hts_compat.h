@@ -78,11 +78,16 @@ typedef struct bam1_t {
 #define bam_seqi(s, i) ((s)[(i) >> 1] >> ((~(i) & 1) << 2) & 0xf)
 
 static inline bam1_t *bam_init1(void) { return (bam1_t *)calloc(1, sizeof(bam1_t)); }
+/* htslib's bam1_t::mempolicy bits (sam.h: bam_set_mempolicy): memory the caller owns is not freed by bam_destroy1, and data the caller owns is never
+ * realloc'ed -- a record that outgrows it moves to malloc'ed memory of its own (sam_realloc_bam_data).  The batch path hands out records whose data lie
+ * in slabs shared by thousands of records (BamRecord.h, detail::Slab). */
+#define BAM_USER_OWNS_STRUCT 1
+#define BAM_USER_OWNS_DATA 2
 static inline void bam_destroy1(bam1_t *b)
 {
     if (!b) return;
-    free(b->data);
-    free(b);
+    if (!(b->mempolicy & BAM_USER_OWNS_DATA)) free(b->data);
+    if (!(b->mempolicy & BAM_USER_OWNS_STRUCT)) free(b);
 }
 static inline int bam_aux_type2size(uint8_t t)
 {
@@ -125,8 +130,16 @@ static inline int bam_aux_append(bam1_t *b, const char tag[2], char type, int le
     uint32_t need = (uint32_t)b->l_data + 3 + (uint32_t)len;
     if (b->m_data < need) {
         uint32_t m = need; --m; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; ++m;   // kroundup32
-        uint8_t *nd = (uint8_t *)realloc(b->data, m);
-        if (!nd) return -1;
+        uint8_t *nd;
+        if (b->mempolicy & BAM_USER_OWNS_DATA) {          /* sam_realloc_bam_data: the caller's memory is left alone, the record gets its own */
+            nd = (uint8_t *)malloc(m);
+            if (!nd) return -1;
+            if (b->l_data > 0) memcpy(nd, b->data, (size_t)b->l_data);
+            b->mempolicy &= ~(uint32_t)BAM_USER_OWNS_DATA;
+        } else {
+            nd = (uint8_t *)realloc(b->data, m);
+            if (!nd) return -1;
+        }
         b->data = nd; b->m_data = m;
     }
     b->data[b->l_data] = (uint8_t)tag[0]; b->data[b->l_data + 1] = (uint8_t)tag[1]; b->data[b->l_data + 2] = (uint8_t)type;

@@ -17,6 +17,7 @@
 
 static __thread orc_fml_counters g_cnt;
 void orc_fml_counters_get(orc_fml_counters *c) { *c = g_cnt; }
+void orc_fml_counters_reset_totals(void) { g_cnt.tot_kmers_inserted = g_cnt.tot_lookups = g_cnt.tot_heap_pops = g_cnt.tot_bases = 0; }
 
 /* ------------------------------------------------------------------------------------------------ options (misc.c, mag.c) */
 
@@ -140,7 +141,7 @@ uint64_t orc_bfc_ch_size(const orc_bfc_ch *ch) { return ch->n; }
 static void ch_insert(orc_bfc_ch *ch, uint64_t key, int is_high)
 {
     uint64_t i = mix64(key) & (ch->cap - 1);
-    ++g_cnt.n_kmers_inserted;
+    ++g_cnt.n_kmers_inserted; ++g_cnt.tot_kmers_inserted;
     while (ch->keys[i] && ch->keys[i] != key + 1) i = (i + 1) & (ch->cap - 1);
     if (!ch->keys[i]) {
         ch->keys[i] = key + 1;
@@ -155,7 +156,7 @@ static void ch_insert(orc_bfc_ch *ch, uint64_t key, int is_high)
 static inline int ch_get(const orc_bfc_ch *ch, uint64_t key)          /* bfc_ch_get: -1 if absent, else the 14-bit value */
 {
     uint64_t i = mix64(key) & (ch->cap - 1);
-    ++g_cnt.n_lookups;
+    ++g_cnt.n_lookups; ++g_cnt.tot_lookups;
     while (ch->keys[i] && ch->keys[i] != key + 1) i = (i + 1) & (ch->cap - 1);
     return ch->keys[i] ? ch->vals[i] & 0x3fff : -1;
 }
@@ -206,7 +207,8 @@ orc_bfc_ch *orc_fml_count(int n, const orc_fseq *seqs, int k, int q)
     uint64_t tot = 0;
     int i, j, l;
     orc_bfc_ch *ch;
-    memset(&g_cnt, 0, sizeof(g_cnt));
+    { const orc_fml_counters keep = g_cnt; memset(&g_cnt, 0, sizeof(g_cnt)); g_cnt.tot_kmers_inserted = keep.tot_kmers_inserted; g_cnt.tot_lookups = keep.tot_lookups;
+      g_cnt.tot_heap_pops = keep.tot_heap_pops; g_cnt.tot_bases = keep.tot_bases; }
     if (k < 1 || k > ORC_BFC_MAX_KMER) return 0;
     for (i = 0; i < n; ++i) tot += seqs[i].l_seq >= k ? seqs[i].l_seq - k + 1 : 0;
     ch = ch_init(k, tot);
@@ -215,7 +217,7 @@ orc_bfc_ch *orc_fml_count(int n, const orc_fseq *seqs, int k, int q)
         kmer_t x = kmer_null;
         uint64_t qmer = 0;
         const uint64_t mask = (1ULL << k) - 1;
-        ++g_cnt.n_reads; g_cnt.n_bases += s->l_seq;
+        ++g_cnt.n_reads; g_cnt.n_bases += s->l_seq; g_cnt.tot_bases += s->l_seq;
         for (j = l = 0; j < s->l_seq; ++j) {
             int c = nt5((uint8_t)s->seq[j]);
             if (c < 4) {
@@ -481,7 +483,7 @@ static int bfc_ec1dir(bfc_ec1buf_t *e, const ecseq_t *seq, ecseq_t *ec, int star
         z = e->heap[0];
         e->heap[0] = e->heap[--e->n_heap];
         if (e->n_heap) ks_heapdown_ec(0, e->n_heap, e->heap);
-        ++g_cnt.n_heap_pops;
+        ++g_cnt.n_heap_pops; ++g_cnt.tot_heap_pops;
         if (z.i - end > o->max_end_ext) stop = 1;
         if (!stop) {
             const ecbase_t *c = z.i < seq->n ? &seq->a[z.i] : 0;

@@ -98,8 +98,13 @@ uint64_t orc_fml_reads_total(int n, const orc_fseq *seqs);
 void  orc_fml_reads_to_flat(int n, const orc_fseq *seqs, char *bases, char *quals /* or NULL */, uint64_t *offs /* n + 1 */);
 
 /* work counters of the last orc_fml_count / correct call on this thread (bench.py: algorithmic bytes of the k-mer counting kernel) */
-typedef struct { uint64_t n_kmers_inserted, n_kmers_distinct, n_lookups, n_reads, n_bases, n_heap_pops; } orc_fml_counters;
+typedef struct {
+    uint64_t n_kmers_inserted, n_kmers_distinct, n_lookups, n_reads, n_bases, n_heap_pops;
+    /* the same since orc_fml_counters_reset_totals() on this thread, over every count / correct / filter pass in between (an fml_assemble makes two counts) */
+    uint64_t tot_kmers_inserted, tot_lookups, tot_heap_pops, tot_bases;
+} orc_fml_counters;
 void orc_fml_counters_get(orc_fml_counters *c);
+void orc_fml_counters_reset_totals(void);
 
 #ifdef __cplusplus
 }

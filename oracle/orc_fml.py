@@ -46,7 +46,8 @@ class Utg(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("n_kmers_inserted", "n_kmers_distinct", "n_lookups", "n_reads", "n_bases", "n_heap_pops")]
+    _fields_ = [(n, C.c_uint64) for n in ("n_kmers_inserted", "n_kmers_distinct", "n_lookups", "n_reads", "n_bases", "n_heap_pops",
+                                          "tot_kmers_inserted", "tot_lookups", "tot_heap_pops", "tot_bases")]
 
 
 def lib():

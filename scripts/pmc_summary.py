@@ -68,6 +68,24 @@ write = sum(g(k, "WRITE_SIZE") for k in seed_all) * 1024.0 / reads
 ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep", "k_first_diag", "k_ext_lanes", "k_cand_lane_prep")]
 ext_inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ext)
 ext_gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ext)
+def wait_frac(k):
+    w = g(k, "SQ_WAVE_CYCLES")
+    return g(k, "SQ_WAIT_ANY") / w if w else None
+
+
+def group(names):
+    """instruction-weighted VALUBusy / lane utilisation / waiting share over the kernels of a stage (full-size launches)"""
+    ks = [k for k in kern if k.split("<")[0] in names]
+    inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ks)
+    gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ks)
+    thr = sum(g(k, "SQ_THREAD_CYCLES_VALU") for k in ks)
+    wav = sum(g(k, "SQ_WAVE_CYCLES") for k in ks)
+    return {"kernels": ks, "valu_busy": (inst * 2.0 / (N_SIMD * gui / N_XCD)) if gui else None, "valu_lane_utilisation": thr / (64.0 * inst) if inst else None,
+            "wait_frac_of_wave_cycles": sum(g(k, "SQ_WAIT_ANY") for k in ks) / wav if wav else None,
+            "fetch_bytes_per_read": sum(g(k, "FETCH_SIZE") for k in ks) * 1024.0 / reads, "write_bytes_per_read": sum(g(k, "WRITE_SIZE") for k in ks) * 1024.0 / reads,
+            "by_kernel": {k: {"valu_busy": valu_busy(k), "valu_lane_utilisation": lane_util(k), "wait_frac_of_wave_cycles": wait_frac(k)} for k in ks}}
+
+
 res = {
     "config": config,
     "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --config %s --no-cpu-baseline --no-extras --verify 0 --steps 2 --warmup 1 "
@@ -84,6 +102,11 @@ res = {
     "ext_valu_busy": (ext_inst * 2.0 / (N_SIMD * ext_gui / N_XCD)) if ext_gui else None,
     "ext_valu_busy_by_kernel": {k: valu_busy(k) for k in ext},
     "ext_valu_lane_utilisation_by_kernel": {k: lane_util(k) for k in ext},
+    # the other stages of a step (bench.py roofline_chain / roofline_fin)
+    "chain": group(("k_chain", "k_chain_coop", "k_part_flags", "k_part_scatter", "k_heavy_keys")),
+    "regions": group(("k_regs1", "k_regs", "k_regs_wave", "k_part_flags_nreg")),
+    "hits": group(("k_hits", "k_hits_sam")),
+    "cigar": group(("k_cig_fast", "k_cig_lanes", "k_cig_dp")),
     "kernels": kern,
 }
 print(json.dumps(res, indent=1))

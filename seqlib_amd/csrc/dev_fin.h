@@ -332,7 +332,7 @@ __device__ __forceinline__ void fin_sync()
 
 template <int MAXQ, typename SC>
 __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt, ReadWS &w, int r, const uint8_t *query, int l_query, SC &sc,
-                            const SortStage *ss = nullptr)
+                            const SortStage *ss = nullptr, bool *defer = nullptr)
 {
         int n = ck.n_reg[r];
         int *a = w.ia;                            // region handles
@@ -383,6 +383,20 @@ __device__ int dev_fin_regs(const DevRef &R, const Chunk &ck, const slx_opt &opt
                          [&](int x, int y) { return ss->k64[x] < ss->k64[y]; },
                          [&](int x, int y) { return G[x].re < G[y].re; });
             if (dbg) t1 = __builtin_readcyclecounter();
+            if (defer && !staged && n <= 64) {          // (64 = REGS_SMALL_N: what the wave kernel's launch for these reads stages in LDS)
+                // Will the loop below reach mem_patch_reg's alignment?  Its first attempt is made on regions that nothing has changed yet (only patches change a
+                // p; removals only take pairs away), so the pairs of the loop over the UNCHANGED regions are a superset of the ones that can come first: none
+                // among them passes mem_patch_reg's own pre-tests -> no alignment in this read.  One that does -> the read goes to the wave kernel untouched
+                // (a[] is only sorted, which that kernel does again from the identity).
+                for (int i = 1; i < n; ++i) {
+                    const DReg &p = G[a[i]];
+                    if (p.rid != G[a[i - 1]].rid || p.rb >= G[a[i - 1]].re + opt.max_chain_gap) continue;
+                    for (int j = i - 1; j >= 0 && p.rid == G[a[j]].rid && p.rb < G[a[j]].re + opt.max_chain_gap; --j) {
+                        const DReg &q = G[a[j]];
+                        if (q.rb < p.rb && dev_patch_pre(R, opt, q.rb, q.re, q.qb, q.qe, q.w, p.rb, p.re, p.qb, p.qe, p.w) >= 0) { *defer = true; return -1; }
+                    }
+                }
+            }
             if (staged) { for (int i = ss->lane; i < n; i += 64) G[i].n_comp = 1; __threadfence_block(); }
             else for (int i = 0; i < n; ++i) G[a[i]].n_comp = 1;
             if (staged) {

@@ -460,6 +460,8 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "xseg_fail")) { if (value < 0) return SLX_EINVAL; al->xseg_fail = (int)value; }
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
+    else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
+    else if (!strcmp(key, "hits_wave")) al->hits_wave = value != 0;
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
@@ -557,6 +559,13 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
         if (!strcmp(key, "pseg_jobs")) {          // mem_patch_reg alignments computed ahead of the region kernel
             long long v = 0;
             auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += wk->pseg_stat; };
+            if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
+            return v;
+        }
+        if (!strcmp(key, "regs_deferred") || !strcmp(key, "hits_wave_reads")) {          // reads k_regs handed to the wave kernel / reads k_hits_wave sorted, since the aligner was created
+            long long v = 0;
+            const int which = key[0] == 'h';
+            auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += (long long)wk->fin_stat[which]; };
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;
         }

@@ -51,6 +51,52 @@ static int cpu_checks(const std::string &prefix, const std::string &tmp)
     CHECK(cig == c2 && cig != c3);
     std::ostringstream s2; s2 << cig;
     CHECK(s2.str() == "5M2I3D4S");
+    // --- the batch path's record memory (BamRecord.h, detail::Slab) and the 4-bit packing of a record's sequence (BWAAligner.h, detail::pack_seq4), no GPU needed
+    {
+        // every length 0..200 on both strands, every kind of letter: the block form (SSE2) == the reference's switch, letter by letter (src/BWAAligner.cpp:208-231)
+        unsigned long long lcg = 12345;
+        auto rnd = [&]() { lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL; return (unsigned)(lcg >> 33); };
+        for (int sl = 0; sl <= 200; ++sl)
+            for (int rev = 0; rev < 2; ++rev)
+                for (int rep = 0; rep < 4; ++rep) {
+                    std::string q((size_t)sl, 'A');
+                    for (auto &c : q) c = "ACGTNacgtnRY-"[rnd() % 100 < 90 ? rnd() & 3 : rnd() % 13];
+                    std::vector<uint8_t> a((size_t)((sl + 1) >> 1) + 1, 0xAB), e((size_t)((sl + 1) >> 1) + 1, 0);
+                    e.back() = 0xAB;
+                    detail::pack_seq4(reinterpret_cast<const uint8_t *>(q.data()), sl, rev != 0, a.data());
+                    detail::pack_seq4_scalar(reinterpret_cast<const uint8_t *>(q.data()), 0, sl, rev != 0, e.data());
+                    CHECK(a == e);          // (and the byte behind the sequence is untouched)
+                }
+        // slabs: allocations of shells and blobs hold the block; it goes when the last one does, whatever the order; a record that outgrows its blob moves out of it
+        std::vector<std::shared_ptr<bam1_t>> keep;
+        {
+            detail::SlabWriter w;
+            w.hint_bytes = 1 << 16;
+            for (int i = 0; i < 20000; ++i) {
+                detail::Slab *slab = w.ensure(300 + 384);
+                auto box = std::allocate_shared<Bam1Box>(detail::SlabAlloc<Bam1Box>(slab));
+                box->b.data = static_cast<uint8_t *>(slab->take(300));
+                slab->retain(); box->slab = slab;
+                box->b.mempolicy = BAM_USER_OWNS_DATA;
+                box->b.m_data = 300; box->b.l_data = 290;
+                std::memset(box->b.data, i & 0xff, 290);
+                if (i % 7 == 0) keep.emplace_back(box, &box->b);          // the others die at once, inside a slab that is still being filled
+            }
+        }
+        for (size_t i = 0; i < keep.size(); ++i) {
+            bam1_t *b = keep[i].get();
+            CHECK(b->data[0] == (uint8_t)((i * 7) & 0xff) && b->data[289] == b->data[0]);
+            if (i % 3 == 0) {          // 290 + 3 + 40 > 300: sam_realloc_bam_data's rule for caller-owned data
+                const uint8_t *old = b->data;
+                char z[40] = "0123456789012345678901234567890123456";
+                CHECK(bam_aux_append(b, "ZZ", 'Z', 40, reinterpret_cast<const uint8_t *>(z)) == 0);
+                CHECK(b->data != old && !(b->mempolicy & BAM_USER_OWNS_DATA) && b->data[0] == (uint8_t)((i * 7) & 0xff) && b->l_data == 333);
+            }
+        }
+        for (size_t i = 0; i < keep.size(); i += 2) keep[i].reset();
+        keep.clear();
+        detail::Slab::trim_pool();
+    }
     // --- BamRecord tags / accessors on a hand-built record
     {
         BamRecord r;

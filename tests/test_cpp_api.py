@@ -66,6 +66,7 @@ def test_cpp_multi_device_handle_and_chunked_pipeline(exe, golden_dir):
     batch by contiguous read ranges) with the batch cut into 257-read chunks, so that the pack / align / build pipeline of
     alignSequences runs many rounds: every BamRecord byte-identical to the one-device, one-chunk pass"""
     r = subprocess.run([exe, "multidev", os.path.join(golden_dir, "tiny.fa"), os.path.join(golden_dir, "sim1_bcr.head3000.fq"), "3000", "2"],
+                       env=dict(os.environ, SEQLIB_AMD_SLAB_MIN_READS="1"),          # records out of shared slabs, as large batches build them
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches=0" in r.stdout
@@ -79,7 +80,8 @@ def test_cpp_bwa_mem_records(exe, golden_dir):
     from oracle import orc
     n = 3000
     fq = os.path.join(golden_dir, "sim2_bcr.head3000.fq")
-    r = subprocess.run([exe, "bwamem", os.path.join(golden_dir, "tiny.fa"), fq, str(n)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "bwamem", os.path.join(golden_dir, "tiny.fa"), fq, str(n)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SEQLIB_AMD_SLAB_MIN_READS="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     got = {}
     for l in r.stdout.strip().split("\n"):
@@ -278,7 +280,8 @@ def test_cpp_fastq_to_sam_pipeline(exe, golden_dir, tmp_path):
     n = 1500
     pre = str(tmp_path / "aln")
     fq = os.path.join(golden_dir, "sim1_bcr.head3000.fq")
-    r = subprocess.run([exe, "pipeline", os.path.join(golden_dir, "tiny.fa"), fq, str(n), pre], capture_output=True, text=True)
+    r = subprocess.run([exe, "pipeline", os.path.join(golden_dir, "tiny.fa"), fq, str(n), pre], capture_output=True, text=True,
+                       env=dict(os.environ, SEQLIB_AMD_SLAB_MIN_READS="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     sam = open(pre + ".sam").read().split("\n")[:-1]
     head, body = [l for l in sam if l.startswith("@")], [l for l in sam if not l.startswith("@")]
@@ -300,9 +303,11 @@ def test_cpp_fastq_to_sam_pipeline(exe, golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hardclip", [0, 1])
-def test_cpp_record_blobs_match_oracle(exe, golden_dir, tmp_path, hardclip):
-    """The BamRecord data block byte for byte (src/BWAAligner.cpp:151-248): qname, CIGAR with op 3 rewritten to S / H, the hard-clip trimming
+@pytest.mark.parametrize("hardclip,slabs", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_cpp_record_blobs_match_oracle(exe, golden_dir, tmp_path, hardclip, slabs):
+    """(slabs = 1: the batch path's records carved out of shared slabs -- include/SeqLib/BamRecord.h, detail::Slab -- as every batch of 8 192 reads or more builds them;
+    forced here on a small batch.)
+    The BamRecord data block byte for byte (src/BWAAligner.cpp:151-248): qname, CIGAR with op 3 rewritten to S / H, the hard-clip trimming
     of the sequence (:164-177), the case-sensitive 4-bit packing (a lower-case base packs as 15, :214-231), N bases, the A<->T-only reversal of
     reverse-strand reads, qual[0] = 0xff, tags NA, NM, AS in that order -- against the block the oracle restates (orc_hit.data), through the
     batch call and the per-read call.  The quality bytes after the first are uninitialised in the reference: masked."""
@@ -324,7 +329,8 @@ def test_cpp_record_blobs_match_oracle(exe, golden_dir, tmp_path, hardclip):
     names_r = ["q%d" % i for i in range(len(reads))]
     path = tmp_path / "reads.tsv"
     path.write_text("".join("%s\t%s\n" % (n, r) for n, r in zip(names_r, reads)))
-    r = subprocess.run([exe, "blob", os.path.join(golden_dir, "tiny.fa"), str(path), str(hardclip), "0"], capture_output=True, text=True)
+    r = subprocess.run([exe, "blob", os.path.join(golden_dir, "tiny.fa"), str(path), str(hardclip), "0"], capture_output=True, text=True,
+                       env=dict(os.environ, SEQLIB_AMD_SLAB_MIN_READS="1" if slabs else "1000000000"))
     assert r.returncode == 0, r.stderr
     got = {"B": {}, "S": {}}
     for line in r.stdout.strip().split("\n"):

@@ -57,6 +57,18 @@ int main(int argc, char **argv)
         for (auto &v : outs) rec2 += v.size();
         // T caller threads on the one aligner, each the reference's loop over its own slice of the reads
         double s3 = 0; size_t rec3 = 0; long n3 = 0;
+        uint64_t rounds0 = 0, calls0 = 0, rounds1 = 0, calls1 = 0;
+        al.CombinedCallStats(rounds0, calls0);
+        double batch_us = 0;
+        if (T > 0) {          // what one shared round costs: T reads as one batch through the same entry a round uses
+            UnalignedSequenceVector few;
+            for (int i = 0; i < T && i < n; ++i) few.emplace_back(names[(size_t)i], seqs[(size_t)i]);
+            std::vector<BamRecordPtrVector> o;
+            al.alignSequences(few, o, false, 0.9, 10);
+            const auto tb = std::chrono::steady_clock::now();
+            for (int rep = 0; rep < 50; ++rep) { o.clear(); al.alignSequences(few, o, false, 0.9, 10); }
+            batch_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count() / 50 * 1e6;
+        }
         if (T > 0) {
             n3 = std::min<long>(n, per_thread * T);
             const long each = n3 / T;
@@ -82,11 +94,13 @@ int main(int argc, char **argv)
             s3 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             rec3 = recs.load();
             if (failed.load()) { std::fprintf(stderr, "percall_bench: %d failures in the threaded loop\n", failed.load()); return 1; }
+            al.CombinedCallStats(rounds1, calls1);
         }
-        std::printf("{\"threads\": {\"value\": %.1f, \"unit\": \"reads/s\", \"caller_threads\": %d, \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, "
+        std::printf("{\"threads\": {\"value\": %.1f, \"unit\": \"reads/s\", \"caller_threads\": %d, \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, \"rounds\": %llu, "
+                    "\"calls_per_round\": %.2f, \"us_per_batch_of_T_reads\": %.1f, "
                     "\"path\": \"T host threads share ONE const BWAAligner, each looping alignSequence over its own reads (re-entrant in the reference, SeqLib/BWAAligner.h:51-63): concurrent calls are "
                     "combined into shared GPU round trips, draws in arrival order\"}, ",
-                    n3 ? (double)n3 / s3 : 0.0, T, n3, rec3, s3);
+                    n3 ? (double)n3 / s3 : 0.0, T, n3, rec3, s3, (unsigned long long)(rounds1 - rounds0), rounds1 > rounds0 ? (double)(calls1 - calls0) / (double)(rounds1 - rounds0) : 0.0, batch_us);
         std::printf("\"value\": %.1f, \"unit\": \"reads/s\", \"us_per_call\": %.2f, \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, "
                     "\"path\": \"C++ SeqLib::BWAAligner::alignSequence, one call per read (the reference's calling convention): one GPU round trip per call\", "
                     "\"deferred\": {\"value\": %.1f, \"unit\": \"reads/s\", \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, "
