@@ -190,6 +190,7 @@ public:
         try { Flush(); } catch (...) {}          // calls still queued by alignSequenceAsync
         for (Staging &st : stage_) { slx_host_free(st.bases); slx_host_free(st.offs); }
         if (al_) slx_aligner_free(al_);
+        if (al2_) slx_aligner_free(al2_);
     }
     BWAAligner(const BWAAligner &) = delete;
     BWAAligner &operator=(const BWAAligner &) = delete;
@@ -346,12 +347,14 @@ private:
     slx_opt memopt_;
     mutable slx_aligner *al_ = nullptr;
     mutable std::once_flag al_once_;
+    mutable slx_aligner *al2_ = nullptr;        // a second device handle (its own copy of the index in HBM, its own workers): the batch path keeps two chunks' calls in flight
+    mutable std::once_flag al2_once_;
     bool copyComment_ = false;
     std::vector<int> devices_;
     mutable std::vector<std::string> names_;   // contig names, for the XA / SA strings
     mutable std::once_flag names_once_;
     struct Staging { char *bases = nullptr; uint64_t *offs = nullptr; size_t cap_bases = 0, cap_reads = 0; };
-    mutable Staging stage_[2];                 // pinned staging of the chunked batch path (kept between calls)
+    mutable Staging stage_[4];                 // pinned staging of the chunked batch path (kept between calls): two slots per call in flight
     mutable std::mutex batch_mu_;              // one chunked batch at a time per aligner (they share the staging)
 
     static long env_long(const char *name, long dflt)
@@ -384,10 +387,22 @@ private:
             if (rc != SLX_OK) throw std::runtime_error(std::string("BWAAligner: ") + slx_last_error());
             al_ = al;
             n_dev_ = dev.empty() ? 1 : (int)dev.size();
+            dev_used_ = dev;
         });
         return al_;
     }
     mutable int n_dev_ = 1;
+    mutable std::vector<int> dev_used_;
+
+    slx_aligner *handle2() const
+    {   // the same devices once more; a failure (no memory for a second copy of the index) leaves the batch path with one call at a time
+        handle();
+        std::call_once(al2_once_, [this]() {
+            slx_aligner *al = nullptr;
+            if (slx_aligner_create(index_->idx_, dev_used_.empty() ? nullptr : dev_used_.data(), (int)dev_used_.size(), &al) == SLX_OK) al2_ = al;
+        });
+        return al2_;
+    }
 
     static std::mutex &rng_mutex() { static std::mutex m; return m; }
 
@@ -631,7 +646,7 @@ private:
         const std::string *seq, *name; BamRecordPtrVector *out; bool hardclip; double ksf; int maxsec;
         bool done = false; std::exception_ptr err;
     };
-    struct Combiner { std::mutex mu; std::condition_variable cv; std::vector<CombReq *> waiting; bool leader = false; uint64_t rounds = 0, calls = 0; };
+    struct Combiner { std::mutex mu; std::condition_variable cv, cv_leader; std::vector<CombReq *> waiting; bool leader = false; uint64_t rounds = 0, calls = 0; size_t last_round = 1; };
     mutable Combiner comb_;
 public:
     // rounds led and calls served by them since the aligner was created (calls / rounds = how many concurrent callers shared a GPU round trip)
@@ -643,11 +658,17 @@ private:
         CombReq me{&seq, &name, &out, hardclip, ksf, maxsec};
         std::unique_lock<std::mutex> lk(comb_.mu);
         comb_.waiting.push_back(&me);
+        if (comb_.leader) comb_.cv_leader.notify_one();          // (a leader may be holding its round open for the callers of the last one)
         for (;;) {
             if (me.done) break;
             if (comb_.leader) { comb_.cv.wait(lk); continue; }
             // lead one round: the waiting calls whose arguments equal the first one's, in arrival order (the others wait for the next round)
             comb_.leader = true;
+            // The callers of a round are released together and come back together: the first one back would lead a round of one while the others queue up behind
+            // it.  When the last round served several callers the leader holds its round open until as many are waiting again -- for at most a tenth of what a
+            // GPU round trip costs.  A lone caller never waits.
+            if (comb_.last_round > 1 && comb_.waiting.size() < comb_.last_round)
+                comb_.cv_leader.wait_for(lk, std::chrono::microseconds(env_long("SEQLIB_AMD_COMBINE_WAIT_US", 40)), [&]() { return comb_.waiting.size() >= comb_.last_round; });
             std::vector<CombReq *> round, rest;
             const CombReq &f = *comb_.waiting.front();
             for (CombReq *r : comb_.waiting) (r->hardclip == f.hardclip && r->ksf == f.ksf && r->maxsec == f.maxsec ? round : rest).push_back(r);
@@ -658,6 +679,7 @@ private:
             lk.lock();
             for (CombReq *r : round) { r->err = err; r->done = true; }
             ++comb_.rounds; comb_.calls += round.size();
+            comb_.last_round = round.size();
             comb_.leader = false;
             comb_.cv.notify_all();
         }
@@ -716,7 +738,7 @@ private:
 
     // the batch: chunks of the read vector through pack (host threads) -> align (GPU) -> records (host threads), overlapped.
     // Tunables (environment): SEQLIB_AMD_THREADS host threads (default: the CPUs the process may use -- hardware threads cut down to the
-    // cgroup CPU quota), SEQLIB_AMD_CHUNK reads per chunk and device (default 4 M), SEQLIB_AMD_TRACE=1 per-chunk timings on stderr.
+    // cgroup CPU quota), SEQLIB_AMD_CHUNK reads per chunk and device (default 8 M), SEQLIB_AMD_TRACE=1 per-chunk timings on stderr.
     void run_batch(const UnalignedSequenceVector &reads, std::vector<BamRecordPtrVector> &out, bool hardclip, double keepSecFrac, int maxSecondary) const
     {
         slx_aligner *al = handle();
@@ -728,7 +750,7 @@ private:
             slx_lrand48_skip_libc((uint64_t)n);
         }
         std::lock_guard<std::mutex> batch(batch_mu_);
-        const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 4000000) * n_dev_);
+        const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 8000000) * n_dev_);
         const int64_t n_chunks = (n + chunk - 1) / chunk;
         unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)detail::effective_cpus());
         T = std::max(1u, std::min(T, 512u));
@@ -741,10 +763,20 @@ private:
         std::vector<ChunkJob> jobs((size_t)n_chunks);
         for (int64_t c = 0; c < n_chunks; ++c) { jobs[(size_t)c].lo = c * chunk; jobs[(size_t)c].hi = std::min(n, (c + 1) * chunk); }
 
-        // pack chunk c into staging slot c & 1: lengths per part -> exclusive scan -> offsets + bases, all on the pool
+        // Two chunks' GPU calls in flight (SEQLIB_AMD_CALLS_IN_FLIGHT, default 2; needs a second device handle = a second copy of the index in HBM): a call ends in the
+        // single-read critical paths of its heaviest reads -- tens of milliseconds whatever the chunk holds -- and begins with its upload; with one call at a time a
+        // 4 M-read chunk took 100 ms where the kernels need 65.  Lane L (a host thread) takes chunks L, L + lanes, ...: packs them, calls its own handle, hands the result
+        // to the record builders.  Read i keeps draw `state + i` whichever lane aligns it.
+        slx_aligner *als[2] = {al, nullptr};
+        int n_lanes = 1;
+        // (not with fewer than eight host threads: a thread inside a GPU call spins on the stream, and two of them take the builders' CPUs -- at 2 threads 9.6 M reads/s
+        // against 13.4 M with one call at a time)
+        if (n_chunks >= 2 && env_long("SEQLIB_AMD_CALLS_IN_FLIGHT", T >= 8 ? 2 : 1) >= 2 && (als[1] = handle2()) != nullptr) n_lanes = 2;
+        const int n_slot = 2 * n_lanes;
+        // pack chunk c into staging slot c % n_slot: lengths per part -> exclusive scan -> offsets + bases, all on the pool
         auto submit_pack = [&](int64_t c) {
             ChunkJob &J = jobs[(size_t)c];
-            Staging &S = stage_[c & 1];
+            Staging &S = stage_[c % n_slot];
             const int64_t m = J.hi - J.lo;
             if ((size_t)m + 1 > S.cap_reads) {
                 slx_host_free(S.offs);
@@ -774,7 +806,7 @@ private:
             }
             J.packed = pool.submit(parts, [&, c](int t) {
                 const ChunkJob &Jc = jobs[(size_t)c];
-                Staging &Sc = stage_[c & 1];
+                Staging &Sc = stage_[c % n_slot];
                 const int64_t mm = Jc.hi - Jc.lo, a = Jc.lo + mm * t / parts, b = Jc.lo + mm * (t + 1) / parts;
                 uint64_t o = Jc.part_bytes[(size_t)t];
                 for (int64_t i = a; i < b; ++i) {
@@ -797,23 +829,25 @@ private:
         const bool trace = env_long("SEQLIB_AMD_TRACE", 0) != 0;
         const auto t_begin = std::chrono::steady_clock::now();
         auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-        try {
-            submit_pack(0);
-            for (int64_t c = 0; c < n_chunks; ++c) {
+        std::atomic<bool> failed{false};
+        auto lane = [&](int L) {
+            // this lane's chunks: c = L, L + n_lanes, ...; chunk c's staging slot was chunk c - n_slot's, a chunk of this lane whose call has returned
+            if (L < n_chunks) submit_pack(L);
+            if (L + n_lanes < n_chunks) submit_pack(L + n_lanes);
+            for (int64_t c = L; c < n_chunks && !failed.load(); c += n_lanes) {
                 ChunkJob &J = jobs[(size_t)c];
                 const auto t_c = std::chrono::steady_clock::now();
                 pool.wait(J.packed);
                 const double ms_packwait = ms_since(t_c);
-                // staging slot (c+1)&1 was last read by the alignment of chunk c-1, which has returned (the records of chunk c-1, being
-                // built meanwhile, read the caller's reads and their own result block); at most two result blocks are alive at a time
-                if (c >= 2) { ChunkJob &P = jobs[(size_t)c - 2]; pool.wait(P.built); slx_hits_free(&P.h); P.have_h = false; }
-                if (c + 1 < n_chunks) submit_pack(c + 1);
-                Staging &S = stage_[c & 1];
+                // at most two result blocks per lane are alive: the records of this lane's chunk before last are done before the next call is made
+                if (c >= 2 * n_lanes) { ChunkJob &P = jobs[(size_t)(c - 2 * n_lanes)]; pool.wait(P.built); slx_hits_free(&P.h); P.have_h = false; }
+                Staging &S = stage_[c % n_slot];
                 const double ms_pre = ms_since(t_c);
-                throw_rc(slx_align_batch(al, &memopt_, S.bases, S.offs, J.hi - J.lo, state, (uint64_t)J.lo, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &J.h));
+                throw_rc(slx_align_batch(als[L], &memopt_, S.bases, S.offs, J.hi - J.lo, state, (uint64_t)J.lo, hardclip ? 1 : 0, keepSecFrac, maxSecondary, &J.h));
                 J.have_h = true;
-                if (trace) std::fprintf(stderr, "[alignSequences] chunk %lld (%lld reads): waited %.1f ms for its pack, %.1f ms until the GPU call, GPU call %.1f ms, t = %.1f ms, %u host threads\n",
-                                        (long long)c, (long long)(J.hi - J.lo), ms_packwait, ms_pre, ms_since(t_c) - ms_pre, ms_since(t_begin), T);
+                if (c + (int64_t)n_slot < n_chunks) submit_pack(c + n_slot);          // (the slot is free again: the call has read it)
+                if (trace) std::fprintf(stderr, "[alignSequences] chunk %lld (%lld reads, lane %d): waited %.1f ms for its pack, %.1f ms until the GPU call, GPU call %.1f ms, t = %.1f ms, %u host threads\n",
+                                        (long long)c, (long long)(J.hi - J.lo), L, ms_packwait, ms_pre, ms_since(t_c) - ms_pre, ms_since(t_begin), T);
                 J.built = pool.submit(parts, [&, c](int t) {
                     const ChunkJob &Jc = jobs[(size_t)c];
                     const int64_t mm = Jc.hi - Jc.lo;
@@ -822,7 +856,7 @@ private:
                     detail::SlabWriter writer;
                     detail::SlabWriter *sw = use_slabs ? &writer : nullptr;
                     const int64_t i0 = mm * t / parts, i1 = mm * (t + 1) / parts;
-                    // the sequence of a record comes from the caller's reads (the staging slot is reused two chunks later)
+                    // the sequence of a record comes from the caller's reads (the staging slot is reused by a later chunk)
                     for (int64_t i = i0; i < i1; ++i) {
                         const UnalignedSequence &us = reads[(size_t)(Jc.lo + i)];
                         if (sw && !(i & 255)) {               // what is left of the stretch sizes the task's last slab: records still to come x (shells + blob of a read like this one)
@@ -833,6 +867,14 @@ private:
                     }
                 }, false);
             }
+        };
+        try {
+            std::exception_ptr err2;
+            std::thread second;
+            if (n_lanes > 1) second = std::thread([&]() { try { lane(1); } catch (...) { err2 = std::current_exception(); failed.store(true); } });
+            try { lane(0); } catch (...) { failed.store(true); if (second.joinable()) second.join(); throw; }
+            if (second.joinable()) second.join();
+            if (err2) std::rethrow_exception(err2);
             const auto t_tail = std::chrono::steady_clock::now();
             for (ChunkJob &J : jobs) if (J.built) { pool.wait(J.built); if (J.have_h) { slx_hits_free(&J.h); J.have_h = false; } }
             if (trace) std::fprintf(stderr, "[alignSequences] records of the last chunks: %.1f ms after the last GPU call; total %.1f ms\n", ms_since(t_tail), ms_since(t_begin));

@@ -136,7 +136,7 @@ public:
 
     void SetMinOverlap(uint32_t m) { opt.min_asm_ovlp = (int)m; }
     void SetAggressiveTrim() { opt.mag_opt.flag |= MAG_F_AGGRESSIVE; }
-    void SetSimplifyBubble() { opt.mag_opt.flag &= ~MAG_F_NO_SIMPL; }          // (the GPU path refuses to assemble with it: bubble.c is not built)
+    void SetSimplifyBubble() { opt.mag_opt.flag &= ~MAG_F_NO_SIMPL; }          // closed bubbles cut down to their two best-supported paths before mag_g_pop_simple (fml_graph.h: simplify_bubble)
     void SetDropOverlapRatio(double ratio) { opt.mag_opt.min_dratio1 = (float)ratio; }
     void SetKmerMinThreshold(int min) { opt.min_cnt = min; }
     void SetKmerMaxThreshold(int max) { opt.max_cnt = max; }

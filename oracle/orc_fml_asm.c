@@ -732,6 +732,123 @@ static void mag_g_pop_open(mag_t *g, int min_elen)
     for (i = 0; i < g->n; ++i) mag_v_pop_open(g, &g->a[i], min_elen);
 }
 
+/* ------------------------------------------------------------------------------------------------ closed bubbles (fermi's bubble.c: mag_g_simplify_bubble)
+ * What FermiAssembler::SetSimplifyBubble switches on (/root/reference/SeqLib/FermiAssembler.h:88-90 clears MAG_F_NO_SIMPL; fermi-lite's fml_opt_init sets it).
+ * Restated from the published algorithm as its author wrote it for fermi (bubble.c), from memory -- fermi-lite is an empty submodule and nothing in the
+ * reference tree holds its output, so this, like the rest of the file, is parity-unpinned against fermi-lite itself.  [CHOICE] marks what is fixed here.
+ *
+ * From an end with two or more neighbours the unitig graph is walked in topological order (a vertex end is expanded when every edge into it has been seen),
+ * carrying for every end reached the two best-supported paths from the start: n = reads on the path (nsr summed, the start's own left out), d = its length in
+ * bases (overlaps taken off), and a back pointer (the end it came through and which of that end's two paths).  The walk fails when more than max_vtx vertices are
+ * touched, a path grows beyond max_dist, a dead end or a cycle back to the start is met.  When the expansion front shrinks to ONE end with nothing pending, that end
+ * closes the bubble: the vertices on its two best paths stay, every other vertex the walk touched is deleted.  (The two paths left are what mag_g_pop_simple then
+ * compares by alignment.)  After all ends: mag_g_merge(g, 0, 0). */
+typedef struct { int64_t id; int cnt[2]; int n[2][2], d[2][2]; int64_t bx[2][2]; int br[2][2]; } tri_t;          /* bx: the end the path left its predecessor through; br: which of the predecessor's two paths */
+typedef struct { int n, m; tri_t *a; int sn, sm; int64_t *stack; int *slot; int64_t n_slot; unsigned char *keep; int keep_m; } mogb_aux_t;
+
+static tri_t *tri_get(mogb_aux_t *a, int64_t idd)          /* the record of idd's vertex, made on first touch (fermi keeps a pointer in the vertex) */
+{
+    tri_t *t;
+    int i, j;
+    if (a->slot[idd >> 1] >= 0) return &a->a[a->slot[idd >> 1]];
+    if (a->n == a->m) { a->m = a->m ? a->m << 1 : 64; a->a = (tri_t*)realloc(a->a, sizeof(tri_t) * a->m); }
+    t = &a->a[a->n];
+    a->slot[idd >> 1] = a->n++;
+    t->id = idd; t->cnt[0] = t->cnt[1] = 0;
+    for (i = 0; i < 2; ++i) for (j = 0; j < 2; ++j) { t->n[i][j] = t->d[i][j] = -0x40000000; t->bx[i][j] = -1; t->br[i][j] = 0; }          /* [CHOICE] fermi: INT_MIN; kept clear of overflow here */
+    return t;
+}
+
+static void mag_vh_simplify_bubble(mag_t *g, int64_t idd, int max_vtx, int max_dist, mogb_aux_t *a)
+{
+    int i, n_pending = 0, failed = 0;
+    magv_t *p = &g->a[idd >> 1], *q;
+    tri_t *tp, *tq;
+    if (p->len < 0 || p->nei[idd & 1].n < 2) return;
+    a->n = a->sn = 0;
+    tp = tri_get(a, idd);
+    tp->d[(idd & 1) ^ 1][0] = -p->len;
+    tp->n[(idd & 1) ^ 1][0] = -p->nsr;
+    if (a->sn == a->sm) { a->sm = a->sm ? a->sm << 1 : 64; a->stack = (int64_t*)realloc(a->stack, sizeof(int64_t) * a->sm); }
+    a->stack[a->sn++] = idd ^ 1;
+    while (a->sn) {
+        int64_t x, y;
+        ku128_v *r;
+        if (a->sn == 1 && a->stack[0] != (idd ^ 1) && n_pending == 0) break;          /* the other end of the bubble */
+        x = a->stack[--a->sn];
+        p = &g->a[x >> 1];
+        tp = tri_get(a, x);
+        r = &p->nei[(x & 1) ^ 1];          /* arrived through end x & 1: the neighbours of the other end are next */
+        if (a->n > max_vtx || tp->d[x & 1][0] > max_dist || tp->d[x & 1][1] > max_dist || r->n == 0) { failed = 1; break; }
+        for (i = 0; i < r->n; ++i) {
+            int nsr, dist, which = 0;
+            if ((int64_t)r->a[i].x < 0) continue;
+            if (edge_is_del(r->a[i])) continue;          /* [CHOICE] fermi cleans the list on first touch; deleted edges never count here either */
+            y = tid2idd(g, r->a[i].x);
+            if (y == (idd ^ 1)) { a->sn = 0; failed = 1; break; }          /* a loop through the start: not a bubble */
+            q = &g->a[y >> 1];
+            if (a->slot[y >> 1] < 0) { ++n_pending; v128_clean(&q->nei[y & 1]); }
+            tq = tri_get(a, y);
+            tp = tri_get(a, x);          /* (the table may have moved) */
+            nsr = tp->n[x & 1][0] + p->nsr;
+            dist = tp->d[x & 1][0] + p->len - (int)r->a[i].y;
+            if (nsr > tq->n[y & 1][0]) {          /* better than the best: that one becomes the second, and p's own second path is tried for second place */
+                tq->n[y & 1][1] = tq->n[y & 1][0]; tq->d[y & 1][1] = tq->d[y & 1][0]; tq->bx[y & 1][1] = tq->bx[y & 1][0]; tq->br[y & 1][1] = tq->br[y & 1][0];
+                tq->n[y & 1][0] = nsr; tq->d[y & 1][0] = dist; tq->bx[y & 1][0] = x ^ 1; tq->br[y & 1][0] = 0;
+                nsr = tp->n[x & 1][1] + p->nsr;
+                dist = tp->d[x & 1][1] + p->len - (int)r->a[i].y;
+                which = 1;
+            }
+            if (nsr > tq->n[y & 1][1]) { tq->n[y & 1][1] = nsr; tq->d[y & 1][1] = dist; tq->bx[y & 1][1] = x ^ 1; tq->br[y & 1][1] = which; }
+            if (++tq->cnt[y & 1] == q->nei[y & 1].n) {          /* every edge into this end has been seen */
+                if (a->sn == a->sm) { a->sm = a->sm ? a->sm << 1 : 64; a->stack = (int64_t*)realloc(a->stack, sizeof(int64_t) * a->sm); }
+                a->stack[a->sn++] = y;
+                --n_pending;
+            }
+        }
+        if (failed) break;
+    }
+    if (!failed && n_pending == 0 && a->sn == 1 && a->stack[0] != (idd ^ 1)) {
+        const int64_t x = a->stack[0];
+        int rank;
+        if (a->keep_m < a->n) { a->keep_m = a->m; a->keep = (unsigned char*)realloc(a->keep, (size_t)a->keep_m); }
+        for (i = 0; i < a->n; ++i) a->keep[i] = 0;
+        a->keep[a->slot[idd >> 1]] = 1; a->keep[a->slot[x >> 1]] = 1;          /* [CHOICE] the two ends of the bubble stay by construction */
+        for (rank = 0; rank < 2; ++rank) {          /* the vertices on the end's best and second-best path */
+            int64_t at = x;
+            int rk = rank;
+            for (;;) {
+                const tri_t *t = &a->a[a->slot[at >> 1]];
+                const int64_t px = t->bx[at & 1][rk];
+                const int prk = t->br[at & 1][rk];
+                if (px < 0) break;                          /* (no second path) */
+                if (px == idd) break;                       /* left the start: done */
+                a->keep[a->slot[px >> 1]] = 1;
+                at = px ^ 1; rk = prk;
+            }
+        }
+        for (i = 0; i < a->n; ++i)
+            if (!a->keep[i]) mag_v_del(g, &g->a[a->a[i].id >> 1]);
+    }
+    for (i = 0; i < a->n; ++i) a->slot[a->a[i].id >> 1] = -1;
+}
+
+static void mag_g_simplify_bubble(mag_t *g, int max_vtx, int max_dist)
+{
+    mogb_aux_t a;
+    int64_t i;
+    memset(&a, 0, sizeof a);
+    a.n_slot = g->n;
+    a.slot = (int*)malloc(sizeof(int) * (g->n + 1));
+    for (i = 0; i < g->n; ++i) a.slot[i] = -1;
+    for (i = 0; i < g->n; ++i) {
+        mag_vh_simplify_bubble(g, i << 1 | 0, max_vtx, max_dist, &a);
+        mag_vh_simplify_bubble(g, i << 1 | 1, max_vtx, max_dist, &a);
+    }
+    free(a.a); free(a.stack); free(a.slot); free(a.keep);
+    mag_g_merge(g, 0, 0);
+}
+
 static void mag_g_clean(mag_t *g, const orc_magopt *opt)          /* mag.c: mag_g_clean */
 {
     int j;
@@ -743,7 +860,7 @@ static void mag_g_clean(mag_t *g, const orc_magopt *opt)          /* mag.c: mag_
     for (j = 2; j <= opt->min_ensr; ++j) mag_g_rm_vext(g, opt->min_elen, j);
     mag_g_merge(g, 0, opt->min_merge_len);
     if (opt->flag & ORC_MAG_F_POPOPEN) { mag_g_pop_open(g, opt->min_elen); mag_g_merge(g, 0, opt->min_merge_len); }
-    /* MAG_F_NO_SIMPL clear -> mag_g_simplify_bubble (bubble.c): not restated; the assemble entry points refuse it */
+    if (!(opt->flag & ORC_MAG_F_NO_SIMPL)) mag_g_simplify_bubble(g, opt->max_bvtx, opt->max_bdist);
     mag_g_pop_simple(g, opt->max_bcov, opt->max_bfrac, opt->min_merge_len, opt->flag & ORC_MAG_F_AGGRESSIVE);
     mag_g_rm_vint(g, opt->min_elen, opt->min_insr, g->min_ovlp);
     mag_g_rm_edge(g, g->min_ovlp, opt->min_dratio1, opt->min_elen, opt->min_ensr);
@@ -949,7 +1066,6 @@ orc_fml_utg *orc_fml_assemble(const orc_fml_opt *opt0, int n_seqs, orc_fseq *seq
     float kcov;
     orc_fml_utg *utg;
     *n_utg = 0;
-    if (!(opt.mag_opt.flag & ORC_MAG_F_NO_SIMPL)) return 0;
     orc_fml_opt_adjust(&opt, n_seqs, seqs);
     if (opt.ec_k >= 0) orc_fml_correct(&opt, n_seqs, seqs);
     kcov = orc_fml_fltuniq(&opt, n_seqs, seqs);
@@ -967,7 +1083,6 @@ orc_fml_utg *orc_fml_direct_assemble(orc_fml_opt *opt, float kcov, int n_seqs, o
 {
     orc_fml_utg *utg;
     *n_utg = 0;
-    if (!(opt->mag_opt.flag & ORC_MAG_F_NO_SIMPL)) return 0;
     opt->mag_opt.min_ensr = opt->mag_opt.min_ensr > kcov * MAG_MIN_NSR_COEF ? opt->mag_opt.min_ensr : (int)(kcov * MAG_MIN_NSR_COEF + .499);
     opt->mag_opt.min_insr = opt->mag_opt.min_ensr - 1;
     utg = assemble_core(opt, n_seqs, seqs, n_utg);

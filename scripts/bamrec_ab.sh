@@ -22,7 +22,7 @@ print("prepared", n, "reads")
 PY
 run() {  # name, env...
   name=$1; shift
-  env "$@" SEQLIB_AMD_TRACE=1 timeout 600 $R/seqlib_amd/bamrec_bench /tmp/bamrec/c3 /tmp/bamrec/reads.bin 150 $N > $OUT/$name.json 2> $OUT/$name.err
+  env "$@" SEQLIB_AMD_TRACE=1 timeout ${BAMREC_TIMEOUT:-300} $R/seqlib_amd/bamrec_bench /tmp/bamrec/c3 /tmp/bamrec/reads.bin 150 $N > $OUT/$name.json 2> $OUT/$name.err
   echo "$name: $(cut -c1-120 $OUT/$name.json)"
 }
 if [ -n "$RUNS" ]; then

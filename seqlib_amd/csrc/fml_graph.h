@@ -421,6 +421,104 @@ struct Graph {
 
     void pop_open(int min_elen) { for (int i = 0; i < (int)v.size(); ++i) pop_open_at(i, min_elen); }
 
+    // Closed bubbles with more than two paths (fermi's bubble.c: mag_g_simplify_bubble; what FermiAssembler::SetSimplifyBubble turns on by clearing
+    // MAG_F_NO_SIMPL, /root/reference/SeqLib/FermiAssembler.h:88-90).  From an end with two or more neighbours the graph is walked in topological order -- an end
+    // is expanded once every edge into it has been seen -- carrying per end reached the two best-supported paths from the start (n: reads on the path, d: its
+    // length with the overlaps taken off, and where it came from).  More than max_vtx vertices, a path beyond max_dist, a dead end or a way back to the start:
+    // no bubble.  When the front shrinks to one end with nothing pending, that end closes the bubble: the vertices on its two best paths stay, the others the
+    // walk touched go.  The checker's restatement (oracle/orc_fml_asm.c: mag_vh_simplify_bubble) is the definition; this is the same walk on this graph's types.
+    struct Tri { int64_t id; int cnt[2]; int n[2][2], d[2][2]; int64_t bx[2][2]; int br[2][2]; };
+    struct BubbleAux { std::vector<Tri> a; std::vector<int64_t> stack; std::vector<int> slot; std::vector<unsigned char> keep; };
+    static Tri &tri_get(BubbleAux &A, int64_t x)
+    {
+        int &sl = A.slot[(size_t)(x >> 1)];
+        if (sl >= 0) return A.a[(size_t)sl];
+        Tri t;
+        t.id = x; t.cnt[0] = t.cnt[1] = 0;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { t.n[i][j] = t.d[i][j] = -0x40000000; t.bx[i][j] = -1; t.br[i][j] = 0; }
+        sl = (int)A.a.size();
+        A.a.push_back(t);
+        return A.a.back();
+    }
+    void simplify_bubble_at(int64_t start, int max_vtx, int max_dist, BubbleAux &A)
+    {
+        {
+            const Vtx &p0 = v[(size_t)(start >> 1)];
+            if (p0.len < 0 || p0.nei[start & 1].size() < 2) return;
+        }
+        A.a.clear(); A.stack.clear();
+        int n_pending = 0;
+        bool failed = false;
+        {
+            const Vtx &p0 = v[(size_t)(start >> 1)];
+            Tri &t0 = tri_get(A, start);
+            t0.d[(start & 1) ^ 1][0] = -p0.len;
+            t0.n[(start & 1) ^ 1][0] = -p0.nsr;
+        }
+        A.stack.push_back(start ^ 1);
+        while (!A.stack.empty()) {
+            if (A.stack.size() == 1 && A.stack[0] != (start ^ 1) && n_pending == 0) break;          // the other end of the bubble
+            const int64_t x = A.stack.back();
+            A.stack.pop_back();
+            const Vtx &p = v[(size_t)(x >> 1)];
+            const std::vector<Nei> &r = p.nei[(x & 1) ^ 1];
+            {
+                const Tri &tp = tri_get(A, x);
+                if ((int)A.a.size() > max_vtx || tp.d[x & 1][0] > max_dist || tp.d[x & 1][1] > max_dist || r.empty()) { failed = true; break; }
+            }
+            for (size_t i = 0; i < r.size(); ++i) {
+                if ((int64_t)r[i].x < 0 || is_del(r[i])) continue;
+                const int64_t y = tid2idd(r[i].x);
+                if (y == (start ^ 1)) { A.stack.clear(); failed = true; break; }          // a loop through the start
+                if (A.slot[(size_t)(y >> 1)] < 0) { ++n_pending; clean(v[(size_t)(y >> 1)].nei[y & 1]); }
+                (void)tri_get(A, y);                              // (may move the table)
+                const Tri &tp = tri_get(A, x);                    // (a reference, as in the checker: on a self-loop tp and tq are one record)
+                Tri &tq = tri_get(A, y);
+                int nsr = tp.n[x & 1][0] + p.nsr, dist = tp.d[x & 1][0] + p.len - (int)r[i].y, which = 0;
+                if (nsr > tq.n[y & 1][0]) {
+                    tq.n[y & 1][1] = tq.n[y & 1][0]; tq.d[y & 1][1] = tq.d[y & 1][0]; tq.bx[y & 1][1] = tq.bx[y & 1][0]; tq.br[y & 1][1] = tq.br[y & 1][0];
+                    tq.n[y & 1][0] = nsr; tq.d[y & 1][0] = dist; tq.bx[y & 1][0] = x ^ 1; tq.br[y & 1][0] = 0;
+                    nsr = tp.n[x & 1][1] + p.nsr;
+                    dist = tp.d[x & 1][1] + p.len - (int)r[i].y;
+                    which = 1;
+                }
+                if (nsr > tq.n[y & 1][1]) { tq.n[y & 1][1] = nsr; tq.d[y & 1][1] = dist; tq.bx[y & 1][1] = x ^ 1; tq.br[y & 1][1] = which; }
+                if (++tq.cnt[y & 1] == (int)v[(size_t)(y >> 1)].nei[y & 1].size()) { A.stack.push_back(y); --n_pending; }
+            }
+            if (failed) break;
+        }
+        if (!failed && n_pending == 0 && A.stack.size() == 1 && A.stack[0] != (start ^ 1)) {
+            const int64_t x = A.stack[0];
+            A.keep.assign(A.a.size(), 0);
+            A.keep[(size_t)A.slot[(size_t)(start >> 1)]] = 1; A.keep[(size_t)A.slot[(size_t)(x >> 1)]] = 1;
+            for (int rank = 0; rank < 2; ++rank) {
+                int64_t at = x;
+                int rk = rank;
+                for (;;) {
+                    const Tri &t = A.a[(size_t)A.slot[(size_t)(at >> 1)]];
+                    const int64_t px = t.bx[at & 1][rk];
+                    const int prk = t.br[at & 1][rk];
+                    if (px < 0 || px == start) break;
+                    A.keep[(size_t)A.slot[(size_t)(px >> 1)]] = 1;
+                    at = px ^ 1; rk = prk;
+                }
+            }
+            for (size_t i = 0; i < A.a.size(); ++i)
+                if (!A.keep[i]) v_del((int)(A.a[i].id >> 1));
+        }
+        for (const Tri &t : A.a) A.slot[(size_t)(t.id >> 1)] = -1;
+    }
+    void simplify_bubble(int max_vtx, int max_dist)
+    {
+        BubbleAux A;
+        A.slot.assign(v.size() + 1, -1);
+        for (int64_t i = 0; i < (int64_t)v.size(); ++i) {
+            simplify_bubble_at(i << 1 | 0, max_vtx, max_dist, A);
+            simplify_bubble_at(i << 1 | 1, max_vtx, max_dist, A);
+        }
+        merge(false, 0);
+    }
+
     void clean_graph(const slx_magopt &o)          // mag.c: mag_g_clean
     {
         if (min_ovlp < o.min_ovlp) min_ovlp = o.min_ovlp;
@@ -431,6 +529,7 @@ struct Graph {
         for (int j = 2; j <= o.min_ensr; ++j) rm_vext(o.min_elen, j);
         merge(false, o.min_merge_len);
         if (o.flag & SLX_MAG_F_POPOPEN) { pop_open(o.min_elen); merge(false, o.min_merge_len); }
+        if (!(o.flag & SLX_MAG_F_NO_SIMPL)) simplify_bubble(o.max_bvtx, o.max_bdist);
         pop_simple(o.max_bcov, o.max_bfrac, o.min_merge_len, (o.flag & SLX_MAG_F_AGGRESSIVE) != 0);
         rm_vint(o.min_elen, o.min_insr, min_ovlp);
         rm_edge(min_ovlp, o.min_dratio1, o.min_elen, o.min_ensr);

@@ -461,7 +461,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
-    else if (!strcmp(key, "hits_wave")) al->hits_wave = value != 0;
+    else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
@@ -562,9 +562,9 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;
         }
-        if (!strcmp(key, "regs_deferred") || !strcmp(key, "hits_wave_reads")) {          // reads k_regs handed to the wave kernel / reads k_hits_wave sorted, since the aligner was created
+        if (!strcmp(key, "regs_deferred")) {          // reads k_regs handed to the wave kernel since the aligner was created
             long long v = 0;
-            const int which = key[0] == 'h';
+            const int which = 0;
             auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += (long long)wk->fin_stat[which]; };
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;
@@ -854,7 +854,7 @@ namespace {
 struct PinBlock { void *p; uint64_t cap; };
 std::mutex g_pin_mu;
 std::vector<PinBlock> g_pin_pool;
-const size_t PIN_KEEP = 2;                      // blocks kept ...
+const size_t PIN_KEEP = 4;                      // blocks kept (the C++ mirror's batch path has up to four results alive: two calls in flight, two being turned into records) ...
 const uint64_t PIN_KEEP_BYTES = 8ull << 30;     // ... and bytes kept, at most (a 50 M-read result is ~2.7 GB); dropped when the last aligner is freed
 void *pin_acquire(uint64_t bytes, uint64_t *cap)
 {

@@ -1,7 +1,8 @@
 """The product's host-side graph stage (seqlib_amd/csrc/fml_graph.h: unitig chaining, mag_g_clean with fermi-lite's Smith-Waterman bubble tests,
 fml_mag2utg) against the CPU checker's (oracle/orc_fml_asm.c) on the SAME overlap graphs, without a GPU: the checker dumps the overlap graph of a
 window, tests/cpp/fml_graph_test.cpp runs the product's code on it.  Windows with two haplotypes (bubbles: SNPs and small indels), repeats, the
-reference's own fixture reads; every flag of mag_g_clean the reference's setters and fml_opt_t constructor can reach except MAG_F_NO_SIMPL cleared."""
+reference's own fixture reads; every flag of mag_g_clean the reference's setters and fml_opt_t constructor can reach, MAG_F_NO_SIMPL cleared (FermiAssembler::SetSimplifyBubble) on windows
+with three and four haplotypes -- bubbles with more than two paths -- included."""
 import os
 import subprocess
 
@@ -99,3 +100,47 @@ def test_bubble_pass_is_live(exe, tmp_path):
         b = F.assemble(o, F.Reads(w[0], w[1]))
         changed += [u["seq"] for u in a] != [u["seq"] for u in b]
     assert changed > 0
+
+
+def _multi_hap_windows(genome):
+    """three / four haplotypes in one window: shared sites with a different allele on every haplotype plus private SNPs close to them -- closed bubbles with
+    more than two paths, what mag_g_simplify_bubble cuts down to the two best-supported ones"""
+    wins = []
+    for seed, (name, a, b), n_hap in ((1, ("abl", 30000, 38000), 4), (2, ("bcr", 60000, 67000), 3), (3, ("tp53", 1000, 8000), 4)):
+        ref = bytearray(genome[name][a:b].upper())
+        rng = np.random.default_rng(900 + seed)
+        haps = [bytearray(ref) for _ in range(n_hap)]
+        shared = rng.integers(300, len(ref) - 300, size=5)
+        for pos in shared:
+            for i, h in enumerate(haps):
+                h[pos] = b"ACGT"[(b"ACGT".index(bytes([ref[pos]])) + i) % 4] if bytes([ref[pos]]) in (b"A", b"C", b"G", b"T") else h[pos]
+                for off in rng.integers(-60, 60, size=2):          # private variants beside the shared site
+                    q = int(pos + off)
+                    if i and bytes([ref[q]]) in (b"A", b"C", b"G", b"T") and rng.random() < 0.5:
+                        h[q] = b"ACGT"[(b"ACGT".index(bytes([ref[q]])) + 1 + i % 2) % 4]
+        rs, qs = [], []
+        for i, h in enumerate(haps):
+            share = (1200, 900, 500, 300)[i]          # unequal support: "best" and "second best" mean something
+            r, q, _ = U.sim_window(bytes(h), share, seed=50 * seed + i, err=0.004)
+            rs += r; qs += q
+        wins.append((rs, qs))
+    return wins
+
+
+@pytest.mark.parametrize("flags", [0, 0x20])
+def test_simplify_bubble_matches_checker(exe, tmp_path, flags):
+    """MAG_F_NO_SIMPL cleared: the product's simplify_bubble (fml_graph.h) == the checker's mag_g_simplify_bubble on the same overlap graphs, and the pass is live
+    (the unitigs differ from those without it on these windows)"""
+    from oracle import orc_fml as F
+    genome = U.fixture_genome()
+    live = 0
+    for wi, w in enumerate(_multi_hap_windows(genome) + _het_windows(genome)[:2]):
+        o = F.default_opt()
+        o.mag_opt.flag = (o.mag_opt.flag | flags) & ~0x80
+        dump = str(tmp_path / ("s%d.bin" % wi))
+        exp = F.assemble(o, F.Reads(w[0], w[1]), dump=dump)
+        _same(_run(exe, dump), exp, "window %d flags %#x, bubbles simplified" % (wi, flags))
+        o2 = F.default_opt()
+        o2.mag_opt.flag |= flags
+        live += [u["seq"] for u in F.assemble(o2, F.Reads(w[0], w[1]))] != [u["seq"] for u in exp]
+    assert live >= 2

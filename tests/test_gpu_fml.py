@@ -352,7 +352,25 @@ def test_direct_assemble_and_options(F, G, ctx, genome):
         exp = F.direct_assemble(fo, 30.0, F.Reads(seqs))
         _same_utgs(got, exp, "direct %d %s" % (min_ovlp, aggressive))
         assert o.mag_opt.min_ensr == fo.mag_opt.min_ensr and o.mag_opt.min_insr == fo.mag_opt.min_insr
-    o = G.default_opt()
-    o.mag_opt.flag &= ~G.MAG_F_NO_SIMPL
-    with pytest.raises(Exception):
-        ctx.direct_assemble(o, 30.0, b, of)
+    # MAG_F_NO_SIMPL cleared (FermiAssembler::SetSimplifyBubble; refused until round 5): windows of three and four haplotypes, whose closed bubbles have more than
+    # two paths, through assemble and direct_assemble against the checker's mag_g_simplify_bubble -- and the pass changes the contigs
+    from tests.test_fml_graph import _multi_hap_windows
+    live = 0
+    for wi, w in enumerate(_multi_hap_windows(genome)):
+        for aggressive in (False, True):
+            o = G.default_opt(); fo = F.default_opt()
+            o.mag_opt.flag &= ~G.MAG_F_NO_SIMPL; fo.mag_opt.flag &= ~G.MAG_F_NO_SIMPL
+            if aggressive:
+                o.mag_opt.flag |= G.MAG_F_AGGRESSIVE; fo.mag_opt.flag |= G.MAG_F_AGGRESSIVE
+            bb, qq, oo = G.flatten(w[0], w[1])
+            got = ctx.assemble(o, bb, qq, oo, [0, len(w[0])])[0]
+            exp = F.assemble(fo, F.Reads(w[0], w[1]))
+            _same_utgs(got, exp, "multi-haplotype window %d, bubbles simplified, aggressive %s" % (wi, aggressive))
+            if not aggressive:
+                plain = F.assemble(F.default_opt(), F.Reads(w[0], w[1]))
+                live += [u["seq"] for u in plain] != [u["seq"] for u in exp]
+        o = G.default_opt(); fo = F.default_opt()
+        o.mag_opt.flag &= ~G.MAG_F_NO_SIMPL; fo.mag_opt.flag &= ~G.MAG_F_NO_SIMPL
+        bb, _, oo = G.flatten(w[0])
+        _same_utgs(ctx.direct_assemble(o, 30.0, bb, oo), F.direct_assemble(fo, 30.0, F.Reads(w[0])), "multi-haplotype window %d, direct" % wi)
+    assert live >= 1

@@ -67,16 +67,13 @@ def test_full_fixture_20000_reads(sl, orc, tiny_gpu, tiny_index, golden_dir):
     assert_same(al.alignSequences(both), exp_both, "both files as one batch, production schedule in ragged chunks")
     # the finalize stage's two hand-overs (round 6) saw work: reads in which mem_patch_reg aligns go from the lane kernel to a wave (k_regs -> k_regs_wave<.., 64>)
     assert al.counter("regs_deferred") > 0
-    # ... and reads with more than 12 hits get the glue's sort + filters one wave each (k_hits_wave): every hit kept (keepSecFrac 0, maxSecondary large), repeats
-    # of the fixture genome plus low-complexity reads
+    # reads with many hits (every hit kept: keepSecFrac 0, maxSecondary large; other filter settings): repeats of the fixture genome plus low-complexity reads
     names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
     rep = [refs[0][p:p + 150] for p in range(7000, 9000, 37)] + ["AC" * 75, "ACG" * 50, "A" * 150, "AAAT" * 37 + "AA", "AG" * 75]
     for ksf, ms in ((0.0, 1 << 20), (0.9, 10), (0.5, 3)):
         al = sl.BWAAligner(tiny_gpu)
         got = al.alignSequences(both[:3000] + rep, keepSecFrac=ksf, maxSecondary=ms)
         assert_same(got, orc.align_batch(orc.default_opt(), tiny_index, both[:3000] + rep, keep_sec_frac=ksf, max_secondary=ms), "many-hit reads, keepSecFrac %g maxSecondary %d" % (ksf, ms))
-    n_many = al.counter("hits_wave_reads")
-    print("regs_deferred / hits_wave_reads:", al.counter("regs_deferred"), n_many)
 
 
 SWEEP_SIZES = (1, 2, 3, 31, 50, 63, 64, 65, 127, 129, 255, 257, 1000)
@@ -85,7 +82,7 @@ SWEEP_KNOBS = ((), (("workers", 1),), (("min_split", 2),), (("chunk_reads", 37),
                (("split_min", 1), ("heavy_seeds", 8), ("ext_split", 0)), (("split_min", 1), ("heavy_seeds", 3), ("coop_lim1", 2), ("coop_lim2", 3)),
                (("split_min", 1), ("heavy_seeds", 8), ("regs_big", 2)), (("split_min", 1), ("heavy_seeds", 8), ("first_diag", 0), ("lane_narrow", 0)),
                (("regs_big", 2),), (("regs_big", 1 << 30),), (("cig_lanes", 0),), (("p2_items", 0),), (("p2_coop", 0),), (("p2_items_cap", 3),), (("dense_sa", 0),),
-               (("chain_mode", 0),), (("wide_index", 1),), (("lut_k", 0),), (("cap_intv", 2),), (("seed_quota", 64),), (("rep_k", 0),), (("regs_defer", 0),), (("hits_wave", 0),),
+               (("chain_mode", 0),), (("wide_index", 1),), (("lut_k", 0),), (("cap_intv", 2),), (("seed_quota", 64),), (("rep_k", 0),), (("regs_defer", 0),),
                (("regs_big", 1 << 30), ("regs_defer", 1)))
 
 
@@ -201,7 +198,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
 
 
 @pytest.mark.parametrize("knob,val", [("cig_lanes", 0), ("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
-                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("hits_wave", 0), ("ext_split", 0), ("wide_index", 1),
+                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("ext_split", 0), ("wide_index", 1),
                                       ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """bwa's sampled-SA walk vs dense SA, odd chunking, a tiny interval capacity that forces the overflow-retry path, the
