@@ -426,7 +426,7 @@ struct Graph {
     // is expanded once every edge into it has been seen -- carrying per end reached the two best-supported paths from the start (n: reads on the path, d: its
     // length with the overlaps taken off, and where it came from).  More than max_vtx vertices, a path beyond max_dist, a dead end or a way back to the start:
     // no bubble.  When the front shrinks to one end with nothing pending, that end closes the bubble: the vertices on its two best paths stay, the others the
-    // walk touched go.  The checker's restatement (oracle/orc_fml_asm.c: mag_vh_simplify_bubble) is the definition; this is the same walk on this graph's types.
+    // walk touched go.  The CPU checker's restatement of mag_vh_simplify_bubble (test infrastructure) is the definition; this is the same walk on this graph's types.
     struct Tri { int64_t id; int cnt[2]; int n[2][2], d[2][2]; int64_t bx[2][2]; int br[2][2]; };
     struct BubbleAux { std::vector<Tri> a; std::vector<int64_t> stack; std::vector<int> slot; std::vector<unsigned char> keep; };
     static Tri &tri_get(BubbleAux &A, int64_t x)

@@ -122,7 +122,7 @@ static int build_lut(slx_aligner *al)
     if ((rc = al->d_lut.ensure(n * sizeof(LutE<I>))) != SLX_OK) return rc;
     hipLaunchKernelGGL(k_kmer_lut<I>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, al->stream, fm, K, al->d_lut.as<LutE<I>>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(al->stream));
+    HIPCHK(slx_wait_stream(al->stream));
     fm.lut = al->d_lut.p; fm.lut_k = K;
     return SLX_OK;
 }
@@ -150,7 +150,7 @@ static int upload_fm(slx_aligner *al)
         hipLaunchKernelGGL(k_occ_build, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, al->stream, al->d_bwt.as<uint32_t>(), (uint64_t)idx->seq_len,
                            al->d_occ.as<uint4>(), n_blocks, sup);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(al->stream));
+        HIPCHK(slx_wait_stream(al->stream));
         fm.occ = al->d_occ.as<uint4>();
         fm.sup = sup;
     }
@@ -173,7 +173,7 @@ static int upload_fm(slx_aligner *al)
         hipLaunchKernelGGL(k_sa_seed<I>, dim3((unsigned)((n_sa + bs - 1) / bs)), dim3(bs), 0, al->stream, fm, al->d_sa_dense.as<I>(), n_sa);
         hipLaunchKernelGGL(k_sa_walk<I>, dim3((unsigned)((n_sa + bs - 1) / bs)), dim3(bs), 0, al->stream, fm, al->d_sa_dense.as<I>(), n_sa);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(al->stream));
+        HIPCHK(slx_wait_stream(al->stream));
     }
     al->have_dense = true;
     return SLX_OK;
@@ -201,7 +201,7 @@ static int build_rep_filter(slx_aligner *al)
     fm.sa_dense = al->d_sa_dense.as<I>();
     hipLaunchKernelGGL(k_rep_filter<I>, dim3(al->n_cu * 64), dim3(256), 0, al->stream, fm, al->ref, al->rep_k, al->d_rep.as<uint32_t>(), bits - 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(al->stream));
+    HIPCHK(slx_wait_stream(al->stream));
     al->rep_mask = bits - 1;
     return SLX_OK;
 }
@@ -229,7 +229,7 @@ static int make_worker_stream(slx_aligner *al, Worker *wk)
 // (re)creates the worker's seeding stream for the current "seed_free_cus" setting
 static int set_seed_stream(slx_aligner *al, Worker *wk)
 {
-    if (wk->seed_stream) { HIPCHK(hipStreamSynchronize(wk->seed_stream)); HIPCHK(hipStreamDestroy(wk->seed_stream)); wk->seed_stream = nullptr; }
+    if (wk->seed_stream) { HIPCHK(slx_wait_stream(wk->seed_stream)); HIPCHK(hipStreamDestroy(wk->seed_stream)); wk->seed_stream = nullptr; }
     if (al->seed_free_cus <= 0) return SLX_OK;
     const int words = (al->n_cu + 31) / 32;
     std::vector<uint32_t> mask((size_t)words, 0u);
@@ -462,6 +462,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
     else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
+    else if (!strcmp(key, "regs_sorted")) al->regs_sorted = value != 0;
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }
     else if (!strcmp(key, "cand_rep")) { if (value < -1 || value > 101) return SLX_EINVAL; al->cand_rep = (int)value; }
@@ -504,7 +505,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
         HIPCHK(hipSetDevice(al->device));
         al->stream_prio = (int)value;
         for (Worker *wk : al->workers) {
-            HIPCHK(hipStreamSynchronize(wk->stream));
+            HIPCHK(slx_wait_stream(wk->stream));
             HIPCHK(hipStreamDestroy(wk->stream));
             wk->stream = nullptr;
             const int rc = make_worker_stream(al, wk);
@@ -648,7 +649,7 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
         hipLaunchKernelGGL(k_len_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, wk->stream, d_offs + r0, n, wk->len_stat.as<unsigned long long>());
         { MailSpec ms{}; ms.src[0] = wk->len_stat.as<unsigned int>(); ms.words[0] = 8; ms.n = 1;
           hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, wk->stream, ms, wk->h_mail); }
-        HIPCHK(hipStreamSynchronize(wk->stream));
+        HIPCHK(slx_wait_stream(wk->stream));
         memcpy(stat, wk->h_mail, 32);
         if (stat[1]) { slx_set_error("read offsets are not monotonic in reads [%lld, %lld)", (long long)r0, (long long)(r0 + n)); return SLX_EINVAL; }
         const int max_len = (int)std::min<unsigned long long>(stat[0], 1u << 30);
@@ -719,7 +720,7 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
         if ((rc = wk->o_cig_off.grow(((size_t)hit_base + 2) * 8, (size_t)hit_base * 8, wk->stream)) != SLX_OK) return rc;
         int64_t lastc[1] = {cig_base};
         HIPCHK(hipMemcpyAsync(wk->o_cig_off.as<int64_t>() + hit_base, lastc, 8, hipMemcpyHostToDevice, wk->stream));
-        HIPCHK(hipStreamSynchronize(wk->stream));
+        HIPCHK(slx_wait_stream(wk->stream));
     }
     wk->n_hits = hit_base; wk->n_cig = cig_base;
     return SLX_OK;
@@ -744,7 +745,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
     EventPair tp;
     HIPCHK(hipEventCreate(&tp.t0)); HIPCHK(hipEventCreate(&tp.t1));
     HIPCHK(hipEventRecord(tp.t0, al->stream));
-    HIPCHK(hipStreamSynchronize(al->stream));
+    HIPCHK(slx_wait_stream(al->stream));
     std::vector<int64_t> lo((size_t)K + 1);
     for (int k = 0; k <= K; ++k) lo[(size_t)k] = n_reads * k / K;
     const bool wide = al->wide;
@@ -830,7 +831,7 @@ static int align_device_locked(slx_aligner *al, const slx_opt *opt, const void *
         if (sam) { r.xa_parent = al->o_xa.as<int32_t>(); r.sub = al->o_sub.as<int32_t>(); }
     }
     HIPCHK(hipEventRecord(tp.t1, al->stream));
-    HIPCHK(hipStreamSynchronize(al->stream));
+    HIPCHK(slx_wait_stream(al->stream));
     float tot = 0;
     (void)hipEventElapsedTime(&tot, tp.t0, tp.t1);
     al->stage_ms[7] = tot;
@@ -1013,7 +1014,7 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
 #undef OUTK
             if (ps.n) hipLaunchKernelGGL(k_pack_small, dim3((unsigned)std::min<uint64_t>(256, (piece_bytes + 4095) / 4096 + 1)), dim3(256), 0, st, ps, (unsigned char *)blk);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(slx_wait_stream(st));
             return (int)SLX_OK;
         }
 #define OUT(field, cnt, base) if ((cnt) > 0) HIPCHK(hipMemcpyAsync(out->field + (base), p.field, (size_t)(cnt) * sizeof *p.field, hipMemcpyDeviceToHost, st))
@@ -1021,7 +1022,7 @@ static int group_align_batch(slx_aligner *grp, const slx_opt *opt, const char *b
         OUT(nm, h, h0); OUT(na, h, h0); OUT(n_cigar_ops, h, h0); OUT(cigar, c, c0);
         if (sam && p.xa_parent) { OUT(xa_parent, h, h0); OUT(sub, h, h0); }
 #undef OUT
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(slx_wait_stream(st));
         return (int)SLX_OK;
     });
     if (rc != SLX_OK) { slx_hits_free(out); return rc; }
@@ -1078,7 +1079,7 @@ extern "C" int slx_align_batch(slx_aligner *al, const slx_opt *opt, const char *
         void *blk = malloc(bytes);
         if (!blk) { slx_set_error("out of host memory (%llu bytes)", (unsigned long long)bytes); return SLX_ENOMEM; }
         hipLaunchKernelGGL(k_pack_small, dim3((unsigned)std::min<uint64_t>(64, (bytes + 4095) / 4096)), dim3(256), 0, al->stream, ps, al->h_bounce);
-        const hipError_t e = hipStreamSynchronize(al->stream);
+        const hipError_t e = slx_wait_stream(al->stream);
         if (e != hipSuccess) { free(blk); HIPCHK(e); }
         memcpy(blk, al->h_bounce, bytes);
         out->n_reads = dv.n_reads; out->n_hits = dv.n_hits; out->n_cigar = dv.n_cigar; out->on_device = 0;
@@ -1139,7 +1140,7 @@ static int pack_locked(slx_aligner *al, const slx_hits *h, void *dst)
         HIPCHK(hipMemcpyAsync(d, hdr, 32, hipMemcpyHostToDevice, al->stream));
         for (const Part &p : parts)
             if (p.bytes) HIPCHK(hipMemcpyAsync(d + p.at, p.src, p.bytes, hipMemcpyDeviceToDevice, al->stream));
-        HIPCHK(hipStreamSynchronize(al->stream));
+        HIPCHK(slx_wait_stream(al->stream));
     } else {
         memcpy(d, hdr, 32);
         for (const Part &p : parts) if (p.bytes) memcpy(d + p.at, p.src, p.bytes);

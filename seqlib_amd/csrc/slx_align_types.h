@@ -81,6 +81,7 @@ struct Worker {
     DevBuf n_chain, n_reg, n_hit, na, frac_rep, zarena, cigpool, counters, lists, hit_cnt, cig_cnt, hit_off_c, cig_off_c;
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
+    DevBuf order_bin, bin_cnt;                                                     // finalize: the multi-region reads binned by region count
     DevBuf defer_list;                                                             // finalize: reads k_regs defers to the wave kernel
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf job_key_in, job_key_out, job_val_in, job_val_out, job_sort_tmp;         // contigs: extension jobs ordered longest first
@@ -118,7 +119,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &defer_list, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &defer_list, &order_bin, &bin_cnt, &snap_ia, &snap_regs, &snap_nreg,
                &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &pseg_jobs, &pseg_idx, &pseg_cnt, &gseg_jobs, &gseg_units, &gseg_wrec, &gseg_wout, &gseg_scratch, &gseg_cnt, &xseg_jobs, &xseg_state, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
@@ -165,6 +166,9 @@ struct slx_aligner {
     int long_guess = 0;           // (see ExtSpec::guess; measured on C5's contigs: 254 ms of extension without the guess, 370 with it)
     int long_budget = 1024;         // long reads (contigs): the extension stage runs in rounds (ExtSpec, dev_types.h); a walk emits at most this many
                                   // seed jobs per read and round; 0 = the walk extends in place (one wave per read does every extension of its read)
+    int regs_sorted = 0;          // 1: the multi-region reads go to k_regs / k_hits binned by region count, most regions first.  Measured SLOWER (C3 64.6 -> 61.8 M reads/s,
+                                  // k_hits 57 -> 133 stream-ms per step): in list order a wave holds one many-region read among sixty small ones and the many waves run side by side;
+                                  // binned, sixty-four many-region reads share a wave and walk their divergent sorts one after another.  Kept as a knob for that A/B
     int small_coop = 1;           // small chunks (below split_min): heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
     int regs_defer = 1;           // k_regs hands reads that need one of mem_patch_reg's alignments to a wave-per-read launch (0: aligns on its lane, as until round 5)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the

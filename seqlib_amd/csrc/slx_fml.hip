@@ -166,7 +166,7 @@ int fml_upload(slx_fml *f, const char *bases, const char *quals, const uint64_t 
     if (total) FML_HIPCHK(hipMemcpyAsync(f->d_bases.p, bases + base0, total, hipMemcpyHostToDevice, f->st));
     if (total && quals) FML_HIPCHK(hipMemcpyAsync(f->d_quals.p, quals + base0, total, hipMemcpyHostToDevice, f->st));
     FML_HIPCHK(hipMemcpyAsync(f->d_offs.p, f->h_offs.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, f->st));
-    FML_HIPCHK(hipStreamSynchronize(f->st));          // h_offs may be rebuilt by the caller's next step
+    FML_HIPCHK(slx_wait_stream(f->st));          // h_offs may be rebuilt by the caller's next step
     return SLX_OK;
 }
 
@@ -419,7 +419,7 @@ static int download_text(slx_fml *f, char *bases, char *quals, const uint64_t *o
     if (!f->total) return SLX_OK;
     FML_HIPCHK(hipMemcpyAsync(bases + offs[0], f->d_bases.p, (size_t)f->total, hipMemcpyDeviceToHost, f->st));
     if (quals && f->has_qual) FML_HIPCHK(hipMemcpyAsync(quals + offs[0], f->d_quals.p, (size_t)f->total, hipMemcpyDeviceToHost, f->st));
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     return SLX_OK;
 }
 
@@ -428,7 +428,7 @@ static int download_trim(slx_fml *f, int32_t *new_start, int32_t *new_len)
     if (!f->n_reads) return SLX_OK;
     FML_HIPCHK(hipMemcpyAsync(new_start, f->d_ns.p, (size_t)f->n_reads * 4, hipMemcpyDeviceToHost, f->st));
     FML_HIPCHK(hipMemcpyAsync(new_len, f->d_nl.p, (size_t)f->n_reads * 4, hipMemcpyDeviceToHost, f->st));
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     return SLX_OK;
 }
 
@@ -458,7 +458,7 @@ extern "C" int slx_fml_correct(slx_fml *f, const slx_fml_opt *opt, char *bases, 
     if ((rc = fml_correct_core_device(f, flt_uniq))) return rc;
     if (flt_uniq) { if ((rc = download_trim(f, new_start, new_len))) return rc; }
     else if ((rc = download_text(f, bases, quals, offs))) return rc;
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     for (int w = 0; w < n_win; ++w) {
         if (kcov) kcov[w] = f->kcov[(size_t)w];
         if (ec_k) ec_k[w] = f->wins[(size_t)w].k;
@@ -479,7 +479,7 @@ extern "C" int slx_fml_count(slx_fml *f, const char *bases, const char *quals, c
     int rc;
     f->have_count = false;
     if ((rc = fml_upload(f, bases, quals, offs, n_reads)) || (rc = fml_setup_windows(f, &o, win_off, 1, k)) || (rc = fml_run_count(f, q))) return rc;
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     f->have_count = true;
     f->count_win = f->wins[0];
     return SLX_OK;
@@ -492,7 +492,7 @@ extern "C" int slx_fml_count_hist(slx_fml *f, uint64_t cnt[256], uint64_t high[6
     FML_HIPCHK(hipSetDevice(f->device));
     int rc;
     if ((rc = fml_run_hist(f))) return rc;
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     for (int i = 0; i < 256; ++i) cnt[i] = f->h_hist[(size_t)i];
     for (int i = 0; i < 64; ++i) high[i] = f->h_hist[(size_t)256 + i];
     if (mode) *mode = f->wins[0].mode;
@@ -516,7 +516,7 @@ extern "C" int slx_fml_count_dump(slx_fml *f, uint64_t *keys, uint16_t *vals, ui
     }
     unsigned long long cnt = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&cnt, f->d_misc.p, 8, hipMemcpyDeviceToHost, f->st);
-    if (e == hipSuccess) e = hipStreamSynchronize(f->st);
+    if (e == hipSuccess) e = slx_wait_stream(f->st);
     std::vector<uint64_t> hk((size_t)std::min<uint64_t>(cnt, cap));
     std::vector<uint16_t> hv(hk.size());
     if (e == hipSuccess && !hk.empty()) e = hipMemcpy(hk.data(), dk.p, hk.size() * 8, hipMemcpyDeviceToHost);
@@ -552,7 +552,7 @@ extern "C" int slx_fml_error_correct(slx_fml *f, const slx_fml_opt *opt, char *b
     if ((rc = flt_uniq ? fml_run_streak(f) : fml_run_ec(f))) return rc;
     if (flt_uniq) { if ((rc = download_trim(f, new_start, new_len))) return rc; }
     else if ((rc = download_text(f, bases, quals, offs))) return rc;
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     if (kcov) *kcov = f->kcov[0];
     if (min_cov) *min_cov = f->wins[0].min_cov;
     return SLX_OK;

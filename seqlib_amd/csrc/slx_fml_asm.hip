@@ -54,7 +54,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
     const auto tm0 = now();
     float tm_strs = 0, tm_gpu = 0, tm_down = 0;
     if (n_win > 65535) { slx_set_error("fml: %d windows in one batch: at most 65535", n_win); return SLX_EUNSUPPORTED; }
-    if (f->st_copy) (void)hipStreamSynchronize(f->st_copy);          // (a call that failed half way may have left its text copy in flight)
+    if (f->st_copy) (void)slx_wait_stream(f->st_copy);          // (a call that failed half way may have left its text copy in flight)
     // (two passes over the windows' reads, each over the host's CPUs: how many strings and bases a window contributes, then -- after a prefix sum over the
     // windows -- the strings themselves; one thread pushing 12.7 M strings back was 64 ms of every 64-window call)
     std::vector<AsmWin> aw((size_t)n_win);
@@ -186,7 +186,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                                (const unsigned long long *)d_hkey, (const unsigned int *)d_hval, hmask, d_rep, d_cont, d_cnt, f->d_tri.as<FmlTriple>(), tri_cap, d_trin);
             FML_HIPCHK(hipGetLastError());
             FML_HIPCHK(hipMemcpyAsync(&n_tri, d_trin, 8, hipMemcpyDeviceToHost, f->st));
-            FML_HIPCHK(hipStreamSynchronize(f->st));
+            FML_HIPCHK(slx_wait_stream(f->st));
             if (n_tri <= tri_cap) break;
             tri_cap = n_tri + n_tri / 8;          // (the marks of containment and the counts are idempotent: the join simply runs again)
             f->tri_per_str = std::max<unsigned long long>(f->tri_per_str, tri_cap / (unsigned long long)n_str + 1);
@@ -201,7 +201,7 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
             FML_HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_sort.p, sb, cnt64, d_eoff, (int)(n_str + 1), f->st));
             FML_HIPCHK(hipMemcpyAsync(&n_edges, d_eoff + n_str, 8, hipMemcpyDeviceToHost, f->st));
             FML_HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));          // (for the counters, read at the end)
-            FML_HIPCHK(hipStreamSynchronize(f->st));
+            FML_HIPCHK(slx_wait_stream(f->st));
         }
         // edges grouped by source | sorted copy (vertices with > 64 overlaps) | irreducible edges | flags | list of those vertices
         FmlDevBuf &d_edges = f->d_scratch;
@@ -222,13 +222,13 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
         if (const char *e = getenv("SLX_FML_BIG_CAP")) { const int v = atoi(e); if (v >= 64 && v < FML_BIG_CAP) big_cap = v; }
         unsigned int n_big = 0, n_huge = 0;
         FML_HIPCHK(hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, f->st));
-        FML_HIPCHK(hipStreamSynchronize(f->st));
+        FML_HIPCHK(slx_wait_stream(f->st));
         if (n_big) {
             hipLaunchKernelGGL(k_asm_reduce_big, dim3(n_big), dim3(256), 0, f->st, d_text.as<unsigned char>(), d_strs.as<FmlStr>(), (const int *)big_list, (const unsigned int *)d_nbig,
                                (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, d_nirr, d_irroff, e_out, d_outn, huge_list, d_nhuge, big_cap);
             FML_HIPCHK(hipGetLastError());
             FML_HIPCHK(hipMemcpyAsync(&n_huge, d_nhuge, 4, hipMemcpyDeviceToHost, f->st));
-            FML_HIPCHK(hipStreamSynchronize(f->st));
+            FML_HIPCHK(slx_wait_stream(f->st));
             if (n_huge) {
                 const dim3 hg(n_huge, FML_HUGE_SLICES);
                 hipLaunchKernelGGL(k_asm_huge_rank, hg, dim3(256), 0, f->st, (const int *)huge_list, (const unsigned long long *)d_eoff, (const unsigned int *)d_cur, (const FmlEdge *)e_raw, e_sorted);
@@ -240,14 +240,14 @@ int build_and_assemble(slx_fml *f, const std::vector<int> &h_ns, const std::vect
                 FML_HIPCHK(hipGetLastError());
             }
         }
-        if (times) { (void)hipStreamSynchronize(f->st); tm_gpu = ms_since(tm0); }
+        if (times) { (void)slx_wait_stream(f->st); tm_gpu = ms_since(tm0); }
         FML_HIPCHK(hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_rep, d_rep, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_cont, d_cont, (size_t)n_str, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_nirr, d_nirr, (size_t)n_str * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(h_irroff, d_irroff, (size_t)n_str * 8, hipMemcpyDeviceToHost, f->st));
         if ((rc = fml_probe_end(f, 4))) return rc;          // synchronises
-        FML_HIPCHK(hipStreamSynchronize(f->st_copy));
+        FML_HIPCHK(slx_wait_stream(f->st_copy));
         if (n_out > out_cap) { slx_set_error("fml: the reduction reserved %llu edge slots, %llu were sized (internal)", n_out, out_cap); return SLX_EINTERNAL; }
         // the edges, then (filled per window below) their targets and lengths as the graph stage wants them: edges | edge_v | edge_len
         if (f->h_asm2.ensure(((size_t)n_out + 1) * (sizeof(FmlEdge) + 8) + 256)) { slx_set_error("fml: out of pinned host memory (%llu edges)", n_out); return SLX_ENOMEM; }
@@ -325,13 +325,13 @@ static int assemble_resident(slx_fml *f, const slx_fml_opt *opt, const int64_t *
     const auto tm0 = std::chrono::steady_clock::now();
     if ((rc = fml_setup_windows(f, opt, win_off, n_win, 0))) return rc;
     if ((rc = fml_correct_core_device(f, 0)) || (rc = fml_correct_core_device(f, 1))) return rc;
-    if (getenv("SLX_FML_TIMES")) { (void)hipStreamSynchronize(f->st); fprintf(stderr, "[fml times] correct + filter on the device: %.1f ms wall\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tm0).count()); }
+    if (getenv("SLX_FML_TIMES")) { (void)slx_wait_stream(f->st); fprintf(stderr, "[fml times] correct + filter on the device: %.1f ms wall\n", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tm0).count()); }
     std::vector<int> ns((size_t)n_reads + 1), nl((size_t)n_reads + 1);
     if (n_reads) {
         FML_HIPCHK(hipMemcpyAsync(ns.data(), f->d_ns.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, f->st));
         FML_HIPCHK(hipMemcpyAsync(nl.data(), f->d_nl.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, f->st));
     }
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     std::vector<slx_fml_opt> wopt(f->wopt);
     for (int w = 0; w < n_win; ++w) {
         slx_magopt &m = wopt[(size_t)w].mag_opt;
@@ -380,7 +380,7 @@ extern "C" int slx_fml_stage(slx_fml *f, const char *bases, const char *quals, c
         FML_HIPCHK(hipMemcpyAsync(f->d_bases0.p, f->d_bases.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
         if (f->has_qual) FML_HIPCHK(hipMemcpyAsync(f->d_quals0.p, f->d_quals.p, (size_t)f->total, hipMemcpyDeviceToDevice, f->st));
     }
-    FML_HIPCHK(hipStreamSynchronize(f->st));
+    FML_HIPCHK(slx_wait_stream(f->st));
     f->staged = true;
     return SLX_OK;
 }

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <mutex>
 #include <vector>
+#include "slx_internal.h"
 #include "seqlib_amd_fml.h"
 #include "dev_fml.h"
 

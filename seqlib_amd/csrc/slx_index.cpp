@@ -310,3 +310,10 @@ extern "C" int slx_index_load(const char *prefix_, slx_index **out)
     *out = idx;
     return SLX_OK;
 }
+
+// ---- how host threads wait for a stream (slx_internal.h: slx_wait_stream) ----
+bool slx_wait_sleeps()
+{
+    const char *e = getenv("SEQLIB_AMD_WAIT");
+    return e && !strcmp(e, "sleep");
+}
