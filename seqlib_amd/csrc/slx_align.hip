@@ -214,7 +214,13 @@ static int env_hw_queues() { const char *e = getenv("GPU_MAX_HW_QUEUES"); const 
 // lose on the runtime's default four hardware queues; with GPU_MAX_HW_QUEUES=8 in the environment (read once, when the HIP runtime
 // initialises) six workers reach 56.2 M (C2 +3 %) -- but every launch then shares the chip with five others (the mean seeding launch of
 // 8.3 M reads takes 209 ms instead of 110) and six workers on four queues lose 10 %, so that stays a setting ("workers"), not the default.
-static int default_workers() { return 3; }
+// Round 6, eight hardware queues exported by the application (the library only reads the variable): 3 / 4 / 6 workers 64.7 / 65.2 / 65.5 M reads/s on C3 (two runs each, alternating):
+// with eight queues the default is six.  SEQLIB_AMD_WORKERS overrides (1..8).
+static int default_workers()
+{
+    if (const char *e = getenv("SEQLIB_AMD_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= SLX_MAX_WORKERS) return v; }
+    return env_hw_queues() >= 8 ? 6 : 3;
+}
 
 static int make_worker_stream(slx_aligner *al, Worker *wk)
 {

@@ -65,7 +65,7 @@ def test_full_fixture_20000_reads(sl, orc, tiny_gpu, tiny_index, golden_dir):
     al.set("chunk_reads", 7777)
     exp_both = orc.align_batch(orc.default_opt(), tiny_index, both)
     assert_same(al.alignSequences(both), exp_both, "both files as one batch, production schedule in ragged chunks")
-    # the finalize stage's two hand-overs (round 6) saw work: reads in which mem_patch_reg aligns go from the lane kernel to a wave (k_regs -> k_regs_wave<.., 64>)
+    # the finalize stage's hand-over (round 6) saw work: reads in which mem_patch_reg aligns go from the lane kernel to a wave (k_regs -> k_regs_wave<.., 64>)
     assert al.counter("regs_deferred") > 0
     # reads with many hits (every hit kept: keepSecFrac 0, maxSecondary large; other filter settings): repeats of the fixture genome plus low-complexity reads
     names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
