@@ -239,8 +239,9 @@ __global__ void __launch_bounds__(128) k_seed2_select(DevFM<I> fm, Chunk ck, Dev
                                                       uint32_t *items, unsigned int *n_items, uint32_t cap_items)
 {
     const slx_opt &opt = dopt.o;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = r < ck.n_reads;
+    const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = ck.spread > 1 ? t_ / ck.spread : t_;          // (a small chunk: one read per wave, on its lane 0)
+    const bool live = r < ck.n_reads && (ck.spread <= 1 || t_ % ck.spread == 0);
     const int n = live ? (int)ck.intv_n[r] : 0;
     unsigned long long mask = 0;
     if (n > 0) {
@@ -403,6 +404,7 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
     // dozens of small launches of a chunk above all -- get onto the CUs while a seeding launch is in flight instead of behind it.
     const slx_opt &opt = dopt.o;
     const int lane = threadIdx.x & 63;
+    const uint32_t pool = ck.spread > 1 ? 1u : (uint32_t)SEED_POOL;          // reads a wave takes from the queue at a time: ONE for a small chunk, so that every read gets a wave of its own
     WorkLists<I> wl;
     wl.base = (IntvE<I> *)ck.lists + (size_t)blockIdx.x * ((size_t)2 * ck.cap_list * 128) + threadIdx.x; wl.stride = 128; wl.cap = ck.cap_list;
     // the first SEED4_WL_LDS entries of both work lists live in LDS (entry-major: lanes at the same entry hit different banks); with the
@@ -525,14 +527,14 @@ __global__ void SEED4_VGPR_ATTR __launch_bounds__(128, (sizeof(I) == 8 ? SEED4_M
                 pending = false;
                 if (base >= n_reads) exhausted = true;
                 else {
-                    res_next = base; res_end = base + SEED_POOL < n_reads ? base + SEED_POOL : n_reads;
-                    taken += SEED_POOL;
+                    res_next = base; res_end = base + pool < n_reads ? base + pool : n_reads;
+                    taken += pool;
                     if (wave_quota && taken >= wave_quota) exhausted = true;      // this wave's share: what is in hand is finished, nothing more is fetched
                 }
             }
             if (pool_next == pool_end && res_next != res_end) { pool_next = res_next; pool_end = res_end; res_next = res_end = 0; }
             if (res_next == res_end && !exhausted) {
-                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)SEED_POOL);
+                if (lane == 0) pend_base = atomicAdd(queue, (unsigned int)pool);
                 pending = true;
             }
             if (phase == S4_INIT) {                     // offsets requested one round ago
@@ -936,8 +938,9 @@ template <typename I>
 __global__ void __launch_bounds__(128) k_seed3m(DevFM<I> fm, DevRef R, Chunk ck, DevOpt dopt, int par_min_len = 0x7fffffff)
 {
     const slx_opt &opt = dopt.o;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = r < ck.n_reads;
+    const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = ck.spread > 1 ? t_ / ck.spread : t_;          // (a small chunk: one read per wave, on its lane 0)
+    bool live = r < ck.n_reads && (ck.spread <= 1 || t_ % ck.spread == 0);
     const uint64_t qoff = live ? ck.offs[r] : 0;
     int len = live ? (int)(ck.offs[r + 1] - qoff) : 0;
     if (len >= par_min_len) { live = false; len = 0; }          // a contig: k_seed3_next + k_seed3_chase below

@@ -85,6 +85,7 @@ struct ExtSpec {
 // one chunk of reads, all device pointers
 struct Chunk {
     int n_reads;
+    int spread;               // 1, or 64 for a small chunk: the lane-per-read kernels of seeding put ONE read on each wave (read = thread / 64, lane 0 works)
     const uint8_t *codes;     // nt4 codes, reads concatenated
     const uint64_t *offs;     // n_reads + 1 (relative to codes)
     uint64_t first_ordinal;   // lrand48 draw index of read 0

@@ -214,12 +214,13 @@ static int env_hw_queues() { const char *e = getenv("GPU_MAX_HW_QUEUES"); const 
 // lose on the runtime's default four hardware queues; with GPU_MAX_HW_QUEUES=8 in the environment (read once, when the HIP runtime
 // initialises) six workers reach 56.2 M (C2 +3 %) -- but every launch then shares the chip with five others (the mean seeding launch of
 // 8.3 M reads takes 209 ms instead of 110) and six workers on four queues lose 10 %, so that stays a setting ("workers"), not the default.
-// Round 6, eight hardware queues exported by the application (the library only reads the variable): 3 / 4 / 6 workers 64.7 / 65.2 / 65.5 M reads/s on C3 (two runs each, alternating):
-// with eight queues the default is six.  SEQLIB_AMD_WORKERS overrides (1..8).
+// Round 6, eight hardware queues exported by the application: 3 / 4 / 6 workers 64.7 / 65.2 / 65.5 M reads/s on C3 device-resident (two runs each, alternating) -- but with six
+// as the default the rest of the line lost more than that gained: BamRecords through the C++ class 46.3 -> 36.2 M reads/s (two calls in flight x six workers on eight queues),
+// C5 11.4 -> 10.1 M, and every launch holds half the reads for the same duration (the per-launch roofline figures halve).  Three stays; SEQLIB_AMD_WORKERS overrides (1..8).
 static int default_workers()
 {
     if (const char *e = getenv("SEQLIB_AMD_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= SLX_MAX_WORKERS) return v; }
-    return env_hw_queues() >= 8 ? 6 : 3;
+    return 3;
 }
 
 static int make_worker_stream(slx_aligner *al, Worker *wk)
@@ -468,6 +469,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
     else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
+    else if (!strcmp(key, "small_spread")) al->small_spread = value != 0;
     else if (!strcmp(key, "regs_sorted")) al->regs_sorted = value != 0;
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }

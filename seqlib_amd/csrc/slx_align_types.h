@@ -66,6 +66,7 @@ static __global__ void k_mail(MailSpec s, unsigned int *dst)
     }
 }
 struct slx_aligner;
+#define SMALL_SPREAD_MAX 512
 
 // One worker = one HIP stream with its own work areas and result buffers.  A large batch is split into contiguous
 // parts that the workers push through the pipeline concurrently, so that the single-read critical paths at the end
@@ -169,6 +170,7 @@ struct slx_aligner {
     int regs_sorted = 0;          // 1: the multi-region reads go to k_regs / k_hits binned by region count, most regions first.  Measured SLOWER (C3 64.6 -> 61.8 M reads/s,
                                   // k_hits 57 -> 133 stream-ms per step): in list order a wave holds one many-region read among sixty small ones and the many waves run side by side;
                                   // binned, sixty-four many-region reads share a wave and walk their divergent sorts one after another.  Kept as a knob for that A/B
+    int small_spread = 1;         // small chunks of short reads (up to SMALL_SPREAD_MAX reads, below split_min): one read per wave through the lane-per-read kernels
     int small_coop = 1;           // small chunks (below split_min): heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
     int regs_defer = 1;           // k_regs hands reads that need one of mem_patch_reg's alignments to a wave-per-read launch (0: aligns on its lane, as until round 5)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
