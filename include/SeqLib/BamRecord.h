@@ -36,8 +36,8 @@ struct Slab {
     // full-size slabs are recycled through a process-wide pool (warm pages: the first touch of fresh memory costs more than everything else a record needs);
     // at most pool_cap() of them are kept -- SEQLIB_AMD_SLAB_POOL_MB, default 2 048 MB -- and trim_pool() returns them to the system
     struct Pool { std::mutex mu; std::vector<Slab *> free_; size_t cap; Pool() { const char *e = std::getenv("SEQLIB_AMD_SLAB_POOL_MB"); cap = (size_t)(e && *e ? std::atol(e) : 2048) * ((size_t)1 << 20) / kBytes; }
-                  ~Pool() { for (Slab *s : free_) std::free(s); } };
-    static Pool &pool() { static Pool p; return p; }
+ };
+    static Pool &pool() { static Pool *p = new Pool; return *p; }          // (never destroyed: records of static lifetime may still release slabs while the process exits)
     static void trim_pool() { Pool &P = pool(); std::lock_guard<std::mutex> g(P.mu); for (Slab *s : P.free_) std::free(s); P.free_.clear(); }
     static Slab *make(size_t bytes)
     {
