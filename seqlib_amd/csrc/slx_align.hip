@@ -470,6 +470,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
     else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
     else if (!strcmp(key, "small_spread")) al->small_spread = value != 0;
+    else if (!strcmp(key, "chain_sorted")) al->chain_sorted = value != 0;
     else if (!strcmp(key, "regs_sorted")) al->regs_sorted = value != 0;
     else if (!strcmp(key, "cand_top")) { if (value < 0) return SLX_EINVAL; al->cand_top = (int)value; }
     else if (!strcmp(key, "cand_rep_max")) { if (value < 0) return SLX_EINVAL; al->cand_rep_max = (int)value; }

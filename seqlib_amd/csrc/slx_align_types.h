@@ -170,6 +170,8 @@ struct slx_aligner {
     int regs_sorted = 0;          // 1: the multi-region reads go to k_regs / k_hits binned by region count, most regions first.  Measured SLOWER (C3 64.6 -> 61.8 M reads/s,
                                   // k_hits 57 -> 133 stream-ms per step): in list order a wave holds one many-region read among sixty small ones and the many waves run side by side;
                                   // binned, sixty-four many-region reads share a wave and walk their divergent sorts one after another.  Kept as a knob for that A/B
+    int chain_sorted = 0;         // experiment: the light reads go to k_chain binned by seed-occurrence count, most first.  Measured: C3 64.4 / 64.6 -> 63.4 / 63.7 M reads/s,
+                                  // the chain group's stream time unchanged (k_chain waits for memory, not for its longest lane): off
     int small_spread = 1;         // small chunks of short reads (up to SMALL_SPREAD_MAX reads, below split_min): one read per wave through the lane-per-read kernels
     int small_coop = 1;           // small chunks (below split_min): heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
     int regs_defer = 1;           // k_regs hands reads that need one of mem_patch_reg's alignments to a wave-per-read launch (0: aligns on its lane, as until round 5)

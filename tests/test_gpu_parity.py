@@ -118,19 +118,22 @@ def test_batch_shape_sweep(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir)
     pool = _sweep_pool(orc, golden_dir, sim_reads)
     opt = orc.default_opt()
     checked = 0
+    batches = []
     for n_i, n in enumerate(SWEEP_SIZES):
         lo = (n_i * 97) % (len(pool) - n)
         seqs = pool[lo:lo + n]
-        exp = orc.align_batch(opt, tiny_index, seqs)
-        # (every knob set on the sizes around the wave boundaries; a third of them on the three largest batches, a different third each -- the driver's GPU test step has
-        # a 20-minute limit and this test is its longest)
-        ks = SWEEP_KNOBS if n < 255 else SWEEP_KNOBS[n_i % 3::3] + SWEEP_KNOBS[:1]
-        for knobs in ks:
-            al = sl.BWAAligner(tiny_gpu)
-            for k, v in knobs:
-                al.set(k, v)
+        batches.append((n, seqs, orc.align_batch(opt, tiny_index, seqs)))
+    # one aligner per knob set, every batch size through it in turn (a handle's work areas and learnt budgets go from a batch of one to a batch of a thousand and back);
+    # every batch starts at draw 0 again
+    for knobs in SWEEP_KNOBS:
+        al = sl.BWAAligner(tiny_gpu)
+        for k, v in knobs:
+            al.set(k, v)
+        for n, seqs, exp in batches + batches[2::-1]:
+            al.ordinal = 0
             assert_same(al.alignSequences(seqs), exp, "n=%d %s" % (n, knobs))
             checked += 1
+    for n, seqs, exp in batches:
         # hard clips, the glue's filters at other settings
         al = sl.BWAAligner(tiny_gpu)
         assert_same(al.alignSequences(seqs, hardclip=True, keepSecFrac=0.0, maxSecondary=3),
@@ -162,7 +165,7 @@ def test_batch_shape_sweep(sl, orc, tiny_gpu, tiny_index, sim_reads, golden_dir)
         if n in (1, 3, 50, 65, 257):
             _check_sam_mode(sl, orc, tiny_gpu, tiny_index, seqs, "n=%d record mode" % n)
             _check_sam_mode(sl, orc, tiny_gpu, tiny_index, seqs, "n=%d record mode, wave region kernel" % n, knobs=(("regs_big", 2), ("split_min", 1), ("heavy_seeds", 8)))
-    assert checked >= 10 * len(SWEEP_KNOBS) + 3 * (len(SWEEP_KNOBS) // 3)
+    assert checked == (len(SWEEP_SIZES) + 3) * len(SWEEP_KNOBS)
 
 
 def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads):
@@ -201,7 +204,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
 
 
 @pytest.mark.parametrize("knob,val", [("cig_lanes", 0), ("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
-                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("regs_sorted", 1), ("small_coop", 0), ("small_spread", 0), ("ext_split", 0), ("wide_index", 1),
+                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("regs_sorted", 1), ("small_coop", 0), ("small_spread", 0), ("chain_sorted", 1), ("ext_split", 0), ("wide_index", 1),
                                       ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """bwa's sampled-SA walk vs dense SA, odd chunking, a tiny interval capacity that forces the overflow-retry path, the
