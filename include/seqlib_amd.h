@@ -119,7 +119,8 @@ int  slx_device_count(void);   /* visible HIP devices (0 without a GPU) */
 int  slx_aligner_create(const slx_index *idx, const int *devices, int n_dev, slx_aligner **out);
 void slx_aligner_free(slx_aligner *al);
 /* Tuning / test knobs; none of them changes a result (tests/test_gpu_parity.py runs each against the oracle).
- *   "workers" 1..8 (3)        host workers = HIP streams a batch is split over (six pay only with GPU_MAX_HW_QUEUES=8 in the environment: +2 %)
+ *   "workers" 1..8 (3)        host workers = HIP streams a batch is split over (six pay only with GPU_MAX_HW_QUEUES=8 in the environment: +1.3 % device-resident, but the
+ *                             C++ batch path and C5 lose more; SEQLIB_AMD_WORKERS in the environment sets the default of new aligners)
  *   "chunk_reads" (1 << 24)   reads per launch of a worker;  "min_split"  smallest batch that is split over workers at all
  *   "dense_sa" 0|1 (1)        1 = suffix array decompressed to sa_intv 1 in HBM, 0 = bwa's sampled-SA walk
  *   "lut_k" -1|0|2..14 (-1)   width of the k-mer table of the seeding kernels (4^k x 8 or 16 bytes); -1 = by index size, 0 = none
@@ -141,6 +142,10 @@ void slx_aligner_free(slx_aligner *al);
  *   "seed_free_cus" 0..24 (0) CUs of every 32 the persistent seeding kernels leave to the other kernels (a CU-masked stream of their own)
  *   "stream_prio" 0|1 (0)     workers' streams at the device's highest priority
  *   "wide_index" 1            test hook: run an index below 2^32 symbols through the u64 kernels
+ *   "regs_defer" 0|1 (1)      the lane-per-read region kernel hands reads in which mem_patch_reg would align to a wave-per-read launch (k_regs -> k_regs_wave<.., 64>)
+ *   "small_coop" 0|1 (1)      chunks below split_min: heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
+ *   "small_spread" 0|1 (1)    chunks of at most 512 short reads: one read per WAVE through the lane-per-read kernels (seeding, k_chain, k_regs, k_hits)
+ *   "regs_sorted", "chain_sorted" 0|1 (0)   experiments kept for their A/B (profiles/r06_knob_ab.txt): reads binned by size before the lane-per-read kernels -- slower
  *   "keep_stages" 1           test hook: keep what slx_debug_stage reads
  * Returns SLX_EINVAL for an unknown key or a value out of range. */
 int  slx_aligner_set(slx_aligner *al, const char *key, int64_t value);
@@ -221,7 +226,8 @@ int  slx_aligner_probe_ms(const slx_aligner *al, float ms[SLX_N_PROBES], int64_t
 int  slx_aligner_probe_launches(const slx_aligner *al);
 /* what the last batch held, by name (diagnostics and tests; -1 = unknown name): "heavy_reads" (reads on the wave-per-read schedule),
  * "p2_calls" (re-seeding calls of pass 2 run one per lane), "p2_coop_calls" (those of them run one per wave), "p2_whole_reads";
- * "workers" = the aligner's worker count (per device) */
+ * "workers" = the aligner's worker count (per device); "hw_queues" = GPU_MAX_HW_QUEUES as the process had it when the aligner was created (4 = unset: the library
+ * reads it, never sets it); "regs_deferred" = reads the lane region kernel handed to the wave kernel since the aligner was created */
 int64_t slx_aligner_counter(const slx_aligner *al, const char *key);
 
 /* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work
