@@ -39,6 +39,9 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include "seqlib_amd.h"
 #include "SeqLib/BWAIndex.h"
 #include "SeqLib/BamRecord.h"
@@ -91,6 +94,12 @@ inline void pack_seq4(const uint8_t *cp, int sl, bool rev, uint8_t *dst)
 inline unsigned effective_cpus()
 {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
+#if defined(__linux__)
+    {   // the affinity mask (taskset, a launcher's binding)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) n = std::min(n, (unsigned)a); }
+    }
+#endif
     auto quota = [](const char *path, const char *path_period) -> double {
         FILE *f = std::fopen(path, "r");
         if (!f) return 0.0;
@@ -752,12 +761,18 @@ private:
         std::lock_guard<std::mutex> batch(batch_mu_);
         const int64_t chunk = std::max<int64_t>(1024, env_long("SEQLIB_AMD_CHUNK", 8000000) * n_dev_);
         const int64_t n_chunks = (n + chunk - 1) / chunk;
-        unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)detail::effective_cpus());
+        // host threads: the CPUs this process may use -- but not fewer than 16 threads when there are fewer than 8 CPUs: measured with the whole process confined to two CPUs
+        // (taskset), 2 / 4 / 16 threads build 9.9 / 11.1 / 14.4 M reads/s (the pool's threads also block -- page faults of fresh record memory, hand-overs -- and the
+        // GPU workers' waiting threads take their share of two CPUs whatever the pool does; 256 threads on a 16-CPU quota, on the other hand, ran at 6.3 M against 14.8 M)
+        const unsigned cpus = detail::effective_cpus();
+        unsigned T = (unsigned)env_long("SEQLIB_AMD_THREADS", (long)(cpus < 8 ? std::min(16u, cpus * 8) : cpus));
         T = std::max(1u, std::min(T, 512u));
         if (n < 8192) T = 1;
         const bool use_slabs = n >= env_long("SEQLIB_AMD_SLAB_MIN_READS", 8192) && env_long("SEQLIB_AMD_SLABS", 1) != 0;
         detail::TaskPool pool(T);
-        const int parts = (int)std::min<int64_t>((int64_t)T * 4, std::max<int64_t>(1, chunk / 2048));   // tasks per stage of a chunk
+        // tasks per stage of a chunk: at least 64 however few threads there are -- a pack request (high priority) waits for the build tasks that are RUNNING, and with two
+        // threads and eight tasks per chunk a build task was a million reads (~120 ms): the next GPU call started that much late (2 threads: 10 -> see profiles/NOTES_r06.md)
+        const int parts = (int)std::min<int64_t>(std::max<int64_t>((int64_t)T * 4, 64), std::max<int64_t>(1, chunk / 2048));
 
         struct ChunkJob { int64_t lo = 0, hi = 0; std::vector<uint64_t> part_bytes; std::shared_ptr<detail::TaskPool::Group> packed, built; slx_hits h; bool have_h = false; };
         std::vector<ChunkJob> jobs((size_t)n_chunks);
@@ -771,7 +786,7 @@ private:
         int n_lanes = 1;
         // (not with fewer than eight host threads: a thread inside a GPU call spins on the stream, and two of them take the builders' CPUs -- at 2 threads 9.6 M reads/s
         // against 13.4 M with one call at a time)
-        if (n_chunks >= 2 && env_long("SEQLIB_AMD_CALLS_IN_FLIGHT", T >= 8 ? 2 : 1) >= 2 && (als[1] = handle2()) != nullptr) n_lanes = 2;
+        if (n_chunks >= 2 && env_long("SEQLIB_AMD_CALLS_IN_FLIGHT", (env_long("SEQLIB_AMD_THREADS", 0) > 0 ? T : cpus) >= 8 ? 2 : 1) >= 2 && (als[1] = handle2()) != nullptr) n_lanes = 2;
         const int n_slot = 2 * n_lanes;
         // pack chunk c into staging slot c % n_slot: lengths per part -> exclusive scan -> offsets + bases, all on the pool
         auto submit_pack = [&](int64_t c) {

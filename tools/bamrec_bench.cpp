@@ -53,7 +53,8 @@ int main(int argc, char **argv)
         }
         std::printf("{\"value\": %.1f, \"unit\": \"reads/s\", \"reads\": %ld, \"records\": %zu, \"seconds\": %.4f, \"host_threads\": %u, "
                     "\"path\": \"C++ SeqLib::BWAAligner::alignSequences: UnalignedSequenceVector -> chunks: pack into pinned staging (host threads) | GPU | BamRecords (host threads), overlapped -> std::vector<BamRecordPtrVector> (sample of the bench reads)\"}\n",
-                    (double)n / best, n, records, best, std::getenv("SEQLIB_AMD_THREADS") ? (unsigned)std::atoi(std::getenv("SEQLIB_AMD_THREADS")) : detail::effective_cpus());
+                    (double)n / best, n, records, best, std::getenv("SEQLIB_AMD_THREADS") ? (unsigned)std::atoi(std::getenv("SEQLIB_AMD_THREADS"))
+                                                      : (detail::effective_cpus() < 8 ? std::min(16u, detail::effective_cpus() * 8) : detail::effective_cpus()));          // (alignSequences' own rule)
     } catch (const std::exception &e) {
         std::fprintf(stderr, "bamrec_bench: %s\n", e.what());
         return 1;
