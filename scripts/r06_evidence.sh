@@ -17,6 +17,6 @@ SEQLIB_AMD_LOCAL_RANKS=8 timeout 900 python bench.py > $OUT/bench_host_budget_2c
 case " $SKIP " in *" prof "*) ;; *)
 bash scripts/profile_round.sh $OUT/c3 C3 > $OUT/profile_c3.log 2>&1
 bash scripts/profile_alone.sh $OUT/alone_C3 C3 16666666 > $OUT/alone_C3.txt 2>&1
-bash scripts/profile_c5.sh $OUT/c5 > $OUT/profile_c5.log 2>&1 ;; esac
+case " $SKIP " in *" c5prof "*) ;; *) bash scripts/profile_c5.sh $OUT/c5 > $OUT/profile_c5.log 2>&1 ;; esac ;; esac
 rm -f /tmp/slx_reads_cache.*
 ls $OUT

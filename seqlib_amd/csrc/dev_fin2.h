@@ -681,7 +681,101 @@ __global__ void __launch_bounds__(64, CIG_MIN_WAVES) k_cig_dp(DevRef R, Chunk ck
     }
 }
 
-__global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave)
+// Reads with many hits (a read inside a repeat keeps hundreds): on one lane the sort of 500 hits is ~30 000 dependent loads while the other 63 lanes of its wave
+// wait -- the whole of k_hits' time was a few thousand such reads (1.5 active lanes per instruction).  k_hits puts reads with more than HITS_BIG hits on a list
+// and k_hits_wave takes them one wave per read: keys in LDS, ranks counted 64 elements at a time against all (every correct sort gives std::sort's order when no
+// two keys are equal; with a tie anywhere the serial algorithm itself runs on lane 0, as before), the filters as a scan with the primary's score carried along.
+#define HITS_BIG 12
+#define HITS_WAVE_N 2048
+__global__ void __launch_bounds__(64) k_hits_wave(Chunk ck, const int *list, const unsigned int *n_list, unsigned int *queue)
+{
+    __shared__ int64_t s_pos[HITS_WAVE_N];
+    __shared__ int s_rid[HITS_WAVE_N], s_mapq[HITS_WAVE_N];
+    const int lane = threadIdx.x;
+    const int n_todo = __builtin_amdgcn_readfirstlane((int)*n_list);
+    for (;;) {
+        int slot = 0;
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));          // the lane number is made opaque INSIDE the loop.  With the loop-invariant `lane == 0` the compiler unswitched this loop on it: lanes 1..63
+                                              // got a copy of the loop in which slot stays 0 and readfirstlane reads lane 1 -- read 0 for ever (the round's first version of this kernel
+                                              // hung; scripts/ubench/hits_wave_test.hip reproduces it with VARIANT 2 and holds the kernel against std::stable_sort on the host)
+        if (l0 == 0) slot = (int)atomicAdd(queue, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= n_todo) break;
+        const int r = list[slot];
+        ReadWS w = make_ws(ck, r);
+        const int nh = __builtin_amdgcn_readfirstlane(ck.n_hit[r]);
+        int *hh = w.ic;
+        auto less_glb = [&](int x, int y) {
+            const DHit &A = w.hits[x], &B = w.hits[y];
+            if (A.mapq != B.mapq) return A.mapq > B.mapq;
+            if (A.rid != B.rid) return A.rid < B.rid;
+            return A.pos < B.pos;
+        };
+        bool serial = nh > HITS_WAVE_N;
+        if (!serial) {
+            __syncthreads();                                  // (the previous read's keys are no longer read)
+            for (int e = lane; e < nh; e += 64) { const DHit &h = w.hits[e]; s_pos[e] = h.pos; s_rid[e] = h.rid; s_mapq[e] = h.mapq; }
+            __syncthreads();
+            bool tie = false;
+            for (int base = 0; base < nh; base += 64) {
+                const int e = base + lane;
+                const bool live = e < nh;
+                const int em = live ? s_mapq[e] : 0, er = live ? s_rid[e] : 0;
+                const int64_t ep = live ? s_pos[e] : 0;
+                int rank = 0;
+                for (int j = 0; j < nh; ++j) {                // (keys broadcast from LDS: every lane reads the same address)
+                    const int jm = s_mapq[j], jr = s_rid[j];
+                    const int64_t jp = s_pos[j];
+                    const bool lt = jm != em ? jm > em : (jr != er ? jr < er : jp < ep);
+                    rank += lt ? 1 : 0;
+                    if (live && j != e && jm == em && jr == er && jp == ep) tie = true;
+                }
+                if (live) hh[rank] = e;                       // (a permutation when no two keys are equal; redone below otherwise)
+            }
+            serial = __any(tie) != 0;
+        }
+        __threadfence_block();
+        if (serial) {
+            if (lane == 0) {
+                for (int i = 0; i < nh; ++i) hh[i] = i;
+                std_sort_idx(nh, hh, less_glb);
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+        // the secondary filters (src/BWAAligner.cpp:136-146) over the sorted hits, 64 at a time: a secondary is tested against the score of the last
+        // non-secondary hit before it (0 if none yet)
+        int n_out = 0;
+        double carry = 0;
+        for (int base = 0; base < nh; base += 64) {
+            const int i = base + lane;
+            const bool live = i < nh;
+            const int hi = live ? hh[i] : 0;
+            int flag = 0, score = 0;
+            if (live) { const DHit &h = w.hits[hi]; flag = h.flag; score = h.score; }
+            const bool isSec = live && (flag & 0x100) != 0;
+            const unsigned long long prim = __ballot(live && !isSec);
+            const unsigned long long below = prim & ((1ULL << lane) - 1ULL);
+            const int src = below ? 63 - (int)__clzll((long long)below) : 0;
+            const int sc_src = __shfl(score, src, 64);         // (every lane takes part)
+            const double primaryScore = below ? (double)sc_src : carry;
+            const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)score);
+            const bool tooMany = isSec && (i > ck.maxSecondary);
+            const bool keep = live && !(tooLow || tooMany);
+            const unsigned long long km = __ballot(keep);
+            const int pos = n_out + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            __syncthreads();                                  // every lane has read its hh[i] before any slot at or below it is rewritten
+            if (keep) hh[pos] = hi;
+            n_out += (int)__popcll(km);
+            if (prim) { const int last = 63 - (int)__clzll((long long)prim); carry = (double)__shfl(score, last, 64); }          // (prim is the same in every lane)
+        }
+        if (lane == 0) ck.n_hit[r] = n_out;
+    }
+}
+
+__global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsigned int *queue, const unsigned int *n_slots, int per_wave, int *big_list = nullptr,
+                                              unsigned int *n_big = nullptr)
 {
     const int n_todo = (int)*n_slots;
     if (per_wave) __builtin_amdgcn_s_setprio(3);
@@ -692,27 +786,30 @@ __global__ void __launch_bounds__(128) k_hits(Chunk ck, const int *order, unsign
         const int r = order ? order[slot] : slot;
         ReadWS w = make_ws(ck, r);
         const int nh = ck.n_hit[r];
-        int *hh = w.ic;
-        for (int i = 0; i < nh; ++i) hh[i] = i;
-        // std::sort(hits, aln_sort) then the secondary filters (src/BWAAligner.cpp:133-146)
-        std_sort_idx(nh, hh, [&](int x, int y) {
-            const DHit &A = w.hits[x], &B = w.hits[y];
-            if (A.mapq != B.mapq) return A.mapq > B.mapq;
-            if (A.rid != B.rid) return A.rid < B.rid;
-            return A.pos < B.pos;
-        });
-        double primaryScore = 0;
-        int n_out = 0;
-        for (int i = 0; i < nh; ++i) {
-            const DHit &h = w.hits[hh[i]];
-            const bool isSec = (h.flag & 0x100) != 0;
-            const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)h.score);
-            const bool tooMany = isSec && (i > ck.maxSecondary);
-            if (tooLow || tooMany) continue;
-            if (!isSec) primaryScore = (double)h.score;
-            hh[n_out++] = hh[i];
+        if (big_list && nh > HITS_BIG) big_list[atomicAdd(n_big, 1u)] = r;          // k_hits_wave's
+        else {
+            int *hh = w.ic;
+            for (int i = 0; i < nh; ++i) hh[i] = i;
+            // std::sort(hits, aln_sort) then the secondary filters (src/BWAAligner.cpp:133-146)
+            std_sort_idx(nh, hh, [&](int x, int y) {
+                const DHit &A = w.hits[x], &B = w.hits[y];
+                if (A.mapq != B.mapq) return A.mapq > B.mapq;
+                if (A.rid != B.rid) return A.rid < B.rid;
+                return A.pos < B.pos;
+            });
+            double primaryScore = 0;
+            int n_out = 0;
+            for (int i = 0; i < nh; ++i) {
+                const DHit &h = w.hits[hh[i]];
+                const bool isSec = (h.flag & 0x100) != 0;
+                const bool tooLow = isSec && (primaryScore * ck.keepSecFrac > (double)h.score);
+                const bool tooMany = isSec && (i > ck.maxSecondary);
+                if (tooLow || tooMany) continue;
+                if (!isSec) primaryScore = (double)h.score;
+                hh[n_out++] = hh[i];
+            }
+            ck.n_hit[r] = n_out;
         }
-        ck.n_hit[r] = n_out;
     }
 }
 

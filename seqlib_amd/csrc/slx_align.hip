@@ -468,6 +468,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "long_budget")) { if (value < 0 || value > (1 << 20)) return SLX_EINVAL; al->long_budget = (int)value; }
     else if (!strcmp(key, "regs_big")) { if (value < 2) return SLX_EINVAL; al->regs_big = (int)value; }
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
+    else if (!strcmp(key, "hits_wave")) al->hits_wave = value != 0;
     else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
     else if (!strcmp(key, "small_spread")) al->small_spread = value != 0;
     else if (!strcmp(key, "chain_sorted")) al->chain_sorted = value != 0;
@@ -572,9 +573,9 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;
         }
-        if (!strcmp(key, "regs_deferred")) {          // reads k_regs handed to the wave kernel since the aligner was created
+        if (!strcmp(key, "regs_deferred") || !strcmp(key, "hits_wave_reads")) {          // reads k_regs handed to the wave kernel / reads k_hits_wave sorted, since the aligner was created
             long long v = 0;
-            const int which = 0;
+            const int which = key[0] == 'h';
             auto take = [&](const slx_aligner *a) { for (const Worker *wk : a->workers) v += (long long)wk->fin_stat[which]; };
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;

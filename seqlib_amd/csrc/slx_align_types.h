@@ -83,7 +83,7 @@ struct Worker {
     DevBuf order_key_in, order_key_out, order_in, order_out, queues, sort_tmp, jobs, fast_list, dp_list, part_flag, part_pos, cand, cand_base,
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
     DevBuf order_bin, bin_cnt;                                                     // finalize: the multi-region reads binned by region count
-    DevBuf defer_list;                                                             // finalize: reads k_regs defers to the wave kernel
+    DevBuf defer_list, hits_big;                                                   // finalize: reads k_regs defers to the wave kernel, reads k_hits leaves to k_hits_wave
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf job_key_in, job_key_out, job_val_in, job_val_out, job_sort_tmp;         // contigs: extension jobs ordered longest first
     DevBuf seed3_buf;                                                              // contigs: pass 3 of seeding from every position (k_seed3_next)
@@ -92,7 +92,7 @@ struct Worker {
     DevBuf xseg_jobs, xseg_state, xseg_units, xseg_out, xseg_wrec, xseg_wout, xseg_scratch, xseg_cnt;     // contigs: long extensions cut into segments (dev_ext_seg.h)
     DevBuf gseg_jobs, gseg_units, gseg_wrec, gseg_wout, gseg_scratch, gseg_cnt;                 // contigs: CIGAR alignments cut into segments (dev_cig_seg.h)
     DevBuf pseg_jobs, pseg_idx, pseg_cnt;                                          // ... and mem_patch_reg's alignments computed ahead of the region kernel
-    unsigned long long fin_stat[2] = {0, 0};                                       // [0] reads deferred by k_regs since the aligner was created
+    unsigned long long fin_stat[2] = {0, 0};                                       // reads deferred by k_regs / left to k_hits_wave since the aligner was created
     unsigned int pseg_stat = 0;                                                    // ... how many
     unsigned int gseg_stat[3] = {0, 0, 0};                                         // ... segments taken as speculated / run again / jobs cut
     unsigned int xseg_stat[4] = {0, 0, 0, 0};                                      // ... segments taken as speculated / computed again / second band tries / sides cut, summed over this worker's launches
@@ -120,7 +120,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &defer_list, &order_bin, &bin_cnt, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &defer_list, &hits_big, &order_bin, &bin_cnt, &snap_ia, &snap_regs, &snap_nreg,
                &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &pseg_jobs, &pseg_idx, &pseg_cnt, &gseg_jobs, &gseg_units, &gseg_wrec, &gseg_wout, &gseg_scratch, &gseg_cnt, &xseg_jobs, &xseg_state, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
@@ -173,6 +173,7 @@ struct slx_aligner {
     int chain_sorted = 0;         // experiment: the light reads go to k_chain binned by seed-occurrence count, most first.  Measured: C3 64.4 / 64.6 -> 63.4 / 63.7 M reads/s,
                                   // the chain group's stream time unchanged (k_chain waits for memory, not for its longest lane): off
     int small_spread = 1;         // small chunks of short reads (up to SMALL_SPREAD_MAX reads, below split_min): one read per wave through the lane-per-read kernels
+    int hits_wave = 1;            // reads with more than HITS_BIG hits: the glue's sort + filters one wave per read (k_hits_wave)
     int small_coop = 1;           // small chunks (below split_min): heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
     int regs_defer = 1;           // k_regs hands reads that need one of mem_patch_reg's alignments to a wave-per-read launch (0: aligns on its lane, as until round 5)
     int regs_big = 48;            // reads with at least this many regions take the wave-per-read region kernel: sorts staged in LDS, the
