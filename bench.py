@@ -129,7 +129,7 @@ def gen_reads(cfg, refs, n_reads, first_block, share=1):
     return out
 
 
-def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
+def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0, timed=True):
     """The CPU oracle (a port of the reference path: it cannot be built from /root/reference) timed on this box's host
     cores as SURVEY 8d(ii) specifies: ONE process, std::thread over disjoint read ranges sharing one read-only index, on all
     `nproc` cores, -O2, one read per call; bounded to ~budget_s of work per thread on a sample of the same reads.  Also returns
@@ -148,6 +148,9 @@ def cpu_baseline(prefix, reads_ascii, cfg_name, budget_s=8.0):
     cnt = orc.counters()
     per_read = {k: v / cal for k, v in cnt.items()}
     rate1 = cal / dt1
+    if not timed:          # N > 1: the baseline is a figure of the N = 1 line; the counters (the rooflines' per-read bytes and cells) are still needed
+        del idx
+        return None, per_read
     per_thread = int(max(200, min(rate1 * budget_s, (len(reads_ascii) - cal) // max(cores, 1))))
     m = per_thread * cores
     sample = np.ascontiguousarray(reads_ascii[cal:cal + m])
@@ -773,7 +776,11 @@ def main():
         idx.WriteIndex(prefix)
         per_read, cpu, match = None, None, None
         if not args.no_cpu_baseline:
-            cpu, per_read = cpu_baseline(prefix, reads, args.config)
+            cpu, per_read = cpu_baseline(prefix, reads, args.config, timed=(world == 1))
+        if world > 1:
+            # the host-to-host rate, the C++ class with BamRecords, the per-call loop and the C5 leg are figures of the one-GPU line: at N > 1 the other ranks
+            # would sit in the closing barrier for minutes (RCCL's watchdog gives a collective ten) while rank 0 measures them on a node it shares with them
+            args.no_extras = True
         if args.verify > 0:
             from oracle import orc
             m = min(args.verify, n)

@@ -12,6 +12,7 @@
 #pragma once
 #include "dev_fin.h"
 #include "dev_ext_reg.h"
+#include "dev_nm8.h"
 
 #ifndef LANE_CIG_BAND
 #define LANE_CIG_BAND 33          // CIGAR jobs whose first band has at most this many columns (w <= 16) run one lane per job (dev_cig_lane.h)
@@ -506,6 +507,67 @@ __global__ void __launch_bounds__(256) k_cig_fast(DevRef R, Chunk ck, FinLists f
         if (base + 3 > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
         ck.cigpool[base + 1] = (uint32_t)lq << 4;
         dev_finish_hit(R, ck, j, l_query, h, (int64_t)base + 1, 1);
+        ck.hits[slot] = h;
+    }
+}
+
+// The same jobs, the NM count wave-cooperative.  One lane per job reads its query 8 bytes at a time from an address 150 bytes from its neighbour's: every load of
+// the wave touches 64 cache lines, a wave's 64 queries (9.6 KB) times the waves of a CU do not stay in its L1 between the 19 steps, and rocprofv3 showed 59 L2 requests
+// and 2.5 KB fetched from HBM per job for the ~330 bytes the job needs (profiles/r06_pmc_summary.json: TCC_REQ 983 M, FETCH_SIZE 41 GB per 16.7 M jobs -- the most
+// bytes per unit of work of any kernel of the chunk).  Here the (job, 8-base chunk) pairs of a wave's 64 jobs are dealt to the lanes chunk-fastest: a load covers the
+// consecutive chunks of three or four jobs -- a dozen lines instead of 64, each fetched once -- a pair's mismatches (dev_nm8.h) go to the job's counter in LDS, and the
+// lane that owns the job finishes the hit as before.
+__global__ void __launch_bounds__(256) k_cig_fast_coop(DevRef R, Chunk ck, FinLists fl)
+{
+    __shared__ uint64_t s_q[4][64];
+    __shared__ int64_t s_rb[4][64];
+    __shared__ int s_lq[4][64], s_nm[4][64];
+    const unsigned int n = *fl.n_fast;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (unsigned int base = (blockIdx.x * 4u + (unsigned int)wv) * 64u; base < n; base += gridDim.x * 256u) {
+        const unsigned int t = base + (unsigned int)lane;
+        const bool valid = t < n;
+        uint32_t slot = 0;
+        DJob j;
+        j.rb = j.re = 0; j.qb = j.qe = 0; j.w2 = j.truesc = 0; j.r = 0; j.pad = 0;
+        int l_query = 0;
+        uint64_t q_at0 = 0;
+        if (valid) {
+            slot = fl.fast_list[t];
+            j = fl.jobs[slot];
+            const uint64_t o0 = ck.offs[j.r];
+            l_query = (int)(ck.offs[j.r + 1] - o0);
+            q_at0 = o0 + (uint64_t)j.qb;
+        }
+        const int lq = valid ? j.qe - j.qb : 0;
+        s_q[wv][lane] = q_at0; s_rb[wv][lane] = j.rb; s_lq[wv][lane] = lq; s_nm[wv][lane] = 0;
+        int nch = (lq + 7) >> 3;                                   // chunks of the wave's longest job
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(nch, d, 64); nch = nch > o ? nch : o; }
+        nch = __builtin_amdgcn_readfirstlane(nch);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nch > 0) {
+            // pair p = step * 64 + lane -> job p / nch, chunk p % nch, kept incrementally
+            int jj = lane / nch, c = lane - jj * nch;
+            const int dj = 64 / nch, dc = 64 - dj * nch;
+            for (; jj < 64; ) {
+                const int i = c << 3, lqj = s_lq[wv][jj];
+                if (i < lqj) {
+                    const int nv = lqj - i < 8 ? lqj - i : 8;
+                    const int m = nm8_chunk(R.pac, R.l_pac, ck.codes + s_q[wv][jj] + (uint64_t)i, s_rb[wv][jj] + i, nv);
+                    if (m) atomicAdd(&s_nm[wv][jj], m);
+                }
+                jj += dj; c += dc;
+                if (c >= nch) { c -= nch; ++jj; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!valid) continue;
+        DHit h = ck.hits[slot];
+        h.nm = s_nm[wv][lane];
+        const unsigned long long cbase = wave_fetch_add_u64(ck.cigused, 3ull);
+        if (cbase + 3 > ck.cigcap) { atomicOr(ck.flags, OVF_CIGAR); continue; }
+        ck.cigpool[cbase + 1] = (uint32_t)lq << 4;
+        dev_finish_hit(R, ck, j, l_query, h, (int64_t)cbase + 1, 1);
         ck.hits[slot] = h;
     }
 }

@@ -5,6 +5,7 @@ import ctypes as C
 import filecmp
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -183,3 +184,14 @@ def test_library_load_leaves_the_environment_alone():
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "None"
     env["GPU_MAX_HW_QUEUES"] = "16"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "16"
+
+
+def test_nm8_chunk_against_the_definition(tmp_path):
+    """k_cig_fast_coop's arithmetic (seqlib_amd/csrc/dev_nm8.h: mismatches of up to eight bases from one 8-byte read of the query and one of the packed
+    text) against bns_get_seq's base at every coordinate: every start, length 1..8, both strands, both ends of the text -- under ASan + UBSan with the text
+    padded by exactly the eight bytes the function may read past its end."""
+    src = os.path.join(ROOT, "tests", "cpp", "nm8_test.cpp")
+    exe = str(tmp_path / "nm8_test")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wno-unknown-pragmas", "-DNM8_PAD=8", "-o", exe, src])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out.strip().endswith(" 0 bad"), out
