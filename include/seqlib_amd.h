@@ -146,6 +146,7 @@ void slx_aligner_free(slx_aligner *al);
  *   "small_coop" 0|1 (1)      chunks below split_min: heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
  *   "small_spread" 0|1 (1)    chunks of at most 512 short reads: one read per WAVE through the lane-per-read kernels (seeding, k_chain, k_regs, k_hits)
  *   "cig_fast_coop" 0|1 (1)   the no-DP CIGARs' NM count wave-cooperative (k_cig_fast_coop: a load covers consecutive 8-base chunks of a few jobs) instead of one lane per job (k_cig_fast)
+ *   "cig_lane_il" 0|1 (1)     k_cig_lanes keeps the traceback bytes of a wave's 64 jobs lane-interleaved in one block of the arena (0: a row-major stretch per job)
  *   "regs_sorted", "chain_sorted" 0|1 (0)   experiments kept for their A/B (profiles/r06_knob_ab.txt): reads binned by size before the lane-per-read kernels -- slower
  *   "keep_stages" 1           test hook: keep what slx_debug_stage reads
  * Returns SLX_EINVAL for an unknown key or a value out of range. */

@@ -21,7 +21,9 @@ typedef uint32_t __attribute__((aligned(1))) z32u;
 // dev_ksw_global2 with the row in LDS: (uint16)h | (uint16)e << 16 per column, and only the band of it: row i touches the columns
 // [i - w, i + w + 1], every column it reads was written by row i - 1 (in its loop or as its eh[end]) or, in row 0, by the initialisation,
 // so column j can live at slot j mod P for any P >= 2 w + 2 -- 34 words per lane for the bands this kernel takes instead of qlen + 1.
-template <typename QF, typename TF>
+// IL: the direction bytes lane-interleaved -- z is the lane's first word of its wave's block, a row is n_col (here: WORDS per row, the band padded to a multiple of four
+// columns) words WAVE words apart, so the four bytes the 64 lanes store together are one 256-byte write instead of 64 partial lines 2-5 KB apart (see k_cig_lanes)
+template <bool IL, typename QF, typename TF>
 __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &o, const MatRows &mr, int w, uint8_t *z, int n_col, uint32_t *row)
 {
     const int o_del = o.o_del, e_del = o.e_del, o_ins = o.o_ins, e_ins = o.e_ins;
@@ -45,7 +47,8 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
         end = i + w + 1 < qlen ? i + w + 1 : qlen;
         if (i > w) { ++sbeg; if (sbeg == P) sbeg = 0; }     // (beg moved one column to the right)
         h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : LANE_NEG;
-        uint8_t *zi = z + (size_t)i * n_col;
+        uint8_t *zi = IL ? nullptr : z + (size_t)i * n_col;
+        uint32_t *zwi = IL ? (uint32_t *)z + (size_t)i * (size_t)n_col * WAVE : nullptr;
         uint32_t zacc = 0;                                  // four direction bytes per store (the arena stretch of a job is padded by 4 bytes)
         int sj = sbeg;                                      // slot of column j
         uint32_t cur = beg < end ? row[sj * WAVE] : 0u;
@@ -74,11 +77,11 @@ __device__ int lane_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt 
             f = f > LANE_NEG ? f : LANE_NEG;          // (an unreachable F stays at the floor instead of drifting down)
             const int zk = (j - beg) & 3;
             zacc |= (uint32_t)d << (zk * 8);
-            if (zk == 3) { *(z32u *)(zi + (j - beg - 3)) = zacc; zacc = 0; }
+            if (zk == 3) { if (IL) zwi[(size_t)((j - beg) >> 2) * WAVE] = zacc; else *(z32u *)(zi + (j - beg - 3)) = zacc; zacc = 0; }
             cur = nxt;
             sj = sn;
         }
-        if (end > beg && ((end - beg) & 3)) *(z32u *)(zi + ((end - beg) & ~3)) = zacc;     // (the bytes past the row's end are the next row's, written later)
+        if (end > beg && ((end - beg) & 3)) { if (IL) zwi[(size_t)((end - beg) >> 2) * WAVE] = zacc; else *(z32u *)(zi + ((end - beg) & ~3)) = zacc; }     // (row-major: the bytes past the row's end are the next row's, written later)
         if (beg >= end) { sj = sbeg + (end - beg); sj = sj < 0 ? sj + P : sj; }             // (an empty row: column end lies left of beg)
         row[sj * WAVE] = pack(h1, LANE_NEG);               // eh[end]
     }
@@ -102,6 +105,11 @@ __device__ __forceinline__ unsigned long long lane_wave_alloc(unsigned long long
     return base + incl - bytes;
 }
 
+// IL (knob cig_lane_il, default on): the traceback arena of a wave's 64 jobs is ONE block, word k of lane L at block[k * 64 + L].  Row-major per job (IL = false) every
+// 4-byte store of the wave went to 64 lines 2-5 KB apart and every line left the L2 partly written: rocprofv3 counted ~400 L2 requests per job and 19 GB written per
+// 16.7 M-read launch (profiles/r06_pmc_summary.json).  Interleaved, a store of the wave is one 256-byte write; the traceback's byte reads of lanes walking their
+// diagonals in step fall into the same lines.  A wave keeps its block for its next 64 jobs when it is large enough.
+template <bool IL>
 __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dopt, FinLists fl, const uint32_t *lane_list, const unsigned int *n_lane, unsigned int *queue)
 {
     const slx_opt &opt = dopt.o;
@@ -110,6 +118,8 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
     __shared__ uint32_t rows[LANE_CIG_SLOTS * WAVE];
     uint32_t *row = rows + lane;
     const unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_lane);
+    uint8_t *zown = nullptr;                 // IL: the wave's block (256-byte aligned) and the words per lane it holds
+    unsigned int zown_words = 0;
     for (;;) {
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(queue, (unsigned int)WAVE);
@@ -159,12 +169,33 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
                 need = (unsigned long long)n_col * (unsigned long long)rlen + 4;
                 if (2 * ww + 2 > LANE_CIG_SLOTS) { need = 0; going = false; wide = true; }     // (cannot happen: the routing in dev_reg_emit computes the same band)
             }
-            const unsigned long long off = lane_wave_alloc(ck.zused, need, lane);
+            unsigned long long off = 0;
+            bool z_ok = true;
+            int z_stride = n_col;                                     // row-major: bytes per row; interleaved: words per row
+            if constexpr (IL) {
+                z_stride = (n_col + 3) >> 2;
+                unsigned int words = going ? (unsigned int)z_stride * (unsigned int)rlen : 0u;
+                for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)words, d, WAVE); words = words > o ? words : o; }
+                words = (unsigned int)__builtin_amdgcn_readfirstlane((int)words);
+                if (words > zown_words) {                             // a new block (the old one stays where it is: the arena only grows within a chunk)
+                    const unsigned long long bytes = (unsigned long long)words * (WAVE * 4ull) + 255ull;
+                    unsigned long long at = 0;
+                    if (lane == 0) at = atomicAdd(ck.zused, bytes);
+                    at = rfl_u64(at);
+                    if (at + bytes > ck.zcap) { zown = nullptr; zown_words = 0; }
+                    else { zown = ck.zarena + ((at + 255ull) & ~255ull); zown_words = words; }
+                }
+                z_ok = zown != nullptr;
+            } else {
+                off = lane_wave_alloc(ck.zused, need, lane);
+                z_ok = off + need <= ck.zcap;
+            }
             if (going) {
-                if (off + need > ck.zcap) { atomicOr(ck.flags, OVF_ZARENA); going = false; failed = true; }
+                if (!z_ok) { atomicOr(ck.flags, OVF_ZARENA); going = false; failed = true; }
                 else {
-                    z = ck.zarena + off;
-                    score = lane_ksw_global2(lq, qf, rlen, tf, opt, mr, ww, z, n_col, row);
+                    z = IL ? zown + 4 * lane : ck.zarena + off;
+                    n_col = z_stride;
+                    score = lane_ksw_global2<IL>(lq, qf, rlen, tf, opt, mr, ww, z, n_col, row);
                     // mem_reg2aln: `if (score == last_sc || w2 == opt->w<<2) break; last_sc = score; w2 <<= 1;` then `while (++i < 3 && score < truesc - a)`
                     if (score == last_sc || w2 == opt.w << 2) going = false;
                     else { last_sc = score; w2 <<= 1; if (!(score < j.truesc - opt.a)) going = false; }
@@ -176,7 +207,12 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
         // one traceback: the ops (end of the alignment first) wait in the lane's LDS row, free now, until the words are reserved
         int n_ops = 0;
         const bool emit = live && !failed;
-        if (valid && emit) dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { if (n_ops < LANE_CIG_SLOTS) row[n_ops * WAVE] = (uint32_t)len << 4 | (uint32_t)op; ++n_ops; });
+        // (n_col: bytes per row of a row-major stretch, words per row of the interleaved block)
+        auto zat = [&](int i, int c) {
+            if constexpr (IL) { const uint32_t wd = ((const uint32_t *)z)[((size_t)i * (size_t)n_col + (size_t)(c >> 2)) * WAVE]; return (int)((wd >> ((c & 3) << 3)) & 0xffu); }
+            else return (int)z[(size_t)i * n_col + c];
+        };
+        if (valid && emit) dev_traceback_at(zat, lq, rlen, w_used, [&](int op, int len) { if (n_ops < LANE_CIG_SLOTS) row[n_ops * WAVE] = (uint32_t)len << 4 | (uint32_t)op; ++n_ops; });
         const bool ops_in_lds = n_ops <= LANE_CIG_SLOTS;
         const unsigned long long cneed = emit ? (unsigned long long)n_ops + 2 : 0ull;
         const unsigned long long cbase = lane_wave_alloc(ck.cigused, cneed, lane);
@@ -185,7 +221,7 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
         uint32_t *cg = ck.cigpool + cbase + 1;
         if (valid) {
             if (ops_in_lds) for (int k = 0; k < n_ops; ++k) cg[k] = row[(n_ops - 1 - k) * WAVE];
-            else { int wp = n_ops; dev_traceback(z, n_col, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; }); }
+            else { int wp = n_ops; dev_traceback_at(zat, lq, rlen, w_used, [&](int op, int len) { cg[--wp] = (uint32_t)len << 4 | (uint32_t)op; }); }
             // NM = mismatches in M + inserted + deleted bases (a D that is the first or last op is not counted)
             int x = 0, y = 0, n_mm = 0, n_gap = 0;
             for (int k = 0; k < n_ops; ++k) {

@@ -55,9 +55,10 @@ __device__ int dev_ksw_global2(int qlen, QF qf, int tlen, TF tf, const slx_opt &
     return eh_h[qlen];
 }
 
-// traceback; F(op, len) is called for merged ops from the END of the alignment to its start
-template <typename F>
-__device__ void dev_traceback(const uint8_t *z, int n_col, int qlen, int tlen, int w, F emit)
+// traceback; F(op, len) is called for merged ops from the END of the alignment to its start.  ZAT(i, c): the direction byte of row i, band column c
+// (the arena's layout is the caller's: row-major bytes for the wave and block kernels, lane-interleaved words for k_cig_lanes)
+template <typename ZAT, typename F>
+__device__ void dev_traceback_at(ZAT zat, int qlen, int tlen, int w, F emit)
 {
     int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
     int cur_op = -1, cur_len = 0;
@@ -66,7 +67,7 @@ __device__ void dev_traceback(const uint8_t *z, int n_col, int qlen, int tlen, i
         else { if (cur_op >= 0) emit(cur_op, cur_len); cur_op = op; cur_len = len; }
     };
     while (i >= 0 && k >= 0) {
-        which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+        which = zat(i, k - (i > w ? i - w : 0)) >> (which << 1) & 3;
         if (which == 0) { unit(0, 1); --i; --k; }
         else if (which == 1) { unit(2, 1); --i; }
         else { unit(1, 1); --k; }
@@ -74,6 +75,11 @@ __device__ void dev_traceback(const uint8_t *z, int n_col, int qlen, int tlen, i
     if (i >= 0) unit(2, i + 1);
     if (k >= 0) unit(1, k + 1);
     if (cur_op >= 0) emit(cur_op, cur_len);
+}
+template <typename F>
+__device__ void dev_traceback(const uint8_t *z, int n_col, int qlen, int tlen, int w, F emit)
+{
+    dev_traceback_at([&](int i, int c) { return (int)z[(size_t)i * n_col + c]; }, qlen, tlen, w, emit);
 }
 
 struct GenCig {               // state of one bwa_gen_cigar2 call, kept so that the traceback can run later

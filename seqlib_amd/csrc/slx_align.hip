@@ -472,6 +472,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "regs_defer")) al->regs_defer = value != 0;
     else if (!strcmp(key, "hits_wave")) al->hits_wave = value != 0;
     else if (!strcmp(key, "cig_fast_coop")) al->cig_fast_coop = value != 0;
+    else if (!strcmp(key, "cig_lane_il")) al->cig_lane_il = value != 0;
     else if (!strcmp(key, "small_coop")) al->small_coop = value != 0;
     else if (!strcmp(key, "small_spread")) al->small_spread = value != 0;
     else if (!strcmp(key, "chain_sorted")) al->chain_sorted = value != 0;

@@ -175,6 +175,7 @@ struct slx_aligner {
     int small_spread = 1;         // small chunks of short reads (up to SMALL_SPREAD_MAX reads, below split_min): one read per wave through the lane-per-read kernels
     int cig_fast_coop = 1;        // the no-DP CIGARs ("<len>M", NM by comparison): the (job, 8-base chunk) pairs of 64 jobs dealt to the lanes of a wave so that a load covers consecutive
                                   // chunks (k_cig_fast_coop) instead of one lane per job reading 150 bytes from its neighbour's (k_cig_fast: 59 L2 requests per job)
+    int cig_lane_il = 1;          // k_cig_lanes: the traceback arena of a wave's 64 jobs lane-interleaved in one block (a store of the wave is one 256-byte write) instead of 64 row-major stretches
     int hits_wave = 1;            // reads with more than HITS_BIG hits: the glue's sort + filters one wave per read (k_hits_wave)
     int small_coop = 1;           // small chunks (below split_min): heavy reads chain one wave each (k_chain_coop) instead of on a lane of k_chain
     int regs_defer = 1;           // k_regs hands reads that need one of mem_patch_reg's alignments to a wave-per-read launch (0: aligns on its lane, as until round 5)
