@@ -134,6 +134,7 @@ void slx_aligner_free(slx_aligner *al);
  *                             chunks of at most 5 M reads
  *   "cig_lanes" 0|1 (1)       CIGAR jobs with a narrow band (<= 33 columns, query <= 158 bases) run one lane per job (k_cig_lanes); k_cig_dp keeps the others
  *   "first_diag" 0|1 (1)      the top-seed extensions that the diagonal answers run one lane per job (k_first_diag); k_ext_first keeps the dynamic program
+ *   "first_lanes" 0|1 (1)     the other top-seed extensions of the light reads (the dynamic program) one lane per job, binned by work (k_first_lanes); 0: one wave per job (k_ext_first)
  *   "lane_narrow" 0|1 (1)     k_ext_lanes keeps 8-bit H / E cells when no score can reach 256
  *   "p2_coop" 0|1 (1)         seeding pass 2: re-seeding calls inside repeats one wave per call (k_seed2_coop); needs p2_items
  *   "p2_items" 0|1 (1)        seeding pass 2: 1 = one lane per re-seeding call, 0 = one lane per read;  "p2_items_cap" (0 = one per read): test hook,

@@ -3,8 +3,8 @@
 KNOB=${KNOB:-cig_lane_il}
 exec < /dev/null
 ulimit -c 0
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06o; mkdir -p $OUT; cd $R
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "full_fixture or edge_cases or option_fuzz_vs or batch_shape or knobs_do_not or stage_by_stage or C1_plumbing or long_reads_seed or contig_length or host_entry_rejects or light_heavy" > $OUT/pytest_subset.txt 2>&1; tail -3 $OUT/pytest_subset.txt
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${TAG:-r06p}; mkdir -p $OUT; cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "${TESTS:-full_fixture or edge_cases or knobs_do_not or stage_by_stage or C1_plumbing or long_reads_seed or light_heavy or C3_chr20 or ecoli_block or option_fuzz_vs}" > $OUT/pytest_subset.txt 2>&1; tail -3 $OUT/pytest_subset.txt
 for rep in 1 2; do
 for v in 1 0; do
 SLX_KNOBS=${KNOB}=$v timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 4 --warmup 1 > $OUT/ab_${v}_$rep.json 2> $OUT/ab_${v}_$rep.err

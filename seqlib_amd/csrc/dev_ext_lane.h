@@ -295,6 +295,79 @@ __global__ void __launch_bounds__(64) k_ext_lanes(DevRef R, Chunk ck, DevOpt dop
     }
 }
 
+// ---------------------------------------------------------------------------------------------- light reads: the top-seed extensions that need the dynamic program, one lane per job
+// k_ext_first gives each of them a wave (~11 000 wave instructions per job of which a band of a few dozen columns uses a fraction of the lanes).  The jobs are independent
+// and come with everything in one 64-byte descriptor, so they can run as the heavy reads' seeds do above, 64 per wave on lane_extend_core -- but a wave then lasts as long
+// as its longest job, and the work of a job goes with the SQUARE of its extension queries (0 .. read length - seed length bases on either side of the seed).  Hence the
+// bins: the jobs k_first_diag left are counting-sorted by sqrt(left^2 + right^2) into 64 classes, most work first, so that the 64 jobs of a wave are alike and the long
+// ones start early (three small launches, no host round trip; the order inside a class is whatever the atomics give: every job writes its own table entry).
+__device__ __forceinline__ int first_job_bin(const FirstJob &j, int max_len)
+{
+    const int left = j.s_qbeg, right = j.l_query - j.s_qbeg - j.s_len;
+    const float w = sqrtf((float)(left * left + right * right));
+    int b = (int)(w * 64.f / (float)(max_len > 0 ? max_len : 1));
+    b = b > 63 ? 63 : (b < 0 ? 0 : b);
+    return 63 - b;
+}
+__global__ void __launch_bounds__(256) k_first_bin_count(const FirstJob *jobs, const unsigned int *dp_list, const unsigned int *n_dp, int max_len, unsigned int *bins)
+{
+    __shared__ unsigned int s[64];
+    if (threadIdx.x < 64) s[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned int n = *n_dp;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) atomicAdd(&s[first_job_bin(jobs[dp_list[t]], max_len)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && s[threadIdx.x]) atomicAdd(&bins[threadIdx.x], s[threadIdx.x]);
+}
+__global__ void k_first_bin_scan(unsigned int *bins)          // bins[64 + b] = where class b starts (then its cursor)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned int acc = 0; for (int b = 0; b < 64; ++b) { bins[64 + b] = acc; acc += bins[b]; } }
+}
+__global__ void __launch_bounds__(256) k_first_bin_scatter(const FirstJob *jobs, const unsigned int *dp_list, const unsigned int *n_dp, int max_len, unsigned int *bins, unsigned int *out)
+{
+    __shared__ unsigned int s_cnt[64], s_base[64];
+    const unsigned int n = *n_dp;
+    for (unsigned int t0 = blockIdx.x * blockDim.x; t0 < n; t0 += gridDim.x * blockDim.x) {          // (block-uniform trip count: the barriers below are reached by all)
+        if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned int t = t0 + threadIdx.x;
+        int b = -1;
+        unsigned int job = 0, my = 0;
+        if (t < n) { job = dp_list[t]; b = first_job_bin(jobs[job], max_len); my = atomicAdd(&s_cnt[b], 1u); }
+        __syncthreads();
+        if (threadIdx.x < 64 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&bins[64 + threadIdx.x], s_cnt[threadIdx.x]);
+        __syncthreads();
+        if (b >= 0) out[s_base[b] + my] = job;
+        __syncthreads();
+    }
+}
+
+template <typename L>
+__global__ void __launch_bounds__(64) k_first_lanes(DevRef R, Chunk ck, DevOpt dopt, unsigned int *queue, const FirstJob *jobs, DReg *first, const unsigned int *list,
+                                                     const unsigned int *n_list, int cols)
+{
+    const slx_opt &opt = dopt.o;
+    const int lane = threadIdx.x;
+    const MatRows mr = make_matrows(opt.mat);
+    extern __shared__ uint32_t lane_lds[];
+    L row;
+    row.init(lane_lds, cols, lane);
+    const unsigned int n_jobs = (unsigned int)__builtin_amdgcn_readfirstlane((int)*n_list);
+    for (;;) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(queue, (unsigned int)WAVE);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_jobs) break;
+        const unsigned int t = base + (unsigned int)lane;
+        if (t < n_jobs) {
+            const unsigned int job = list[t];
+            const FirstJob j = jobs[job];
+            const DReg a = lane_extend_core<L>(R, opt, mr, ck.codes + j.q_off, j.l_query, j.s_qbeg, j.s_len, j.s_rbeg, j.rmax0, j.rmax1, j.rid, j.frac_rep, row);
+            first[job] = a;                              // seedcov is filled in by k_ext_replay
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- light reads: the diagonal, one lane per job
 // Most top-seed extensions of the light reads are answered by the diagonal alone (diag_extend, dev_ext_reg.h: at most oe - 1 lost against a
 // perfect match).  One wave per job that is ~1 000 instructions around two short scans -- 12.8 of k_ext_first's 20 ms per 8.3 M reads;

@@ -483,6 +483,7 @@ extern "C" int slx_aligner_set(slx_aligner *al, const char *key, int64_t value)
     else if (!strcmp(key, "cand_lanes")) { if (value < -1 || value > 1) return SLX_EINVAL; al->cand_lanes = (int)value; }
     else if (!strcmp(key, "cig_lanes")) al->cig_lanes = value != 0;
     else if (!strcmp(key, "first_diag")) al->first_diag = value != 0;
+    else if (!strcmp(key, "first_lanes")) al->first_lanes = value != 0;
     else if (!strcmp(key, "lane_narrow")) al->lane_narrow = value != 0;
     else if (!strcmp(key, "lane_pad")) al->lane_pad = (int)value;
     else if (!strcmp(key, "cand_lane_seeds")) { if (value < 1) return SLX_EINVAL; al->cand_lane_seeds = (int)value; }

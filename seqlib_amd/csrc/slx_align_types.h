@@ -84,6 +84,7 @@ struct Worker {
         cand_cnt, cand_off, dbg_cyc, order_tmp, first_tab, first_cnt, first_off, fb_list, first_jobs, len_stat, s_score, long_list, long_scratch, huge_rows;
     DevBuf order_bin, bin_cnt;                                                     // finalize: the multi-region reads binned by region count
     DevBuf defer_list, hits_big;                                                   // finalize: reads k_regs defers to the wave kernel, reads k_hits leaves to k_hits_wave
+    DevBuf first_sorted, first_bins;                                               // k_first_lanes: the DP jobs of the light reads' top seeds binned by work
     DevBuf p2mask, p2list, p2items, p2long, lane_jobs, first_dp, cig_lane_list;               // seeding pass 2: calls to make per read, reads with any (k_seed2_select)
     DevBuf job_key_in, job_key_out, job_val_in, job_val_out, job_sort_tmp;         // contigs: extension jobs ordered longest first
     DevBuf seed3_buf;                                                              // contigs: pass 3 of seeding from every position (k_seed3_next)
@@ -120,7 +121,7 @@ struct Worker {
                &c_pos, &c_head, &c_tail, &c_n, &c_rid, &c_w, &c_first, &c_kept, &ia, &ib, &ic, &srt, &regs, &hits, &n_chain, &n_reg, &n_hit,
                &na, &frac_rep, &zarena, &cigpool, &counters, &lists, &hit_cnt, &cig_cnt, &hit_off_c, &cig_off_c, &order_key_in,
                &order_key_out, &order_in, &order_out, &queues, &sort_tmp, &jobs, &fast_list, &dp_list, &part_flag, &part_pos, &cand, &cand_base,
-               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &cig_lane_list, &defer_list, &hits_big, &order_bin, &bin_cnt, &snap_ia, &snap_regs, &snap_nreg,
+               &cand_cnt, &cand_off, &dbg_cyc, &order_tmp, &first_tab, &first_cnt, &first_off, &fb_list, &first_jobs, &len_stat, &s_score, &long_list, &long_scratch, &huge_rows, &p2mask, &p2list, &p2items, &p2long, &lane_jobs, &first_dp, &first_sorted, &first_bins, &cig_lane_list, &defer_list, &hits_big, &order_bin, &bin_cnt, &snap_ia, &snap_regs, &snap_nreg,
                &memo_idx, &memo_jobs, &memo_tab, &round_list, &todo_a, &todo_b, &spec_cnt, &seed3_buf, &job_key_in, &job_key_out, &job_val_in, &job_val_out, &job_sort_tmp, &pseg_jobs, &pseg_idx, &pseg_cnt, &gseg_jobs, &gseg_units, &gseg_wrec, &gseg_wout, &gseg_scratch, &gseg_cnt, &xseg_jobs, &xseg_state, &xseg_units, &xseg_out, &xseg_wrec, &xseg_wout, &xseg_scratch, &xseg_cnt,
                &o_hit_off, &o_rid, &o_pos, &o_flag, &o_mapq, &o_score, &o_nm, &o_na, &o_ncig, &o_cig_off, &o_cigar, &o_xa, &o_sub};
         for (auto &e : ev) e = nullptr;
@@ -191,6 +192,8 @@ struct slx_aligner {
                                   // of those reads hides behind the other workers, and the lane kernel extends every seed, twice what the walk extends)
     int cand_lane_seeds = 64;
     int cig_lanes = 1;            // 1 = CIGAR jobs with a narrow band run one lane per job (k_cig_lanes); k_cig_dp keeps the wide ones
+    int first_lanes = 1;          // 1 = the top-seed extensions of the light reads that need the dynamic program run one LANE per job, binned by work (k_first_lanes), where
+                                  // the rows fit the LDS (reads up to 704 bp, scores as for k_ext_lanes); 0 = one wave per job (k_ext_first)
     int first_diag = 1;           // 1 = the top-seed extensions the diagonal answers run one LANE per job (k_first_diag); k_ext_first keeps the others
     int lane_narrow = 1;          // 1 = 8-bit H / E cells in k_ext_lanes when no score can reach 256 (half the LDS per wave)
     int lane_pad = 0;             // tuning: extra LDS columns per lane of k_ext_lanes (lowers its occupancy)

@@ -84,7 +84,7 @@ SWEEP_KNOBS = ((), (("workers", 1),), (("min_split", 2),), (("chunk_reads", 37),
                (("split_min", 1), ("heavy_seeds", 8), ("regs_big", 2)), (("split_min", 1), ("heavy_seeds", 8), ("first_diag", 0), ("lane_narrow", 0)),
                (("regs_big", 2),), (("regs_big", 1 << 30),), (("cig_lanes", 0),), (("p2_items", 0),), (("p2_coop", 0),), (("p2_items_cap", 3),), (("dense_sa", 0),),
                (("chain_mode", 0),), (("wide_index", 1),), (("lut_k", 0),), (("cap_intv", 2),), (("seed_quota", 64),), (("rep_k", 0),), (("regs_defer", 0),), (("hits_wave", 0),), (("regs_sorted", 1),), (("small_coop", 0),), (("small_spread", 0),),
-               (("regs_big", 1 << 30), ("regs_defer", 1)), (("cig_fast_coop", 0),), (("cig_lane_il", 0),))
+               (("regs_big", 1 << 30), ("regs_defer", 1)), (("cig_fast_coop", 0),), (("cig_lane_il", 0),), (("first_lanes", 0),), (("first_lanes", 1), ("lane_narrow", 0)))
 
 
 def _sweep_pool(orc, golden_dir, sim_reads):
@@ -205,7 +205,7 @@ def test_light_heavy_split_small_chunk(sl, orc, tiny_gpu, tiny_index, sim_reads)
 
 
 @pytest.mark.parametrize("knob,val", [("cig_lanes", 0), ("rep_k", 0), ("rep_k", 12), ("p2_items", 0), ("p2_coop", 0), ("p2_items_cap", 3), ("p2_items_cap", 40), ("seed_quota", 64), ("dense_sa", 0), ("chunk_reads", 777), ("cap_intv", 2), ("min_split", 100), ("workers", 1), ("chain_mode", 0),
-                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("hits_wave", 0), ("cig_fast_coop", 0), ("cig_lane_il", 0), ("regs_sorted", 1), ("small_coop", 0), ("small_spread", 0), ("chain_sorted", 1), ("ext_split", 0), ("wide_index", 1),
+                                      ("regs_big", 2), ("regs_big", 5), ("regs_big", 700), ("regs_big", 1073741824), ("regs_defer", 0), ("hits_wave", 0), ("cig_fast_coop", 0), ("cig_lane_il", 0), ("first_lanes", 0), ("regs_sorted", 1), ("small_coop", 0), ("small_spread", 0), ("chain_sorted", 1), ("ext_split", 0), ("wide_index", 1),
                                       ("lut_k", 0), ("lut_k", 12)])
 def test_knobs_do_not_change_results(sl, orc, tiny_gpu, tiny_index, sim_reads, knob, val):
     """bwa's sampled-SA walk vs dense SA, odd chunking, a tiny interval capacity that forces the overflow-retry path, the
