@@ -1,5 +1,6 @@
 """Summarises the rocprofv3 passes written by scripts/profile_round.sh:
    python scripts/pmc_summary.py <out_dir> <config> > profiles/rNN_pmc_summary.json
+   python scripts/pmc_summary.py <summary.json> <config>      recomputes the derived figures (stage groups) from the per-kernel counters of an earlier summary
 Per kernel: mean counter values over the full-size launches (the largest launches of each kernel).
 
 Units, as found on this gfx950 / ROCm 7.2 (cross-checked between counters of the same launches):
@@ -22,7 +23,8 @@ import collections, csv, glob, json, sys
 out_dir, config = sys.argv[1], sys.argv[2]
 N_SIMD, N_XCD = 1024, 8
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out_dir + "/pmc*/**/*counter_collection.csv", recursive=True):
+prior = json.load(open(out_dir)) if out_dir.endswith(".json") else None
+for f in ([] if prior else glob.glob(out_dir + "/pmc*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         if "rocprim" in name or "rocclr" in name or "hipcub" in name:
@@ -35,6 +37,8 @@ for k, d in acc.items():
         big = [x for x in v if x >= 0.5 * max(v)] or v       # full-size launches only
         kern[k][c] = sum(big) / len(big)
         n_launch[k] = max(n_launch.get(k, 0), len(big))
+if prior:
+    kern = prior["kernels"]
 
 
 def g(k, c):
@@ -56,8 +60,11 @@ def lane_util(k):
 
 
 try:
-    bench = json.loads(open(out_dir + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
-    reads = bench["reads_per_seed_launch"]
+    if prior:
+        bench, reads = None, prior["reads_per_launch"]
+    else:
+        bench = json.loads(open(out_dir + "/bench_under_rocprof.json").read().strip().splitlines()[-1])
+        reads = bench["reads_per_seed_launch"]
 except Exception:
     bench, reads = None, {"C2": 10e6 / 3, "C3": 50e6 / 6}.get(config, 1.0)
 seed12 = ([k for k in pick("k_seed12") if ", 1>" in k] or pick("k_seed12") or ["k_seed12m"])[0]      # pass 1 (the bulk); pass 2 is k_seed12m<.., 2>
@@ -65,7 +72,7 @@ seed12_p2 = ([k for k in pick("k_seed12") if ", 2>" in k] or [None])[0]
 seed_all = pick("k_seed")                     # k_seed12m, k_seed3m, k_seed_epi
 fetch = sum(g(k, "FETCH_SIZE") for k in seed_all) * 1024.0 / reads
 write = sum(g(k, "WRITE_SIZE") for k in seed_all) * 1024.0 / reads
-ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_ext_replay", "k_extend_reg", "k_first_prep", "k_first_diag", "k_ext_lanes", "k_cand_lane_prep")]
+ext = [k for k in kern if k.split("<")[0] in ("k_extend_cand", "k_ext_first", "k_first_lanes", "k_first_bin_count", "k_first_bin_scatter", "k_ext_replay", "k_extend_reg", "k_first_prep", "k_first_diag", "k_ext_lanes", "k_cand_lane_prep")]
 ext_inst = sum(g(k, "SQ_ACTIVE_INST_VALU") for k in ext)
 ext_gui = sum(g(k, "GRBM_GUI_ACTIVE") for k in ext)
 def wait_frac(k):
@@ -106,7 +113,7 @@ res = {
     "chain": group(("k_chain", "k_chain_coop", "k_part_flags", "k_part_scatter", "k_heavy_keys")),
     "regions": group(("k_regs1", "k_regs", "k_regs_wave", "k_part_flags_nreg")),
     "hits": group(("k_hits", "k_hits_sam")),
-    "cigar": group(("k_cig_fast", "k_cig_lanes", "k_cig_dp")),
+    "cigar": group(("k_cig_fast", "k_cig_fast_coop", "k_cig_lanes", "k_cig_dp")),
     "kernels": kern,
 }
 print(json.dumps(res, indent=1))
