@@ -230,7 +230,8 @@ int  slx_aligner_probe_launches(const slx_aligner *al);
 /* what the last batch held, by name (diagnostics and tests; -1 = unknown name): "heavy_reads" (reads on the wave-per-read schedule),
  * "p2_calls" (re-seeding calls of pass 2 run one per lane), "p2_coop_calls" (those of them run one per wave), "p2_whole_reads";
  * "workers" = the aligner's worker count (per device); "hw_queues" = GPU_MAX_HW_QUEUES as the process had it when the aligner was created (4 = unset: the library
- * reads it, never sets it); "regs_deferred" = reads the lane region kernel handed to the wave kernel since the aligner was created */
+ * reads it, never sets it); "regs_deferred" = reads the lane region kernel handed to the wave kernel since the aligner was created;
+ * "retries" = chunks run again after an overflow of their work areas since the aligner was created (a steady workload shows 0 after its first call) */
 int64_t slx_aligner_counter(const slx_aligner *al, const char *key);
 
 /* Test hook (per-stage differential tests): intermediate results of one read of the LAST batch, copied out of the device work

@@ -177,6 +177,10 @@ __global__ void __launch_bounds__(64) k_cig_lanes(DevRef R, Chunk ck, DevOpt dop
                 unsigned int words = going ? (unsigned int)z_stride * (unsigned int)rlen : 0u;
                 for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)words, d, WAVE); words = words > o ? words : o; }
                 words = (unsigned int)__builtin_amdgcn_readfirstlane((int)words);
+                // (the first block of a wave is sized for the largest job of the chunk -- cap_list is its longest read + 1 -- so that a wave allocates once and the host
+                // knows the stage's demand beforehand: LANE_IL_WORDS, slx_align.hip)
+                const unsigned int std_words = (unsigned int)LANE_IL_WORDS(ck.cap_list - 1);
+                if (words > zown_words && words < std_words) words = std_words;
                 if (words > zown_words) {                             // a new block (the old one stays where it is: the arena only grows within a chunk)
                     const unsigned long long bytes = (unsigned long long)words * (WAVE * 4ull) + 255ull;
                     unsigned long long at = 0;

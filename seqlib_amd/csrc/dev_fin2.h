@@ -26,6 +26,10 @@
 // ... and so must the largest match score x LANE_CIG_MAXQ (same check): an unreachable cell (the floor + at most a read's worth of match
 // scores) then stays below every reachable one (above -LANE_FIN_LIMIT), and both fit 16 bits
 static_assert(LANE_NEG + LANE_FIN_LIMIT <= -LANE_FIN_LIMIT && LANE_NEG >= -32768 && LANE_FIN_LIMIT <= 32767, "16-bit cells of k_cig_lanes");
+// words per lane of a wave's lane-interleaved traceback block (k_cig_lanes<true>) that hold ANY job the routing sends to that kernel in a chunk whose longest read has max_len
+// bases: a band of at most LANE_CIG_BAND columns is nine words per row, and the band covers the length difference with three columns to spare (w >= dl + 3, 2 w + 1 <=
+// LANE_CIG_BAND), so a job has at most lq + 13 rows
+#define LANE_IL_WORDS(max_len) (((LANE_CIG_BAND + 3) / 4) * (((max_len) < LANE_CIG_MAXQ ? (max_len) : LANE_CIG_MAXQ) + 16))
 struct alignas(8) DJob {      // one pending bwa_gen_cigar2 sequence (mem_reg2aln's do/while)
     int64_t rb, re;
     int qb, qe;

@@ -578,6 +578,11 @@ extern "C" int64_t slx_aligner_counter(const slx_aligner *al, const char *key)
             if (al->is_group) for (const slx_aligner *sub : al->subs) take(sub); else take(al);
             return v;
         }
+        if (!strcmp(key, "retries")) {          // chunks run again after an overflow of their work areas (interval lists, traceback arena, CIGAR pool) since the aligner was created
+            long long v = 0;
+            if (al->is_group) for (const slx_aligner *sub : al->subs) v += sub->n_retries; else v = al->n_retries;
+            return v;
+        }
         if (!strcmp(key, "regs_deferred") || !strcmp(key, "hits_wave_reads")) {          // reads k_regs handed to the wave kernel / reads k_hits_wave sorted, since the aligner was created
             long long v = 0;
             const int which = key[0] == 'h';
@@ -685,7 +690,12 @@ static int worker_run(slx_aligner *al, Worker *wk, const slx_opt *opt, const uin
             caps.cigcap = std::max<unsigned long long>(al->cig_floor, (unsigned long long)n * al->cig_per_read + 4096);
         }
         // on top of the per-read budgets: the stretches the waves of k_cig_dp take for themselves and the CIGAR words they reserve ahead
-        const unsigned long long z_waves = (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_Z;
+        // ... and the blocks of k_cig_lanes<true>: every wave that takes jobs keeps ONE lane-interleaved block sized for the largest job the routing can send it
+        // (LANE_IL_WORDS, dev_cig_lane.h), so what the stage can ask for is known before the chunk runs -- without it a first call of a few hundred thousand reads
+        // overflowed the per-read budget (760 waves x 370 KB against 64 MB + 512 B per read) and ran its chunk twice
+        const unsigned long long lane_blocks = (unsigned long long)std::min<long long>((long long)al->n_cu * 16, (long long)n * 4 / 64 + 1);
+        const unsigned long long z_waves = (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_Z +
+                                           (al->cig_lane_il ? lane_blocks * ((unsigned long long)LANE_IL_WORDS(max_len) * 256ull + 255ull) : 0ull);
         const unsigned long long cig_waves = (unsigned long long)std::min(n, al->n_cu * 32) * CIG_WAVE_WORDS;
         caps.zcap += z_waves; caps.cigcap += cig_waves;
         for (int attempt = 0;; ++attempt) {
