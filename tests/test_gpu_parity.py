@@ -253,6 +253,22 @@ def test_small_batch_does_not_inflate_the_budgets_of_the_next_large_one(sl, tiny
     assert_same(got, exp, "large batch after small ones")
 
 
+def test_first_call_of_a_mid_size_batch_runs_no_chunk_twice(sl, tiny_gpu, sim_reads):
+    """k_cig_lanes keeps the traceback bytes of a wave's 64 jobs in one lane-interleaved block (382 KB for 150 bp reads); the per-read arena budget does not hold those
+    blocks for a first call of a few hundred thousand reads, so the library sizes the arena for them before the chunk runs (slx_align.hip, LANE_IL_WORDS) -- otherwise
+    the chunk overflows, doubles its arena and runs again.  Either layout, same results, no chunk run twice."""
+    (_, s1), (_, s2) = sim_reads
+    big = (list(s1[:5000]) + list(s2[:5000])) * 24              # 240 000 fixture reads: 80 000 per worker
+    res = []
+    for il in (1, 0):
+        al = sl.BWAAligner(tiny_gpu)
+        al.set("cig_lane_il", il)
+        res.append(al.alignSequences(big))
+        assert al.counter("retries") == 0, "cig_lane_il=%d: %d chunk(s) ran again" % (il, al.counter("retries"))
+    assert int(res[0]["hit_off"][-1]) > 0
+    assert_same(res[0], res[1], "interleaved against row-major traceback arena")
+
+
 def test_edge_cases(sl, orc, tiny_gpu, tiny_index, golden_dir):
     """empty / too-short / all-N / N-containing / low-complexity / ragged lengths / lower case"""
     names, refs = orc.read_fasta(os.path.join(golden_dir, "tiny.fa"))
