@@ -130,6 +130,27 @@ static int cpu_checks(const std::string &prefix, const std::string &tmp)
     CHECK_THROWS(idx->ChrIDToName(-1), std::out_of_range);
     BamHeader hh = idx->HeaderFromIndex();
     CHECK(hh.NumSequences() == 4 && hh.IDtoName(1) == "abl" && hh.GetSequenceLength(1) == 178633);
+    // --- BamHeader's own surface (/root/reference/SeqLib/BamHeader.h:36-107, src/BamHeader.cpp:12-140)
+    {
+        CHECK(hh.IsOpen() && !hh.isEmpty() && hh.Name2ID("abl") == 1 && hh.Name2ID("nope") == -1);
+        CHECK(hh.GetSequenceLength("abl") == 178633 && hh.GetSequenceLength("nope") == -1 && hh.GetSequenceLength(4) == -1);
+        const HeaderSequenceVector hsv = hh.GetHeaderSequenceVector();
+        CHECK(hsv.size() == 4 && hsv[0].Name == "bcr" && hsv[3].Name == "myc" && hsv[1].Length == 178633u);
+        BamHeader h2(hsv);                                   // names and lengths -> "@HD VN:1.4" + one @SQ line each
+        CHECK(h2.IsOpen() && h2.NumSequences() == 4 && h2.IDtoName(3) == "myc" && h2.GetSequenceLength("bcr") == hh.GetSequenceLength(0));
+        CHECK(h2.AsString().rfind("@HD\tVN:1.4\n@SQ\tSN:bcr\tLN:", 0) == 0);
+        BamHeader h3(h2.AsString());                         // ... and that text parses back to the same dictionary
+        CHECK(h3.NumSequences() == 4 && h3.Name2ID("myc") == 3 && h3.GetSequenceLength(2) == h2.GetSequenceLength(2));
+        BamHeader none;                                      // uninitialised: no sequences, IDtoName says so
+        CHECK(!none.IsOpen() && none.isEmpty() && none.NumSequences() == 0 && none.GetSequenceLength(0) == -1 && none.Name2ID("bcr") == -1);
+        CHECK_THROWS(none.IDtoName(0), std::out_of_range);
+        CHECK_THROWS(hh.IDtoName(-1), std::invalid_argument);
+        CHECK_THROWS(hh.IDtoName(4), std::out_of_range);
+        BamHeader only_hd("@HD\tVN:1.6\n");                  // a header without @SQ lines is open and holds no sequences
+        CHECK(only_hd.IsOpen() && !only_hd.isEmpty() && only_hd.NumSequences() == 0);
+        BamHeader twice("@SQ\tSN:x\tLN:5\n@SQ\tSN:x\tLN:7\n");  // of two sequences of one name the first keeps it
+        CHECK(twice.NumSequences() == 2 && twice.Name2ID("x") == 0 && twice.GetSequenceLength("x") == 5);
+    }
     std::ostringstream s3; s3 << *idx;
     CHECK(s3.str() == "[BWAIndex] #seqs=4 pac_len=354751 holes=0");
     idx->WriteIndex(tmp);
