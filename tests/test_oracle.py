@@ -336,3 +336,20 @@ def test_edge_cases(orc, tiny_index):
     assert orc.align_sequence(opt, tiny_index, "ACGTACGTAC") == []          # shorter than min_seed_len
     assert orc.align_sequence(opt, tiny_index, "N" * 150) == []
     assert orc.align_sequence(opt, tiny_index, "ACGT" * 40) == [] or True   # low complexity: must not crash
+
+
+def test_bench_cpu_baseline_counters_without_the_timed_leg(orc, golden_dir, sim_reads):
+    """bench.py at N > 1 (rank 0): the rooflines still need the oracle's per-read counts (Occ blocks, SA lookups, DP cells ...), the timed multi-thread baseline is a figure
+    of the N = 1 line only.  cpu_baseline(timed=False) returns (None, counts) from a short single-thread calibration; timed=True on the same reads returns both, with the
+    same counts."""
+    import numpy as np
+    import bench
+    (_, s1), _ = sim_reads
+    (_, s2) = sim_reads[1]
+    reads = np.frombuffer("".join(s[:100] for s in list(s1) + list(s2) if len(s) >= 100).encode(), dtype=np.uint8).reshape(-1, 100)      # 6 000: 2 000 calibrate, the rest is the timed sample
+    prefix = os.path.join(golden_dir, "tiny.fa")
+    cpu0, per0 = bench.cpu_baseline(prefix, reads, "fixture", timed=False)
+    assert cpu0 is None and per0["n_occ_block"] > 0 and per0["read_bases"] == 100.0 and per0["n_hits"] > 0.5
+    cpu1, per1 = bench.cpu_baseline(prefix, reads, "fixture", budget_s=0.05, timed=True)
+    assert per1 == per0
+    assert cpu1["kind"] == "port" and cpu1["unit"] == "reads/s" and cpu1["value"] > 0 and cpu1["cores"] >= 1
